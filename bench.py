@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Solver-update benchmark: DPM-Solver++(2M), 20 steps, [256,4,64,64] fp16, frozen model_fn (BASELINE.json
+configs[1]) on N GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A *step* is one complete 20-stage sampling trajectory of one batch of 256 latents: 20 launches of the fused
+stage kernel through the C ABI's native loop (dpm_plan_run), the network frozen (its output pre-staged in a
+buffer distinct from x), every input resident in HBM before the clock starts.  Steps cycle through
+`--sets` independent buffer sets (default 8 x 64 MiB = 512 MiB) so that consecutive trajectories cannot live in
+the 256 MiB Infinity Cache: in real use a UNet runs between two solver stages and evicts it anyway.
+
+One JSON line on rank 0:
+  value              whole-job Msamples/s = N * K * 256 / wall, wall = barrier/sync-bracketed, max over ranks
+  roofline           HBM roofline of the dominant kernel (2M steady-state stage: reads x, eps, m_prev; writes
+                     x_next, m = 5 * n * sizeof(dtype) algorithmic bytes per launch); `achieved` uses the kernel's
+                     own duration measured live with hipExtLaunchKernelGGL start/stop events on the launch stream
+                     (dpm_plan_run_timed) -- the quantity rocprofv3 --kernel-trace reports (profiles/).
+  cpu_baseline       the numpy oracle (oracle/dpm_oracle.py, a port of the reference algorithm) timed on one host
+                     core, rank 0, N=1 only, on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B, SHAPE, STEPS_SOLVER = 256, (4, 64, 64), 20
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured float4-copy ceiling is ~6290
+
+
+def sd_alphas_cumprod():
+    betas = np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=np.float64) ** 2
+    return np.cumprod(1.0 - betas).astype(np.float32)
+
+
+def make_sets(n_sets, dtype, dev, seed):
+    """n_sets independent buffer sets: x_T, frozen eps, 3 state scratch buffers, 2 history slots."""
+    from dpm_solver_amd import _lib as L
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    sets = []
+    for _ in range(n_sets):
+        x_T = torch.randn((B,) + SHAPE, generator=g).to(dev, dtype)
+        eps = torch.randn((B,) + SHAPE, generator=g).to(dev, dtype)
+        xb = [x_T] + [torch.empty_like(x_T) for _ in range(3)]
+        hb = [torch.empty_like(x_T) for _ in range(2)]
+        rb = L.RunBuffers()
+        for i in range(4):
+            rb.xbuf[i] = xb[i].data_ptr()
+        for i in range(2):
+            rb.hist[i] = hb[i].data_ptr()
+        rb.e0 = eps.data_ptr()
+        rb.n, rb.batch = x_T.numel(), B
+        rb.state_dtype = rb.eps_dtype = {torch.float16: L.DTYPE_F16, torch.float32: L.DTYPE_F32,
+                                         torch.bfloat16: L.DTYPE_BF16}[dtype]
+        sets.append(dict(rb=rb, x=xb, h=hb, eps=eps))
+    return sets
+
+
+def cpu_baseline(ac, budget_s=20.0):
+    """numpy oracle (port of the reference's algorithm, one thread) on the same workload, bounded sample."""
+    from oracle import dpm_oracle as O
+    osch = O.Schedule.from_alphas_cumprod(ac)
+    rng = np.random.default_rng(0)
+    bs = 64
+    x = rng.standard_normal((bs,) + SHAPE).astype(np.float32)
+    eps = rng.standard_normal((bs,) + SHAPE).astype(np.float32)
+    sol = O.Solver(O.wrap_model(lambda xx, t: eps, osch), osch, algorithm_type="dpmsolver++")
+    sol.sample(x[:4], steps=STEPS_SOLVER, order=2)          # warm-up (page in, allocator)
+    sol = O.Solver(O.wrap_model(lambda xx, t: eps, osch), osch, algorithm_type="dpmsolver++")
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        sol.sample(x, steps=STEPS_SOLVER, order=2)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s * 0.5 or n >= 64:
+            break
+    return dict(value=bs * n / el / 1e6, unit="Msamples/s", cores=1, kind="port",
+                sample="%d trajectories of [%d,4,64,64] fp32 (numpy oracle, frozen eps), %.1f s" % (n, bs, el))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--sets", type=int, default=8, help="independent buffer sets cycled through (cache defeat)")
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    dtype = {"fp16": torch.float16, "fp32": torch.float32, "bf16": torch.bfloat16}[args.dtype]
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))     # "nccl" is RCCL on ROCm
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import dpm_solver_amd as D
+    from dpm_solver_amd import _lib as L
+
+    ac = sd_alphas_cumprod()
+    ns = D.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(ac))
+    dpm = D.DPM_Solver(D.model_wrapper(lambda x, t: x, ns), ns, algorithm_type="dpmsolver++", state_dtype=dtype)
+    plan = dpm._get_plan(method="multistep", order=2, steps=STEPS_SOLVER, skip_type="time_uniform",
+                         solver_type="dpmsolver", lower_order_final=True, denoise_to_zero=False,
+                         t_T=1.0, t_0=1.0 / ns.total_N)
+    n_stages = len(plan.stages)
+    sets = make_sets(args.sets, dtype, dev, seed=1234 + rank)          # independent samples per rank (seed + rank)
+    stream = torch.cuda.current_stream(dev)
+    sptr = C.c_void_p(stream.cuda_stream)
+    res = C.c_int(-1)
+
+    def trajectory(i):
+        L.check(L.lib.dpm_plan_run(plan.handle, C.byref(sets[i % len(sets)]["rb"]), None, None, sptr, C.byref(res)))
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # ---- parity spot check outside the timed region: native loop == Python host loop (same kernels) ---------
+    s0 = sets[0]
+    dchk = D.DPM_Solver(D.model_wrapper(lambda x, t: s0["eps"], ns), ns, state_dtype=dtype)
+    want = dchk.sample(s0["x"][0], steps=STEPS_SOLVER, order=2)
+    trajectory(0)
+    torch.cuda.synchronize(dev)
+    assert torch.equal(s0["x"][res.value], want), "native loop and Python loop disagree"
+
+    for i in range(args.warmup):
+        trajectory(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        trajectory(i)
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+
+    # ---- roofline: kernel-only durations, HIP events attached to each launch on the launch stream ------------
+    n_el = B * int(np.prod(SHAPE))
+    esz = torch.empty((), dtype=dtype).element_size()
+    reps = max(2 * len(sets), 16)
+    ms = np.zeros((reps, n_stages), dtype=np.float64)
+    buf = (C.c_float * n_stages)()
+    for r in range(reps):
+        L.check(L.lib.dpm_plan_run_timed(plan.handle, C.byref(sets[r % len(sets)]["rb"]), sptr, buf, C.byref(res)))
+        ms[r] = np.frombuffer(buf, dtype=np.float32)
+    steady = ms[:, 1:n_stages - 1]                       # stages 1..18: the 5-stream 2M kernel
+    k_us = float(steady.mean() * 1e3)
+    alg_bytes = 5 * n_el * esz
+    achieved = alg_bytes / (k_us * 1e-6) / 1e9
+    traj_alg_bytes = (18 * 5 + 2 * 4) * n_el * esz       # 98 N elements per 20-step trajectory
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per launch from rocprofv3 --pmc passes
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.dtype, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                    kernel="stage_kernel<%s,%s,FORM_TWO,GUIDE_NONE> (2M steady state)" % (args.dtype, args.dtype),
+                    kernel_us=round(k_us, 3), kernel_us_min=round(float(steady.min() * 1e3), 3),
+                    algorithmic_bytes_per_launch=alg_bytes,
+                    first_last_stage_us=[round(float(ms[:, 0].mean() * 1e3), 3), round(float(ms[:, -1].mean() * 1e3), 3)],
+                    trajectory_kernel_sum_us=round(float(ms.sum(axis=1).mean() * 1e3), 2))
+
+    # ---- the single end-of-sampling collective of the sharded path: all-gather of the final x (timed apart) ---
+    gather_ms = None
+    if dist is not None:
+        final = sets[(args.steps - 1) % len(sets)]["x"][res.value]
+        out = torch.empty((world,) + tuple(final.shape), dtype=final.dtype, device=dev)
+        dist.all_gather_into_tensor(out, final)                          # warm-up (communicator setup)
+        barrier()
+        tg = time.perf_counter()
+        dist.all_gather_into_tensor(out, final)
+        barrier()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        assert torch.equal(out[rank], final)
+
+    if rank == 0:
+        samples = world * args.steps * B
+        line = {
+            "metric": "solver-update Msamples/sec, DPM-Solver++(2M) 20-step, Bx4x64x64",
+            "value": round(samples / wall / 1e6, 4), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"fp16": "f16", "fp32": "f32", "bf16": "bf16"}[args.dtype], "data": "synthetic",
+            "config": {"workload": "DPM-Solver++ 2M, 20 steps, [256,4,64,64] %s per GPU, frozen model_fn (eps pre-staged), "
+                                   "SD-v1 scaled-linear schedule, time_uniform" % args.dtype,
+                       "batch_per_gpu": B, "solver_stages_per_step": n_stages, "buffer_sets": len(sets),
+                       "parallelism": "batch-sharded x%d, no data-path collective" % world},
+            "msample_steps_per_s": round(samples * n_stages / wall / 1e6, 3),
+            "effective_GBps_incl_launch_gaps": round(traj_alg_bytes * args.steps / wall / 1e9, 1),
+            "roofline": roofline,
+            "gather_ms": None if gather_ms is None else round(gather_ms, 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(ac)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

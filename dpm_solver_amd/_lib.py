@@ -1,0 +1,151 @@
+"""ctypes binding of the C ABI declared in include/dpm_hip.h.
+
+The shared library is built in-tree by `__graft_entry__.build()` (hipcc, --offload-arch=gfx950) as
+dpm_solver_amd/libdpm_hip.so.  There is no fallback: if it is missing the import fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdpm_hip.so")
+
+# ---- enumerations (mirror include/dpm_hip.h) --------------------------------------------------
+DPM_OK = 0
+ERR_ARG, ERR_UNSUPPORTED, ERR_ALIGN, ERR_NOMEM, ERR_CALLBACK = -1, -2, -3, -4, -5
+ALGO = {"dpmsolver": 0, "dpmsolver++": 1}
+SOLVER = {"dpmsolver": 0, "taylor": 1}
+METHOD = {"multistep": 0, "singlestep": 1, "singlestep_fixed": 2}
+SKIP = {"time_uniform": 0, "logSNR": 1, "time_quadratic": 2}
+MODEL = {"noise": 0, "x_start": 1, "v": 2, "score": 3}
+GUIDE = {"uncond": 0, "classifier-free": 1, "classifier": 2}
+DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
+EVAL_LOG_ALPHA, EVAL_ALPHA, EVAL_STD, EVAL_LAMBDA, EVAL_INV_LAMBDA = 0, 1, 2, 3, 4
+FORM_LIN1, FORM_TWO, FORM_MS3, FORM_SS3T, FORM_DENOISE = 0, 1, 2, 3, 4
+F_TO_X0, F_STORE_M, F_BASE_HIST, F_THRESH, F_USER_X0 = 1, 2, 4, 8, 16
+SRC_STATE, SRC_TMP = 0, 1
+
+
+class Stage(C.Structure):
+    _fields_ = [
+        ("index", C.c_int32), ("form", C.c_int32), ("flags", C.c_uint32), ("model_type", C.c_int32),
+        ("guidance", C.c_int32), ("outer_step", C.c_int32), ("emits_state", C.c_int32),
+        ("x_src", C.c_int32), ("xe_src", C.c_int32), ("h1_slot", C.c_int32), ("h2_slot", C.c_int32),
+        ("m_slot", C.c_int32),
+        ("t_eval", C.c_float), ("t_input", C.c_float), ("t_out", C.c_float),
+        ("alpha_e", C.c_float), ("sigma_e", C.c_float), ("cfg_scale", C.c_float), ("cg_scale", C.c_float),
+        ("cx", C.c_float), ("c0", C.c_float), ("c1", C.c_float), ("c2", C.c_float),
+        ("k", C.c_float * 5), ("thr_ratio", C.c_float), ("thr_max", C.c_float),
+    ]
+
+    def copy(self):
+        s = Stage()
+        C.memmove(C.byref(s), C.byref(self), C.sizeof(Stage))
+        return s
+
+
+class Buffers(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("xe", C.c_void_p), ("e0", C.c_void_p), ("e1", C.c_void_p), ("g", C.c_void_p),
+        ("h1", C.c_void_p), ("h2", C.c_void_p), ("x_out", C.c_void_p), ("m_out", C.c_void_p),
+        ("workspace", C.c_void_p), ("n", C.c_int64), ("batch", C.c_int64),
+        ("state_dtype", C.c_int32), ("eps_dtype", C.c_int32),
+    ]
+
+
+class PlanDesc(C.Structure):
+    _fields_ = [
+        ("algorithm_type", C.c_int32), ("method", C.c_int32), ("order", C.c_int32), ("steps", C.c_int32),
+        ("skip_type", C.c_int32), ("solver_type", C.c_int32), ("lower_order_final", C.c_int32),
+        ("denoise_to_zero", C.c_int32), ("model_type", C.c_int32), ("guidance", C.c_int32),
+        ("thresholding", C.c_int32), ("reserved", C.c_int32),
+        ("t_start", C.c_double), ("t_end", C.c_double), ("guidance_scale", C.c_double),
+        ("thr_ratio", C.c_double), ("thr_max", C.c_double),
+    ]
+
+
+class RunBuffers(C.Structure):
+    _fields_ = [
+        ("xbuf", C.c_void_p * 4), ("hist", C.c_void_p * 3), ("e0", C.c_void_p), ("e1", C.c_void_p),
+        ("workspace", C.c_void_p), ("n", C.c_int64), ("batch", C.c_int64),
+        ("state_dtype", C.c_int32), ("eps_dtype", C.c_int32),
+    ]
+
+
+MODEL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Stage), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+
+# every symbol include/dpm_hip.h declares: (name, restype, argtypes)
+_P = C.POINTER
+_SIGNATURES = [
+    ("dpm_schedule_create_betas_f32", C.c_int, [_P(C.c_float), C.c_int, C.c_int, _P(C.c_void_p)]),
+    ("dpm_schedule_create_betas_f64", C.c_int, [_P(C.c_double), C.c_int, C.c_int, _P(C.c_void_p)]),
+    ("dpm_schedule_create_alphas_cumprod_f32", C.c_int, [_P(C.c_float), C.c_int, C.c_int, _P(C.c_void_p)]),
+    ("dpm_schedule_create_alphas_cumprod_f64", C.c_int, [_P(C.c_double), C.c_int, C.c_int, _P(C.c_void_p)]),
+    ("dpm_schedule_create_log_alpha", C.c_int, [_P(C.c_float), C.c_int, _P(C.c_void_p)]),
+    ("dpm_schedule_create_linear", C.c_int, [C.c_double, C.c_double, _P(C.c_void_p)]),
+    ("dpm_schedule_destroy", None, [C.c_void_p]),
+    ("dpm_schedule_is_discrete", C.c_int, [C.c_void_p]),
+    ("dpm_schedule_total_N", C.c_int, [C.c_void_p]),
+    ("dpm_schedule_tables", C.c_int, [C.c_void_p, _P(_P(C.c_float)), _P(_P(C.c_float)), _P(C.c_int)]),
+    ("dpm_schedule_eval", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), C.c_int, _P(C.c_float)]),
+    ("dpm_time_steps", C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, _P(C.c_float)]),
+    ("dpm_singlestep_orders", C.c_int, [C.c_int, C.c_int, _P(C.c_int), _P(C.c_int)]),
+    ("dpm_singlestep_grid", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                      _P(C.c_float), _P(C.c_int), _P(C.c_int)]),
+    ("dpm_plan_create", C.c_int, [C.c_void_p, _P(PlanDesc), _P(C.c_void_p)]),
+    ("dpm_plan_destroy", None, [C.c_void_p]),
+    ("dpm_plan_num_stages", C.c_int, [C.c_void_p]),
+    ("dpm_plan_num_slots", C.c_int, [C.c_void_p]),
+    ("dpm_plan_stage", C.c_int, [C.c_void_p, C.c_int, _P(Stage)]),
+    ("dpm_plan_timesteps", C.c_int, [C.c_void_p, _P(C.c_float), C.c_int, _P(C.c_int)]),
+    ("dpm_coef_first", C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, _P(Stage)]),
+    ("dpm_coef_multistep", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_float), C.c_float, _P(Stage)]),
+    ("dpm_coef_singlestep", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_double,
+                                      C.c_double, C.c_int, _P(Stage)]),
+    ("dpm_coef_prologue", C.c_int, [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_double, _P(Stage)]),
+    ("dpm_stage_launch", C.c_int, [_P(Stage), _P(Buffers), C.c_void_p]),
+    ("dpm_threshold_workspace_bytes", C.c_size_t, [C.c_int64, C.c_int64]),
+    ("dpm_add_noise_launch", C.c_int, [C.c_void_p, _P(C.c_float), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_int64, C.c_int, C.c_void_p]),
+    ("dpm_adaptive_error_launch", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p,
+                                            C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
+    ("dpm_plan_run", C.c_int, [C.c_void_p, _P(RunBuffers), C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int)]),
+    ("dpm_stage_launch_timed", C.c_int, [_P(Stage), _P(Buffers), C.c_void_p, _P(C.c_float)]),
+    ("dpm_plan_run_timed", C.c_int, [C.c_void_p, _P(RunBuffers), C.c_void_p, _P(C.c_float), _P(C.c_int)]),
+    ("dpm_version", C.c_int, []),
+    ("dpm_last_error", C.c_char_p, []),
+    ("dpm_device_info", C.c_int, [_P(C.c_int), _P(C.c_int), C.c_char_p, C.c_int]),
+]
+SYMBOLS = [s[0] for s in _SIGNATURES]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "dpm_solver_amd: %s not found.  Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU / PyTorch fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in _SIGNATURES:
+        fn = getattr(lib, name)  # AttributeError if the library is stale
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class DpmError(RuntimeError):
+    pass
+
+
+def check(rc):
+    """Map a C status to the reference's exception convention: argument errors are
+    ValueError, everything else RuntimeError."""
+    if rc == DPM_OK:
+        return
+    msg = lib.dpm_last_error().decode("utf-8", "replace")
+    if rc == ERR_ARG:
+        raise ValueError(msg)
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise DpmError("dpm_hip error %d: %s" % (rc, msg))

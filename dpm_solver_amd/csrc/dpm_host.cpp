@@ -1,0 +1,888 @@
+// dpm_host.cpp -- host side of the C ABI in include/dpm_hip.h: noise schedule, time grids and the
+// planner that unrolls DPM_Solver.sample() into per-stage coefficient records.
+//
+// No device code here.  Everything is computed ONCE per sample() call, on the host, in the
+// reference's own fp32 operation order (the reference carries every schedule scalar as a 0-dim or
+// (1,)-shaped fp32 tensor), so that the coefficients agree with the reference to the last bit except
+// where an elementary function (exp/log/expm1/log1p) rounds differently: here they are evaluated in
+// double and rounded once, i.e. correctly rounded fp32.  Must be compiled with -ffp-contract=off.
+//
+// `ref :NNN` = line in the reference's dpm_solver_pytorch.py.
+#include "dpm_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------
+// error text
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+int dpm_set_error(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+extern "C" const char* dpm_last_error(void) { return g_err.c_str(); }
+extern "C" int dpm_version(void) { return DPM_HIP_VERSION; }
+
+// ------------------------------------------------------------------------------------------------
+// correctly rounded fp32 elementary functions
+// ------------------------------------------------------------------------------------------------
+namespace {
+inline float f_exp(float x) { return (float)std::exp((double)x); }
+inline float f_log(float x) { return (float)std::log((double)x); }
+inline float f_expm1(float x) { return (float)std::expm1((double)x); }
+inline float f_log1p(float x) { return (float)std::log1p((double)x); }
+inline float f_sqrt(float x) { return std::sqrt(x); }
+// torch.logaddexp
+inline float f_logaddexp(float a, float b) {
+  float m = a > b ? a : b;
+  return m + f_log1p(f_exp(-std::fabs(a - b)));
+}
+
+// torch.linspace on CPU for fp32: fp32 step, filled from both ends, one fused multiply-add per point
+// (checked bitwise against torch.linspace in tests/test_planner.py).
+void linspace32(float start, float end, int n, float* out) {
+  if (n <= 0) return;
+  if (n == 1) {
+    out[0] = start;
+    return;
+  }
+  const float step = (end - start) / (float)(n - 1);
+  const int half = n / 2;
+  for (int i = 0; i < n; ++i)
+    out[i] = i < half ? std::fma(step, (float)i, start) : std::fma(-step, (float)(n - i - 1), end);
+}
+
+// interpolate_fn (ref :1253-1292): piecewise-linear through (xp, yp), xp ascending, outermost segments
+// extended.  The reference locates the segment by sorting [x, xp]; a binary search finds the same one.
+float interp32(float x, const float* xp, const float* yp, int K) {
+  int idx = (int)(std::lower_bound(xp, xp + K, x) - xp);  // #{xp < x}
+  int i0 = idx == 0 ? 0 : (idx == K ? K - 2 : idx - 1);
+  int i1 = i0 + 1;
+  return yp[i0] + (x - xp[i0]) * (yp[i1] - yp[i0]) / (xp[i1] - xp[i0]);
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// schedule
+// ------------------------------------------------------------------------------------------------
+struct dpm_schedule {
+  bool discrete = true;
+  int total_N = 1000;
+  std::vector<float> la, t;        // log_alpha_array, t_array (ref :105,:107)
+  std::vector<float> la_rev, t_rev;  // flipped copies for inverse_lambda (ref :166)
+  double beta0 = 0.1, beta1 = 20.0;
+
+  float log_alpha(float tt) const {  // marginal_log_mean_coeff, ref :127-134
+    if (discrete) return interp32(tt, t.data(), la.data(), total_N);
+    return -0.25f * (tt * tt) * (float)(beta1 - beta0) - 0.5f * tt * (float)beta0;
+  }
+  float alpha(float tt) const { return f_exp(log_alpha(tt)); }                                  // ref :140
+  float std_(float tt) const { return f_sqrt(1.f - f_exp(2.f * log_alpha(tt))); }               // ref :146
+  float lambda(float tt) const {                                                                // ref :152-154
+    float l = log_alpha(tt);
+    return l - 0.5f * f_log(1.f - f_exp(2.f * l));
+  }
+  float inv_lambda(float lam) const {  // ref :156-167
+    if (!discrete) {
+      float tmp = (float)(2. * (beta1 - beta0)) * f_logaddexp(-2.f * lam, 0.f);
+      float delta = (float)(beta0 * beta0) + tmp;
+      return tmp / (f_sqrt(delta) + (float)beta0) / (float)(beta1 - beta0);
+    }
+    float l = -0.5f * f_logaddexp(0.f, -2.f * lam);
+    return interp32(l, la_rev.data(), t_rev.data(), total_N);
+  }
+};
+
+namespace {
+int finish_discrete(std::vector<float>&& la, dpm_schedule** out) {
+  if (la.size() < 2) return dpm_set_error(DPM_ERR_ARG, "discrete schedule needs >= 2 entries after clipping, got %zu", la.size());
+  dpm_schedule* s = new (std::nothrow) dpm_schedule;
+  if (!s) return dpm_set_error(DPM_ERR_NOMEM, "out of memory");
+  s->discrete = true;
+  s->la = std::move(la);
+  s->total_N = (int)s->la.size();
+  std::vector<float> full(s->total_N + 1);
+  linspace32(0.f, 1.f, s->total_N + 1, full.data());  // ref :107
+  s->t.assign(full.begin() + 1, full.end());
+  s->la_rev.assign(s->la.rbegin(), s->la.rend());
+  s->t_rev.assign(s->t.rbegin(), s->t.rend());
+  *out = s;
+  return DPM_OK;
+}
+
+// numerical_clip_alpha (ref :114-125), generic over the arithmetic type the caller's array came in
+template <typename T>
+size_t clip_len(const std::vector<T>& la) {
+  const T cl = (T)-5.1;
+  std::vector<T> lam(la.size());
+  for (size_t i = 0; i < la.size(); ++i) {
+    T ls;
+    if (sizeof(T) == 4)
+      ls = (T)(0.5f * f_log(1.f - f_exp(2.f * (float)la[i])));
+    else
+      ls = (T)(0.5 * std::log(1. - std::exp(2. * (double)la[i])));
+    lam[i] = la[i] - ls;
+  }
+  // searchsorted(flip(lam), cl, right=False) = #{lam_flipped < cl}, lam_flipped ascending
+  std::vector<T> fl(lam.rbegin(), lam.rend());
+  size_t idx = std::lower_bound(fl.begin(), fl.end(), cl) - fl.begin();
+  return la.size() - idx;
+}
+}  // namespace
+
+extern "C" int dpm_schedule_create_betas_f32(const float* betas, int n, int clip, dpm_schedule** out) {
+  if (!betas || !out || n < 2) return dpm_set_error(DPM_ERR_ARG, "betas: need n >= 2 and non-null pointers");
+  std::vector<float> la(n);
+  double acc = 0.;  // torch CPU cumsum accumulates fp32 in double, rounding each prefix (ref :100)
+  for (int i = 0; i < n; ++i) {
+    acc += (double)f_log(1.f - betas[i]);
+    la[i] = 0.5f * (float)acc;
+  }
+  if (clip) la.resize(clip_len(la));
+  return finish_discrete(std::move(la), out);
+}
+
+extern "C" int dpm_schedule_create_betas_f64(const double* betas, int n, int clip, dpm_schedule** out) {
+  if (!betas || !out || n < 2) return dpm_set_error(DPM_ERR_ARG, "betas: need n >= 2 and non-null pointers");
+  std::vector<double> la(n);
+  double acc = 0.;
+  for (int i = 0; i < n; ++i) {
+    acc += std::log(1. - betas[i]);
+    la[i] = 0.5 * acc;
+  }
+  if (clip) la.resize(clip_len(la));
+  return finish_discrete(std::vector<float>(la.begin(), la.end()), out);  // .to(dtype=float32), ref :105
+}
+
+extern "C" int dpm_schedule_create_alphas_cumprod_f32(const float* ac, int n, int clip, dpm_schedule** out) {
+  if (!ac || !out || n < 2) return dpm_set_error(DPM_ERR_ARG, "alphas_cumprod: need n >= 2 and non-null pointers");
+  std::vector<float> la(n);
+  for (int i = 0; i < n; ++i) la[i] = 0.5f * f_log(ac[i]);  // ref :103
+  if (clip) la.resize(clip_len(la));
+  return finish_discrete(std::move(la), out);
+}
+
+extern "C" int dpm_schedule_create_alphas_cumprod_f64(const double* ac, int n, int clip, dpm_schedule** out) {
+  if (!ac || !out || n < 2) return dpm_set_error(DPM_ERR_ARG, "alphas_cumprod: need n >= 2 and non-null pointers");
+  std::vector<double> la(n);
+  for (int i = 0; i < n; ++i) la[i] = 0.5 * std::log(ac[i]);
+  if (clip) la.resize(clip_len(la));
+  return finish_discrete(std::vector<float>(la.begin(), la.end()), out);
+}
+
+extern "C" int dpm_schedule_create_log_alpha(const float* log_alpha, int n, dpm_schedule** out) {
+  if (!log_alpha || !out || n < 2) return dpm_set_error(DPM_ERR_ARG, "log_alpha: need n >= 2 and non-null pointers");
+  return finish_discrete(std::vector<float>(log_alpha, log_alpha + n), out);
+}
+
+extern "C" int dpm_schedule_create_linear(double beta_0, double beta_1, dpm_schedule** out) {
+  if (!out) return dpm_set_error(DPM_ERR_ARG, "null out");
+  dpm_schedule* s = new (std::nothrow) dpm_schedule;
+  if (!s) return dpm_set_error(DPM_ERR_NOMEM, "out of memory");
+  s->discrete = false;
+  s->total_N = 1000;  // ref :110
+  s->beta0 = beta_0;
+  s->beta1 = beta_1;
+  *out = s;
+  return DPM_OK;
+}
+
+extern "C" void dpm_schedule_destroy(dpm_schedule* s) { delete s; }
+extern "C" int dpm_schedule_is_discrete(const dpm_schedule* s) { return s && s->discrete; }
+extern "C" int dpm_schedule_total_N(const dpm_schedule* s) { return s ? s->total_N : 0; }
+
+extern "C" int dpm_schedule_tables(const dpm_schedule* s, const float** log_alpha, const float** t_array, int* K) {
+  if (!s || !s->discrete) return dpm_set_error(DPM_ERR_ARG, "tables exist only for discrete schedules");
+  if (log_alpha) *log_alpha = s->la.data();
+  if (t_array) *t_array = s->t.data();
+  if (K) *K = s->total_N;
+  return DPM_OK;
+}
+
+extern "C" int dpm_schedule_eval(const dpm_schedule* s, int what, const float* in, int n, float* out) {
+  if (!s || (n > 0 && (!in || !out))) return dpm_set_error(DPM_ERR_ARG, "schedule_eval: null pointer");
+  for (int i = 0; i < n; ++i) {
+    switch (what) {
+      case DPM_EVAL_LOG_ALPHA: out[i] = s->log_alpha(in[i]); break;
+      case DPM_EVAL_ALPHA: out[i] = s->alpha(in[i]); break;
+      case DPM_EVAL_STD: out[i] = s->std_(in[i]); break;
+      case DPM_EVAL_LAMBDA: out[i] = s->lambda(in[i]); break;
+      case DPM_EVAL_INV_LAMBDA: out[i] = s->inv_lambda(in[i]); break;
+      default: return dpm_set_error(DPM_ERR_ARG, "schedule_eval: unknown quantity %d", what);
+    }
+  }
+  return DPM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// time grids
+// ------------------------------------------------------------------------------------------------
+namespace {
+int time_steps(const dpm_schedule* s, int skip, double t_T, double t_0, int N, float* out) {
+  switch (skip) {
+    case DPM_SKIP_TIME_UNIFORM:  // ref :474
+      linspace32((float)t_T, (float)t_0, N + 1, out);
+      return DPM_OK;
+    case DPM_SKIP_LOGSNR: {  // ref :469-472
+      float lT = s->lambda((float)t_T), l0 = s->lambda((float)t_0);
+      linspace32(lT, l0, N + 1, out);
+      for (int i = 0; i <= N; ++i) out[i] = s->inv_lambda(out[i]);
+      return DPM_OK;
+    }
+    case DPM_SKIP_TIME_QUADRATIC:  // ref :476-478
+      linspace32((float)std::pow(t_T, 0.5), (float)std::pow(t_0, 0.5), N + 1, out);
+      for (int i = 0; i <= N; ++i) out[i] = out[i] * out[i];
+      return DPM_OK;
+  }
+  return dpm_set_error(DPM_ERR_ARG, "Unsupported skip_type %d, need to be 'logSNR' or 'time_uniform' or 'time_quadratic'", skip);
+}
+
+int singlestep_orders(int steps, int order, std::vector<int>& orders, int& K) {  // ref :514-533
+  orders.clear();
+  if (order == 3) {
+    K = steps / 3 + 1;
+    if (steps % 3 == 0) {
+      orders.assign(std::max(K - 2, 0), 3);
+      orders.push_back(2);
+      orders.push_back(1);
+    } else if (steps % 3 == 1) {
+      orders.assign(K - 1, 3);
+      orders.push_back(1);
+    } else {
+      orders.assign(K - 1, 3);
+      orders.push_back(2);
+    }
+  } else if (order == 2) {
+    if (steps % 2 == 0) {
+      K = steps / 2;
+      orders.assign(K, 2);
+    } else {
+      K = steps / 2 + 1;
+      orders.assign(K - 1, 2);
+      orders.push_back(1);
+    }
+  } else if (order == 1) {
+    K = steps;
+    orders.assign(steps, 1);
+  } else {
+    return dpm_set_error(DPM_ERR_ARG, "'order' must be '1' or '2' or '3'.");
+  }
+  return DPM_OK;
+}
+
+int singlestep_grid(const dpm_schedule* s, int steps, int order, int skip, double t_T, double t_0,
+                    std::vector<float>& outer, std::vector<int>& orders) {
+  int K = 0;
+  int rc = singlestep_orders(steps, order, orders, K);
+  if (rc) return rc;
+  if (skip == DPM_SKIP_LOGSNR) {  // ref :536
+    outer.resize(K + 1);
+    return time_steps(s, skip, t_T, t_0, K, outer.data());
+  }
+  std::vector<float> full(steps + 1);  // ref :538
+  rc = time_steps(s, skip, t_T, t_0, steps, full.data());
+  if (rc) return rc;
+  outer.clear();
+  int pos = 0;
+  outer.push_back(full[0]);
+  for (int o : orders) {
+    pos += o;
+    if (pos > steps) return dpm_set_error(DPM_ERR_ARG, "singlestep: steps=%d too small for order %d", steps, order);
+    outer.push_back(full[pos]);
+  }
+  return DPM_OK;
+}
+}  // namespace
+
+extern "C" int dpm_time_steps(const dpm_schedule* s, int skip_type, double t_T, double t_0, int N, float* out) {
+  if (!s || !out || N < 1) return dpm_set_error(DPM_ERR_ARG, "time_steps: bad arguments");
+  return time_steps(s, skip_type, t_T, t_0, N, out);
+}
+
+extern "C" int dpm_singlestep_orders(int steps, int order, int* orders, int* n_orders) {
+  std::vector<int> o;
+  int K;
+  int rc = singlestep_orders(steps, order, o, K);
+  if (rc) return rc;
+  if (orders) std::copy(o.begin(), o.end(), orders);
+  if (n_orders) *n_orders = (int)o.size();
+  return DPM_OK;
+}
+
+extern "C" int dpm_singlestep_grid(const dpm_schedule* s, int steps, int order, int skip_type, double t_T, double t_0,
+                                   float* outer, int* orders, int* n_orders) {
+  if (!s) return dpm_set_error(DPM_ERR_ARG, "null schedule");
+  std::vector<float> g;
+  std::vector<int> o;
+  int rc = singlestep_grid(s, steps, order, skip_type, t_T, t_0, g, o);
+  if (rc) return rc;
+  if (outer) std::copy(g.begin(), g.end(), outer);
+  if (orders) std::copy(o.begin(), o.end(), orders);
+  if (n_orders) *n_orders = (int)o.size();
+  return DPM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// coefficient builders
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Marg {
+  float lam, la, sig;
+};
+inline Marg marg(const dpm_schedule* s, float t) { return Marg{s->lambda(t), s->log_alpha(t), s->std_(t)}; }
+
+void stage_init(dpm_stage* st) {
+  std::memset(st, 0, sizeof *st);
+  st->h1_slot = st->h2_slot = st->m_slot = -1;
+  st->emits_state = 1;
+  st->cfg_scale = 1.f;
+  st->thr_ratio = 0.995f;
+  st->thr_max = 1.f;
+}
+
+void set_prologue(const dpm_schedule* s, float t_eval, int model_type, int guidance, double scale, dpm_stage* st) {
+  st->t_eval = t_eval;
+  // get_model_input_time (ref :271-280)
+  st->t_input = s->discrete ? (t_eval - (float)(1. / s->total_N)) * 1000.f : t_eval;
+  st->alpha_e = s->alpha(t_eval);
+  st->sigma_e = s->std_(t_eval);
+  st->model_type = model_type;
+  st->guidance = guidance;
+  st->cfg_scale = (float)scale;
+  st->cg_scale = (float)scale * st->sigma_e;  // ref :321
+}
+
+// dpm_solver_first_update (ref :547-592)
+void coef_first(const dpm_schedule* s, bool pp, float ts, float tt, dpm_stage* st) {
+  Marg a = marg(s, ts), b = marg(s, tt);
+  float h = b.lam - a.lam;
+  st->form = DPM_FORM_LIN1;
+  if (pp) {
+    float phi_1 = f_expm1(-h);
+    st->cx = b.sig / a.sig;
+    st->c0 = f_exp(b.la) * phi_1;
+  } else {
+    float phi_1 = f_expm1(h);
+    st->cx = f_exp(b.la - a.la);
+    st->c0 = b.sig * phi_1;
+  }
+  st->t_out = tt;
+}
+
+// multistep_dpm_solver_second_update (ref :796-852)
+void coef_ms2(const dpm_schedule* s, bool pp, int solver, float tp1, float tp0, float tt, dpm_stage* st) {
+  float lam_p1 = s->lambda(tp1);
+  Marg p0 = marg(s, tp0), t = marg(s, tt);
+  float a_t = f_exp(t.la);
+  float h_0 = p0.lam - lam_p1;
+  float h = t.lam - p0.lam;
+  float r0 = h_0 / h;
+  st->form = DPM_FORM_TWO;
+  st->k[0] = 1.f / r0;
+  if (pp) {
+    float phi_1 = f_expm1(-h);
+    st->cx = t.sig / p0.sig;
+    st->c0 = a_t * phi_1;
+    st->c1 = solver == DPM_SOLVER_DPMSOLVER ? 0.5f * (a_t * phi_1) : -(a_t * (phi_1 / h + 1.f));
+  } else {
+    float phi_1 = f_expm1(h);
+    st->cx = f_exp(t.la - p0.la);
+    st->c0 = t.sig * phi_1;
+    st->c1 = solver == DPM_SOLVER_DPMSOLVER ? 0.5f * (t.sig * phi_1) : t.sig * (phi_1 / h - 1.f);
+  }
+  st->t_out = tt;
+}
+
+// multistep_dpm_solver_third_update (ref :854-904); the reference ignores solver_type here
+void coef_ms3(const dpm_schedule* s, bool pp, float tp2, float tp1, float tp0, float tt, dpm_stage* st) {
+  float lam_p2 = s->lambda(tp2), lam_p1 = s->lambda(tp1);
+  Marg p0 = marg(s, tp0), t = marg(s, tt);
+  float a_t = f_exp(t.la);
+  float h_1 = lam_p1 - lam_p2;
+  float h_0 = p0.lam - lam_p1;
+  float h = t.lam - p0.lam;
+  float r0 = h_0 / h, r1 = h_1 / h;
+  st->form = DPM_FORM_MS3;
+  st->k[0] = 1.f / r0;
+  st->k[1] = 1.f / r1;
+  st->k[2] = r0 / (r0 + r1);
+  st->k[3] = 1.f / (r0 + r1);
+  if (pp) {
+    float phi_1 = f_expm1(-h);
+    float phi_2 = phi_1 / h + 1.f;
+    float phi_3 = phi_2 / h - 0.5f;
+    st->cx = t.sig / p0.sig;
+    st->c0 = a_t * phi_1;
+    st->c1 = -(a_t * phi_2);
+    st->c2 = a_t * phi_3;
+  } else {
+    float phi_1 = f_expm1(h);
+    float phi_2 = phi_1 / h - 1.f;
+    float phi_3 = phi_2 / h - 0.5f;
+    st->cx = f_exp(t.la - p0.la);
+    st->c0 = t.sig * phi_1;
+    st->c1 = t.sig * phi_2;
+    st->c2 = t.sig * phi_3;
+  }
+  st->t_out = tt;
+}
+
+// r1/r2 of the singlestep solvers are Python floats (defaults / user floats: scalar-scalar arithmetic
+// in double, one rounding when the product meets a tensor) or fp32 tensors (sample(): ref :1224-1227).
+struct R {
+  double d;
+  bool tensor;
+  float f() const { return (float)d; }
+};
+inline float r_div(double num, R r) { return r.tensor ? (float)num / r.f() : (float)(num / r.d); }
+inline float r_ratio(R a, R b) { return (a.tensor) ? a.f() / b.f() : (float)(a.d / b.d); }
+inline float r_diff(R a, R b) { return (a.tensor) ? a.f() - b.f() : (float)(a.d - b.d); }
+
+// singlestep_dpm_solver_second_update (ref :594-673): two stages
+void coef_ss2(const dpm_schedule* s, bool pp, int solver, float ts, float tt, R r1, dpm_stage* A, dpm_stage* B,
+              float* t_s1) {
+  Marg ms = marg(s, ts), mt = marg(s, tt);
+  float h = mt.lam - ms.lam;
+  float s1 = s->inv_lambda(ms.lam + r1.f() * h);
+  Marg m1 = marg(s, s1);
+  float a_s1 = f_exp(m1.la), a_t = f_exp(mt.la);
+  *t_s1 = s1;
+  A->form = DPM_FORM_LIN1;
+  B->form = DPM_FORM_TWO;
+  B->flags |= DPM_F_BASE_HIST;
+  B->k[0] = 1.f;
+  if (pp) {
+    float phi_11 = f_expm1(-r1.f() * h);
+    float phi_1 = f_expm1(-h);
+    A->cx = m1.sig / ms.sig;
+    A->c0 = a_s1 * phi_11;
+    B->cx = mt.sig / ms.sig;
+    B->c0 = a_t * phi_1;
+    B->c1 = solver == DPM_SOLVER_DPMSOLVER ? r_div(0.5, r1) * (a_t * phi_1)
+                                           : -(r_div(1., r1) * (a_t * (phi_1 / h + 1.f)));
+  } else {
+    float phi_11 = f_expm1(r1.f() * h);
+    float phi_1 = f_expm1(h);
+    A->cx = f_exp(m1.la - ms.la);
+    A->c0 = m1.sig * phi_11;
+    B->cx = f_exp(mt.la - ms.la);
+    B->c0 = mt.sig * phi_1;
+    B->c1 = solver == DPM_SOLVER_DPMSOLVER ? r_div(0.5, r1) * (mt.sig * phi_1)
+                                           : r_div(1., r1) * (mt.sig * (phi_1 / h - 1.f));
+  }
+  A->t_out = s1;
+  B->t_out = tt;
+}
+
+// singlestep_dpm_solver_third_update (ref :675-794): three stages
+void coef_ss3(const dpm_schedule* s, bool pp, int solver, float ts, float tt, R r1, R r2, dpm_stage* A,
+              dpm_stage* B, dpm_stage* C, float* t_s1, float* t_s2) {
+  Marg ms = marg(s, ts), mt = marg(s, tt);
+  float h = mt.lam - ms.lam;
+  float s1 = s->inv_lambda(ms.lam + r1.f() * h);
+  float s2 = s->inv_lambda(ms.lam + r2.f() * h);
+  Marg m1 = marg(s, s1), m2 = marg(s, s2);
+  float a_s1 = f_exp(m1.la), a_s2 = f_exp(m2.la), a_t = f_exp(mt.la);
+  *t_s1 = s1;
+  *t_s2 = s2;
+  A->form = DPM_FORM_LIN1;
+  B->form = DPM_FORM_TWO;
+  B->flags |= DPM_F_BASE_HIST;
+  B->k[0] = 1.f;
+  const bool taylor = solver == DPM_SOLVER_TAYLOR;
+  C->form = taylor ? DPM_FORM_SS3T : DPM_FORM_TWO;
+  if (!taylor) {
+    C->flags |= DPM_F_BASE_HIST;
+    C->k[0] = 1.f;
+  } else {
+    C->k[0] = r_div(1., r1);
+    C->k[1] = r_div(1., r2);
+    C->k[2] = r2.f();
+    C->k[3] = r1.f();
+    C->k[4] = r_diff(r2, r1);
+  }
+  float phi_1, phi_2, phi_3, phi_11, phi_12, phi_22;
+  if (pp) {
+    phi_11 = f_expm1(-r1.f() * h);
+    phi_12 = f_expm1(-r2.f() * h);
+    phi_1 = f_expm1(-h);
+    phi_22 = f_expm1(-r2.f() * h) / (r2.f() * h) + 1.f;
+    phi_2 = phi_1 / h + 1.f;
+    phi_3 = phi_2 / h - 0.5f;
+    A->cx = m1.sig / ms.sig;
+    A->c0 = a_s1 * phi_11;
+    B->cx = m2.sig / ms.sig;
+    B->c0 = a_s2 * phi_12;
+    B->c1 = -(r_ratio(r2, r1) * (a_s2 * phi_22));
+    C->cx = mt.sig / ms.sig;
+    C->c0 = a_t * phi_1;
+    if (!taylor) {
+      C->c1 = -(r_div(1., r2) * (a_t * phi_2));
+    } else {
+      C->c1 = -(a_t * phi_2);
+      C->c2 = a_t * phi_3;
+    }
+  } else {
+    phi_11 = f_expm1(r1.f() * h);
+    phi_12 = f_expm1(r2.f() * h);
+    phi_1 = f_expm1(h);
+    phi_22 = f_expm1(r2.f() * h) / (r2.f() * h) - 1.f;
+    phi_2 = phi_1 / h - 1.f;
+    phi_3 = phi_2 / h - 0.5f;
+    A->cx = f_exp(m1.la - ms.la);
+    A->c0 = m1.sig * phi_11;
+    B->cx = f_exp(m2.la - ms.la);
+    B->c0 = m2.sig * phi_12;
+    B->c1 = r_ratio(r2, r1) * (m2.sig * phi_22);
+    C->cx = f_exp(mt.la - ms.la);
+    C->c0 = mt.sig * phi_1;
+    if (!taylor) {
+      C->c1 = r_div(1., r2) * (mt.sig * phi_2);
+    } else {
+      C->c1 = mt.sig * phi_2;
+      C->c2 = mt.sig * phi_3;
+    }
+  }
+  A->t_out = s1;
+  B->t_out = s2;
+  C->t_out = tt;
+}
+
+int check_enum(int v, int lo, int hi, const char* what) {
+  if (v < lo || v > hi) return dpm_set_error(DPM_ERR_ARG, "%s out of range: %d", what, v);
+  return DPM_OK;
+}
+}  // namespace
+
+extern "C" int dpm_coef_prologue(const dpm_schedule* s, float t_eval, int model_type, int guidance,
+                                 double guidance_scale, dpm_stage* st) {
+  if (!s || !st) return dpm_set_error(DPM_ERR_ARG, "null pointer");
+  if (check_enum(model_type, 0, 3, "model_type") || check_enum(guidance, 0, 2, "guidance")) return DPM_ERR_ARG;
+  set_prologue(s, t_eval, model_type, guidance, guidance_scale, st);
+  return DPM_OK;
+}
+
+extern "C" int dpm_coef_first(const dpm_schedule* s, int algo, float t_s, float t_t, dpm_stage* out) {
+  if (!s || !out) return dpm_set_error(DPM_ERR_ARG, "null pointer");
+  if (check_enum(algo, 0, 1, "algorithm_type")) return DPM_ERR_ARG;
+  stage_init(out);
+  coef_first(s, algo == DPM_ALGO_DPMSOLVERPP, t_s, t_t, out);
+  if (algo == DPM_ALGO_DPMSOLVERPP) out->flags |= DPM_F_TO_X0;
+  set_prologue(s, t_s, DPM_MODEL_NOISE, DPM_GUIDE_NONE, 1., out);
+  return DPM_OK;
+}
+
+extern "C" int dpm_coef_multistep(const dpm_schedule* s, int algo, int solver_type, int order, const float* t_prev,
+                                  float t_t, dpm_stage* out) {
+  if (!s || !out || !t_prev) return dpm_set_error(DPM_ERR_ARG, "null pointer");
+  if (check_enum(algo, 0, 1, "algorithm_type")) return DPM_ERR_ARG;
+  if (order < 1 || order > 3) return dpm_set_error(DPM_ERR_ARG, "Solver order must be 1 or 2 or 3, got %d", order);
+  if (order == 2 && (solver_type < 0 || solver_type > 1))
+    return dpm_set_error(DPM_ERR_ARG, "'solver_type' must be either 'dpmsolver' or 'taylor', got %d", solver_type);
+  const bool pp = algo == DPM_ALGO_DPMSOLVERPP;
+  stage_init(out);
+  if (order == 1)
+    coef_first(s, pp, t_prev[0], t_t, out);
+  else if (order == 2)
+    coef_ms2(s, pp, solver_type, t_prev[0], t_prev[1], t_t, out);
+  else
+    coef_ms3(s, pp, t_prev[0], t_prev[1], t_prev[2], t_t, out);
+  if (pp) out->flags |= DPM_F_TO_X0;
+  set_prologue(s, t_prev[order - 1], DPM_MODEL_NOISE, DPM_GUIDE_NONE, 1., out);
+  return DPM_OK;
+}
+
+extern "C" int dpm_coef_singlestep(const dpm_schedule* s, int algo, int solver_type, int order, float t_s, float t_t,
+                                   double r1, double r2, int r_mode, dpm_stage* out) {
+  if (!s || !out) return dpm_set_error(DPM_ERR_ARG, "null pointer");
+  if (check_enum(algo, 0, 1, "algorithm_type")) return DPM_ERR_ARG;
+  if (order < 1 || order > 3) return dpm_set_error(DPM_ERR_ARG, "Solver order must be 1 or 2 or 3, got %d", order);
+  if (order >= 2 && (solver_type < 0 || solver_type > 1))
+    return dpm_set_error(DPM_ERR_ARG, "'solver_type' must be either 'dpmsolver' or 'taylor', got %d", solver_type);
+  const bool pp = algo == DPM_ALGO_DPMSOLVERPP;
+  for (int i = 0; i < order; ++i) {
+    stage_init(&out[i]);
+    out[i].index = i;
+    if (pp) out[i].flags |= DPM_F_TO_X0;
+  }
+  float te[3] = {t_s, 0.f, 0.f};
+  R R1{r1, r_mode != 0}, R2{r2, r_mode != 0};
+  if (order == 1) {
+    coef_first(s, pp, t_s, t_t, &out[0]);
+  } else if (order == 2) {
+    coef_ss2(s, pp, solver_type, t_s, t_t, R1, &out[0], &out[1], &te[1]);
+  } else {
+    coef_ss3(s, pp, solver_type, t_s, t_t, R1, R2, &out[0], &out[1], &out[2], &te[1], &te[2]);
+  }
+  for (int i = 0; i < order; ++i) {
+    set_prologue(s, te[i], DPM_MODEL_NOISE, DPM_GUIDE_NONE, 1., &out[i]);
+    const bool last = i == order - 1;
+    out[i].emits_state = last;
+    out[i].x_src = DPM_SRC_STATE;
+    out[i].xe_src = i == 0 ? DPM_SRC_STATE : DPM_SRC_TMP;
+    if (i == 0 && order > 1) {
+      out[i].flags |= DPM_F_STORE_M;
+      out[i].m_slot = 0;
+    }
+    if (i >= 1) out[i].h1_slot = 0;
+    if (order == 3 && solver_type == DPM_SOLVER_TAYLOR) {
+      if (i == 1) {
+        out[i].flags |= DPM_F_STORE_M;
+        out[i].m_slot = 1;
+      }
+      if (i == 2) out[i].h2_slot = 1;
+    }
+  }
+  return DPM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// plan
+// ------------------------------------------------------------------------------------------------
+struct dpm_plan {
+  std::vector<dpm_stage> stages;
+  std::vector<float> grid;
+  int slots = 0;
+};
+
+extern "C" int dpm_plan_create(const dpm_schedule* s, const dpm_plan_desc* d, dpm_plan** out) {
+  if (!s || !d || !out) return dpm_set_error(DPM_ERR_ARG, "null pointer");
+  if (check_enum(d->algorithm_type, 0, 1, "algorithm_type") || check_enum(d->model_type, 0, 3, "model_type") ||
+      check_enum(d->guidance, 0, 2, "guidance_type"))
+    return DPM_ERR_ARG;
+  if (d->method < 0 || d->method > 2) return dpm_set_error(DPM_ERR_ARG, "Got wrong method %d", d->method);
+  if (d->skip_type < 0 || d->skip_type > 2)
+    return dpm_set_error(DPM_ERR_ARG, "Unsupported skip_type %d, need to be 'logSNR' or 'time_uniform' or 'time_quadratic'", d->skip_type);
+  if (d->solver_type < 0 || d->solver_type > 1)
+    return dpm_set_error(DPM_ERR_ARG, "'solver_type' must be either 'dpmsolver' or 'taylor', got %d", d->solver_type);
+  if (!(d->t_end > 0) || !(d->t_start > 0))
+    return dpm_set_error(DPM_ERR_ARG, "Time range needs to be greater than 0. For discrete-time DPMs, it needs to be in [1 / N, 1], where N is the length of betas array");
+  if (d->steps < 1) return dpm_set_error(DPM_ERR_ARG, "steps must be >= 1, got %d", d->steps);
+  const bool pp = d->algorithm_type == DPM_ALGO_DPMSOLVERPP;
+  const double t_T = d->t_start, t_0 = d->t_end;
+  dpm_plan* p = new (std::nothrow) dpm_plan;
+  if (!p) return dpm_set_error(DPM_ERR_NOMEM, "out of memory");
+  int rc = DPM_OK;
+  int last_step = 0;
+
+  auto finish_stage = [&](dpm_stage& st, float t_eval) {
+    st.index = (int)p->stages.size();
+    if (pp) st.flags |= DPM_F_TO_X0;
+    if (pp && d->thresholding) st.flags |= DPM_F_THRESH;
+    st.thr_ratio = (float)d->thr_ratio;
+    st.thr_max = (float)d->thr_max;
+    set_prologue(s, t_eval, d->model_type, d->guidance, d->guidance_scale, &st);
+    p->stages.push_back(st);
+  };
+
+  if (d->method == DPM_METHOD_MULTISTEP) {
+    const int S = d->steps, P = d->order;
+    if (P < 1 || P > 3) rc = dpm_set_error(DPM_ERR_ARG, "Solver order must be 1 or 2 or 3, got %d", P);
+    if (!rc && S < P) rc = dpm_set_error(DPM_ERR_ARG, "multistep needs steps >= order (steps=%d, order=%d)", S, P);
+    if (!rc) {
+      p->grid.resize(S + 1);
+      rc = time_steps(s, d->skip_type, t_T, t_0, S, p->grid.data());  // ref :1173
+    }
+    if (!rc) {
+      const float* ts = p->grid.data();
+      std::vector<int> ord(S);
+      for (int i = 0; i < S; ++i) {
+        int step = i + 1;  // the reference's loop variable: this stage produces x at ts[step]
+        if (step < P)
+          ord[i] = step;  // warm-up, ref :1185-1187
+        else
+          ord[i] = (d->lower_order_final && S < 10) ? std::min(P, S + 1 - step) : P;  // ref :1198-1201
+      }
+      for (int i = 0; i < S; ++i) {
+        dpm_stage st;
+        stage_init(&st);
+        if (ord[i] == 1)
+          coef_first(s, pp, ts[i], ts[i + 1], &st);
+        else if (ord[i] == 2)
+          coef_ms2(s, pp, d->solver_type, ts[i - 1], ts[i], ts[i + 1], &st);
+        else
+          coef_ms3(s, pp, ts[i - 2], ts[i - 1], ts[i], ts[i + 1], &st);
+        st.outer_step = i + 1;
+        if (P >= 2) {
+          if (ord[i] >= 2) st.h1_slot = (i - 1) % P;
+          if (ord[i] >= 3) st.h2_slot = (i - 2) % P;
+          bool needed = false;  // does a later stage read this stage's model value?
+          for (int j = i + 1; j < S && j <= i + 2; ++j)
+            if (ord[j] > j - i) needed = true;
+          if (needed) {
+            st.flags |= DPM_F_STORE_M;
+            st.m_slot = i % P;
+          }
+        }
+        finish_stage(st, ts[i]);
+      }
+      p->slots = P >= 2 ? P : 0;
+      last_step = S;
+    }
+  } else {
+    std::vector<float> outer;
+    std::vector<int> orders;
+    if (d->order < 1 || d->order > 3) rc = dpm_set_error(DPM_ERR_ARG, "'order' must be '1' or '2' or '3'.");
+    if (!rc) {
+      if (d->method == DPM_METHOD_SINGLESTEP) {
+        rc = singlestep_grid(s, d->steps, d->order, d->skip_type, t_T, t_0, outer, orders);  // ref :1216
+      } else {
+        int K = d->steps / d->order;  // ref :1218-1220
+        if (K < 1) rc = dpm_set_error(DPM_ERR_ARG, "singlestep_fixed needs steps >= order");
+        if (!rc) {
+          orders.assign(K, d->order);
+          outer.resize(K + 1);
+          rc = time_steps(s, d->skip_type, t_T, t_0, K, outer.data());
+        }
+      }
+    }
+    if (!rc) {
+      p->grid = outer;
+      int slots = 0;
+      for (size_t j = 0; j < orders.size() && !rc; ++j) {
+        const int o = orders[j];
+        const float ts_ = outer[j], tt_ = outer[j + 1];
+        float inner[4], lam[4];
+        rc = time_steps(s, d->skip_type, (double)ts_, (double)tt_, o, inner);  // ref :1223
+        if (rc) break;
+        for (int i = 0; i <= o; ++i) lam[i] = s->lambda(inner[i]);
+        float hh = lam[o] - lam[0];
+        double r1 = o >= 2 ? (double)((lam[1] - lam[0]) / hh) : 0.;  // ref :1226-1227 (fp32 tensors)
+        double r2 = o >= 3 ? (double)((lam[2] - lam[0]) / hh) : 0.;
+        dpm_stage st[3];
+        rc = dpm_coef_singlestep(s, d->algorithm_type, d->solver_type, o, ts_, tt_, r1, r2, 1, st);
+        if (rc) break;
+        for (int i = 0; i < o; ++i) {
+          st[i].outer_step = (int)j;
+          float te = st[i].t_eval;
+          if (st[i].m_slot >= 0) slots = std::max(slots, st[i].m_slot + 1);
+          finish_stage(st[i], te);
+        }
+      }
+      p->slots = slots;
+      last_step = (int)orders.size() - 1;
+    }
+  }
+  if (!rc && d->denoise_to_zero) {  // ref :1235-1241, :541-545
+    dpm_stage st;
+    stage_init(&st);
+    st.form = DPM_FORM_DENOISE;
+    st.outer_step = last_step + 1;
+    st.t_out = (float)t_0;
+    finish_stage(st, (float)t_0);
+    dpm_stage& b = p->stages.back();
+    b.flags |= DPM_F_TO_X0;  // data_prediction_fn also under algorithm_type='dpmsolver'
+    if (d->thresholding) b.flags |= DPM_F_THRESH;
+  }
+  if (rc) {
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return DPM_OK;
+}
+
+extern "C" void dpm_plan_destroy(dpm_plan* p) { delete p; }
+extern "C" int dpm_plan_num_stages(const dpm_plan* p) { return p ? (int)p->stages.size() : 0; }
+extern "C" int dpm_plan_num_slots(const dpm_plan* p) { return p ? p->slots : 0; }
+
+extern "C" int dpm_plan_stage(const dpm_plan* p, int i, dpm_stage* out) {
+  if (!p || !out || i < 0 || i >= (int)p->stages.size()) return dpm_set_error(DPM_ERR_ARG, "plan_stage: bad index %d", i);
+  *out = p->stages[i];
+  return DPM_OK;
+}
+
+extern "C" int dpm_plan_timesteps(const dpm_plan* p, float* out, int cap, int* n) {
+  if (!p) return dpm_set_error(DPM_ERR_ARG, "null plan");
+  if (n) *n = (int)p->grid.size();
+  if (out) {
+    if (cap < (int)p->grid.size()) return dpm_set_error(DPM_ERR_ARG, "timesteps: capacity %d < %zu", cap, p->grid.size());
+    std::copy(p->grid.begin(), p->grid.end(), out);
+  }
+  return DPM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// native sample loop (buffer choreography shared with the Python shim)
+// ------------------------------------------------------------------------------------------------
+// launch hooks implemented in dpm_kernels.hip
+int dpm_stage_launch_ev(const dpm_stage* st, const dpm_buffers* b, void* stream, void* ev_start, void* ev_stop);
+int dpm_timing_begin(int n, void*** starts, void*** stops);
+int dpm_timing_end(int n, void** starts, void** stops, void* stream, float* ms);
+
+static int plan_run_impl(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model_cb model, void* user, void* stream,
+                         int* result, void** ev_start, void** ev_stop) {
+  if (!p || !rb) return dpm_set_error(DPM_ERR_ARG, "null pointer");
+  for (int i = 0; i < 4; ++i)
+    if (!rb->xbuf[i]) return dpm_set_error(DPM_ERR_ARG, "plan_run: xbuf[%d] is null", i);
+  for (int i = 0; i < p->slots; ++i)
+    if (!rb->hist[i]) return dpm_set_error(DPM_ERR_ARG, "plan_run: hist[%d] is null (plan needs %d slots)", i, p->slots);
+  int state = 0, tmp = -1;
+  for (const dpm_stage& st : p->stages) {
+    const int xe = st.xe_src == DPM_SRC_TMP ? tmp : state;
+    if (xe < 0) return dpm_set_error(DPM_ERR_ARG, "plan_run: stage %d reads TMP before it exists", st.index);
+    int out = 1;  // xbuf[0] (the caller's x_T) is never written
+    while (out == state || out == xe) ++out;
+    if (model) {
+      int rc = model(user, &st, rb->xbuf[xe], rb->e0, rb->e1, stream);
+      if (rc) return dpm_set_error(DPM_ERR_CALLBACK, "model callback failed at stage %d (rc=%d)", st.index, rc);
+    }
+    dpm_buffers b;
+    std::memset(&b, 0, sizeof b);
+    b.x = rb->xbuf[state];
+    b.xe = xe == state ? nullptr : rb->xbuf[xe];
+    b.e0 = rb->e0;
+    b.e1 = rb->e1;
+    b.h1 = st.h1_slot >= 0 ? rb->hist[st.h1_slot] : nullptr;
+    b.h2 = st.h2_slot >= 0 ? rb->hist[st.h2_slot] : nullptr;
+    b.x_out = rb->xbuf[out];
+    b.m_out = st.m_slot >= 0 ? rb->hist[st.m_slot] : nullptr;
+    b.workspace = rb->workspace;
+    b.n = rb->n;
+    b.batch = rb->batch;
+    b.state_dtype = rb->state_dtype;
+    b.eps_dtype = rb->eps_dtype;
+    int rc = dpm_stage_launch_ev(&st, &b, stream, ev_start ? ev_start[st.index] : nullptr,
+                                 ev_stop ? ev_stop[st.index] : nullptr);
+    if (rc) return rc;
+    if (st.emits_state) {
+      state = out;
+      tmp = -1;
+    } else {
+      tmp = out;
+    }
+  }
+  if (result) *result = state;
+  return DPM_OK;
+}
+
+extern "C" int dpm_plan_run(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model_cb model, void* user, void* stream,
+                            int* result) {
+  return plan_run_impl(p, rb, model, user, stream, result, nullptr, nullptr);
+}
+
+extern "C" int dpm_plan_run_timed(const dpm_plan* p, const dpm_run_buffers* rb, void* stream, float* ms_per_stage,
+                                  int* result) {
+  if (!p || !ms_per_stage) return dpm_set_error(DPM_ERR_ARG, "null pointer");
+  const int n = (int)p->stages.size();
+  void **starts = nullptr, **stops = nullptr;
+  int rc = dpm_timing_begin(n, &starts, &stops);
+  if (rc) return rc;
+  rc = plan_run_impl(p, rb, nullptr, nullptr, stream, result, starts, stops);
+  int rc2 = dpm_timing_end(n, starts, stops, stream, rc ? nullptr : ms_per_stage);
+  return rc ? rc : rc2;
+}

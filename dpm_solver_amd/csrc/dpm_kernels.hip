@@ -1,0 +1,699 @@
+// dpm_kernels.hip -- gfx950 (MI355X, CDNA4) device code of the DPM-Solver engine.
+//
+// One fused, HBM-streaming kernel per solver stage:
+//
+//   raw network output(s) --CFG blend / classifier term--> --x_start|v|score -> eps--> --eps -> x0-->
+//   --dynamic thresholding--> mn   ;   x_out = exponential-integrator combination of x, mn, h1, h2
+//
+// Memory-bound (~0.5 flop/B): no MFMA.  What matters is (i) 16-byte coalesced accesses -- each lane moves
+// 8 consecutive elements per tensor per iteration, a wavefront 512 contiguous elements, (ii) all loads of
+// an iteration issued before the first use, (iii) >= 2048 workgroups of 256 threads so every CU holds 8
+// waves per SIMD, (iv) the per-stage scalars arrive as kernel arguments, i.e. in SGPRs via the scalar
+// cache, so the vector pipeline only ever sees the five streams.  The arithmetic keeps the reference's
+// association and is compiled with -ffp-contract=off: given equal coefficients the result is bit-identical
+// to the reference's chain of ATen kernels (no fused multiply-adds there either).
+//
+// `ref :NNN` = line in the reference's dpm_solver_pytorch.py.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_ext.h>
+
+#include <cstdint>
+#include <cstring>
+#include <new>
+
+#include "dpm_hip.h"
+
+int dpm_set_error(int code, const char* fmt, ...);  // dpm_host.cpp
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// element types
+// ------------------------------------------------------------------------------------------------
+struct bf16_t {
+  uint16_t v;
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(__half v) { return __half2float(v); }
+__device__ __forceinline__ float to_f32(bf16_t v) { return __uint_as_float((uint32_t)v.v << 16); }
+
+template <typename T>
+__device__ __forceinline__ T from_f32(float v);
+template <>
+__device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ __half from_f32<__half>(float v) { return __float2half_rn(v); }
+template <>
+__device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) {
+  uint32_t u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return bf16_t{(uint16_t)((u >> 16) | 0x40)};  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                                   // round to nearest even
+  return bf16_t{(uint16_t)(u >> 16)};
+}
+
+constexpr int EPT = 8;  // elements per lane per iteration: 2 x 16 B (fp32) or 1 x 16 B (fp16/bf16)
+
+template <typename T>
+struct alignas(sizeof(T) * EPT) Pack {
+  T v[EPT];
+};
+
+template <typename T>
+__device__ __forceinline__ void load_pack(const T* __restrict__ p, int64_t group, float (&out)[EPT]) {
+  const Pack<T> r = reinterpret_cast<const Pack<T>*>(p)[group];  // lowers to global_load_dwordx4 (x2 for fp32)
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) out[j] = to_f32(r.v[j]);
+}
+
+template <typename T>
+__device__ __forceinline__ void store_pack(T* __restrict__ p, int64_t group, const float (&in)[EPT]) {
+  Pack<T> r;
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) r.v[j] = from_f32<T>(in[j]);
+  reinterpret_cast<Pack<T>*>(p)[group] = r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-stage scalars (kernel argument => SGPRs)
+// ------------------------------------------------------------------------------------------------
+struct KParams {
+  float alpha_e, sigma_e, cfg_scale, cg_scale;
+  float cx, c0, c1, c2;
+  float k0, k1, k2, k3, k4;
+  uint32_t flags;
+  int32_t model_type;
+};
+
+// raw network output -> noise prediction (noise_pred_fn, ref :288-298)
+__device__ __forceinline__ float to_noise(float o, float xe, const KParams& p) {
+  switch (p.model_type) {
+    case DPM_MODEL_X_START: return (xe - p.alpha_e * o) / p.sigma_e;
+    case DPM_MODEL_V: return p.alpha_e * o + p.sigma_e * xe;
+    case DPM_MODEL_SCORE: return (-p.sigma_e) * o;
+    default: return o;
+  }
+}
+
+// everything up to (not including) thresholding: returns eps, or x0 when DPM_F_TO_X0
+template <int GUIDE>
+__device__ __forceinline__ float prologue(float xe, float o0, float o1, float gg, const KParams& p) {
+  float eps;
+  if (GUIDE == DPM_GUIDE_CFG) {  // ref :326-330: uncond + scale * (cond - uncond)
+    float nu = to_noise(o1, xe, p), nc = to_noise(o0, xe, p);
+    eps = nu + p.cfg_scale * (nc - nu);
+  } else if (GUIDE == DPM_GUIDE_CLASSIFIER) {  // ref :321
+    eps = to_noise(o0, xe, p) - p.cg_scale * gg;
+  } else {
+    eps = to_noise(o0, xe, p);
+  }
+  if (p.flags & DPM_F_TO_X0) return (xe - p.sigma_e * eps) / p.alpha_e;  // ref :439
+  return eps;
+}
+
+// the exponential-integrator combination, reference association
+template <int FORM>
+__device__ __forceinline__ float combine(float x, float mn, float h1, float h2, const KParams& p) {
+  if (FORM == DPM_FORM_LIN1) {
+    return p.cx * x - p.c0 * mn;  // ref :573-576, :585-588
+  } else if (FORM == DPM_FORM_TWO) {
+    float D = p.k0 * (mn - h1);
+    float P = (p.flags & DPM_F_BASE_HIST) ? h1 : mn;
+    return (p.cx * x - p.c0 * P) - p.c1 * D;  // ref :827-851 (multistep), :636-669, :728-778 (singlestep)
+  } else if (FORM == DPM_FORM_MS3) {
+    float D1_0 = p.k0 * (mn - h1);  // ref :880-883
+    float D1_1 = p.k1 * (h1 - h2);
+    float dd = D1_0 - D1_1;
+    float D1 = D1_0 + p.k2 * dd;
+    float D2 = p.k3 * dd;
+    return ((p.cx * x - p.c0 * mn) - p.c1 * D1) - p.c2 * D2;  // ref :888-903
+  } else if (FORM == DPM_FORM_SS3T) {
+    float D1_0 = p.k0 * (h2 - h1);  // h1 = model_s, h2 = model_s1, mn = model_s2; ref :741-750, :780-789
+    float D1_1 = p.k1 * (mn - h1);
+    float D1 = (p.k2 * D1_0 - p.k3 * D1_1) / p.k4;
+    float D2 = (2.f * (D1_1 - D1_0)) / p.k4;
+    return ((p.cx * x - p.c0 * h1) - p.c1 * D1) - p.c2 * D2;
+  } else {
+    return mn;  // DPM_FORM_DENOISE, ref :541-545
+  }
+}
+
+template <int FORM>
+struct FormTraits {
+  static constexpr bool needs_x = FORM != DPM_FORM_DENOISE;
+  static constexpr bool needs_h1 = FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3 || FORM == DPM_FORM_SS3T;
+  static constexpr bool needs_h2 = FORM == DPM_FORM_MS3 || FORM == DPM_FORM_SS3T;
+};
+
+// ------------------------------------------------------------------------------------------------
+// the streaming stage kernel
+// ------------------------------------------------------------------------------------------------
+template <typename TS, typename TE, int FORM, int GUIDE, bool XE>
+__global__ __launch_bounds__(256) void stage_kernel(const TS* __restrict__ x, const TS* __restrict__ xe,
+                                                    const TE* __restrict__ e0, const TE* __restrict__ e1,
+                                                    const TE* __restrict__ g, const TS* __restrict__ h1,
+                                                    const TS* __restrict__ h2, TS* __restrict__ xo,
+                                                    TS* __restrict__ mo, int64_t n, KParams p) {
+  using FT = FormTraits<FORM>;
+  const bool need_xe = (p.flags & DPM_F_TO_X0) || p.model_type == DPM_MODEL_X_START || p.model_type == DPM_MODEL_V;
+  const bool store_m = p.flags & DPM_F_STORE_M;
+  const int64_t ngroups = n / EPT;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += stride) {
+    float vx[EPT], vxe[EPT], v0[EPT], v1[EPT], vg[EPT], vh1[EPT], vh2[EPT];
+    // issue every load of the iteration before the first use
+    if (FT::needs_x || (!XE && need_xe)) load_pack(x, gi, vx);
+    if (XE && need_xe) load_pack(xe, gi, vxe);
+    load_pack(e0, gi, v0);
+    if (GUIDE == DPM_GUIDE_CFG) load_pack(e1, gi, v1);
+    if (GUIDE == DPM_GUIDE_CLASSIFIER) load_pack(g, gi, vg);
+    if (FT::needs_h1) load_pack(h1, gi, vh1);
+    if (FT::needs_h2) load_pack(h2, gi, vh2);
+    float ox[EPT], om[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      const float xej = XE ? vxe[j] : vx[j];
+      const float mn = prologue<GUIDE>(xej, v0[j], GUIDE == DPM_GUIDE_CFG ? v1[j] : 0.f,
+                                       GUIDE == DPM_GUIDE_CLASSIFIER ? vg[j] : 0.f, p);
+      om[j] = mn;
+      ox[j] = combine<FORM>(FT::needs_x ? vx[j] : 0.f, mn, FT::needs_h1 ? vh1[j] : 0.f, FT::needs_h2 ? vh2[j] : 0.f, p);
+    }
+    store_pack(xo, gi, ox);
+    if (store_m) store_pack(mo, gi, om);
+  }
+  // ragged tail (n % 8 elements): first lanes of block 0, scalar
+  const int64_t tail0 = ngroups * EPT;
+  if (blockIdx.x == 0 && tail0 + threadIdx.x < n) {
+    const int64_t i = tail0 + threadIdx.x;
+    const float xv = (FT::needs_x || (!XE && need_xe)) ? to_f32(x[i]) : 0.f;
+    const float xev = XE ? (need_xe ? to_f32(xe[i]) : 0.f) : xv;
+    const float mn = prologue<GUIDE>(xev, to_f32(e0[i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[i]) : 0.f,
+                                     GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[i]) : 0.f, p);
+    xo[i] = from_f32<TS>(combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[i]) : 0.f, FT::needs_h2 ? to_f32(h2[i]) : 0.f, p));
+    if (store_m) mo[i] = from_f32<TS>(mn);
+  }
+}
+
+// same arithmetic, one element per lane: used when a pointer is not 16/32-byte aligned (views with offsets)
+template <typename TS, typename TE, int FORM, int GUIDE, bool XE>
+__global__ __launch_bounds__(256) void stage_kernel_scalar(const TS* __restrict__ x, const TS* __restrict__ xe,
+                                                           const TE* __restrict__ e0, const TE* __restrict__ e1,
+                                                           const TE* __restrict__ g, const TS* __restrict__ h1,
+                                                           const TS* __restrict__ h2, TS* __restrict__ xo,
+                                                           TS* __restrict__ mo, int64_t n, KParams p) {
+  using FT = FormTraits<FORM>;
+  const bool need_xe = (p.flags & DPM_F_TO_X0) || p.model_type == DPM_MODEL_X_START || p.model_type == DPM_MODEL_V;
+  const bool store_m = p.flags & DPM_F_STORE_M;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float xv = (FT::needs_x || (!XE && need_xe)) ? to_f32(x[i]) : 0.f;
+    const float xev = XE ? (need_xe ? to_f32(xe[i]) : 0.f) : xv;
+    const float mn = prologue<GUIDE>(xev, to_f32(e0[i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[i]) : 0.f,
+                                     GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[i]) : 0.f, p);
+    xo[i] = from_f32<TS>(combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[i]) : 0.f, FT::needs_h2 ? to_f32(h2[i]) : 0.f, p));
+    if (store_m) mo[i] = from_f32<TS>(mn);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dynamic thresholding (ref :416-425): one workgroup per sample, x0 resident in LDS.
+//
+//   s = quantile(|x0|, ratio) over the sample  -> exact order statistics by an 8/8/8/7-bit radix select on
+//       the bit pattern of |x0| (non-negative floats order like their bit patterns), histogram in LDS,
+//       bin search by wavefront prefix sums; the fractional rank is the reference's fp32 `ratio*(n-1)`.
+//   s = max(s, max_val);  x0 <- clamp(x0, -s, s) / s;  then the same combine as the streaming kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int THR_THREADS = 1024;
+
+struct ThrParams {
+  int64_t per_sample;
+  int32_t lo, hi;  // floor / ceil of the fp32 rank (ascending order)
+  float w;         // fractional part
+  float max_val;
+};
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+template <typename TS, typename TE, int FORM, int GUIDE, bool XE>
+__global__ __launch_bounds__(THR_THREADS) void stage_thresh_kernel(
+    const TS* __restrict__ x, const TS* __restrict__ xe, const TE* __restrict__ e0, const TE* __restrict__ e1,
+    const TE* __restrict__ g, const TS* __restrict__ h1, const TS* __restrict__ h2, TS* __restrict__ xo,
+    TS* __restrict__ mo, KParams p, ThrParams tp) {
+  using FT = FormTraits<FORM>;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  float* sx0 = reinterpret_cast<float*>(lds_raw);                 // [per_sample]
+  uint32_t* hist = reinterpret_cast<uint32_t*>(sx0 + tp.per_sample);  // [256]
+  uint32_t* misc = hist + 256;                                    // [4]: prefix, k, count, min-above
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int64_t base = (int64_t)blockIdx.x * tp.per_sample;
+  const int n = (int)tp.per_sample;
+  const bool store_m = p.flags & DPM_F_STORE_M;
+
+  // phase 1: x0 for the whole sample -> LDS
+  for (int i = tid; i < n; i += THR_THREADS) {
+    const int64_t gi = base + i;
+    const float xev = to_f32(XE ? xe[gi] : x[gi]);
+    sx0[i] = prologue<GUIDE>(xev, to_f32(e0[gi]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[gi]) : 0.f,
+                             GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[gi]) : 0.f, p);
+  }
+  if (tid == 0) {
+    misc[0] = 0u;               // prefix bits decided so far
+    misc[1] = (uint32_t)tp.lo;  // rank still to resolve inside the prefix group
+  }
+  __syncthreads();
+
+  // phase 2: radix select of the lo-th smallest |x0|
+  uint32_t known_mask = 0u;
+#pragma unroll 1
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = pass == 0 ? 23 : pass == 1 ? 15 : pass == 2 ? 7 : 0;
+    const uint32_t dmask = pass == 3 ? 0x7fu : 0xffu;
+    if (tid < 256) hist[tid] = 0u;
+    __syncthreads();
+    const uint32_t prefix = misc[0];
+    for (int i = tid; i < n; i += THR_THREADS) {
+      const uint32_t u = __float_as_uint(sx0[i]) & 0x7fffffffu;
+      if ((u & known_mask) == prefix) atomicAdd(&hist[(u >> shift) & dmask], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {  // wavefront 0: locate the bin holding rank k
+      const uint32_t k = misc[1];
+      uint32_t c[4], tot = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        c[j] = hist[lane * 4 + j];
+        tot += c[j];
+      }
+      const uint32_t incl = wave_incl_scan(tot, lane);
+      const uint64_t ball = __ballot(incl > k);
+      const int owner = __ffsll((long long)ball) - 1;
+      if (lane == owner) {
+        uint32_t before = incl - tot;
+        int j = 0;
+        while (j < 3 && before + c[j] <= k) {
+          before += c[j];
+          ++j;
+        }
+        misc[0] = prefix | ((uint32_t)(lane * 4 + j) << shift);
+        misc[1] = k - before;
+        misc[2] = c[j];
+      }
+    }
+    known_mask |= dmask << shift;
+    __syncthreads();
+  }
+  const uint32_t a_bits = misc[0];
+  float a = __uint_as_float(a_bits), b = a;
+  if (tp.hi != tp.lo && misc[1] + 1u >= misc[2]) {
+    // the next order statistic is the smallest value above a: wavefront min, then one LDS atomic per wave
+    __syncthreads();
+    if (tid == 0) misc[3] = 0x7fffffffu;
+    __syncthreads();
+    uint32_t m = 0x7fffffffu;
+    for (int i = tid; i < n; i += THR_THREADS) {
+      const uint32_t u = __float_as_uint(sx0[i]) & 0x7fffffffu;
+      if (u > a_bits && u < m) m = u;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint32_t o = __shfl_xor(m, d, 64);
+      m = o < m ? o : m;
+    }
+    if (lane == 0) atomicMin(&misc[3], m);
+    __syncthreads();
+    b = __uint_as_float(misc[3]);
+  }
+  // torch.quantile 'linear' = ATen lerp(a, b, w)
+  const float diff = b - a;
+  const float q = tp.w < 0.5f ? a + tp.w * diff : b - diff * (1.f - tp.w);
+  const float s = fmaxf(q, tp.max_val);  // ref :423
+
+  // phase 3: clamp, scale, combine, store
+  for (int i = tid; i < n; i += THR_THREADS) {
+    const int64_t gi = base + i;
+    const float x0 = sx0[i];
+    const float mn = fminf(fmaxf(x0, -s), s) / s;  // ref :424
+    const float xv = FT::needs_x ? to_f32(x[gi]) : 0.f;
+    xo[gi] = from_f32<TS>(combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[gi]) : 0.f,
+                                        FT::needs_h2 ? to_f32(h2[gi]) : 0.f, p));
+    if (store_m) mo[gi] = from_f32<TS>(mn);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// add_noise (ref :1012-1030):  out = alpha*x + sigma*noise
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void add_noise_kernel(const T* __restrict__ x, const T* __restrict__ nz,
+                                                        T* __restrict__ out, int64_t n, float alpha, float sigma) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = from_f32<T>(alpha * to_f32(x[i]) + sigma * to_f32(nz[i]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// adaptive solver error norm (ref :999-1001): one workgroup per sample
+//   delta = max(atol, rtol*max(|x_lower|, |x_prev|));  E_b = sqrt(mean(((x_higher - x_lower)/delta)^2))
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void adaptive_error_kernel(const T* __restrict__ xl, const T* __restrict__ xh,
+                                                              const T* __restrict__ xp, float atol, float rtol,
+                                                              float* __restrict__ e_out, int64_t per_sample) {
+  __shared__ double part[16];
+  const int64_t base = (int64_t)blockIdx.x * per_sample;
+  double acc = 0.;
+  for (int64_t i = threadIdx.x; i < per_sample; i += blockDim.x) {
+    const float l = to_f32(xl[base + i]), h = to_f32(xh[base + i]), pv = to_f32(xp[base + i]);
+    const float delta = fmaxf(atol, rtol * fmaxf(fabsf(l), fabsf(pv)));
+    const float v = (h - l) / delta;
+    acc += (double)(v * v);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
+    e_out[blockIdx.x] = sqrtf((float)(t / (double)per_sample));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch plumbing
+// ------------------------------------------------------------------------------------------------
+struct DeviceInfo {
+  int n_cu = 0;
+  int lds = 0;
+  char arch[64] = {0};
+  bool ok = false;
+};
+
+const DeviceInfo& device_info() {
+  static thread_local int cached_dev = -1;
+  static thread_local DeviceInfo info;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return info;
+  if (dev != cached_dev || !info.ok) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+      info.n_cu = prop.multiProcessorCount;
+      info.lds = (int)prop.maxSharedMemoryPerMultiProcessor;
+      std::strncpy(info.arch, prop.gcnArchName, sizeof(info.arch) - 1);
+      info.ok = true;
+      cached_dev = dev;
+    }
+  }
+  return info;
+}
+
+inline bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+KParams make_params(const dpm_stage* st) {
+  KParams p;
+  p.alpha_e = st->alpha_e;
+  p.sigma_e = st->sigma_e;
+  p.cfg_scale = st->cfg_scale;
+  p.cg_scale = st->cg_scale;
+  p.cx = st->cx;
+  p.c0 = st->c0;
+  p.c1 = st->c1;
+  p.c2 = st->c2;
+  p.k0 = st->k[0];
+  p.k1 = st->k[1];
+  p.k2 = st->k[2];
+  p.k3 = st->k[3];
+  p.k4 = st->k[4];
+  p.flags = st->flags;
+  p.model_type = st->model_type;
+  return p;
+}
+
+constexpr int64_t THR_LDS_EXTRA = (256 + 8) * 4;
+
+struct LaunchCtx {
+  hipStream_t stream;
+  hipEvent_t start, stop;  // both null: plain launch; else hipExtLaunchKernelGGL brackets the kernel itself
+};
+
+template <typename K, typename... Args>
+void launch(K kern, dim3 grid, dim3 block, size_t lds, const LaunchCtx& c, Args... args) {
+  if (c.start || c.stop)
+    hipExtLaunchKernelGGL(kern, grid, block, lds, c.stream, c.start, c.stop, 0, args...);
+  else
+    hipLaunchKernelGGL(kern, grid, block, lds, c.stream, args...);
+}
+
+template <typename TS, typename TE, int FORM, int GUIDE, bool XE>
+int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& stream) {
+  const KParams p = make_params(st);
+  const TS* x = static_cast<const TS*>(b->x);
+  const TS* xe = static_cast<const TS*>(b->xe);
+  const TE* e0 = static_cast<const TE*>(b->e0);
+  const TE* e1 = static_cast<const TE*>(b->e1);
+  const TE* g = static_cast<const TE*>(b->g);
+  const TS* h1 = static_cast<const TS*>(b->h1);
+  const TS* h2 = static_cast<const TS*>(b->h2);
+  TS* xo = static_cast<TS*>(b->x_out);
+  TS* mo = static_cast<TS*>(b->m_out);
+  const DeviceInfo& di = device_info();
+  const int n_cu = di.n_cu > 0 ? di.n_cu : 256;
+
+  if (st->flags & DPM_F_THRESH) {
+    const int64_t per_sample = b->n / b->batch;
+    const int64_t lds_bytes = per_sample * 4 + THR_LDS_EXTRA;
+    const int64_t lds_cap = di.lds > 0 ? di.lds : 160 * 1024;
+    if (lds_bytes > lds_cap)
+      return dpm_set_error(DPM_ERR_UNSUPPORTED,
+                           "dynamic thresholding: sample of %lld elements exceeds the LDS-resident path (max %lld)",
+                           (long long)per_sample, (long long)((lds_cap - THR_LDS_EXTRA) / 4));
+    ThrParams tp;
+    tp.per_sample = per_sample;
+    // torch.quantile: rank = q * (n - 1) evaluated in fp32 (q is an fp32 tensor)
+    const float rank = st->thr_ratio * (float)(per_sample - 1);
+    tp.lo = (int32_t)floorf(rank);
+    tp.hi = (int32_t)ceilf(rank);
+    tp.w = rank - (float)tp.lo;
+    tp.max_val = st->thr_max;
+    auto kern = stage_thresh_kernel<TS, TE, FORM, GUIDE, XE>;
+    if (lds_bytes > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds_bytes);
+      if (e != hipSuccess) return dpm_set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    launch(kern, dim3((unsigned)b->batch), dim3(THR_THREADS), (size_t)lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo, p,
+           tp);
+  } else {
+    const size_t as = sizeof(TS) * EPT, ae = sizeof(TE) * EPT;
+    const bool vec = aligned(x, as) && aligned(xe, as) && aligned(h1, as) && aligned(h2, as) && aligned(xo, as) &&
+                     aligned(mo, as) && aligned(e0, ae) && aligned(e1, ae) && aligned(g, ae);
+    // enough workgroups to give every CU 8 waves/SIMD in one residency wave; grid-stride beyond that
+    const int64_t work = vec ? (b->n + EPT - 1) / EPT : b->n;
+    int64_t blocks = (work + 255) / 256;
+    const int64_t cap = (int64_t)n_cu * 16;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    if (vec)
+      launch(stage_kernel<TS, TE, FORM, GUIDE, XE>, dim3((unsigned)blocks), dim3(256), 0, stream, x, xe, e0, e1, g, h1, h2,
+             xo, mo, b->n, p);
+    else
+      launch(stage_kernel_scalar<TS, TE, FORM, GUIDE, XE>, dim3((unsigned)blocks), dim3(256), 0, stream, x, xe, e0, e1, g,
+             h1, h2, xo, mo, b->n, p);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return dpm_set_error((int)e, "stage kernel launch failed: %s", hipGetErrorString(e));
+  return DPM_OK;
+}
+
+template <typename TS, typename TE, int FORM, int GUIDE>
+int launch_xe(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& s) {
+  return (b->xe != nullptr && b->xe != b->x) ? launch_typed<TS, TE, FORM, GUIDE, true>(st, b, s)
+                                            : launch_typed<TS, TE, FORM, GUIDE, false>(st, b, s);
+}
+
+template <typename TS, typename TE, int FORM>
+int launch_guide(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& s) {
+  switch (st->guidance) {
+    case DPM_GUIDE_NONE: return launch_xe<TS, TE, FORM, DPM_GUIDE_NONE>(st, b, s);
+    case DPM_GUIDE_CFG: return launch_xe<TS, TE, FORM, DPM_GUIDE_CFG>(st, b, s);
+    case DPM_GUIDE_CLASSIFIER: return launch_xe<TS, TE, FORM, DPM_GUIDE_CLASSIFIER>(st, b, s);
+  }
+  return dpm_set_error(DPM_ERR_ARG, "unknown guidance %d", st->guidance);
+}
+
+template <typename TS, typename TE>
+int launch_form(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& s) {
+  switch (st->form) {
+    case DPM_FORM_LIN1: return launch_guide<TS, TE, DPM_FORM_LIN1>(st, b, s);
+    case DPM_FORM_TWO: return launch_guide<TS, TE, DPM_FORM_TWO>(st, b, s);
+    case DPM_FORM_MS3: return launch_guide<TS, TE, DPM_FORM_MS3>(st, b, s);
+    case DPM_FORM_SS3T: return launch_guide<TS, TE, DPM_FORM_SS3T>(st, b, s);
+    case DPM_FORM_DENOISE: return launch_guide<TS, TE, DPM_FORM_DENOISE>(st, b, s);
+  }
+  return dpm_set_error(DPM_ERR_ARG, "unknown update form %d", st->form);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+int dpm_stage_launch_ev(const dpm_stage* st, const dpm_buffers* b, void* stream, void* ev_start, void* ev_stop) {
+  if (!st || !b) return dpm_set_error(DPM_ERR_ARG, "stage_launch: null pointer");
+  if (b->n < 0 || b->batch < 1 || (b->n % b->batch) != 0)
+    return dpm_set_error(DPM_ERR_ARG, "stage_launch: n=%lld is not a multiple of batch=%lld", (long long)b->n, (long long)b->batch);
+  if (b->n == 0) return DPM_OK;  // empty batch: nothing to do (torch allows zero-sized tensors)
+  const bool needs_x = st->form != DPM_FORM_DENOISE;
+  const bool needs_h1 = st->form == DPM_FORM_TWO || st->form == DPM_FORM_MS3 || st->form == DPM_FORM_SS3T;
+  const bool needs_h2 = st->form == DPM_FORM_MS3 || st->form == DPM_FORM_SS3T;
+  const bool need_xe = (st->flags & DPM_F_TO_X0) || st->model_type == DPM_MODEL_X_START || st->model_type == DPM_MODEL_V;
+  if (!b->e0 || !b->x_out) return dpm_set_error(DPM_ERR_ARG, "stage_launch: e0 / x_out must not be null");
+  if ((needs_x || need_xe) && !b->x && !b->xe) return dpm_set_error(DPM_ERR_ARG, "stage_launch: x is null");
+  if (needs_x && !b->x) return dpm_set_error(DPM_ERR_ARG, "stage_launch: x is null");
+  if (needs_h1 && !b->h1) return dpm_set_error(DPM_ERR_ARG, "stage_launch: form %d needs h1", st->form);
+  if (needs_h2 && !b->h2) return dpm_set_error(DPM_ERR_ARG, "stage_launch: form %d needs h2", st->form);
+  if ((st->flags & DPM_F_STORE_M) && !b->m_out) return dpm_set_error(DPM_ERR_ARG, "stage_launch: STORE_M without m_out");
+  if (st->guidance == DPM_GUIDE_CFG && !b->e1) return dpm_set_error(DPM_ERR_ARG, "stage_launch: CFG needs e1");
+  if (st->guidance == DPM_GUIDE_CLASSIFIER && !b->g) return dpm_set_error(DPM_ERR_ARG, "stage_launch: classifier guidance needs g");
+  dpm_buffers bb = *b;
+  if (!bb.x) bb.x = bb.xe;  // DENOISE form: only the evaluation state exists
+  const LaunchCtx s{static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop)};
+  const int sd = bb.state_dtype, ed = bb.eps_dtype;
+  if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_F32) return launch_form<float, float>(st, &bb, s);
+  if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_F16) return launch_form<float, __half>(st, &bb, s);
+  if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_BF16) return launch_form<float, bf16_t>(st, &bb, s);
+  if (sd == DPM_DTYPE_F16 && ed == DPM_DTYPE_F16) return launch_form<__half, __half>(st, &bb, s);
+  if (sd == DPM_DTYPE_BF16 && ed == DPM_DTYPE_BF16) return launch_form<bf16_t, bf16_t>(st, &bb, s);
+  return dpm_set_error(DPM_ERR_UNSUPPORTED, "stage_launch: unsupported dtype pair state=%d eps=%d", sd, ed);
+}
+
+extern "C" int dpm_stage_launch(const dpm_stage* st, const dpm_buffers* b, void* stream) {
+  return dpm_stage_launch_ev(st, b, stream, nullptr, nullptr);
+}
+
+int dpm_timing_begin(int n, void*** starts, void*** stops) {
+  void** a = new (std::nothrow) void*[2 * (size_t)n]();
+  if (!a) return dpm_set_error(DPM_ERR_NOMEM, "out of memory");
+  for (int i = 0; i < 2 * n; ++i) {
+    hipEvent_t e;
+    hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) {
+      for (int j = 0; j < i; ++j) hipEventDestroy(static_cast<hipEvent_t>(a[j]));
+      delete[] a;
+      return dpm_set_error((int)rc, "hipEventCreate: %s", hipGetErrorString(rc));
+    }
+    a[i] = e;
+  }
+  *starts = a;
+  *stops = a + n;
+  return DPM_OK;
+}
+
+int dpm_timing_end(int n, void** starts, void** stops, void* stream, float* ms) {
+  int ret = DPM_OK;
+  hipError_t rc = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+  if (rc != hipSuccess) ret = dpm_set_error((int)rc, "hipStreamSynchronize: %s", hipGetErrorString(rc));
+  for (int i = 0; i < n; ++i) {
+    if (ms && ret == DPM_OK) {
+      rc = hipEventElapsedTime(&ms[i], static_cast<hipEvent_t>(starts[i]), static_cast<hipEvent_t>(stops[i]));
+      if (rc != hipSuccess) ret = dpm_set_error((int)rc, "hipEventElapsedTime(stage %d): %s", i, hipGetErrorString(rc));
+    }
+  }
+  for (int i = 0; i < 2 * n; ++i) hipEventDestroy(static_cast<hipEvent_t>(starts[i]));
+  delete[] starts;
+  return ret;
+}
+
+extern "C" int dpm_stage_launch_timed(const dpm_stage* st, const dpm_buffers* b, void* stream, float* ms) {
+  if (!ms) return dpm_set_error(DPM_ERR_ARG, "null pointer");
+  void **starts = nullptr, **stops = nullptr;
+  int rc = dpm_timing_begin(1, &starts, &stops);
+  if (rc) return rc;
+  rc = dpm_stage_launch_ev(st, b, stream, starts[0], stops[0]);
+  int rc2 = dpm_timing_end(1, starts, stops, stream, rc ? nullptr : ms);
+  return rc ? rc : rc2;
+}
+
+extern "C" size_t dpm_threshold_workspace_bytes(int64_t batch, int64_t per_sample) {
+  (void)batch;
+  (void)per_sample;
+  return 0;  // the LDS-resident path needs no global scratch
+}
+
+extern "C" int dpm_add_noise_launch(const dpm_schedule* s, const float* t_host, int nt, const void* x, const void* noise,
+                                    void* out, int64_t n, int dtype, void* stream) {
+  if (!s || !t_host || !x || !noise || !out || nt < 1 || n < 0) return dpm_set_error(DPM_ERR_ARG, "add_noise: bad arguments");
+  if (n == 0) return DPM_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const DeviceInfo& di = device_info();
+  int64_t blocks = (n + 255) / 256;
+  const int64_t cap = (int64_t)(di.n_cu > 0 ? di.n_cu : 256) * 16;
+  if (blocks > cap) blocks = cap;
+  for (int j = 0; j < nt; ++j) {
+    float a = 0.f, sg = 0.f;
+    dpm_schedule_eval(s, DPM_EVAL_ALPHA, &t_host[j], 1, &a);
+    dpm_schedule_eval(s, DPM_EVAL_STD, &t_host[j], 1, &sg);
+    const int64_t off = (int64_t)j * n;
+    switch (dtype) {
+      case DPM_DTYPE_F32:
+        hipLaunchKernelGGL(add_noise_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x,
+                           (const float*)noise + off, (float*)out + off, n, a, sg);
+        break;
+      case DPM_DTYPE_F16:
+        hipLaunchKernelGGL(add_noise_kernel<__half>, dim3((unsigned)blocks), dim3(256), 0, st, (const __half*)x,
+                           (const __half*)noise + off, (__half*)out + off, n, a, sg);
+        break;
+      case DPM_DTYPE_BF16:
+        hipLaunchKernelGGL(add_noise_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x,
+                           (const bf16_t*)noise + off, (bf16_t*)out + off, n, a, sg);
+        break;
+      default: return dpm_set_error(DPM_ERR_UNSUPPORTED, "add_noise: unsupported dtype %d", dtype);
+    }
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return dpm_set_error((int)e, "add_noise launch failed: %s", hipGetErrorString(e));
+  return DPM_OK;
+}
+
+extern "C" int dpm_adaptive_error_launch(const void* x_lower, const void* x_higher, const void* x_prev, float atol,
+                                         float rtol, float* e_out, int64_t batch, int64_t per_sample, int dtype,
+                                         void* stream) {
+  if (!x_lower || !x_higher || !x_prev || !e_out || batch < 1 || per_sample < 1)
+    return dpm_set_error(DPM_ERR_ARG, "adaptive_error: bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (dtype) {
+    case DPM_DTYPE_F32:
+      hipLaunchKernelGGL(adaptive_error_kernel<float>, dim3((unsigned)batch), dim3(1024), 0, st, (const float*)x_lower,
+                         (const float*)x_higher, (const float*)x_prev, atol, rtol, e_out, per_sample);
+      break;
+    case DPM_DTYPE_F16:
+      hipLaunchKernelGGL(adaptive_error_kernel<__half>, dim3((unsigned)batch), dim3(1024), 0, st, (const __half*)x_lower,
+                         (const __half*)x_higher, (const __half*)x_prev, atol, rtol, e_out, per_sample);
+      break;
+    default: return dpm_set_error(DPM_ERR_UNSUPPORTED, "adaptive_error: unsupported dtype %d", dtype);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return dpm_set_error((int)e, "adaptive_error launch failed: %s", hipGetErrorString(e));
+  return DPM_OK;
+}
+
+extern "C" int dpm_device_info(int* n_cu, int* lds_bytes, char* arch, int arch_len) {
+  const DeviceInfo& di = device_info();
+  if (!di.ok) return dpm_set_error((int)hipErrorNoDevice, "no HIP device available");
+  if (n_cu) *n_cu = di.n_cu;
+  if (lds_bytes) *lds_bytes = di.lds;
+  if (arch && arch_len > 0) {
+    std::strncpy(arch, di.arch, arch_len - 1);
+    arch[arch_len - 1] = 0;
+  }
+  return DPM_OK;
+}

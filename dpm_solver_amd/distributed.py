@@ -1,0 +1,76 @@
+"""Batch-sharded sampling across the GPUs of one node: one process per GPU, torch.distributed over RCCL
+(backend "nccl" on ROCm) / xGMI.
+
+The solver path shards by independent samples: no operation of sample() couples two samples, so
+each rank owns a contiguous slice of the batch, its own plan copy and network replica, and nothing crosses
+ranks until the single all-gather of the finished samples.  (The reference itself never moves a tensor between
+ranks: examples/ddpm_and_guided-diffusion/main.py:249-265 spawns one process per GPU with seed + rank and each
+writes its own PNGs.)  The 'adaptive' method is the one exception -- its error norm takes a max over the batch
+(dpm_solver_pytorch.py:1001) -- and is rejected here.
+"""
+import torch
+import torch.distributed as dist
+
+
+def rank_seed(seed, rank=None):
+    """Per-rank RNG convention of the reference harness: args.seed + rank (main.py:262-265)."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    return int(seed) + int(rank)
+
+
+def shard_bounds(batch, rank, world):
+    """[lo, hi) of rank's contiguous slice; the first `batch % world` ranks get one extra sample."""
+    base, extra = divmod(int(batch), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_batch(x, rank=None, world=None, group=None):
+    """This rank's slice of a batch-leading tensor (also use it for per-sample conditioning)."""
+    if world is None:
+        world = dist.get_world_size(group)
+    if rank is None:
+        rank = dist.get_rank(group)
+    lo, hi = shard_bounds(x.shape[0], rank, world)
+    return x[lo:hi]
+
+
+def gather_samples(x_local, batch=None, group=None):
+    """The one collective of the sharded path: all-gather the finished shards into the full batch on every rank.
+    Equal shards use a single all_gather_into_tensor (one RCCL call; on the fully connected xGMI mesh each
+    rank's shard goes to its 7 peers over 7 distinct links).  Ragged shards are padded to the largest one."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return x_local
+    n_local = torch.tensor([x_local.shape[0]], device=x_local.device, dtype=torch.int64)
+    if batch is not None and batch % world == 0:
+        sizes = [batch // world] * world
+    else:
+        all_n = [torch.zeros_like(n_local) for _ in range(world)]
+        dist.all_gather(all_n, n_local, group=group)
+        sizes = [int(v.item()) for v in all_n]
+    mx = max(sizes)
+    xl = x_local.contiguous()
+    if xl.shape[0] != mx:
+        pad = torch.zeros((mx - xl.shape[0],) + tuple(xl.shape[1:]), dtype=xl.dtype, device=xl.device)
+        xl = torch.cat([xl, pad])
+    out = torch.empty((world * mx,) + tuple(xl.shape[1:]), dtype=xl.dtype, device=xl.device)
+    dist.all_gather_into_tensor(out, xl, group=group)
+    if all(s == mx for s in sizes):
+        return out
+    return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)])
+
+
+def sample_sharded(solver, x_T, group=None, gather=True, **sample_kwargs):
+    """DPM_Solver.sample() on this rank's shard of x_T (a full-batch tensor present on every rank, or already a
+    shard when `gather=False`), followed by the all-gather of the results."""
+    if sample_kwargs.get("method", "multistep") == "adaptive":
+        raise NotImplementedError("adaptive step sizes couple the whole batch (cross-batch max of the error norm); "
+                                  "batch sharding would change the result")
+    if sample_kwargs.get("return_intermediate"):
+        raise NotImplementedError("return_intermediate is per-rank state; gather the shards yourself")
+    full = x_T.shape[0]
+    xs = shard_batch(x_T, group=group) if gather else x_T
+    out = solver.sample(xs, **sample_kwargs)
+    return gather_samples(out, batch=full, group=group) if gather else out

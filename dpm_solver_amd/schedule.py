@@ -1,0 +1,97 @@
+"""NoiseScheduleVP -- host mirror of the reference class (dpm_solver_pytorch.py:6-167).
+
+Same constructor, attributes and methods; the arithmetic lives in the C planner
+(csrc/dpm_host.cpp), which reproduces the reference's fp32 operation order.  The marginal_* /
+inverse_lambda methods are host functions (the hot loop never calls them: every scalar a sampling
+run needs is precomputed into the plan); calling them on a device tensor copies it to the host.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+class NoiseScheduleVP:
+    def __init__(self, schedule='discrete', betas=None, alphas_cumprod=None, continuous_beta_0=0.1,
+                 continuous_beta_1=20., dtype=torch.float32):
+        if schedule not in ['discrete', 'linear']:
+            raise ValueError("Unsupported noise schedule {}. The schedule needs to be 'discrete' or 'linear'".format(schedule))
+        self.schedule = schedule
+        self.T = 1.
+        self._h = C.c_void_p()
+        self._clip = getattr(self, "_clip", True)
+        if schedule == 'discrete':
+            src = betas if betas is not None else alphas_cumprod
+            assert src is not None
+            arr = src.detach().cpu().numpy() if torch.is_tensor(src) else np.asarray(src)
+            arr = np.ascontiguousarray(arr.reshape(-1))
+            f64 = arr.dtype == np.float64
+            if not f64:
+                arr = np.ascontiguousarray(arr, dtype=np.float32)
+            name = "dpm_schedule_create_%s_%s" % ("betas" if betas is not None else "alphas_cumprod",
+                                                  "f64" if f64 else "f32")
+            ptr = arr.ctypes.data_as(C.POINTER(C.c_double if f64 else C.c_float))
+            L.check(getattr(L.lib, name)(ptr, int(arr.shape[0]), 1 if self._clip else 0, C.byref(self._h)))
+            la, ta, K = C.POINTER(C.c_float)(), C.POINTER(C.c_float)(), C.c_int()
+            L.check(L.lib.dpm_schedule_tables(self._h, C.byref(la), C.byref(ta), C.byref(K)))
+            self.total_N = K.value
+            self.log_alpha_array = torch.from_numpy(np.ctypeslib.as_array(la, (K.value,)).copy()).reshape((1, -1)).to(dtype=dtype)
+            self.t_array = torch.from_numpy(np.ctypeslib.as_array(ta, (K.value,)).copy()).reshape((1, -1)).to(dtype=dtype)
+        else:
+            self.total_N = 1000
+            self.beta_0 = continuous_beta_0
+            self.beta_1 = continuous_beta_1
+            L.check(L.lib.dpm_schedule_create_linear(float(continuous_beta_0), float(continuous_beta_1), C.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                L.lib.dpm_schedule_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # ---- host evaluation ------------------------------------------------------------------
+    def _eval_np(self, what, v):
+        v = np.ascontiguousarray(np.asarray(v, dtype=np.float32).reshape(-1))
+        out = np.empty_like(v)
+        L.check(L.lib.dpm_schedule_eval(self._h, what, v.ctypes.data_as(C.POINTER(C.c_float)), int(v.shape[0]),
+                                        out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def _eval(self, what, t):
+        if not torch.is_tensor(t):
+            t = torch.as_tensor(t, dtype=torch.float32)
+        out = torch.from_numpy(self._eval_np(what, t.detach().to(device="cpu", dtype=torch.float32).numpy()))
+        # the reference flattens for 'discrete' (reshape((-1))) and keeps the shape for 'linear'
+        if self.schedule != 'discrete':
+            out = out.reshape(t.shape)
+        return out.to(device=t.device)
+
+    def marginal_log_mean_coeff(self, t):
+        """log(alpha_t) of a continuous-time label t in [0, T]  (ref :127-134)."""
+        return self._eval(L.EVAL_LOG_ALPHA, t)
+
+    def marginal_alpha(self, t):
+        """alpha_t  (ref :136-140)."""
+        return self._eval(L.EVAL_ALPHA, t)
+
+    def marginal_std(self, t):
+        """sigma_t  (ref :142-146)."""
+        return self._eval(L.EVAL_STD, t)
+
+    def marginal_lambda(self, t):
+        """lambda_t = log(alpha_t) - log(sigma_t)  (ref :148-154)."""
+        return self._eval(L.EVAL_LAMBDA, t)
+
+    def inverse_lambda(self, lamb):
+        """t of a given half-logSNR lambda_t  (ref :156-167)."""
+        if not torch.is_tensor(lamb):
+            lamb = torch.as_tensor(lamb, dtype=torch.float32)
+        out = torch.from_numpy(self._eval_np(L.EVAL_INV_LAMBDA, lamb.detach().to(device="cpu", dtype=torch.float32).numpy()))
+        if self.schedule != 'discrete':
+            out = out.reshape(lamb.shape)
+        return out.to(device=lamb.device)

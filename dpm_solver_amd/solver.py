@@ -1,0 +1,624 @@
+"""DPM_Solver -- host mirror of the reference class (dpm_solver_pytorch.py:337-1245).
+
+Same constructor, same `.sample()` / `.inverse()` / `.add_noise()` and the same public per-update
+methods.  What differs is where the work happens:
+
+  * every scalar of a sampling run is computed once by the C planner into a list of stages
+    (`dpm_plan_create`); this class only walks that list;
+  * per stage it calls the opaque network (PyTorch-ROCm, current stream) and then launches ONE fused
+    HIP kernel through the C ABI (`dpm_stage_launch`) on the same stream;
+  * there is no CPU path: tensors must live on an AMD GPU, and a missing library fails at import.
+
+`ref :NNN` = line in the reference's dpm_solver_pytorch.py.
+"""
+import ctypes as C
+import inspect
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .wrapper import WrappedModel
+
+_DT = {torch.float32: L.DTYPE_F32, torch.float16: L.DTYPE_F16, torch.bfloat16: L.DTYPE_BF16}
+_F32 = np.float32
+
+
+def _require_gpu(x):
+    if not torch.is_tensor(x) or not x.is_cuda:
+        raise RuntimeError(
+            "dpm_solver_amd runs on MI355X (gfx950) through its HIP library; got a %s tensor. There is no "
+            "CPU fallback -- move the state and the model to the GPU." % (x.device if torch.is_tensor(x) else type(x)))
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None):
+    """One `dpm_stage_launch` on the current stream.  Allocates x_out (and m_out when the stage stores
+    its model value) through torch's caching allocator; returns (x_out, m_out)."""
+    ref_t = x if x is not None else xe
+    dev = ref_t.device
+    sd = state_dtype
+
+    def S(t):  # state-typed, contiguous
+        if t is None:
+            return None
+        if t.dtype != sd:
+            t = t.to(sd)
+        return t if t.is_contiguous() else t.contiguous()
+
+    x, xe, h1, h2 = S(x), S(xe), S(h1), S(h2)
+    ed = e0.dtype
+    if ed not in _DT or (sd != torch.float32 and ed != sd):
+        ed = sd  # only (fp32 state, any eps) and equal low-precision pairs have kernels
+
+    def E(t):
+        if t is None:
+            return None
+        if t.dtype != ed:
+            t = t.to(ed)
+        return t if t.is_contiguous() else t.contiguous()
+
+    e0, e1, g = E(e0), E(e1), E(g)
+    if xe is not None and x is not None and xe.data_ptr() == x.data_ptr():
+        xe = None
+    shape = ref_t.shape
+    x_out = torch.empty(shape, dtype=sd, device=dev)
+    store = bool(st.flags & L.F_STORE_M) if want_m is None else want_m
+    m_out = torch.empty(shape, dtype=sd, device=dev) if store else None
+    if store:
+        st.flags |= L.F_STORE_M
+    else:
+        st.flags &= ~L.F_STORE_M
+    b = L.Buffers()
+    b.x, b.xe, b.e0, b.e1, b.g = _ptr(x), _ptr(xe), _ptr(e0), _ptr(e1), _ptr(g)
+    b.h1, b.h2, b.x_out, b.m_out = _ptr(h1), _ptr(h2), _ptr(x_out), _ptr(m_out)
+    b.workspace = None
+    b.n = ref_t.numel()
+    b.batch = max(int(shape[0]), 1) if len(shape) > 0 else 1
+    b.state_dtype = _DT[sd]
+    b.eps_dtype = _DT[ed]
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        L.check(L.lib.dpm_stage_launch(C.byref(st), C.byref(b), C.c_void_p(stream)))
+    return x_out, m_out
+
+
+class _Plan:
+    """A frozen `dpm_plan` plus the per-device time tensors handed to the network / callbacks."""
+
+    def __init__(self, sched_handle, desc):
+        self.handle = C.c_void_p()
+        L.check(L.lib.dpm_plan_create(sched_handle, C.byref(desc), C.byref(self.handle)))
+        n = L.lib.dpm_plan_num_stages(self.handle)
+        self.slots = L.lib.dpm_plan_num_slots(self.handle)
+        self.stages = []
+        for i in range(n):
+            st = L.Stage()
+            L.check(L.lib.dpm_plan_stage(self.handle, i, C.byref(st)))
+            self.stages.append(st)
+        self._dev = {}
+
+    def times(self, device):
+        """(t_eval, t_input, t_out) as fp32 device vectors, one host-to-device copy per plan and device."""
+        key = str(device)
+        if key not in self._dev:
+            arr = np.array([[s.t_eval for s in self.stages], [s.t_input for s in self.stages],
+                            [s.t_out for s in self.stages]], dtype=np.float32)
+            self._dev[key] = torch.from_numpy(arr).to(device)
+        return self._dev[key]
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            try:
+                L.lib.dpm_plan_destroy(self.handle)
+            except Exception:
+                pass
+            self.handle = None
+
+
+class DPM_Solver:
+    def __init__(self, model_fn, noise_schedule, algorithm_type="dpmsolver++", correcting_x0_fn=None,
+                 correcting_xt_fn=None, thresholding_max_val=1., dynamic_thresholding_ratio=0.995,
+                 state_dtype=None):
+        """Construct a DPM-Solver (signature of ref :338-347; `state_dtype` is an extension).
+
+        state_dtype: dtype the solver keeps x and the cached model values in.  None follows the reference:
+        with a 'discrete' schedule a half-precision x_T is promoted to fp32 by the first update (the
+        reference's coefficients are (1,)-shaped fp32 tensors), with 'linear' it keeps x's dtype.
+        """
+        self.model = lambda x, t: model_fn(x, t.expand((x.shape[0])))
+        self._model_fn = model_fn
+        self._wrapped = model_fn if isinstance(model_fn, WrappedModel) else None
+        self.noise_schedule = noise_schedule
+        assert algorithm_type in ["dpmsolver", "dpmsolver++"]
+        self.algorithm_type = algorithm_type
+        self._thresholding = correcting_x0_fn == "dynamic_thresholding"
+        if self._thresholding:
+            self.correcting_x0_fn = self.dynamic_thresholding_fn
+            self._user_x0 = None
+        else:
+            self.correcting_x0_fn = correcting_x0_fn
+            self._user_x0 = correcting_x0_fn
+        self._user_x0_nargs = None
+        if self._user_x0 is not None:
+            try:  # the older vendored revision calls correcting_x0_fn(x0) with one argument
+                self._user_x0_nargs = len([p for p in inspect.signature(self._user_x0).parameters.values()
+                                           if p.default is p.empty and p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)])
+            except (TypeError, ValueError):
+                self._user_x0_nargs = 2
+        self.correcting_xt_fn = correcting_xt_fn
+        self.dynamic_thresholding_ratio = dynamic_thresholding_ratio
+        self.thresholding_max_val = thresholding_max_val
+        self._state_dtype = state_dtype
+        self._plans = {}
+
+    # ------------------------------------------------------------------------------------------
+    # helpers
+    # ------------------------------------------------------------------------------------------
+    @property
+    def _h(self):
+        return self.noise_schedule._h
+
+    @property
+    def _algo(self):
+        return L.ALGO[self.algorithm_type]
+
+    def _model_codes(self):
+        if self._wrapped is not None:
+            w = self._wrapped
+            return L.MODEL[w.model_type], L.GUIDE[w.effective_guidance], float(w.guidance_scale)
+        return L.MODEL["noise"], L.GUIDE["uncond"], 1.0
+
+    def _sdtype(self, x):
+        if self._state_dtype is not None:
+            return self._state_dtype
+        if x.dtype not in _DT:
+            raise NotImplementedError("dpm_solver_amd: state dtype %s is not supported (fp32 / fp16 / bf16)" % x.dtype)
+        if self.noise_schedule.schedule == 'discrete':
+            return torch.float32
+        return x.dtype
+
+    @staticmethod
+    def _tf(t):
+        """time argument (tensor of one element, or float) -> fp32 host value"""
+        if torch.is_tensor(t):
+            return float(t.detach().reshape(-1)[0].float().item())
+        return float(_F32(t))
+
+    def _tt(self, value, device, shape1=False):
+        t = torch.full((1,) if shape1 else (), float(value), dtype=torch.float32, device=device)
+        return t
+
+    def _call_x0(self, x0, t):
+        if self._user_x0_nargs == 1:
+            return self._user_x0(x0)
+        return self._user_x0(x0, t)
+
+    def _network(self, x_eval, t_eval_t, t_input_t):
+        """the opaque call: raw output(s) of the network at (x_eval, t)"""
+        B = x_eval.shape[0]
+        if self._wrapped is not None:
+            w = self._wrapped
+            t2 = t_input_t.expand(2 * B) if w.effective_guidance == "classifier-free" else None
+            return w.raw_outputs(x_eval, t_eval_t.expand(B), t_input_t.expand(B), t2)
+        return self._model_fn(x_eval, t_eval_t.expand(B)), None, None
+
+    def _prep_stage(self, st):
+        """stage flags that depend on this solver's correctors"""
+        if st.flags & L.F_TO_X0:
+            if self._thresholding:
+                st.flags |= L.F_THRESH
+                st.thr_ratio = float(self.dynamic_thresholding_ratio)
+                st.thr_max = float(self.thresholding_max_val)
+        return st
+
+    def _run_stage(self, st, x, xe, outs, h1, h2, sd, t_eval_t, want_m=None):
+        """outs = (e0, e1, g) fresh network outputs.  Handles a *callable* correcting_x0_fn by splitting the
+        stage: prologue kernel -> user function (opaque torch) -> combination kernel."""
+        e0, e1, g = outs
+        if self._user_x0 is not None and (st.flags & L.F_TO_X0):
+            s1 = st.copy()
+            s1.form = L.FORM_DENOISE
+            s1.flags = L.F_TO_X0
+            x0, _ = _launch_stage(s1, None, xe if xe is not None else x, e0, e1, g, None, None, sd, want_m=False)
+            x0 = self._call_x0(x0, t_eval_t)                                             # ref :440-441
+            return self._run_given(st, x, x0, h1, h2, sd, want_m)
+        return _launch_stage(st, x, xe, e0, e1, g, h1, h2, sd, want_m=want_m)
+
+    def _run_given(self, st, x, m, h1, h2, sd, want_m=None):
+        """the update of `st` with the model value already known (no prologue)"""
+        s2 = st.copy()
+        s2.flags = st.flags & L.F_BASE_HIST
+        s2.model_type = L.MODEL["noise"]
+        s2.guidance = L.GUIDE["uncond"]
+        store = bool(st.flags & L.F_STORE_M) if want_m is None else want_m
+        x_out, _ = _launch_stage(s2, x if x is not None else m, None, m, None, None, h1, h2, sd, want_m=False)
+        return x_out, (m if store else None)
+
+    # ------------------------------------------------------------------------------------------
+    # model evaluations (ref :416-451, :541-545)
+    # ------------------------------------------------------------------------------------------
+    def dynamic_thresholding_fn(self, x0, t=None):
+        """The dynamic thresholding method (ref :416-425) as one kernel launch."""
+        _require_gpu(x0)
+        st = L.Stage()
+        st.h1_slot = st.h2_slot = st.m_slot = -1
+        st.form = L.FORM_DENOISE
+        st.flags = L.F_THRESH
+        st.thr_ratio = float(self.dynamic_thresholding_ratio)
+        st.thr_max = float(self.thresholding_max_val)
+        st.alpha_e, st.sigma_e, st.cfg_scale = 1.0, 0.0, 1.0
+        sd = x0.dtype if x0.dtype in _DT else torch.float32
+        out, _ = _launch_stage(st, None, x0, x0, None, None, None, None, sd, want_m=False)
+        return out
+
+    def _eval_model(self, x, t, to_x0):
+        _require_gpu(x)
+        tf = self._tf(t)
+        mt, gd, sc = self._model_codes()
+        st = L.Stage()
+        st.h1_slot = st.h2_slot = st.m_slot = -1
+        L.check(L.lib.dpm_coef_prologue(self._h, tf, mt, gd, sc, C.byref(st)))
+        st.form = L.FORM_DENOISE
+        st.flags = L.F_TO_X0 if to_x0 else 0
+        self._prep_stage(st)
+        dev = x.device
+        outs = self._network(x, self._tt(st.t_eval, dev), self._tt(st.t_input, dev))
+        sd = self._sdtype(x)
+        out, _ = self._run_stage(st, None, x, outs, None, None, sd, t if torch.is_tensor(t) else self._tt(tf, dev), want_m=False)
+        return out
+
+    def noise_prediction_fn(self, x, t):
+        """Return the noise prediction model (ref :427-431)."""
+        return self._eval_model(x, t, to_x0=False)
+
+    def data_prediction_fn(self, x, t):
+        """Return the data prediction model, with corrector (ref :433-442)."""
+        return self._eval_model(x, t, to_x0=True)
+
+    def model_fn(self, x, t):
+        """noise prediction for 'dpmsolver', data prediction for 'dpmsolver++' (ref :444-451)."""
+        return self._eval_model(x, t, to_x0=self.algorithm_type == "dpmsolver++")
+
+    def denoise_to_zero_fn(self, x, s):
+        """ref :541-545"""
+        return self.data_prediction_fn(x, s)
+
+    # ------------------------------------------------------------------------------------------
+    # time grids (ref :453-539)
+    # ------------------------------------------------------------------------------------------
+    def get_time_steps(self, skip_type, t_T, t_0, N, device):
+        if skip_type not in L.SKIP:
+            raise ValueError("Unsupported skip_type {}, need to be 'logSNR' or 'time_uniform' or 'time_quadratic'".format(skip_type))
+        out = np.empty(N + 1, dtype=np.float32)
+        L.check(L.lib.dpm_time_steps(self._h, L.SKIP[skip_type], float(t_T), float(t_0), int(N),
+                                     out.ctypes.data_as(C.POINTER(C.c_float))))
+        return torch.from_numpy(out).to(device)
+
+    def get_orders_and_timesteps_for_singlestep_solver(self, steps, order, skip_type, t_T, t_0, device):
+        if order not in (1, 2, 3):
+            raise ValueError("'order' must be '1' or '2' or '3'.")
+        if skip_type not in L.SKIP:
+            raise ValueError("Unsupported skip_type {}, need to be 'logSNR' or 'time_uniform' or 'time_quadratic'".format(skip_type))
+        outer = np.empty(steps + 2, dtype=np.float32)
+        orders = (C.c_int * (steps + 1))()
+        n = C.c_int()
+        L.check(L.lib.dpm_singlestep_grid(self._h, int(steps), int(order), L.SKIP[skip_type], float(t_T), float(t_0),
+                                          outer.ctypes.data_as(C.POINTER(C.c_float)), orders, C.byref(n)))
+        return torch.from_numpy(outer[: n.value + 1].copy()).to(device), [int(orders[i]) for i in range(n.value)]
+
+    # ------------------------------------------------------------------------------------------
+    # public per-update methods (ref :547-954)
+    # ------------------------------------------------------------------------------------------
+    def _exec_single(self, stages, x, given, want):
+        """Run 1-3 singlestep stages starting from state x.  `given[i]` = model value already known for
+        stage i; `want` = return the model values.  Returns (x_t, [m_0, m_1, m_2])."""
+        _require_gpu(x)
+        dev = x.device
+        sd = self._sdtype(x)
+        mt, gd, sc = self._model_codes()
+        n = len(stages)
+        ms = [given.get(i) for i in range(n)]
+        tmp = None
+        x_t = None
+        for i, st in enumerate(stages):
+            last = i == n - 1
+            if not last and ms[i] is not None and ms[i + 1] is not None:
+                continue                      # this stage's output would only feed an evaluation we already have
+            h1 = ms[0] if st.h1_slot >= 0 else None
+            h2 = ms[1] if st.h2_slot >= 0 else None
+            if ms[i] is not None:
+                out, _ = self._run_given(st, x, ms[i], h1, h2, sd, want_m=False)
+            else:
+                xe = x if i == 0 else tmp
+                L.check(L.lib.dpm_coef_prologue(self._h, st.t_eval, mt, gd, sc, C.byref(st)))
+                self._prep_stage(st)
+                outs = self._network(xe, self._tt(st.t_eval, dev), self._tt(st.t_input, dev))
+                need_m = want or (i == 0 and n > 1) or (i == 1 and n == 3 and stages[2].h2_slot >= 0)
+                out, m = self._run_stage(st, x, None if i == 0 else xe, outs, h1, h2, sd, self._tt(st.t_eval, dev),
+                                         want_m=need_m)
+                ms[i] = m
+            if last:
+                x_t = out
+            else:
+                tmp = out
+        return x_t, ms
+
+    def dpm_solver_first_update(self, x, s, t, model_s=None, return_intermediate=False):
+        """DPM-Solver-1 (equivalent to DDIM) from time `s` to time `t` (ref :547-592)."""
+        st = (L.Stage * 1)()
+        L.check(L.lib.dpm_coef_singlestep(self._h, self._algo, 0, 1, self._tf(s), self._tf(t), 0., 0., 0, st))
+        x_t, ms = self._exec_single([st[0]], x, {0: model_s} if model_s is not None else {}, return_intermediate)
+        return (x_t, {'model_s': ms[0]}) if return_intermediate else x_t
+
+    def singlestep_dpm_solver_second_update(self, x, s, t, r1=0.5, model_s=None, return_intermediate=False,
+                                            solver_type='dpmsolver'):
+        """Singlestep solver DPM-Solver-2 from time `s` to time `t` (ref :594-673)."""
+        if solver_type not in ['dpmsolver', 'taylor']:
+            raise ValueError("'solver_type' must be either 'dpmsolver' or 'taylor', got {}".format(solver_type))
+        if r1 is None:
+            r1 = 0.5
+        mode = 1 if torch.is_tensor(r1) else 0
+        st = (L.Stage * 2)()
+        L.check(L.lib.dpm_coef_singlestep(self._h, self._algo, L.SOLVER[solver_type], 2, self._tf(s), self._tf(t),
+                                          self._tf(r1) if mode else float(r1), 0., mode, st))
+        x_t, ms = self._exec_single([st[0], st[1]], x, {0: model_s} if model_s is not None else {}, return_intermediate)
+        return (x_t, {'model_s': ms[0], 'model_s1': ms[1]}) if return_intermediate else x_t
+
+    def singlestep_dpm_solver_third_update(self, x, s, t, r1=1. / 3., r2=2. / 3., model_s=None, model_s1=None,
+                                           return_intermediate=False, solver_type='dpmsolver'):
+        """Singlestep solver DPM-Solver-3 from time `s` to time `t` (ref :675-794)."""
+        if solver_type not in ['dpmsolver', 'taylor']:
+            raise ValueError("'solver_type' must be either 'dpmsolver' or 'taylor', got {}".format(solver_type))
+        if r1 is None:
+            r1 = 1. / 3.
+        if r2 is None:
+            r2 = 2. / 3.
+        mode = 1 if (torch.is_tensor(r1) or torch.is_tensor(r2)) else 0
+        st = (L.Stage * 3)()
+        L.check(L.lib.dpm_coef_singlestep(self._h, self._algo, L.SOLVER[solver_type], 3, self._tf(s), self._tf(t),
+                                          self._tf(r1) if mode else float(r1), self._tf(r2) if mode else float(r2),
+                                          mode, st))
+        given = {}
+        if model_s is not None:
+            given[0] = model_s
+        if model_s1 is not None:
+            given[1] = model_s1
+        stages = [st[0], st[1], st[2]]
+        if 1 in given and 0 not in given:
+            # reference: model_s is evaluated at (x, s) even when model_s1 is supplied (ref :720-721)
+            given[0] = self.model_fn(x, s)
+        # the taylor combination reads model_s1 (h2): keep it even when not asked for
+        x_t, ms = self._exec_single(stages, x, given, return_intermediate or solver_type == 'taylor')
+        return (x_t, {'model_s': ms[0], 'model_s1': ms[1], 'model_s2': ms[2]}) if return_intermediate else x_t
+
+    def _multistep(self, x, model_prev_list, t_prev_list, t, order, solver_type):
+        _require_gpu(x)
+        tp = (C.c_float * order)(*[self._tf(v) for v in t_prev_list[-order:]])
+        st = L.Stage()
+        L.check(L.lib.dpm_coef_multistep(self._h, self._algo, L.SOLVER[solver_type], order, tp, self._tf(t), C.byref(st)))
+        h1 = model_prev_list[-2] if order >= 2 else None
+        h2 = model_prev_list[-3] if order >= 3 else None
+        x_t, _ = self._run_given(st, x, model_prev_list[-1], h1, h2, self._sdtype(x), want_m=False)
+        return x_t
+
+    def multistep_dpm_solver_second_update(self, x, model_prev_list, t_prev_list, t, solver_type="dpmsolver"):
+        """Multistep solver DPM-Solver-2 from time `t_prev_list[-1]` to time `t` (ref :796-852)."""
+        if solver_type not in ['dpmsolver', 'taylor']:
+            raise ValueError("'solver_type' must be either 'dpmsolver' or 'taylor', got {}".format(solver_type))
+        return self._multistep(x, model_prev_list, t_prev_list, t, 2, solver_type)
+
+    def multistep_dpm_solver_third_update(self, x, model_prev_list, t_prev_list, t, solver_type='dpmsolver'):
+        """Multistep solver DPM-Solver-3 from time `t_prev_list[-1]` to time `t` (ref :854-904)."""
+        return self._multistep(x, model_prev_list, t_prev_list, t, 3, solver_type if solver_type in L.SOLVER else 'dpmsolver')
+
+    def singlestep_dpm_solver_update(self, x, s, t, order, return_intermediate=False, solver_type='dpmsolver',
+                                     r1=None, r2=None):
+        """Singlestep DPM-Solver with the order `order` from time `s` to time `t` (ref :906-930)."""
+        if order == 1:
+            return self.dpm_solver_first_update(x, s, t, return_intermediate=return_intermediate)
+        elif order == 2:
+            return self.singlestep_dpm_solver_second_update(x, s, t, return_intermediate=return_intermediate,
+                                                            solver_type=solver_type, r1=r1)
+        elif order == 3:
+            return self.singlestep_dpm_solver_third_update(x, s, t, return_intermediate=return_intermediate,
+                                                           solver_type=solver_type, r1=r1, r2=r2)
+        else:
+            raise ValueError("Solver order must be 1 or 2 or 3, got {}".format(order))
+
+    def multistep_dpm_solver_update(self, x, model_prev_list, t_prev_list, t, order, solver_type='dpmsolver'):
+        """Multistep DPM-Solver with the order `order` from time `t_prev_list[-1]` to time `t` (ref :932-954)."""
+        if order == 1:
+            return self.dpm_solver_first_update(x, t_prev_list[-1], t, model_s=model_prev_list[-1])
+        elif order == 2:
+            return self.multistep_dpm_solver_second_update(x, model_prev_list, t_prev_list, t, solver_type=solver_type)
+        elif order == 3:
+            return self.multistep_dpm_solver_third_update(x, model_prev_list, t_prev_list, t, solver_type=solver_type)
+        else:
+            raise ValueError("Solver order must be 1 or 2 or 3, got {}".format(order))
+
+    # ------------------------------------------------------------------------------------------
+    # adaptive step size (ref :956-1010): the control loop is host logic, the work is stage kernels
+    # ------------------------------------------------------------------------------------------
+    def dpm_solver_adaptive(self, x, order, t_T, t_0, h_init=0.05, atol=0.0078, rtol=0.05, theta=0.9, t_err=1e-5,
+                            solver_type='dpmsolver'):
+        _require_gpu(x)
+        ns = self.noise_schedule
+        lam = lambda v: _F32(ns._eval_np(L.EVAL_LAMBDA, [v])[0])
+        s = _F32(t_T)
+        lambda_s = lam(s)
+        lambda_0 = lam(_F32(t_0))
+        h = _F32(h_init)
+        x_prev = x
+        nfe = 0
+        if order == 2:
+            r1 = 0.5
+            lower_update = lambda x, s, t: self.dpm_solver_first_update(x, s, t, return_intermediate=True)
+            higher_update = lambda x, s, t, **kw: self.singlestep_dpm_solver_second_update(
+                x, s, t, r1=r1, solver_type=solver_type, **kw)
+        elif order == 3:
+            r1, r2 = 1. / 3., 2. / 3.
+            lower_update = lambda x, s, t: self.singlestep_dpm_solver_second_update(
+                x, s, t, r1=r1, return_intermediate=True, solver_type=solver_type)
+            higher_update = lambda x, s, t, **kw: self.singlestep_dpm_solver_third_update(
+                x, s, t, r1=r1, r2=r2, solver_type=solver_type, **kw)
+        else:
+            raise ValueError("For adaptive step size solver, order must be 2 or 3, got {}".format(order))
+        B = x.shape[0]
+        per_sample = x.numel() // max(B, 1)
+        e_dev = torch.empty((B,), dtype=torch.float32, device=x.device)
+        while abs(_F32(s - _F32(t_0))) > t_err:
+            t = _F32(ns._eval_np(L.EVAL_INV_LAMBDA, [_F32(lambda_s + h)])[0])
+            x_lower, lower_noise_kwargs = lower_update(x, float(s), float(t))
+            x_higher = higher_update(x, float(s), float(t), **lower_noise_kwargs)
+            xp = x_prev if x_prev.dtype == x_lower.dtype else x_prev.to(x_lower.dtype)
+            with torch.cuda.device(x.device):
+                L.check(L.lib.dpm_adaptive_error_launch(
+                    _ptr(x_lower), _ptr(x_higher), _ptr(xp.contiguous()), float(atol), float(rtol), _ptr(e_dev), B,
+                    per_sample, _DT[x_lower.dtype], C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+            E = _F32(e_dev.max().item())             # the one host sync per iteration, as in the reference (ref :1002)
+            if E <= 1.:
+                x = x_higher
+                s = t
+                x_prev = x_lower
+                lambda_s = lam(s)
+            h = min(_F32(_F32(theta) * h * _F32(np.float64(E) ** (-1. / order))), _F32(lambda_0 - lambda_s))
+            nfe += order
+        print('adaptive solver nfe', nfe)
+        return x
+
+    # ------------------------------------------------------------------------------------------
+    # add_noise / inverse / sample (ref :1012-1245)
+    # ------------------------------------------------------------------------------------------
+    def add_noise(self, x, t, noise=None):
+        """xt = alpha_t * x + sigma_t * noise for every t; returns (t_size, batch, *shape) (ref :1012-1030)."""
+        _require_gpu(x)
+        th = t.detach().to(device="cpu", dtype=torch.float32).reshape(-1).numpy().copy()
+        nt = int(th.shape[0])
+        if noise is None:
+            noise = torch.randn((nt, *x.shape), device=x.device)
+        xd = x.contiguous()
+        if xd.dtype not in _DT:
+            raise NotImplementedError("add_noise: dtype %s" % xd.dtype)
+        nz = noise.to(xd.dtype).contiguous()
+        out = torch.empty((nt, *x.shape), dtype=xd.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            L.check(L.lib.dpm_add_noise_launch(self._h, th.ctypes.data_as(C.POINTER(C.c_float)), nt, _ptr(xd), _ptr(nz),
+                                               _ptr(out), xd.numel(), _DT[xd.dtype],
+                                               C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        return out.squeeze(0) if nt == 1 else out
+
+    def inverse(self, x, steps=20, t_start=None, t_end=None, order=2, skip_type='time_uniform',
+                method='multistep', lower_order_final=True, denoise_to_zero=False, solver_type='dpmsolver',
+                atol=0.0078, rtol=0.05, return_intermediate=False):
+        """Inverse the sample `x` from time `t_start` to `t_end` by DPM-Solver (ref :1032-1045)."""
+        t_0 = 1. / self.noise_schedule.total_N if t_start is None else t_start
+        t_T = self.noise_schedule.T if t_end is None else t_end
+        assert t_0 > 0 and t_T > 0, "Time range needs to be greater than 0. For discrete-time DPMs, it needs to be in [1 / N, 1], where N is the length of betas array"
+        return self.sample(x, steps=steps, t_start=t_0, t_end=t_T, order=order, skip_type=skip_type,
+                           method=method, lower_order_final=lower_order_final, denoise_to_zero=denoise_to_zero,
+                           solver_type=solver_type, atol=atol, rtol=rtol, return_intermediate=return_intermediate)
+
+    def _get_plan(self, **kw):
+        mt, gd, sc = self._model_codes()
+        key = (tuple(sorted(kw.items())), mt, gd, sc, self._thresholding, float(self.dynamic_thresholding_ratio),
+               float(self.thresholding_max_val), self.algorithm_type)
+        plan = self._plans.get(key)
+        if plan is None:
+            d = L.PlanDesc()
+            d.algorithm_type = self._algo
+            d.method = L.METHOD[kw["method"]]
+            d.order = int(kw["order"])
+            d.steps = int(kw["steps"])
+            d.skip_type = L.SKIP[kw["skip_type"]]
+            d.solver_type = L.SOLVER[kw["solver_type"]]
+            d.lower_order_final = int(bool(kw["lower_order_final"]))
+            d.denoise_to_zero = int(bool(kw["denoise_to_zero"]))
+            d.model_type, d.guidance, d.guidance_scale = mt, gd, sc
+            d.thresholding = int(self._thresholding)
+            d.t_start, d.t_end = float(kw["t_T"]), float(kw["t_0"])
+            d.thr_ratio = float(self.dynamic_thresholding_ratio)
+            d.thr_max = float(self.thresholding_max_val)
+            plan = _Plan(self._h, d)
+            self._plans[key] = plan
+        return plan
+
+    def sample(self, x, steps=20, t_start=None, t_end=None, order=2, skip_type='time_uniform',
+               method='multistep', lower_order_final=True, denoise_to_zero=False, solver_type='dpmsolver',
+               atol=0.0078, rtol=0.05, return_intermediate=False):
+        """Compute the sample at time `t_end` by DPM-Solver, given the initial `x` at time `t_start`
+        (signature and semantics of ref :1047-1245; see that docstring for the argument meanings)."""
+        t_0 = 1. / self.noise_schedule.total_N if t_end is None else t_end
+        t_T = self.noise_schedule.T if t_start is None else t_start
+        assert t_0 > 0 and t_T > 0, "Time range needs to be greater than 0. For discrete-time DPMs, it needs to be in [1 / N, 1], where N is the length of betas array"
+        if return_intermediate:
+            assert method in ['multistep', 'singlestep', 'singlestep_fixed'], "Cannot use adaptive solver when saving intermediate values"
+        if self.correcting_xt_fn is not None:
+            assert method in ['multistep', 'singlestep', 'singlestep_fixed'], "Cannot use adaptive solver when correcting_xt_fn is not None"
+        _require_gpu(x)
+        device = x.device
+        intermediates = []
+        cxt = self.correcting_xt_fn
+        with torch.no_grad():
+            if method == 'adaptive':
+                x = self.dpm_solver_adaptive(x, order=order, t_T=t_T, t_0=t_0, atol=atol, rtol=rtol, solver_type=solver_type)
+                if denoise_to_zero:
+                    x = self.denoise_to_zero_fn(x, self._tt(t_0, device, shape1=True))
+            elif method in ['multistep', 'singlestep', 'singlestep_fixed']:
+                if skip_type not in L.SKIP:
+                    raise ValueError("Unsupported skip_type {}, need to be 'logSNR' or 'time_uniform' or 'time_quadratic'".format(skip_type))
+                if solver_type not in L.SOLVER:
+                    raise ValueError("'solver_type' must be either 'dpmsolver' or 'taylor', got {}".format(solver_type))
+                if method == 'multistep':
+                    assert steps >= order
+                    if order not in (1, 2, 3):
+                        raise ValueError("Solver order must be 1 or 2 or 3, got {}".format(order))
+                elif order not in (1, 2, 3):
+                    raise ValueError("'order' must be '1' or '2' or '3'.")
+                plan = self._get_plan(method=method, order=order, steps=steps, skip_type=skip_type, solver_type=solver_type,
+                                      lower_order_final=lower_order_final, denoise_to_zero=denoise_to_zero,
+                                      t_T=float(t_T), t_0=float(t_0))
+                x = self._run_plan(plan, x, method, cxt, return_intermediate, intermediates)
+            else:
+                raise ValueError("Got wrong method {}".format(method))
+        if return_intermediate:
+            return x, intermediates
+        else:
+            return x
+
+    def _run_plan(self, plan, x, method, cxt, keep, intermediates):
+        device = x.device
+        sd = self._sdtype(x)
+        T = plan.times(device)            # [3, n_stages]: t_eval, t_input, t_out
+        state = x
+        tmp = None
+        hist = [None] * max(plan.slots, 1)
+        for i, ps in enumerate(plan.stages):
+            st = ps.copy()                # launches may edit flags
+            xe = tmp if st.xe_src == L.SRC_TMP else state
+            outs = self._network(xe, T[0, i], T[1, i])
+            if i == 0 and method == 'multistep':
+                # ref :1179-1183: the model sees the caller's x_T; the corrector and the list see it afterwards
+                if cxt is not None:
+                    state = cxt(state, T[0, 0], 0)
+                if keep:
+                    intermediates.append(state)
+            h1 = hist[st.h1_slot] if st.h1_slot >= 0 else None
+            h2 = hist[st.h2_slot] if st.h2_slot >= 0 else None
+            x_out, m_out = self._run_stage(st, state, xe, outs, h1, h2, sd, T[0, i])
+            if st.m_slot >= 0:
+                hist[st.m_slot] = m_out
+            if st.emits_state:
+                if cxt is not None:
+                    t_cb = T[2, i].reshape(1) if st.form == L.FORM_DENOISE else T[2, i]
+                    x_out = cxt(x_out, t_cb, st.outer_step)
+                if keep:
+                    intermediates.append(x_out)
+                state = x_out
+                tmp = None
+            else:
+                tmp = x_out
+        return state

@@ -1,0 +1,236 @@
+/*
+ * dpm_hip.h -- C ABI of the MI355X-native DPM-Solver / DPM-Solver++ sampling engine.
+ *
+ * The reference (LuChengTHU/dpm-solver, dpm_solver_pytorch.py) has no FFI boundary: its "plugin
+ * interface" is the Python API  NoiseScheduleVP / model_wrapper / DPM_Solver  (README.md:380).
+ * This header is the boundary a host in any language binds to *under* that API; the Python
+ * mirror in dpm_solver_amd/ is one such host (ctypes).
+ *
+ * Design:
+ *   - every scalar of the noise schedule (alpha_t, sigma_t, lambda_t, h, r, phi_k) is computed
+ *     ONCE on the host by the planner, in the reference's own fp32 operation order, and frozen
+ *     into a list of `dpm_stage` records -- one per network evaluation;
+ *   - the device runs exactly one fused streaming kernel per stage:
+ *        raw network output(s) -> [CFG blend | classifier term] -> [x_start/v/score -> eps]
+ *        -> [eps -> x0] -> [dynamic thresholding] -> exponential-integrator update
+ *     reading the state x, the fresh output(s) and 0-2 cached model values, writing x_next and
+ *     (if a later stage needs it) the new model value;
+ *   - the library never allocates or frees user-visible device memory: every buffer is the
+ *     caller's, every launch is asynchronous on the caller's HIP stream, nothing synchronises.
+ *
+ * Conventions: plain C types only.  Return value 0 = DPM_OK, negative = argument/state error
+ * (dpm_last_error() has the text), positive = a hipError_t from the HIP runtime.  No function
+ * throws or aborts.  Handles are immutable after creation and may be shared between threads.
+ * `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ */
+#ifndef DPM_HIP_H
+#define DPM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPM_HIP_VERSION 100 /* major*10000 + minor*100 + patch */
+
+/* ---- status --------------------------------------------------------------------------- */
+enum {
+  DPM_OK = 0,
+  DPM_ERR_ARG = -1,         /* bad argument value (ValueError at the Python layer)            */
+  DPM_ERR_UNSUPPORTED = -2, /* valid in the reference, not (yet) built here -- never silent   */
+  DPM_ERR_ALIGN = -3,       /* reserved                                                      */
+  DPM_ERR_NOMEM = -4,
+  DPM_ERR_CALLBACK = -5     /* the model callback of dpm_plan_run returned non-zero           */
+};
+
+/* ---- enumerations (values are ABI) ----------------------------------------------------- */
+enum { DPM_ALGO_DPMSOLVER = 0, DPM_ALGO_DPMSOLVERPP = 1 };        /* algorithm_type, ref :342,:406 */
+enum { DPM_SOLVER_DPMSOLVER = 0, DPM_SOLVER_TAYLOR = 1 };         /* solver_type,    ref :611      */
+enum { DPM_METHOD_MULTISTEP = 0, DPM_METHOD_SINGLESTEP = 1, DPM_METHOD_SINGLESTEP_FIXED = 2 }; /* ref :1171,:1214 */
+enum { DPM_SKIP_TIME_UNIFORM = 0, DPM_SKIP_LOGSNR = 1, DPM_SKIP_TIME_QUADRATIC = 2 };          /* ref :468-478    */
+enum { DPM_MODEL_NOISE = 0, DPM_MODEL_X_START = 1, DPM_MODEL_V = 2, DPM_MODEL_SCORE = 3 };     /* ref :288-298    */
+enum { DPM_GUIDE_NONE = 0, DPM_GUIDE_CFG = 1, DPM_GUIDE_CLASSIFIER = 2 };                      /* ref :313-330    */
+enum { DPM_DTYPE_F32 = 0, DPM_DTYPE_F16 = 1, DPM_DTYPE_BF16 = 2 };
+enum { DPM_EVAL_LOG_ALPHA = 0, DPM_EVAL_ALPHA = 1, DPM_EVAL_STD = 2, DPM_EVAL_LAMBDA = 3, DPM_EVAL_INV_LAMBDA = 4 };
+
+/* update forms.  `mn` = model value produced by this stage's prologue, h1/h2 = cached values.  */
+enum {
+  DPM_FORM_LIN1 = 0,    /* out = cx*x - c0*mn                                         (ref :573,:585)        */
+  DPM_FORM_TWO = 1,     /* D = k0*(mn-h1); out = (cx*x - c0*P) - c1*D, P = BASE_HIST ? h1 : mn
+                           (ref :636-646,:659-669,:728-739,:767-778,:827-851)                               */
+  DPM_FORM_MS3 = 2,     /* multistep third order (ref :879-903)                                              */
+  DPM_FORM_SS3T = 3,    /* singlestep third order, 'taylor' final combination (ref :741-750,:780-789)        */
+  DPM_FORM_DENOISE = 4, /* out = mn  (denoise_to_zero, ref :541-545,:1235-1237)                              */
+  DPM_FORM_COUNT = 5
+};
+
+/* dpm_stage.flags */
+#define DPM_F_TO_X0 1u      /* prologue converts eps -> x0 = (xe - sigma*eps)/alpha   (ref :439)              */
+#define DPM_F_STORE_M 2u    /* write mn to m_out (a later stage reads it as h1/h2)                            */
+#define DPM_F_BASE_HIST 4u  /* FORM_TWO: first-order term uses h1 (singlestep) instead of mn (multistep)      */
+#define DPM_F_THRESH 8u     /* dynamic thresholding of x0 (ref :416-425)                                      */
+#define DPM_F_USER_X0 16u   /* host applies a callable correcting_x0_fn: stage is split by the host shim       */
+
+/* buffer roles for the host-side loop */
+enum { DPM_SRC_STATE = 0, DPM_SRC_TMP = 1 };
+
+/* ---- one stage = one network evaluation + one fused kernel ----------------------------- */
+typedef struct dpm_stage {
+  int32_t index;       /* position in the plan                                                   */
+  int32_t form;        /* DPM_FORM_*                                                             */
+  uint32_t flags;      /* DPM_F_*                                                                */
+  int32_t model_type;  /* DPM_MODEL_*  : conversion applied to the raw network output            */
+  int32_t guidance;    /* DPM_GUIDE_*                                                            */
+  int32_t outer_step;  /* `step` handed to correcting_xt_fn(x, t, step) for this stage's output  */
+  int32_t emits_state; /* 1: x_out is a solver state x_i (goes to `intermediates`), 0: mid-stage */
+  int32_t x_src;       /* DPM_SRC_*: which buffer is the update's x                              */
+  int32_t xe_src;      /* DPM_SRC_*: which buffer the network was evaluated on                   */
+  int32_t h1_slot;     /* history slot read as h1, -1 = none                                     */
+  int32_t h2_slot;     /* history slot read as h2, -1 = none                                     */
+  int32_t m_slot;      /* history slot written with mn, -1 = none                                */
+  float t_eval;        /* continuous time of the network evaluation (fp32 as the reference)      */
+  float t_input;       /* model time label: (t - 1/N)*1000 for discrete schedules (ref :278)     */
+  float t_out;         /* continuous time of x_out                                               */
+  float alpha_e;       /* alpha(t_eval)                                                          */
+  float sigma_e;       /* sigma(t_eval)                                                          */
+  float cfg_scale;     /* guidance_scale as fp32 (ref :330)                                      */
+  float cg_scale;      /* fl(guidance_scale * sigma(t_eval))  (ref :321)                         */
+  float cx, c0, c1, c2; /* update coefficients, reference association (see kernels)              */
+  float k[5];          /* difference-quotient scalars: 1/r0, 1/r1, ...                           */
+  float thr_ratio;     /* dynamic_thresholding_ratio                                             */
+  float thr_max;       /* thresholding_max_val                                                   */
+} dpm_stage;
+
+/* ---- buffers of one launch ------------------------------------------------------------- */
+typedef struct dpm_buffers {
+  const void* x;    /* state the update starts from                          [n] state dtype     */
+  const void* xe;   /* state the network saw (NULL = same as x)              [n] state dtype     */
+  const void* e0;   /* raw network output (conditional half under CFG)       [n] eps dtype       */
+  const void* e1;   /* raw unconditional output (CFG only)                   [n] eps dtype       */
+  const void* g;    /* classifier gradient (classifier guidance only)        [n] eps dtype       */
+  const void* h1;   /* cached model value                                    [n] state dtype     */
+  const void* h2;   /* cached model value                                    [n] state dtype     */
+  void* x_out;      /* result of the update                                  [n] state dtype     */
+  void* m_out;      /* new model value (only if DPM_F_STORE_M)               [n] state dtype     */
+  void* workspace;  /* thresholding scratch, dpm_threshold_workspace_bytes() bytes (may be NULL) */
+  int64_t n;          /* total elements = batch * per_sample                                     */
+  int64_t batch;      /* number of independent samples                                           */
+  int32_t state_dtype; /* DPM_DTYPE_* of x, xe, h1, h2, x_out, m_out                             */
+  int32_t eps_dtype;   /* DPM_DTYPE_* of e0, e1, g                                               */
+} dpm_buffers;
+
+/* ---- noise schedule (NoiseScheduleVP, ref :6-167) --------------------------------------- */
+typedef struct dpm_schedule dpm_schedule;
+
+/* discrete-time schedules; `clip` != 0 applies numerical_clip_alpha at lambda = -5.1 (ref :114-125). */
+int dpm_schedule_create_betas_f32(const float* betas, int n, int clip, dpm_schedule** out);           /* ref :100 */
+int dpm_schedule_create_betas_f64(const double* betas, int n, int clip, dpm_schedule** out);
+int dpm_schedule_create_alphas_cumprod_f32(const float* ac, int n, int clip, dpm_schedule** out);      /* ref :103 */
+int dpm_schedule_create_alphas_cumprod_f64(const double* ac, int n, int clip, dpm_schedule** out);
+int dpm_schedule_create_log_alpha(const float* log_alpha, int n, dpm_schedule** out);                  /* ready table */
+int dpm_schedule_create_linear(double beta_0, double beta_1, dpm_schedule** out);                      /* ref :109-112 */
+void dpm_schedule_destroy(dpm_schedule* s);
+int dpm_schedule_is_discrete(const dpm_schedule* s);
+int dpm_schedule_total_N(const dpm_schedule* s);                                                       /* ref :106,:110 */
+/* borrowed pointers into the handle: log_alpha_array / t_array of ref :105,:107 (K floats each). */
+int dpm_schedule_tables(const dpm_schedule* s, const float** log_alpha, const float** t_array, int* K);
+/* marginal_log_mean_coeff / marginal_alpha / marginal_std / marginal_lambda / inverse_lambda (ref :127-167) */
+int dpm_schedule_eval(const dpm_schedule* s, int what, const float* in, int n, float* out);
+
+/* ---- time grids (ref :453-539) ---------------------------------------------------------- */
+int dpm_time_steps(const dpm_schedule* s, int skip_type, double t_T, double t_0, int N, float* out /* N+1 */);
+int dpm_singlestep_orders(int steps, int order, int* orders /* >= steps */, int* n_orders);
+int dpm_singlestep_grid(const dpm_schedule* s, int steps, int order, int skip_type, double t_T, double t_0,
+                        float* outer /* >= steps+1 */, int* orders /* >= steps */, int* n_orders);
+
+/* ---- plan: DPM_Solver.sample() unrolled into stages (ref :1047-1245) ---------------------- */
+typedef struct dpm_plan_desc {
+  int32_t algorithm_type;    /* DPM_ALGO_*                        */
+  int32_t method;            /* DPM_METHOD_*                      */
+  int32_t order;             /* 1..3                              */
+  int32_t steps;             /* NFE                               */
+  int32_t skip_type;         /* DPM_SKIP_*                        */
+  int32_t solver_type;       /* DPM_SOLVER_*                      */
+  int32_t lower_order_final; /* bool                              */
+  int32_t denoise_to_zero;   /* bool                              */
+  int32_t model_type;        /* DPM_MODEL_*                       */
+  int32_t guidance;          /* DPM_GUIDE_*                       */
+  int32_t thresholding;      /* bool: correcting_x0_fn == "dynamic_thresholding" */
+  int32_t reserved;
+  double t_start;            /* t_T                               */
+  double t_end;              /* t_0                               */
+  double guidance_scale;
+  double thr_ratio;          /* dynamic_thresholding_ratio        */
+  double thr_max;            /* thresholding_max_val              */
+} dpm_plan_desc;
+
+typedef struct dpm_plan dpm_plan;
+int dpm_plan_create(const dpm_schedule* s, const dpm_plan_desc* d, dpm_plan** out);
+void dpm_plan_destroy(dpm_plan* p);
+int dpm_plan_num_stages(const dpm_plan* p);
+int dpm_plan_num_slots(const dpm_plan* p);                 /* history buffers the loop needs      */
+int dpm_plan_stage(const dpm_plan* p, int i, dpm_stage* out);
+int dpm_plan_timesteps(const dpm_plan* p, float* out, int cap, int* n); /* solver grid t_0..t_K    */
+
+/* ---- coefficient builders for the reference's public per-update methods -------------------- */
+/* dpm_solver_first_update (ref :547-592) */
+int dpm_coef_first(const dpm_schedule* s, int algo, float t_s, float t_t, dpm_stage* out);
+/* multistep_dpm_solver_update (ref :932-954): t_prev[0..order-1] oldest..newest */
+int dpm_coef_multistep(const dpm_schedule* s, int algo, int solver_type, int order, const float* t_prev, float t_t,
+                       dpm_stage* out);
+/* singlestep_dpm_solver_update (ref :906-930): fills `order` stages.  r_mode 0: r1/r2 are the reference's
+   Python-float defaults or user floats (double arithmetic then one fp32 rounding), 1: fp32 tensors. */
+int dpm_coef_singlestep(const dpm_schedule* s, int algo, int solver_type, int order, float t_s, float t_t,
+                        double r1, double r2, int r_mode, dpm_stage* out /* [order] */);
+/* fill the prologue scalars (alpha_e, sigma_e, t_input, guidance) of a stage evaluated at t */
+int dpm_coef_prologue(const dpm_schedule* s, float t_eval, int model_type, int guidance, double guidance_scale,
+                      dpm_stage* inout);
+
+/* ---- device side --------------------------------------------------------------------------- */
+/* one fused stage kernel, asynchronous on `stream` */
+int dpm_stage_launch(const dpm_stage* st, const dpm_buffers* b, void* stream);
+/* scratch needed by stages with DPM_F_THRESH (0 when the sample fits the LDS-resident path) */
+size_t dpm_threshold_workspace_bytes(int64_t batch, int64_t per_sample);
+/* x_t = alpha_t*x + sigma_t*noise for nt times (add_noise, ref :1012-1030); out is [nt, n] */
+int dpm_add_noise_launch(const dpm_schedule* s, const float* t_host, int nt, const void* x, const void* noise,
+                         void* out, int64_t n, int dtype, void* stream);
+/* per-sample error norm of the adaptive solver (ref :999-1001): E_b = sqrt(mean(((xh-xl)/delta)^2)) */
+int dpm_adaptive_error_launch(const void* x_lower, const void* x_higher, const void* x_prev, float atol, float rtol,
+                              float* e_out /* [batch] device */, int64_t batch, int64_t per_sample, int dtype,
+                              void* stream);
+
+/* native sample loop for non-Python hosts and for the solver-only benchmark.
+   model(user, stage, x, t_input, t_eval, e0_out, e1_out): evaluate the network on x, write the raw output(s);
+   NULL means the outputs are already staged in e0/e1 (frozen model).  All buffers are the caller's:
+   xbuf[0] holds x_T and is only read; xbuf[1..3] are state-sized scratch the loop rotates through;
+   hist[num_slots] cache model values.  On return *result is the index of the xbuf holding the final sample. */
+typedef int (*dpm_model_cb)(void* user, const dpm_stage* st, const void* x, void* e0, void* e1, void* stream);
+typedef struct dpm_run_buffers {
+  void* xbuf[4];
+  void* hist[3];
+  void* e0;
+  void* e1;
+  void* workspace;
+  int64_t n, batch;
+  int32_t state_dtype, eps_dtype;
+} dpm_run_buffers;
+int dpm_plan_run(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model_cb model, void* user, void* stream,
+                 int* result);
+/* profiling variants: every kernel is launched with hipExtLaunchKernelGGL start/stop events, so the reported
+   time is the kernel's own execution time (what rocprofv3 --kernel-trace reports), without launch gaps.
+   dpm_plan_run_timed runs the frozen-model trajectory, synchronises the stream once at the end and fills
+   ms_per_stage[num_stages]. */
+int dpm_stage_launch_timed(const dpm_stage* st, const dpm_buffers* b, void* stream, float* ms);
+int dpm_plan_run_timed(const dpm_plan* p, const dpm_run_buffers* rb, void* stream, float* ms_per_stage, int* result);
+
+/* ---- misc ---------------------------------------------------------------------------------- */
+int dpm_version(void);
+const char* dpm_last_error(void); /* thread-local text of the last non-zero return */
+int dpm_device_info(int* n_cu, int* lds_bytes, char* arch, int arch_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPM_HIP_H */

@@ -1,0 +1,87 @@
+"""numpy test double of `dpm_stage_launch` -- TEST INFRASTRUCTURE, never imported by the product.
+
+`-m "not gpu"` tests monkeypatch `dpm_solver_amd.solver._launch_stage` with `launch_stage_double` so that
+the complete host side (C planner coefficients, plan walking, buffer roles, wrapper batching, callbacks,
+dtype policy) can be run on CPU tensors and compared with the goldens generated from the reference.
+The arithmetic restates the device functions `prologue<>` / `combine<>` of
+dpm_solver_amd/csrc/dpm_kernels.hip one to one, in np.float32; the GPU parity tests then only have to show
+kernel == this double (they show more: kernel vs oracle and vs goldens directly).
+"""
+import numpy as np
+import torch
+
+from dpm_solver_amd import _lib as L
+from oracle import dpm_oracle as O
+
+F32 = np.float32
+
+
+def _np(t):
+    return None if t is None else t.detach().cpu().float().numpy()
+
+
+def to_noise(o, xe, st):
+    a, s = F32(st.alpha_e), F32(st.sigma_e)
+    if st.model_type == L.MODEL["x_start"]:
+        return (xe - a * o) / s
+    if st.model_type == L.MODEL["v"]:
+        return a * o + s * xe
+    if st.model_type == L.MODEL["score"]:
+        return (-s) * o
+    return o
+
+
+def prologue(st, xe, e0, e1, g):
+    if st.guidance == L.GUIDE["classifier-free"]:
+        nu, nc = to_noise(e1, xe, st), to_noise(e0, xe, st)
+        eps = nu + F32(st.cfg_scale) * (nc - nu)
+    elif st.guidance == L.GUIDE["classifier"]:
+        eps = to_noise(e0, xe, st) - F32(st.cg_scale) * g
+    else:
+        eps = to_noise(e0, xe, st)
+    if st.flags & L.F_TO_X0:
+        return ((xe - F32(st.sigma_e) * eps) / F32(st.alpha_e)).astype(F32)
+    return eps.astype(F32)
+
+
+def combine(st, x, mn, h1, h2):
+    cx, c0, c1, c2 = F32(st.cx), F32(st.c0), F32(st.c1), F32(st.c2)
+    k = [F32(v) for v in st.k]
+    if st.form == L.FORM_LIN1:
+        return cx * x - c0 * mn
+    if st.form == L.FORM_TWO:
+        D = k[0] * (mn - h1)
+        P = h1 if (st.flags & L.F_BASE_HIST) else mn
+        return (cx * x - c0 * P) - c1 * D
+    if st.form == L.FORM_MS3:
+        D1_0 = k[0] * (mn - h1)
+        D1_1 = k[1] * (h1 - h2)
+        dd = D1_0 - D1_1
+        D1 = D1_0 + k[2] * dd
+        D2 = k[3] * dd
+        return ((cx * x - c0 * mn) - c1 * D1) - c2 * D2
+    if st.form == L.FORM_SS3T:
+        D1_0 = k[0] * (h2 - h1)
+        D1_1 = k[1] * (mn - h1)
+        D1 = (k[2] * D1_0 - k[3] * D1_1) / k[4]
+        D2 = (F32(2.0) * (D1_1 - D1_0)) / k[4]
+        return ((cx * x - c0 * h1) - c1 * D1) - c2 * D2
+    if st.form == L.FORM_DENOISE:
+        return mn
+    raise AssertionError(st.form)
+
+
+def launch_stage_double(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None):
+    ref_t = x if x is not None else xe
+    xn, xen = _np(x), _np(xe)
+    if xen is None:
+        xen = xn
+    if xn is None:
+        xn = xen
+    mn = prologue(st, xen, _np(e0), _np(e1), _np(g))
+    if st.flags & L.F_THRESH:
+        mn = O.dynamic_threshold(mn, F32(st.thr_ratio), F32(st.thr_max))
+    out = combine(st, xn, mn, _np(h1), _np(h2)).astype(F32)
+    store = bool(st.flags & L.F_STORE_M) if want_m is None else want_m
+    conv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(state_dtype).reshape(ref_t.shape)
+    return conv(out), (conv(mn) if store else None)

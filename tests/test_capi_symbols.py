@@ -1,0 +1,43 @@
+"""The C-ABI library loads without a GPU and exports every function include/dpm_hip.h declares."""
+import ctypes
+import os
+import re
+
+import dpm_solver_amd
+from dpm_solver_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "dpm_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int|void|size_t|char\s*\*|const char\s*\*)\s+\**(dpm_[A-Za-z0-9_]+)\s*\(", src, flags=re.M)
+    return sorted(set(names))
+
+
+def test_header_functions_are_exported_and_bound():
+    decl = declared_functions()
+    assert len(decl) >= 30, decl
+    lib = ctypes.CDLL(L.LIB_PATH)
+    for name in decl:
+        assert hasattr(lib, name), "libdpm_hip.so does not export %s" % name
+    assert sorted(L.SYMBOLS) == decl, (set(decl) ^ set(L.SYMBOLS))
+
+
+def test_struct_layouts_match_header():
+    # sizes are part of the ABI: Stage = 12 int32 + 18 float, Buffers = 10 ptr + 2 int64 + 2 int32
+    assert ctypes.sizeof(L.Stage) == 12 * 4 + 18 * 4
+    assert ctypes.sizeof(L.Buffers) == 10 * 8 + 2 * 8 + 2 * 4
+    assert ctypes.sizeof(L.PlanDesc) == 12 * 4 + 5 * 8
+    assert ctypes.sizeof(L.RunBuffers) == 4 * 8 + 3 * 8 + 3 * 8 + 2 * 8 + 2 * 4
+
+
+def test_version_and_error_text():
+    assert L.lib.dpm_version() == 100
+    rc = L.lib.dpm_time_steps(None, 0, 1.0, 0.001, 5, None)
+    assert rc == L.ERR_ARG and b"time_steps" in L.lib.dpm_last_error()
+
+
+def test_package_reports_library_path():
+    assert os.path.exists(dpm_solver_amd.LIB_PATH)

@@ -1,0 +1,71 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard a batch, sample their shards (host logic + numpy kernel
+double), all-gather, and must reproduce the unsharded result bit for bit (batch-shard invariance)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, batch, q):
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cases as C
+        import dpm_solver_amd.solver as S
+        from dpm_solver_amd import distributed as DD
+        from engine_cases import build_solver, sample_kwargs
+        from kernel_double import launch_stage_double
+        S._launch_stage = launch_stage_double
+        S._require_gpu = lambda x: None
+        case = dict(C.E2E_BY_NAME["cfg_ms2"], shape=(batch, 4, 8, 8))
+        x = torch.from_numpy(C.x_T_for(case))
+        lo, hi = DD.shard_bounds(batch, rank, world)
+        # per-sample conditioning is sharded the same way as the state
+        scase = dict(case, shape=(hi - lo, 4, 8, 8))
+        dpm = build_solver(scase, "cpu")
+        kw = sample_kwargs(case, return_intermediate=False)
+        out = DD.sample_sharded(dpm, x, **kw)
+        full = build_solver(case, "cpu").sample(x, **kw)
+        ok = bool(torch.equal(out, full)) and out.shape[0] == batch
+        with pytest.raises(NotImplementedError):
+            DD.sample_sharded(dpm, x, method="adaptive")
+        assert DD.rank_seed(7) == 7 + rank
+        q.put((rank, ok, tuple(out.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch", [4, 5])
+def test_sharded_sampling_matches_unsharded(batch):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + batch
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, batch, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] for r in res), res
+
+
+def test_shard_bounds_cover_batch():
+    from dpm_solver_amd.distributed import shard_bounds
+    for b in [0, 1, 7, 8, 9, 256]:
+        for w in [1, 2, 3, 8]:
+            spans = [shard_bounds(b, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == b
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1

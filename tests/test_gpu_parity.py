@@ -1,0 +1,345 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the numpy oracle, the reference goldens and
+size-independent properties at BASELINE.json's full sizes.  Run on an MI355X:  pytest -m gpu
+"""
+import ctypes as C_
+
+import numpy as np
+import pytest
+import torch
+
+import cases as C
+import dpm_solver_amd as D
+import dpm_solver_amd.solver as S
+from conftest import rel_err
+from dpm_solver_amd import _lib as L
+from engine_cases import build_solver, make_schedule, run_case, sample_kwargs, tt
+from kernel_double import launch_stage_double
+from oracle import dpm_oracle as O
+import test_oracle_golden as TO
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+TOL = 1e-5          # north-star tolerance: max|a-b| / max|b|, fp32 state
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert torch.cuda.is_available(), "these tests need a GPU; run with -m 'not gpu' elsewhere"
+    yield
+    torch.cuda.synchronize()
+
+
+def test_library_and_device():
+    n_cu, lds = C_.c_int(), C_.c_int()
+    arch = C_.create_string_buffer(64)
+    L.check(L.lib.dpm_device_info(C_.byref(n_cu), C_.byref(lds), arch, 64))
+    assert arch.value.decode().startswith("gfx950"), arch.value
+    assert n_cu.value >= 64 and lds.value >= 64 * 1024
+    print("device:", arch.value.decode(), n_cu.value, "CUs", lds.value, "B LDS")
+
+
+# ------------------------------------------------------------------------------------------------
+# end to end: HIP engine vs goldens from the real reference, vs oracle, vs the numpy kernel double
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", [c["name"] for c in C.E2E_CASES])
+def test_e2e_vs_reference_goldens_and_oracle(golden, name, monkeypatch):
+    case = C.E2E_BY_NAME[name]
+    trace = []
+    xf, inter = run_case(case, DEV, trace)
+    g = lambda k: golden.get("e2e", "e2e/%s/%s" % (name, k))
+    assert xf.is_cuda and xf.dtype == torch.float32
+    assert len(inter) == int(g("n_intermediates"))
+    got = xf.cpu().numpy()
+    e_ref = rel_err(got, g("final"))
+    assert e_ref < TOL, ("vs reference golden", e_ref)
+    xo, _ = TO.run_oracle_case(case)
+    e_or = rel_err(got, xo)
+    assert e_or < TOL, ("vs oracle", e_or)
+    if case["intermediates"]:
+        ri = g("intermediates")
+        for i, v in enumerate(inter):
+            assert rel_err(v.float().cpu().numpy(), ri[i]) < TOL, i
+    np.testing.assert_array_equal(np.array([b for b, _ in trace]), g("trace_b"))
+    # same host logic with the numpy kernel double on CPU: the device arithmetic is bit-identical
+    monkeypatch.setattr(S, "_launch_stage", launch_stage_double)
+    monkeypatch.setattr(S, "_require_gpu", lambda x: None)
+    xd, _ = run_case(case, "cpu")
+    np.testing.assert_array_equal(got, xd.numpy())
+
+
+# ------------------------------------------------------------------------------------------------
+# per-update methods (ref :547-954)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sname", ["sd", "vp_linear"])
+@pytest.mark.parametrize("algo", ["dpmsolver++", "dpmsolver"])
+def test_public_update_methods(golden, sname, algo):
+    g = lambda k: torch.from_numpy(golden.get("updates", k)).to(DEV)
+    r = lambda k: golden.get("updates", k)
+    x, m = g("upd/x"), [g("upd/m%d" % i) for i in range(3)]
+    t = [torch.tensor([v], device=DEV) for v in golden.get("updates", "upd/t")]
+    ns = make_schedule(sname)
+    dpm = D.DPM_Solver(D.model_wrapper(lambda xx, tv: C.model_half(xx, tv), ns), ns, algorithm_type=algo)
+    pre = "upd/%s/%s/" % (sname, algo)
+    tol = 3e-6
+    assert rel_err(dpm.dpm_solver_first_update(x, t[2], t[3], model_s=m[2]).cpu().numpy(), r(pre + "first")) < tol
+    for st in ["dpmsolver", "taylor"]:
+        got = dpm.multistep_dpm_solver_second_update(x, [m[1], m[2]], [t[1], t[2]], t[3], solver_type=st)
+        assert rel_err(got.cpu().numpy(), r(pre + "ms2/" + st)) < tol
+        got = dpm.multistep_dpm_solver_third_update(x, m, t[:3], t[3], solver_type=st)
+        assert rel_err(got.cpu().numpy(), r(pre + "ms3/" + st)) < tol
+        for (r1, r2, tag) in [(None, None, "def"), (0.3, 0.75, "cust")]:
+            xt, im = dpm.singlestep_dpm_solver_second_update(x, t[2], t[3], r1=r1, return_intermediate=True, solver_type=st)
+            assert rel_err(xt.cpu().numpy(), r(pre + "ss2/%s/%s/x_t" % (st, tag))) < tol
+            xt, im = dpm.singlestep_dpm_solver_third_update(x, t[2], t[3], r1=r1, r2=r2, return_intermediate=True,
+                                                            solver_type=st)
+            assert rel_err(xt.cpu().numpy(), r(pre + "ss3/%s/%s/x_t" % (st, tag))) < tol
+            assert rel_err(im["model_s2"].cpu().numpy(), r(pre + "ss3/%s/%s/model_s2" % (st, tag))) < tol
+
+
+# ------------------------------------------------------------------------------------------------
+# dynamic thresholding: exact order statistics (ref :416-425)
+# ------------------------------------------------------------------------------------------------
+def test_dynamic_thresholding_bit_exact(golden):
+    ns = make_schedule("ddpm")
+    for tag in "abcde":
+        g = lambda k: golden.get("quantile", "quant/%s/%s" % (tag, k))
+        p, mv = g("p_mv")
+        dpm = D.DPM_Solver(lambda x, t: x, ns, correcting_x0_fn="dynamic_thresholding",
+                           thresholding_max_val=float(mv), dynamic_thresholding_ratio=float(p))
+        y = dpm.dynamic_thresholding_fn(torch.from_numpy(g("x0")).to(DEV), None)
+        np.testing.assert_array_equal(y.cpu().numpy(), g("y"))          # vs torch.quantile in the reference
+    # ties / plateaus / all-equal / negative zeros / n = 1, 2: against the oracle
+    rng = np.random.default_rng(0)
+    for shape, p in [((3, 1, 1, 1), 0.995), ((3, 1, 1, 2), 0.5), ((4, 1, 7, 9), 0.3), ((2, 3, 37, 41), 0.995),
+                     ((2, 1, 100, 100), 0.999), ((5, 3, 64, 64), 0.0), ((2, 3, 96, 96), 0.75)]:
+        x0 = (rng.standard_normal(shape) * 2.0).astype(F32)
+        x0.reshape(shape[0], -1)[0, ::3] = np.float32(1.25)               # plateaus
+        x0.reshape(shape[0], -1)[-1, :] = np.float32(-0.0)
+        dpm = D.DPM_Solver(lambda x, t: x, ns, correcting_x0_fn="dynamic_thresholding", dynamic_thresholding_ratio=p)
+        y = dpm.dynamic_thresholding_fn(torch.from_numpy(x0).to(DEV), None)
+        np.testing.assert_array_equal(y.cpu().numpy(), O.dynamic_threshold(x0, p, 1.0))
+
+
+def test_dynamic_thresholding_sample_too_large_fails_loudly():
+    ns = make_schedule("ddpm")
+    dpm = D.DPM_Solver(lambda x, t: x, ns, correcting_x0_fn="dynamic_thresholding")
+    with pytest.raises(NotImplementedError, match="LDS-resident"):
+        dpm.dynamic_thresholding_fn(torch.zeros(1, 3, 256, 256, device=DEV), None)
+
+
+# ------------------------------------------------------------------------------------------------
+# add_noise, model evaluation methods, adaptive
+# ------------------------------------------------------------------------------------------------
+def test_add_noise(golden):
+    for sname in ["sd", "vp_linear"]:
+        dpm = D.DPM_Solver(lambda x, t: x, make_schedule(sname))
+        for tag in ["one", "three"]:
+            g = lambda k: golden.get("add_noise", "addnoise/%s/%s/%s" % (sname, tag, k))
+            y = dpm.add_noise(tt(g("x"), DEV), tt(g("t"), DEV), noise=tt(g("noise"), DEV))
+            assert y.shape == g("y").shape
+            assert rel_err(y.cpu().numpy(), g("y")) < 2e-6
+
+
+def test_model_evaluation_methods():
+    for name in ["mt_v", "cfg_ms2", "clsg_ms2", "cfg5_thresh_small", "mt_xstart_noise"]:
+        case = C.E2E_BY_NAME[name]
+        dpm = build_solver(case, DEV)
+        osol = TO.build_oracle_solver(case)
+        xn = C.x_T_for(case)
+        x = tt(xn, DEV)
+        t = torch.tensor([0.6172], device=DEV)
+        want_eps = osol.noise_pred(xn, F32(0.6172))
+        want_x0 = osol.data_pred(xn, F32(0.6172))
+        assert rel_err(dpm.noise_prediction_fn(x, t).cpu().numpy(), want_eps) < 2e-6
+        assert rel_err(dpm.data_prediction_fn(x, t).cpu().numpy(), want_x0) < 2e-6
+        assert rel_err(dpm._wrapped(x, t.expand(x.shape[0])).cpu().numpy(), want_eps) < 2e-6
+
+
+@pytest.mark.parametrize("name,sname,order,algo", [("a12", "vp_linear", 2, "dpmsolver"), ("a23", "vp_linear", 3, "dpmsolver"),
+                                                   ("a23pp", "sd", 3, "dpmsolver++")])
+def test_adaptive(golden, capsys, name, sname, order, algo):
+    ns = make_schedule(sname)
+    dpm = D.DPM_Solver(D.model_wrapper(lambda xx, t: C.model_half(xx, t), ns), ns, algorithm_type=algo)
+    g = lambda k: golden.get("adaptive", "adaptive/%s/%s" % (name, k))
+    xf = dpm.sample(tt(g("x"), DEV), method="adaptive", order=order, t_end=1e-3)
+    out = capsys.readouterr().out
+    assert out.strip() == "adaptive solver nfe %d" % int(g("nfe"))      # same accept/reject sequence as the reference
+    assert rel_err(xf.cpu().numpy(), g("final")) < 5e-5
+
+
+def test_callbacks(golden):
+    case = C.E2E_BY_NAME["cfg1_small"]
+    ns = make_schedule("sd")
+    x = tt(C.x_T_for(case), DEV)
+    mask = torch.from_numpy(golden.get("callbacks", "cb/mask")).to(DEV)
+    cxt = lambda xt, t, step: xt * mask + (1.0 - mask) * (0.25 * step)
+    cx0 = lambda x0, t: torch.clamp(x0, -1.5, 1.5)
+    fn = D.model_wrapper(lambda xx, t: C.model_half(xx, t), ns)
+    for tag, kw in [("xt", dict(correcting_xt_fn=cxt)), ("x0", dict(correcting_x0_fn=cx0)),
+                    ("both", dict(correcting_xt_fn=cxt, correcting_x0_fn=cx0))]:
+        for method, order, steps in [("multistep", 2, 8), ("singlestep", 3, 8)]:
+            dpm = D.DPM_Solver(fn, ns, **kw)
+            xf, inter = dpm.sample(x, steps=steps, order=order, method=method, denoise_to_zero=True, return_intermediate=True)
+            pre = "cb/%s/%s/" % (tag, method)
+            assert rel_err(xf.cpu().numpy(), golden.get("callbacks", pre + "final")) < TOL
+            ri = golden.get("callbacks", pre + "intermediates")
+            for i, v in enumerate(inter):
+                assert rel_err(v.cpu().numpy(), ri[i]) < TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# dtypes, ragged sizes, unaligned views, empty batch
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sdt,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+def test_low_precision_state(sdt, tol):
+    """fp16 / bf16 state (BASELINE cfg2's bandwidth mode): fp32 math, one rounding per stored tensor.  The
+    reference itself cannot hold a half-precision state with a discrete schedule (it promotes), so the
+    comparison is against the fp32 oracle with the half-precision tolerance stated here."""
+    case = dict(C.E2E_BY_NAME["cfg1_small"], shape=(4, 4, 64, 64))
+    xo, _ = TO.run_oracle_case(case)
+    dpm = build_solver(case, DEV, state_dtype=sdt)
+    x = tt(C.x_T_for(case), DEV).to(sdt)
+    xf = dpm.sample(x, **sample_kwargs(case, False))
+    assert xf.dtype == sdt
+    assert rel_err(xf.float().cpu().numpy(), xo) < tol
+
+
+@pytest.mark.parametrize("edt", [torch.float16, torch.bfloat16])
+def test_half_eps_fp32_state(edt):
+    """SD under autocast: the UNet returns fp16 eps, the solver state stays fp32."""
+    case = dict(C.E2E_BY_NAME["cfg1_small"], shape=(2, 4, 32, 32), model="half")
+    ns = make_schedule("sd")
+    net = lambda x, t: (x * 0.5).to(edt)
+    onet = lambda x, t: torch.from_numpy(x * F32(0.5)).to(edt).float().numpy()      # same rounding of eps
+    dpm = D.DPM_Solver(D.model_wrapper(net, ns), ns)
+    osch = TO.make_schedule("sd")
+    xo = O.Solver(O.wrap_model(onet, osch), osch).sample(C.x_T_for(case), steps=20)
+    xf = dpm.sample(tt(C.x_T_for(case), DEV), steps=20)
+    assert xf.dtype == torch.float32
+    assert rel_err(xf.cpu().numpy(), xo) < TOL
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (3, 1, 1, 7), (2, 3, 5, 7), (1, 4, 64, 64), (5, 3, 33, 31)])
+def test_ragged_sizes_and_unaligned_views(shape):
+    case = dict(C.E2E_BY_NAME["ms3"], shape=shape, model="tdep")
+    xo, _ = TO.run_oracle_case(case)
+    xf, _ = run_case(case, DEV)
+    assert rel_err(xf.cpu().numpy(), xo) < TOL
+    # state handed over as a view with a 4-byte storage offset: the launcher must take the scalar kernel
+    dpm = build_solver(case, DEV)
+    n = int(np.prod(shape))
+    buf = torch.zeros(n + 1, device=DEV)
+    buf[1:] = tt(C.x_T_for(case), DEV).reshape(-1)
+    xv = buf[1:].reshape(shape)
+    assert xv.data_ptr() % 16 != 0
+    xf2 = dpm.sample(xv, **sample_kwargs(case, False))
+    np.testing.assert_array_equal(xf2.cpu().numpy(), xf.cpu().numpy())
+
+
+def test_empty_batch():
+    ns = make_schedule("sd")
+    dpm = D.DPM_Solver(D.model_wrapper(lambda x, t: x, ns), ns)
+    out = dpm.sample(torch.zeros(0, 4, 8, 8, device=DEV), steps=5)
+    assert out.shape == (0, 4, 8, 8)
+
+
+def test_cpu_tensor_rejected():
+    ns = make_schedule("sd")
+    dpm = D.DPM_Solver(D.model_wrapper(lambda x, t: x, ns), ns)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dpm.sample(torch.zeros(2, 4, 8, 8), steps=5)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties
+# ------------------------------------------------------------------------------------------------
+def _sd_solver(model=lambda x, t: x, **kw):
+    ns = make_schedule("sd")
+    return D.DPM_Solver(D.model_wrapper(model, ns), ns, **kw)
+
+
+@pytest.mark.parametrize("sdt", [torch.float16, torch.float32])
+def test_cfg2_full_size_shard_invariance_and_linearity(sdt):
+    """[256,4,64,64], DPM-Solver++(2M), 20 steps.  (i) batch-shard invariance: sampling the whole batch equals
+    sampling its shards (what the 8-GPU run relies on), bit for bit; (ii) with a linear frozen network the
+    solver is linear in x_T: scaling by 2 is exact in binary floating point; (iii) a slice matches the oracle."""
+    rng = np.random.default_rng(5)
+    xn = rng.standard_normal((256, 4, 64, 64)).astype(F32)
+    x = torch.from_numpy(xn).to(DEV).to(sdt)
+    dpm = _sd_solver(state_dtype=sdt)
+    full = dpm.sample(x, steps=20)
+    assert full.dtype == sdt
+    parts = torch.cat([dpm.sample(x[i:i + 64], steps=20) for i in range(0, 256, 64)])
+    assert torch.equal(full, parts)
+    twice = dpm.sample(x * 2, steps=20)
+    if sdt == torch.float32:
+        assert torch.equal(twice, full * 2)
+    else:   # values in fp16's subnormal range round differently after doubling: one subnormal ulp at most
+        assert float((twice.float() - 2 * full.float()).abs().max()) <= 2.0 ** -23
+    osch = TO.make_schedule("sd")
+    xs = x[:2].float().cpu().numpy()
+    xo = O.Solver(O.wrap_model(lambda a, t: a, osch), osch).sample(xs, steps=20)
+    assert rel_err(full[:2].float().cpu().numpy(), xo) < (TOL if sdt == torch.float32 else 4e-3)
+
+
+def test_cfg3_full_size_shard_invariance():
+    """[64,3,256,256] fp32, DPM-Solver-3 singlestep, 15 NFE, CFG 7.5 (network batch 128)."""
+    case = dict(C.E2E_BY_NAME["cfg3_dpmsolver"], shape=(64, 3, 256, 256))
+    rng = np.random.default_rng(6)
+    x = torch.from_numpy(rng.standard_normal(case["shape"]).astype(F32)).to(DEV)
+    dpm = build_solver(case, DEV)
+    full = dpm.sample(x, **sample_kwargs(case, False))
+    case8 = dict(case, shape=(8, 3, 256, 256))
+    dpm8 = build_solver(case8, DEV)
+    part = dpm8.sample(x[8:16], **sample_kwargs(case, False))
+    assert torch.equal(full[8:16], part)
+    small = dict(case, shape=(2, 3, 256, 256))
+    xo, _ = TO.build_oracle_solver(small).sample(x[:2].cpu().numpy(), **sample_kwargs(case, True))
+    assert rel_err(full[:2].cpu().numpy(), xo) < TOL
+
+
+def test_cfg5_full_size_thresholding():
+    """[32,3,64,64] pixel space, 2M++ with dynamic thresholding, 25 steps: every sample equals the oracle's."""
+    case = dict(C.E2E_BY_NAME["cfg5_thresh"], shape=(32, 3, 64, 64))
+    xo, _ = TO.run_oracle_case(case)
+    xf, _ = run_case(case, DEV)
+    assert rel_err(xf.cpu().numpy(), xo) < TOL
+    assert float(xf.abs().max()) <= 1.5
+
+
+# ------------------------------------------------------------------------------------------------
+# the native sample loop of the C ABI (dpm_plan_run) == the Python loop
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("method,order,steps", [("multistep", 2, 20), ("multistep", 3, 12), ("singlestep", 3, 14)])
+def test_plan_run_native_loop_matches_python_loop(method, order, steps):
+    ns = make_schedule("sd")
+    shape = (8, 4, 64, 64)
+    rng = np.random.default_rng(9)
+    x = torch.from_numpy(rng.standard_normal(shape).astype(F32)).to(DEV)
+    eps = torch.from_numpy(rng.standard_normal(shape).astype(F32)).to(DEV)       # frozen network output
+    dpm = D.DPM_Solver(D.model_wrapper(lambda xx, t: eps, ns), ns)
+    want = dpm.sample(x, steps=steps, order=order, method=method, solver_type="taylor")
+    plan = dpm._get_plan(method=method, order=order, steps=steps, skip_type="time_uniform", solver_type="taylor",
+                         lower_order_final=True, denoise_to_zero=False, t_T=1.0, t_0=1.0 / ns.total_N)
+    xb = [x.clone(), torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)]
+    hb = [torch.empty_like(x) for _ in range(3)]
+    rb = L.RunBuffers()
+    for i in range(4):
+        rb.xbuf[i] = xb[i].data_ptr()
+    for i in range(3):
+        rb.hist[i] = hb[i].data_ptr()
+    rb.e0 = eps.data_ptr()
+    rb.n, rb.batch, rb.state_dtype, rb.eps_dtype = x.numel(), shape[0], L.DTYPE_F32, L.DTYPE_F32
+    res = C_.c_int(-1)
+    L.check(L.lib.dpm_plan_run(plan.handle, C_.byref(rb), None, None,
+                               C_.c_void_p(torch.cuda.current_stream().cuda_stream), C_.byref(res)))
+    torch.cuda.synchronize()
+    assert torch.equal(xb[res.value], want)
+    assert torch.equal(xb[0], x)                                   # the caller's x_T is never written
+    # profiling variant: same result, one kernel-only duration per stage
+    ms = (C_.c_float * len(plan.stages))()
+    L.check(L.lib.dpm_plan_run_timed(plan.handle, C_.byref(rb), C_.c_void_p(torch.cuda.current_stream().cuda_stream),
+                                     ms, C_.byref(res)))
+    assert torch.equal(xb[res.value], want)
+    assert all(0.0 < v < 5.0 for v in ms), list(ms)

@@ -1,0 +1,249 @@
+"""Host side of the engine on CPU: C planner + Python mirror classes, with the HIP kernel replaced by the
+numpy test double (tests/kernel_double.py).  Compared against goldens generated from the real reference.
+
+What this pins without a GPU: every coefficient the planner produces (through their effect on full
+trajectories), the stage list / buffer-role choreography of sample(), wrapper batching for CFG and
+classifier guidance, time labels handed to the network, callbacks, dtype promotion, error conventions.
+"""
+import ctypes as C_
+
+import numpy as np
+import pytest
+import torch
+
+import cases as C
+import dpm_solver_amd as D
+import dpm_solver_amd.solver as S
+import dpm_solver_amd.wrapper as W
+from conftest import rel_err
+from dpm_solver_amd import _lib as L
+from engine_cases import build_solver, make_schedule, run_case, sample_kwargs, tt
+from kernel_double import launch_stage_double
+from oracle import dpm_oracle as O
+
+F32 = np.float32
+TOL = 1e-5
+
+
+@pytest.fixture(autouse=True)
+def cpu_double(monkeypatch):
+    monkeypatch.setattr(S, "_launch_stage", launch_stage_double)
+    monkeypatch.setattr(S, "_require_gpu", lambda x: None)
+
+
+def test_linspace_and_time_grids_bitwise_vs_torch_and_golden(golden):
+    ns = make_schedule("sd")
+    dpm = D.DPM_Solver(lambda x, t: x, ns)
+    for (a, b, n) in [(1.0, 1e-3, 20), (1.0, 1e-3, 15), (1.0, 1e-4, 10), (0.8, 0.0123, 6), (1.0, 0.001, 1000)]:
+        got = dpm.get_time_steps("time_uniform", a, b, n, "cpu")
+        assert torch.equal(got, torch.linspace(a, b, n + 1))
+    for key in golden.keys("timesteps"):
+        parts = key.split("/")
+        if parts[0] == "tsteps":
+            _, name, skip, spec = parts
+            tT, t0, N = spec.split("_")
+            dpm = D.DPM_Solver(lambda x, t: x, make_schedule(name))
+            got = dpm.get_time_steps(skip, float(tT), float(t0), int(N), "cpu").numpy()
+            np.testing.assert_allclose(got, golden.get("timesteps", key), rtol=2e-5, atol=2e-7)
+        elif parts[0] == "ssgrid" and parts[-1] == "t":
+            _, name, skip, spec, _ = parts
+            order, steps = map(int, spec.split("_"))
+            dpm = D.DPM_Solver(lambda x, t: x, make_schedule(name))
+            outer, orders = dpm.get_orders_and_timesteps_for_singlestep_solver(steps, order, skip, 1.0, 1e-3, "cpu")
+            assert orders == list(golden.get("timesteps", key[:-2] + "/orders"))
+            np.testing.assert_allclose(outer.numpy(), golden.get("timesteps", key), rtol=2e-5, atol=2e-7)
+
+
+@pytest.mark.parametrize("name", C.SCHEDULE_NAMES)
+def test_schedule_matches_oracle_bitwise_and_golden(golden, name):
+    """C planner (fp32, reference op order) == numpy oracle bit for bit; both within ulps of the reference."""
+    ns = make_schedule(name)
+    g = lambda k: golden.get("schedules", "sched/%s/%s" % (name, k))
+    import test_oracle_golden as T
+    osch = T.make_schedule(name)
+    assert ns.total_N == int(g("total_N")) == osch.total_N
+    if ns.schedule == "discrete":
+        np.testing.assert_array_equal(ns.log_alpha_array.numpy()[0], osch.log_alpha)
+        np.testing.assert_array_equal(ns.t_array.numpy(), g("t_array"))
+        assert ns.log_alpha_array.shape == (1, ns.total_N) and ns.t_array.shape == (1, ns.total_N)
+    t = torch.from_numpy(g("t"))
+    ok = np.isfinite(g("lambda"))
+    for meth, ofn, key in [("marginal_log_mean_coeff", osch.log_alpha_t, "log_mean_coeff"),
+                           ("marginal_alpha", osch.alpha, "alpha"), ("marginal_std", osch.std, "std"),
+                           ("marginal_lambda", osch.lam, "lambda")]:
+        got = getattr(ns, meth)(t).numpy()
+        np.testing.assert_array_equal(got[ok], ofn(g("t"))[ok])
+        np.testing.assert_allclose(got, g(key), rtol=2e-5, atol=2e-6)
+    lq = g("lambda_q")
+    fin = np.isfinite(lq)
+    np.testing.assert_array_equal(ns.inverse_lambda(torch.from_numpy(lq)).numpy()[fin], osch.inv_lam(lq)[fin])
+    # shape conventions of the reference: flattened for discrete, preserved for linear
+    q = torch.tensor(0.4321)
+    assert ns.marginal_lambda(q).shape == (torch.Size([1]) if ns.schedule == "discrete" else torch.Size([]))
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in C.E2E_CASES])
+def test_e2e_host_logic_against_reference_goldens(golden, name):
+    case = C.E2E_BY_NAME[name]
+    trace = []
+    xf, inter = run_case(case, "cpu", trace)
+    g = lambda k: golden.get("e2e", "e2e/%s/%s" % (name, k))
+    assert xf.dtype == torch.float32
+    assert len(inter) == int(g("n_intermediates"))
+    # time labels and batch sizes the network saw (CFG doubles the batch)
+    np.testing.assert_array_equal(np.array([b for b, _ in trace]), g("trace_b"))
+    np.testing.assert_allclose(np.array([float(t.reshape(-1)[0]) for _, t in trace], dtype=F32), g("trace_t"),
+                               rtol=1e-5, atol=2e-3)
+    for b, t in trace:
+        assert t.shape == (b,) and t.dtype == torch.float32
+    e = rel_err(xf.numpy(), g("final"))
+    assert e < TOL, e
+    if case["intermediates"]:
+        ri = g("intermediates")
+        for i, v in enumerate(inter):
+            assert rel_err(v.float().numpy(), ri[i]) < TOL, i
+
+
+def test_callbacks(golden):
+    case = C.E2E_BY_NAME["cfg1_small"]
+    ns = make_schedule("sd")
+    x = tt(C.x_T_for(case), "cpu")
+    mask = torch.from_numpy(golden.get("callbacks", "cb/mask"))
+    seen = []
+
+    def cxt(xt, t, step):
+        seen.append((step, tuple(t.shape)))
+        return xt * mask + (1.0 - mask) * (0.25 * step)
+
+    cx0 = lambda x0, t: torch.clamp(x0, -1.5, 1.5)
+    cx0_old = lambda x0: torch.clamp(x0, -1.5, 1.5)          # one-argument form of the older vendored revision
+    fn = D.model_wrapper(lambda xx, t: C.model_half(xx, t), ns)
+    for tag, kw in [("xt", dict(correcting_xt_fn=cxt)), ("x0", dict(correcting_x0_fn=cx0)),
+                    ("both", dict(correcting_xt_fn=cxt, correcting_x0_fn=cx0)), ("x0", dict(correcting_x0_fn=cx0_old))]:
+        for method, order, steps in [("multistep", 2, 8), ("singlestep", 3, 8)]:
+            seen.clear()
+            dpm = D.DPM_Solver(fn, ns, **kw)
+            xf, inter = dpm.sample(x, steps=steps, order=order, method=method, denoise_to_zero=True,
+                                   return_intermediate=True)
+            pre = "cb/%s/%s/" % (tag, method)
+            assert rel_err(xf.numpy(), golden.get("callbacks", pre + "final")) < TOL
+            ri = golden.get("callbacks", pre + "intermediates")
+            assert len(inter) == ri.shape[0]
+            for i, v in enumerate(inter):
+                assert rel_err(v.numpy(), ri[i]) < TOL
+            if "correcting_xt_fn" in kw:
+                steps_seen = [s for s, _ in seen]
+                assert steps_seen == (list(range(0, 10)) if method == "multistep" else list(range(0, 4)))   # orders [3,3,2] + denoise
+                assert seen[-1][1] == (1,)          # denoise_to_zero hands a (1,)-shaped t (ref :1236)
+
+
+@pytest.mark.parametrize("sname", ["sd", "vp_linear", "cosine4000"])
+@pytest.mark.parametrize("algo", ["dpmsolver++", "dpmsolver"])
+def test_public_update_methods(golden, sname, algo):
+    g = lambda k: torch.from_numpy(golden.get("updates", k))
+    x, m = g("upd/x"), [g("upd/m%d" % i) for i in range(3)]
+    t = [torch.tensor([v]) for v in golden.get("updates", "upd/t")]
+    ns = make_schedule(sname)
+    dpm = D.DPM_Solver(D.model_wrapper(lambda xx, tv: C.model_half(xx, tv), ns), ns, algorithm_type=algo)
+    pre = "upd/%s/%s/" % (sname, algo)
+    tol = 3e-6
+    assert rel_err(dpm.dpm_solver_first_update(x, t[2], t[3], model_s=m[2]).numpy(), g(pre + "first").numpy()) < tol
+    assert rel_err(dpm.multistep_dpm_solver_update(x, [m[2]], [t[2]], t[3], 1).numpy(), g(pre + "first").numpy()) < tol
+    for st in ["dpmsolver", "taylor"]:
+        got = dpm.multistep_dpm_solver_second_update(x, [m[1], m[2]], [t[1], t[2]], t[3], solver_type=st)
+        assert rel_err(got.numpy(), g(pre + "ms2/" + st).numpy()) < tol
+        got = dpm.multistep_dpm_solver_third_update(x, m, t[:3], t[3], solver_type=st)
+        assert rel_err(got.numpy(), g(pre + "ms3/" + st).numpy()) < tol
+        for (r1, r2, tag) in [(None, None, "def"), (0.3, 0.75, "cust")]:
+            xt, im = dpm.singlestep_dpm_solver_second_update(x, t[2], t[3], r1=r1, return_intermediate=True, solver_type=st)
+            assert rel_err(xt.numpy(), g(pre + "ss2/%s/%s/x_t" % (st, tag)).numpy()) < tol
+            assert rel_err(im["model_s1"].numpy(), g(pre + "ss2/%s/%s/model_s1" % (st, tag)).numpy()) < tol
+            xt, im = dpm.singlestep_dpm_solver_third_update(x, t[2], t[3], r1=r1, r2=r2, return_intermediate=True,
+                                                            solver_type=st)
+            assert rel_err(xt.numpy(), g(pre + "ss3/%s/%s/x_t" % (st, tag)).numpy()) < tol
+            assert rel_err(im["model_s1"].numpy(), g(pre + "ss3/%s/%s/model_s1" % (st, tag)).numpy()) < tol
+            assert rel_err(im["model_s2"].numpy(), g(pre + "ss3/%s/%s/model_s2" % (st, tag)).numpy()) < tol
+            # supplying model_s / model_s1 (what the adaptive solver does, ref :997-998) gives the same x_t
+            xt2 = dpm.singlestep_dpm_solver_third_update(x, t[2], t[3], r1=r1, r2=r2, solver_type=st,
+                                                         model_s=im["model_s"], model_s1=im["model_s1"])
+            assert rel_err(xt2.numpy(), xt.numpy()) < 1e-7
+            assert rel_err(dpm.singlestep_dpm_solver_update(x, t[2], t[3], 3, solver_type=st, r1=r1, r2=r2).numpy(),
+                           xt.numpy()) == 0.0
+
+
+def test_model_evaluation_methods(golden):
+    """noise_prediction_fn / data_prediction_fn / model_fn / WrappedModel.__call__ vs the oracle."""
+    import test_oracle_golden as T
+    monkey_launch = launch_stage_double
+    W_launch = S._launch_stage
+    assert W_launch is monkey_launch
+    for name in ["mt_v", "cfg_ms2", "clsg_ms2", "cfg5_thresh_small"]:
+        case = C.E2E_BY_NAME[name]
+        dpm = build_solver(case, "cpu")
+        osol = T.build_oracle_solver(case)
+        x = tt(C.x_T_for(case), "cpu")
+        t = torch.tensor([0.6172])
+        want_eps = osol.noise_pred(x.numpy(), F32(0.6172))
+        want_x0 = osol.data_pred(x.numpy(), F32(0.6172))
+        assert rel_err(dpm.noise_prediction_fn(x, t).numpy(), want_eps) < 2e-6
+        assert rel_err(dpm.data_prediction_fn(x, t).numpy(), want_x0) < 2e-6
+        assert rel_err(dpm.model_fn(x, t).numpy(), want_x0 if case["algorithm_type"] == "dpmsolver++" else want_eps) < 2e-6
+        # the wrapper object itself is the reference's model_fn(x, t_continuous) -> noise
+        eps = dpm._wrapped(x, t.expand(x.shape[0]))
+        assert rel_err(eps.numpy(), want_eps) < 2e-6
+
+
+def test_plan_structure_2m():
+    """The north-star path: 20-step DPM-Solver++(2M) = 20 stages, 18 of them the 5-stream steady state."""
+    ns = make_schedule("sd")
+    dpm = D.DPM_Solver(D.model_wrapper(lambda x, t: x, ns), ns)
+    plan = dpm._get_plan(method="multistep", order=2, steps=20, skip_type="time_uniform", solver_type="dpmsolver",
+                         lower_order_final=True, denoise_to_zero=False, t_T=1.0, t_0=1e-3)
+    st = plan.stages
+    assert len(st) == 20 and plan.slots == 2
+    assert st[0].form == L.FORM_LIN1 and st[0].flags & L.F_STORE_M and st[0].h1_slot == -1
+    for i in range(1, 20):
+        assert st[i].form == L.FORM_TWO and st[i].h1_slot == (i - 1) % 2 and not (st[i].flags & L.F_BASE_HIST)
+        assert bool(st[i].flags & L.F_STORE_M) == (i < 19)      # the last stage writes no model value
+        assert st[i].m_slot == (i % 2 if i < 19 else -1)
+    assert all(s.flags & L.F_TO_X0 for s in st) and all(s.emits_state for s in st)
+    assert abs(st[0].t_input - 999.0) < 1e-3 and abs(st[19].t_input - 49.95) < 1e-3   # SURVEY 8c anchors
+
+
+def test_error_conventions():
+    ns = make_schedule("sd")
+    with pytest.raises(ValueError, match="Unsupported noise schedule"):
+        D.NoiseScheduleVP("cosine_typo")
+    dpm = D.DPM_Solver(D.model_wrapper(lambda x, t: x, ns), ns)
+    x = torch.zeros(2, 4, 8, 8)
+    with pytest.raises(ValueError, match="Unsupported skip_type"):
+        dpm.sample(x, skip_type="bogus")
+    with pytest.raises(ValueError, match="Got wrong method"):
+        dpm.sample(x, method="bogus")
+    with pytest.raises(ValueError, match="'solver_type' must be either"):
+        dpm.sample(x, solver_type="bogus")
+    with pytest.raises(ValueError, match="must be '1' or '2' or '3'"):
+        dpm.sample(x, method="singlestep", order=4)
+    with pytest.raises(ValueError, match="Solver order must be 1 or 2 or 3"):
+        dpm.sample(x, method="multistep", order=4, steps=20)
+    with pytest.raises(AssertionError):
+        dpm.sample(x, method="multistep", order=3, steps=2)
+    with pytest.raises(AssertionError):
+        dpm.sample(x, t_end=0.0)
+    with pytest.raises(AssertionError, match="Cannot use adaptive solver"):
+        dpm.sample(x, method="adaptive", return_intermediate=True)
+    with pytest.raises(AssertionError):
+        D.DPM_Solver(lambda x, t: x, ns, algorithm_type="bogus")
+    with pytest.raises(AssertionError):
+        D.model_wrapper(lambda x, t: x, ns, model_type="bogus")
+    with pytest.raises(ValueError, match="Solver order must be 1 or 2 or 3"):
+        dpm.multistep_dpm_solver_update(x, [x], [torch.tensor([0.5])], torch.tensor([0.4]), 4)
+
+
+def test_no_cpu_fallback(monkeypatch):
+    """Without the test double the product refuses CPU tensors instead of silently computing on the host."""
+    monkeypatch.undo()
+    ns = make_schedule("sd")
+    dpm = D.DPM_Solver(D.model_wrapper(lambda x, t: x, ns), ns)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dpm.sample(torch.zeros(2, 4, 8, 8), steps=5)
