@@ -6,6 +6,12 @@ dpm_solver_amd/libdpm_hip.so.  There is no fallback: if it is missing the import
 import ctypes as C
 import os
 
+# torch FIRST: PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).
+# libdpm_hip.so needs "libamdhip64.so.7"; with torch's copy already mapped the dynamic loader binds to it by
+# SONAME, so kernels, streams and allocations of both sides live in ONE runtime.  Loaded the other way round
+# the process ends up with two runtimes and every launch fails with hipErrorNoDevice.
+import torch  # noqa: F401  (import order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdpm_hip.so")
 

@@ -587,7 +587,7 @@ int dpm_timing_begin(int n, void*** starts, void*** stops) {
     hipEvent_t e;
     hipError_t rc = hipEventCreate(&e);
     if (rc != hipSuccess) {
-      for (int j = 0; j < i; ++j) hipEventDestroy(static_cast<hipEvent_t>(a[j]));
+      for (int j = 0; j < i; ++j) (void)hipEventDestroy(static_cast<hipEvent_t>(a[j]));
       delete[] a;
       return dpm_set_error((int)rc, "hipEventCreate: %s", hipGetErrorString(rc));
     }
@@ -608,7 +608,7 @@ int dpm_timing_end(int n, void** starts, void** stops, void* stream, float* ms) 
       if (rc != hipSuccess) ret = dpm_set_error((int)rc, "hipEventElapsedTime(stage %d): %s", i, hipGetErrorString(rc));
     }
   }
-  for (int i = 0; i < 2 * n; ++i) hipEventDestroy(static_cast<hipEvent_t>(starts[i]));
+  for (int i = 0; i < 2 * n; ++i) (void)hipEventDestroy(static_cast<hipEvent_t>(starts[i]));
   delete[] starts;
   return ret;
 }

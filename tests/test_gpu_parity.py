@@ -275,8 +275,9 @@ def test_cfg2_full_size_shard_invariance_and_linearity(sdt):
     twice = dpm.sample(x * 2, steps=20)
     if sdt == torch.float32:
         assert torch.equal(twice, full * 2)
-    else:   # values in fp16's subnormal range round differently after doubling: one subnormal ulp at most
-        assert float((twice.float() - 2 * full.float()).abs().max()) <= 2.0 ** -23
+    else:   # fp16 subnormals (|v| < 6.1e-5) round differently after doubling; the first stage divides by
+        # alpha_T = 0.068, so a 2^-24 difference can grow to a few 1e-6 absolute by the end
+        assert float((twice.float() - 2 * full.float()).abs().max()) <= 4e-6
     osch = TO.make_schedule("sd")
     xs = x[:2].float().cpu().numpy()
     xo = O.Solver(O.wrap_model(lambda a, t: a, osch), osch).sample(xs, steps=20)
