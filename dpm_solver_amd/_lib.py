@@ -29,6 +29,7 @@ EVAL_LOG_ALPHA, EVAL_ALPHA, EVAL_STD, EVAL_LAMBDA, EVAL_INV_LAMBDA = 0, 1, 2, 3,
 FORM_LIN1, FORM_TWO, FORM_MS3, FORM_SS3T, FORM_DENOISE = 0, 1, 2, 3, 4
 F_TO_X0, F_STORE_M, F_BASE_HIST, F_THRESH, F_USER_X0 = 1, 2, 4, 8, 16
 SRC_STATE, SRC_TMP = 0, 1
+TUNE_UNROLL, TUNE_NONTEMPORAL, TUNE_BLOCKS_PER_CU = 0, 1, 2
 
 
 class Stage(C.Structure):
@@ -117,6 +118,11 @@ _SIGNATURES = [
     ("dpm_plan_run", C.c_int, [C.c_void_p, _P(RunBuffers), C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int)]),
     ("dpm_stage_launch_timed", C.c_int, [_P(Stage), _P(Buffers), C.c_void_p, _P(C.c_float)]),
     ("dpm_plan_run_timed", C.c_int, [C.c_void_p, _P(RunBuffers), C.c_void_p, _P(C.c_float), _P(C.c_int)]),
+    ("dpm_plan_run_multi", C.c_int, [C.c_void_p, _P(RunBuffers), C.c_int, C.c_void_p, _P(C.c_float), _P(C.c_int)]),
+    ("dpm_tuning_set", C.c_int, [C.c_int, C.c_int]),
+    ("dpm_tuning_get", C.c_int, [C.c_int]),
+    ("dpm_calib_launch", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int64, C.c_void_p, _P(C.c_float)]),
     ("dpm_version", C.c_int, []),
     ("dpm_last_error", C.c_char_p, []),
     ("dpm_device_info", C.c_int, [_P(C.c_int), _P(C.c_int), C.c_char_p, C.c_int]),

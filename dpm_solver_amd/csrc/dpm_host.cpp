@@ -886,3 +886,61 @@ extern "C" int dpm_plan_run_timed(const dpm_plan* p, const dpm_run_buffers* rb, 
   int rc2 = dpm_timing_end(n, starts, stops, stream, rc ? nullptr : ms_per_stage);
   return rc ? rc : rc2;
 }
+
+extern "C" int dpm_plan_run_multi(const dpm_plan* p, const dpm_run_buffers* rbs, int n_req, void* stream, float* ms,
+                                  int* results) {
+  if (!p || !rbs || n_req < 1) return dpm_set_error(DPM_ERR_ARG, "plan_run_multi: bad arguments");
+  const int ns = (int)p->stages.size();
+  for (int r = 0; r < n_req; ++r) {
+    for (int i = 0; i < 4; ++i)
+      if (!rbs[r].xbuf[i]) return dpm_set_error(DPM_ERR_ARG, "plan_run_multi: request %d xbuf[%d] is null", r, i);
+    for (int i = 0; i < p->slots; ++i)
+      if (!rbs[r].hist[i]) return dpm_set_error(DPM_ERR_ARG, "plan_run_multi: request %d hist[%d] is null", r, i);
+  }
+  void **starts = nullptr, **stops = nullptr;
+  if (ms) {
+    int rc = dpm_timing_begin(n_req * ns, &starts, &stops);
+    if (rc) return rc;
+  }
+  std::vector<int> state(n_req, 0), tmp(n_req, -1);
+  int rc = DPM_OK;
+  for (const dpm_stage& st : p->stages) {
+    for (int r = 0; r < n_req && !rc; ++r) {
+      const dpm_run_buffers& rb = rbs[r];
+      const int xe = st.xe_src == DPM_SRC_TMP ? tmp[r] : state[r];
+      int out = 1;
+      while (out == state[r] || out == xe) ++out;
+      dpm_buffers b;
+      std::memset(&b, 0, sizeof b);
+      b.x = rb.xbuf[state[r]];
+      b.xe = xe == state[r] ? nullptr : rb.xbuf[xe];
+      b.e0 = rb.e0;
+      b.e1 = rb.e1;
+      b.h1 = st.h1_slot >= 0 ? rb.hist[st.h1_slot] : nullptr;
+      b.h2 = st.h2_slot >= 0 ? rb.hist[st.h2_slot] : nullptr;
+      b.x_out = rb.xbuf[out];
+      b.m_out = st.m_slot >= 0 ? rb.hist[st.m_slot] : nullptr;
+      b.workspace = rb.workspace;
+      b.n = rb.n;
+      b.batch = rb.batch;
+      b.state_dtype = rb.state_dtype;
+      b.eps_dtype = rb.eps_dtype;
+      const int k = r * ns + st.index;
+      rc = dpm_stage_launch_ev(&st, &b, stream, starts ? starts[k] : nullptr, stops ? stops[k] : nullptr);
+      if (st.emits_state) {
+        state[r] = out;
+        tmp[r] = -1;
+      } else {
+        tmp[r] = out;
+      }
+    }
+    if (rc) break;
+  }
+  if (ms) {
+    int rc2 = dpm_timing_end(n_req * ns, starts, stops, stream, rc ? nullptr : ms);
+    if (!rc) rc = rc2;
+  }
+  if (!rc && results)
+    for (int r = 0; r < n_req; ++r) results[r] = state[r];
+  return rc;
+}

@@ -53,26 +53,80 @@ __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) {
   return bf16_t{(uint16_t)(u >> 16)};
 }
 
-constexpr int EPT = 8;  // elements per lane per iteration: 2 x 16 B (fp32) or 1 x 16 B (fp16/bf16)
+constexpr int EPT = 8;  // elements per lane per access group: 2 x 16 B (fp32) or 1 x 16 B (fp16/bf16)
 
-template <typename T>
-struct alignas(sizeof(T) * EPT) Pack {
-  T v[EPT];
-};
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <typename T>
-__device__ __forceinline__ void load_pack(const T* __restrict__ p, int64_t group, float (&out)[EPT]) {
-  const Pack<T> r = reinterpret_cast<const Pack<T>*>(p)[group];  // lowers to global_load_dwordx4 (x2 for fp32)
-#pragma unroll
-  for (int j = 0; j < EPT; ++j) out[j] = to_f32(r.v[j]);
+template <bool NT>
+__device__ __forceinline__ u32x4 ld16(const u32x4* p) {
+  return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st16(u32x4* p, u32x4 v) {
+  if (NT)
+    __builtin_nontemporal_store(v, p);
+  else
+    *p = v;
 }
 
-template <typename T>
-__device__ __forceinline__ void store_pack(T* __restrict__ p, int64_t group, const float (&in)[EPT]) {
-  Pack<T> r;
+// 8 consecutive elements of group `group` -> fp32.  Always global_load_dwordx4 (x2 for fp32).
+template <bool NT>
+__device__ __forceinline__ void load_pack(const float* __restrict__ p, int64_t group, float (&out)[EPT]) {
+  const u32x4* q = reinterpret_cast<const u32x4*>(p) + group * 2;
+  const u32x4 a = ld16<NT>(q), b = ld16<NT>(q + 1);
 #pragma unroll
-  for (int j = 0; j < EPT; ++j) r.v[j] = from_f32<T>(in[j]);
-  reinterpret_cast<Pack<T>*>(p)[group] = r;
+  for (int j = 0; j < 4; ++j) {
+    out[j] = __uint_as_float(a[j]);
+    out[4 + j] = __uint_as_float(b[j]);
+  }
+}
+template <bool NT>
+__device__ __forceinline__ void load_pack(const __half* __restrict__ p, int64_t group, float (&out)[EPT]) {
+  const u32x4 a = ld16<NT>(reinterpret_cast<const u32x4*>(p) + group);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    out[2 * j] = __half2float(__ushort_as_half((unsigned short)(a[j] & 0xffffu)));
+    out[2 * j + 1] = __half2float(__ushort_as_half((unsigned short)(a[j] >> 16)));
+  }
+}
+template <bool NT>
+__device__ __forceinline__ void load_pack(const bf16_t* __restrict__ p, int64_t group, float (&out)[EPT]) {
+  const u32x4 a = ld16<NT>(reinterpret_cast<const u32x4*>(p) + group);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    out[2 * j] = __uint_as_float(a[j] << 16);
+    out[2 * j + 1] = __uint_as_float(a[j] & 0xffff0000u);
+  }
+}
+
+template <bool NT>
+__device__ __forceinline__ void store_pack(float* __restrict__ p, int64_t group, const float (&in)[EPT]) {
+  u32x4 a, b;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    a[j] = __float_as_uint(in[j]);
+    b[j] = __float_as_uint(in[4 + j]);
+  }
+  u32x4* q = reinterpret_cast<u32x4*>(p) + group * 2;
+  st16<NT>(q, a);
+  st16<NT>(q + 1, b);
+}
+template <bool NT>
+__device__ __forceinline__ void store_pack(__half* __restrict__ p, int64_t group, const float (&in)[EPT]) {
+  u32x4 a;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    a[j] = (uint32_t)__half_as_ushort(__float2half_rn(in[2 * j])) |
+           ((uint32_t)__half_as_ushort(__float2half_rn(in[2 * j + 1])) << 16);
+  st16<NT>(reinterpret_cast<u32x4*>(p) + group, a);
+}
+template <bool NT>
+__device__ __forceinline__ void store_pack(bf16_t* __restrict__ p, int64_t group, const float (&in)[EPT]) {
+  u32x4 a;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    a[j] = (uint32_t)from_f32<bf16_t>(in[2 * j]).v | ((uint32_t)from_f32<bf16_t>(in[2 * j + 1]).v << 16);
+  st16<NT>(reinterpret_cast<u32x4*>(p) + group, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -86,8 +140,26 @@ struct KParams {
   int32_t model_type;
 };
 
+// Compile-time knowledge about the prologue.  SPEC_GENERIC reads model_type / TO_X0 from the stage record at
+// run time (wave-uniform scalar branches); the two hot specialisations fix them so the inner loop is
+// branch-free: SPEC_NOISE_X0 = noise-prediction network + eps -> x0 (dpmsolver++), SPEC_NOISE_EPS = noise
+// prediction kept (dpmsolver).
+enum { SPEC_GENERIC = 0, SPEC_NOISE_X0 = 1, SPEC_NOISE_EPS = 2 };
+
+template <int SPEC>
+__device__ __forceinline__ bool spec_to_x0(const KParams& p) {
+  return SPEC == SPEC_GENERIC ? (p.flags & DPM_F_TO_X0) != 0 : SPEC == SPEC_NOISE_X0;
+}
+template <int SPEC>
+__device__ __forceinline__ bool spec_need_xe(const KParams& p) {
+  if (SPEC != SPEC_GENERIC) return SPEC == SPEC_NOISE_X0;
+  return (p.flags & DPM_F_TO_X0) || p.model_type == DPM_MODEL_X_START || p.model_type == DPM_MODEL_V;
+}
+
 // raw network output -> noise prediction (noise_pred_fn, ref :288-298)
+template <int SPEC>
 __device__ __forceinline__ float to_noise(float o, float xe, const KParams& p) {
+  if (SPEC != SPEC_GENERIC) return o;
   switch (p.model_type) {
     case DPM_MODEL_X_START: return (xe - p.alpha_e * o) / p.sigma_e;
     case DPM_MODEL_V: return p.alpha_e * o + p.sigma_e * xe;
@@ -96,19 +168,19 @@ __device__ __forceinline__ float to_noise(float o, float xe, const KParams& p) {
   }
 }
 
-// everything up to (not including) thresholding: returns eps, or x0 when DPM_F_TO_X0
-template <int GUIDE>
+// everything up to (not including) thresholding: returns eps, or x0 when the stage converts (DPM_F_TO_X0)
+template <int GUIDE, int SPEC = SPEC_GENERIC>
 __device__ __forceinline__ float prologue(float xe, float o0, float o1, float gg, const KParams& p) {
   float eps;
   if (GUIDE == DPM_GUIDE_CFG) {  // ref :326-330: uncond + scale * (cond - uncond)
-    float nu = to_noise(o1, xe, p), nc = to_noise(o0, xe, p);
+    float nu = to_noise<SPEC>(o1, xe, p), nc = to_noise<SPEC>(o0, xe, p);
     eps = nu + p.cfg_scale * (nc - nu);
   } else if (GUIDE == DPM_GUIDE_CLASSIFIER) {  // ref :321
-    eps = to_noise(o0, xe, p) - p.cg_scale * gg;
+    eps = to_noise<SPEC>(o0, xe, p) - p.cg_scale * gg;
   } else {
-    eps = to_noise(o0, xe, p);
+    eps = to_noise<SPEC>(o0, xe, p);
   }
-  if (p.flags & DPM_F_TO_X0) return (xe - p.sigma_e * eps) / p.alpha_e;  // ref :439
+  if (spec_to_x0<SPEC>(p)) return (xe - p.sigma_e * eps) / p.alpha_e;  // ref :439
   return eps;
 }
 
@@ -149,38 +221,52 @@ struct FormTraits {
 // ------------------------------------------------------------------------------------------------
 // the streaming stage kernel
 // ------------------------------------------------------------------------------------------------
-template <typename TS, typename TE, int FORM, int GUIDE, bool XE>
+template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int SPEC, int U, int NT>
 __global__ __launch_bounds__(256) void stage_kernel(const TS* __restrict__ x, const TS* __restrict__ xe,
                                                     const TE* __restrict__ e0, const TE* __restrict__ e1,
                                                     const TE* __restrict__ g, const TS* __restrict__ h1,
                                                     const TS* __restrict__ h2, TS* __restrict__ xo,
                                                     TS* __restrict__ mo, int64_t n, KParams p) {
   using FT = FormTraits<FORM>;
-  const bool need_xe = (p.flags & DPM_F_TO_X0) || p.model_type == DPM_MODEL_X_START || p.model_type == DPM_MODEL_V;
+  const bool need_xe = spec_need_xe<SPEC>(p);
   const bool store_m = p.flags & DPM_F_STORE_M;
   const int64_t ngroups = n / EPT;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += stride) {
-    float vx[EPT], vxe[EPT], v0[EPT], v1[EPT], vg[EPT], vh1[EPT], vh2[EPT];
-    // issue every load of the iteration before the first use
-    if (FT::needs_x || (!XE && need_xe)) load_pack(x, gi, vx);
-    if (XE && need_xe) load_pack(xe, gi, vxe);
-    load_pack(e0, gi, v0);
-    if (GUIDE == DPM_GUIDE_CFG) load_pack(e1, gi, v1);
-    if (GUIDE == DPM_GUIDE_CLASSIFIER) load_pack(g, gi, vg);
-    if (FT::needs_h1) load_pack(h1, gi, vh1);
-    if (FT::needs_h2) load_pack(h2, gi, vh2);
-    float ox[EPT], om[EPT];
+  // a tile = 256 consecutive groups (one per lane of the workgroup); a workgroup iteration covers U tiles and
+  // issues the loads of all of them before the first use
+  const int64_t ntiles = (ngroups + 255) / 256;
+  for (int64_t t0 = (int64_t)blockIdx.x * U; t0 < ntiles; t0 += (int64_t)gridDim.x * U) {
+    float vx[U][EPT], vxe[U][EPT], v0[U][EPT], v1[U][EPT], vg[U][EPT], vh1[U][EPT], vh2[U][EPT];
 #pragma unroll
-    for (int j = 0; j < EPT; ++j) {
-      const float xej = XE ? vxe[j] : vx[j];
-      const float mn = prologue<GUIDE>(xej, v0[j], GUIDE == DPM_GUIDE_CFG ? v1[j] : 0.f,
-                                       GUIDE == DPM_GUIDE_CLASSIFIER ? vg[j] : 0.f, p);
-      om[j] = mn;
-      ox[j] = combine<FORM>(FT::needs_x ? vx[j] : 0.f, mn, FT::needs_h1 ? vh1[j] : 0.f, FT::needs_h2 ? vh2[j] : 0.f, p);
+    for (int u = 0; u < U; ++u) {
+      const int64_t gi = (t0 + u) * 256 + threadIdx.x;
+      if (gi < ngroups) {
+        if (FT::needs_x || (!XE && need_xe)) load_pack<(NT & 1) != 0>(x, gi, vx[u]);
+        if (XE && need_xe) load_pack<(NT & 1) != 0>(xe, gi, vxe[u]);
+        load_pack<(NT & 1) != 0>(e0, gi, v0[u]);
+        if (GUIDE == DPM_GUIDE_CFG) load_pack<(NT & 1) != 0>(e1, gi, v1[u]);
+        if (GUIDE == DPM_GUIDE_CLASSIFIER) load_pack<(NT & 1) != 0>(g, gi, vg[u]);
+        if (FT::needs_h1) load_pack<(NT & 1) != 0>(h1, gi, vh1[u]);
+        if (FT::needs_h2) load_pack<(NT & 1) != 0>(h2, gi, vh2[u]);
+      }
     }
-    store_pack(xo, gi, ox);
-    if (store_m) store_pack(mo, gi, om);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t gi = (t0 + u) * 256 + threadIdx.x;
+      if (gi < ngroups) {
+        float ox[EPT], om[EPT];
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+          const float xej = XE ? vxe[u][j] : vx[u][j];
+          const float mn = prologue<GUIDE, SPEC>(xej, v0[u][j], GUIDE == DPM_GUIDE_CFG ? v1[u][j] : 0.f,
+                                                 GUIDE == DPM_GUIDE_CLASSIFIER ? vg[u][j] : 0.f, p);
+          om[j] = mn;
+          ox[j] = combine<FORM>(FT::needs_x ? vx[u][j] : 0.f, mn, FT::needs_h1 ? vh1[u][j] : 0.f,
+                                FT::needs_h2 ? vh2[u][j] : 0.f, p);
+        }
+        store_pack<(NT & 2) != 0>(xo, gi, ox);
+        if (store_m) store_pack<(NT & 4) != 0>(mo, gi, om);
+      }
+    }
   }
   // ragged tail (n % 8 elements): first lanes of block 0, scalar
   const int64_t tail0 = ngroups * EPT;
@@ -188,8 +274,8 @@ __global__ __launch_bounds__(256) void stage_kernel(const TS* __restrict__ x, co
     const int64_t i = tail0 + threadIdx.x;
     const float xv = (FT::needs_x || (!XE && need_xe)) ? to_f32(x[i]) : 0.f;
     const float xev = XE ? (need_xe ? to_f32(xe[i]) : 0.f) : xv;
-    const float mn = prologue<GUIDE>(xev, to_f32(e0[i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[i]) : 0.f,
-                                     GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[i]) : 0.f, p);
+    const float mn = prologue<GUIDE, SPEC>(xev, to_f32(e0[i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[i]) : 0.f,
+                                           GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[i]) : 0.f, p);
     xo[i] = from_f32<TS>(combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[i]) : 0.f, FT::needs_h2 ? to_f32(h2[i]) : 0.f, p));
     if (store_m) mo[i] = from_f32<TS>(mn);
   }
@@ -440,6 +526,28 @@ KParams make_params(const dpm_stage* st) {
 
 constexpr int64_t THR_LDS_EXTRA = (256 + 8) * 4;
 
+// launch-shape defaults (chosen on MI355X) and the run-time tuning hooks
+// nt mask: bit 0 = nt loads, bit 1 = nt x_out store, bit 2 = nt m_out store.  Measured on [256,4,64,64]
+// (tools/tune2.py, profiles/r01_tuning.md): 2-byte states are fastest with streaming (nt) loads and an nt store of
+// the model value, both when the buffers are warm in the Infinity Cache and when they come from HBM; 4-byte states
+// are fastest with the default cache policy.
+constexpr int DEF_U = 1;
+template <typename TS>
+struct DefNT {
+  static constexpr int value = sizeof(TS) == 2 ? 5 : 0;
+};
+struct Tuning {
+  int unroll = 0;           // tiles per workgroup iteration: 1, 2;  0 = default
+  int nontemporal = -1;     // nt mask; -1 = per-dtype default
+  int blocks_per_cu = 8;    // grid cap = CUs x this (8 x 256 threads = every SIMD holds 8 waves)
+};
+Tuning g_tuning;
+
+template <int FORM, int GUIDE, bool XE>
+struct HotCombo {
+  static constexpr bool value = (FORM == DPM_FORM_TWO || FORM == DPM_FORM_LIN1) && GUIDE == DPM_GUIDE_NONE && !XE;
+};
+
 struct LaunchCtx {
   hipStream_t stream;
   hipEvent_t start, stop;  // both null: plain launch; else hipExtLaunchKernelGGL brackets the kernel itself
@@ -496,18 +604,52 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
     const size_t as = sizeof(TS) * EPT, ae = sizeof(TE) * EPT;
     const bool vec = aligned(x, as) && aligned(xe, as) && aligned(h1, as) && aligned(h2, as) && aligned(xo, as) &&
                      aligned(mo, as) && aligned(e0, ae) && aligned(e1, ae) && aligned(g, ae);
-    // enough workgroups to give every CU 8 waves/SIMD in one residency wave; grid-stride beyond that
-    const int64_t work = vec ? (b->n + EPT - 1) / EPT : b->n;
-    int64_t blocks = (work + 255) / 256;
-    const int64_t cap = (int64_t)n_cu * 16;
-    if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
-    if (vec)
-      launch(stage_kernel<TS, TE, FORM, GUIDE, XE>, dim3((unsigned)blocks), dim3(256), 0, stream, x, xe, e0, e1, g, h1, h2,
-             xo, mo, b->n, p);
-    else
+    if (!vec) {
+      int64_t blocks = (b->n + 255) / 256;
+      const int64_t cap = (int64_t)n_cu * 16;
+      if (blocks > cap) blocks = cap;
       launch(stage_kernel_scalar<TS, TE, FORM, GUIDE, XE>, dim3((unsigned)blocks), dim3(256), 0, stream, x, xe, e0, e1, g,
              h1, h2, xo, mo, b->n, p);
+    } else {
+      // specialise the prologue when the stage allows it (noise-prediction network: the common case)
+      const bool noise = st->model_type == DPM_MODEL_NOISE;
+      const int spec = !noise ? SPEC_GENERIC : ((st->flags & DPM_F_TO_X0) ? SPEC_NOISE_X0 : SPEC_NOISE_EPS);
+      const int64_t ntiles = ((b->n / EPT) + 255) / 256;
+      const Tuning tn = g_tuning;
+      auto grid_for = [&](int u) {
+        int64_t blocks = (ntiles + u - 1) / u;
+        const int64_t cap = (int64_t)n_cu * tn.blocks_per_cu;
+        if (blocks > cap) blocks = cap;
+        return dim3((unsigned)(blocks < 1 ? 1 : blocks));
+      };
+#define DPM_LAUNCH(SPEC_, U_, NT_)                                                                                  \
+  launch(stage_kernel<TS, TE, FORM, GUIDE, XE, SPEC_, U_, NT_>, grid_for(U_), dim3(256), 0, stream, x, xe, e0, e1, g, \
+         h1, h2, xo, mo, b->n, p)
+      if (spec == SPEC_GENERIC) {
+        DPM_LAUNCH(SPEC_GENERIC, 1, DefNT<TS>::value);
+      } else if (spec == SPEC_NOISE_EPS) {
+        DPM_LAUNCH(SPEC_NOISE_EPS, DEF_U, DefNT<TS>::value);
+      } else if (HotCombo<FORM, GUIDE, XE>::value) {
+        // tuning variants exist only for the north-star kernels (2M / 1st-order update, no guidance)
+        const int key = (tn.unroll <= 0 || tn.nontemporal < 0) ? -1 : tn.unroll * 8 + (tn.nontemporal & 7);
+        switch (key) {
+          case 8 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 1, 0); break;
+          case 8 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 1, 1); break;
+          case 8 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 1, 5); break;
+          case 8 + 6: DPM_LAUNCH(SPEC_NOISE_X0, 1, 6); break;
+          case 8 + 7: DPM_LAUNCH(SPEC_NOISE_X0, 1, 7); break;
+          case 16 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 2, 0); break;
+          case 16 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 2, 1); break;
+          case 16 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 2, 5); break;
+          case 16 + 6: DPM_LAUNCH(SPEC_NOISE_X0, 2, 6); break;
+          case 16 + 7: DPM_LAUNCH(SPEC_NOISE_X0, 2, 7); break;
+          default: DPM_LAUNCH(SPEC_NOISE_X0, DEF_U, DefNT<TS>::value); break;
+        }
+      } else {
+        DPM_LAUNCH(SPEC_NOISE_X0, DEF_U, DefNT<TS>::value);
+      }
+#undef DPM_LAUNCH
+    }
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return dpm_set_error((int)e, "stage kernel launch failed: %s", hipGetErrorString(e));
@@ -684,6 +826,96 @@ extern "C" int dpm_adaptive_error_launch(const void* x_lower, const void* x_high
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return dpm_set_error((int)e, "adaptive_error launch failed: %s", hipGetErrorString(e));
   return DPM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// calibration kernels: what the memory system sustains for this access pattern and size, with no arithmetic.
+// kind 0: copy (1 read + 1 write stream); kind 1: 3 read + 2 write streams (the 2M stage's pattern).
+// ------------------------------------------------------------------------------------------------
+namespace {
+template <int BLOCK, int KIND, int NT>
+__global__ __launch_bounds__(BLOCK) void calib_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b,
+                                                      const u32x4* __restrict__ c, u32x4* __restrict__ d,
+                                                      u32x4* __restrict__ e, int64_t nvec) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < nvec; i += stride) {
+    if (KIND == 0) {
+      st16<(NT & 2) != 0>(d + i, ld16<(NT & 1) != 0>(a + i));
+    } else {
+      const u32x4 va = ld16<(NT & 1) != 0>(a + i), vb = ld16<(NT & 1) != 0>(b + i), vc = ld16<(NT & 1) != 0>(c + i);
+      st16<(NT & 2) != 0>(d + i, va ^ vb);
+      st16<(NT & 4) != 0>(e + i, vb ^ vc);
+    }
+  }
+}
+
+template <int BLOCK, int KIND>
+void calib_nt(int nt, dim3 grid, const LaunchCtx& c, const u32x4* a, const u32x4* b, const u32x4* cc, u32x4* d, u32x4* e,
+              int64_t nvec) {
+  switch (nt) {
+    case 1: launch(calib_kernel<BLOCK, KIND, 1>, grid, dim3(BLOCK), 0, c, a, b, cc, d, e, nvec); break;
+    case 5: launch(calib_kernel<BLOCK, KIND, 5>, grid, dim3(BLOCK), 0, c, a, b, cc, d, e, nvec); break;
+    case 7: launch(calib_kernel<BLOCK, KIND, 7>, grid, dim3(BLOCK), 0, c, a, b, cc, d, e, nvec); break;
+    default: launch(calib_kernel<BLOCK, KIND, 0>, grid, dim3(BLOCK), 0, c, a, b, cc, d, e, nvec); break;
+  }
+}
+}  // namespace
+
+extern "C" int dpm_calib_launch(int kind, int block, int blocks_per_cu, int nt, const void* a, const void* b, const void* c,
+                                void* d, void* e, int64_t nbytes, void* stream, float* ms) {
+  if (!a || !d || nbytes < 16 || (kind == 1 && (!b || !c || !e))) return dpm_set_error(DPM_ERR_ARG, "calib: bad arguments");
+  const int64_t nvec = nbytes / 16;
+  const DeviceInfo& di = device_info();
+  int64_t blocks = (nvec + block - 1) / block;
+  const int64_t cap = (int64_t)(di.n_cu > 0 ? di.n_cu : 256) * blocks_per_cu;
+  if (blocks > cap) blocks = cap;
+  void **starts = nullptr, **stops = nullptr;
+  if (ms) {
+    int rc = dpm_timing_begin(1, &starts, &stops);
+    if (rc) return rc;
+  }
+  const LaunchCtx ctx{static_cast<hipStream_t>(stream), ms ? static_cast<hipEvent_t>(starts[0]) : nullptr,
+                      ms ? static_cast<hipEvent_t>(stops[0]) : nullptr};
+  const u32x4 *pa = (const u32x4*)a, *pb = (const u32x4*)b, *pc = (const u32x4*)c;
+  u32x4 *pd = (u32x4*)d, *pe = (u32x4*)e;
+  const dim3 grid((unsigned)blocks);
+  int rc = DPM_OK;
+  if (kind == 0 && block == 256) calib_nt<256, 0>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
+  else if (kind == 0 && block == 512) calib_nt<512, 0>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
+  else if (kind == 0 && block == 1024) calib_nt<1024, 0>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
+  else if (kind == 1 && block == 256) calib_nt<256, 1>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
+  else if (kind == 1 && block == 512) calib_nt<512, 1>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
+  else if (kind == 1 && block == 1024) calib_nt<1024, 1>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
+  else rc = dpm_set_error(DPM_ERR_ARG, "calib: kind %d / block %d not built", kind, block);
+  if (ms) {
+    int rc2 = dpm_timing_end(1, starts, stops, stream, rc ? nullptr : ms);
+    if (!rc) rc = rc2;
+  }
+  return rc;
+}
+
+extern "C" int dpm_tuning_set(int knob, int value) {
+  switch (knob) {
+    case DPM_TUNE_UNROLL:
+      if (value != 0 && value != 1 && value != 2) return dpm_set_error(DPM_ERR_ARG, "unroll must be 0 (default), 1 or 2");
+      g_tuning.unroll = value;
+      return DPM_OK;
+    case DPM_TUNE_NONTEMPORAL: g_tuning.nontemporal = value < 0 ? -1 : (value & 7); return DPM_OK;
+    case DPM_TUNE_BLOCKS_PER_CU:
+      if (value < 1 || value > 64) return dpm_set_error(DPM_ERR_ARG, "blocks_per_cu must be in 1..64");
+      g_tuning.blocks_per_cu = value;
+      return DPM_OK;
+  }
+  return dpm_set_error(DPM_ERR_ARG, "unknown tuning knob %d", knob);
+}
+
+extern "C" int dpm_tuning_get(int knob) {
+  switch (knob) {
+    case DPM_TUNE_UNROLL: return g_tuning.unroll;
+    case DPM_TUNE_NONTEMPORAL: return g_tuning.nontemporal;
+    case DPM_TUNE_BLOCKS_PER_CU: return g_tuning.blocks_per_cu;
+  }
+  return -1;
 }
 
 extern "C" int dpm_device_info(int* n_cu, int* lds_bytes, char* arch, int arch_len) {

@@ -225,6 +225,21 @@ int dpm_plan_run(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model_cb mode
 int dpm_stage_launch_timed(const dpm_stage* st, const dpm_buffers* b, void* stream, float* ms);
 int dpm_plan_run_timed(const dpm_plan* p, const dpm_run_buffers* rb, void* stream, float* ms_per_stage, int* result);
 
+/* several independent sampling requests advanced stage by stage (request 0 stage s, request 1 stage s, ...):
+   what a server holding n requests in flight does, and -- with a frozen model -- the HBM-cold measurement
+   mode of bench.py: between two stages of one request the other n-1 requests stream their buffers through the
+   Infinity Cache.  ms (optional, [n_req * num_stages], request-major) receives kernel-only durations. */
+int dpm_plan_run_multi(const dpm_plan* p, const dpm_run_buffers* rbs, int n_req, void* stream, float* ms, int* results);
+
+/* ---- launch-shape tuning hooks (autotuning / benchmarking; defaults are the measured best) --------- */
+enum { DPM_TUNE_UNROLL = 0, DPM_TUNE_NONTEMPORAL = 1, DPM_TUNE_BLOCKS_PER_CU = 2 };
+int dpm_tuning_set(int knob, int value);
+int dpm_tuning_get(int knob);
+/* memory-system calibration with no arithmetic (kind 0: copy; kind 1: 3 read + 2 write streams, the 2M stage's
+   pattern) over nbytes per stream; block in {256,512,1024}; nt mask as DPM_TUNE_NONTEMPORAL; ms = kernel time. */
+int dpm_calib_launch(int kind, int block, int blocks_per_cu, int nt, const void* a, const void* b, const void* c,
+                     void* d, void* e, int64_t nbytes, void* stream, float* ms);
+
 /* ---- misc ---------------------------------------------------------------------------------- */
 int dpm_version(void);
 const char* dpm_last_error(void); /* thread-local text of the last non-zero return */

@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Launch-shape sweep of the north-star kernel on the GPU (run via gpurun).  For each (dtype, unroll,
+non-temporal, blocks/CU) it reports, for the steady-state 2M stage on [256,4,64,64]:
+  seq : trajectories one after the other, 8 buffer sets rotated per trajectory (within a trajectory the 56/112 MiB
+        working set can stay in the 256 MiB Infinity Cache)
+  cold: 8 requests advanced stage by stage (dpm_plan_run_multi): every stream comes from HBM
+kernel-only microseconds (hipExtLaunchKernelGGL events) and wall microseconds per launch."""
+import ctypes as C
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+import bench as BN
+import dpm_solver_amd as D
+from dpm_solver_amd import _lib as L
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    ac = BN.sd_alphas_cumprod()
+    ns = D.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(ac))
+    res = C.c_int(-1)
+    sptr = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    rows = []
+    dtypes = sys.argv[1].split(",") if len(sys.argv) > 1 else ["fp16", "fp32"]
+    for dname in dtypes:
+        dtype = {"fp16": torch.float16, "fp32": torch.float32}[dname]
+        dpm = D.DPM_Solver(D.model_wrapper(lambda x, t: x, ns), ns, state_dtype=dtype)
+        plan = dpm._get_plan(method="multistep", order=2, steps=20, skip_type="time_uniform", solver_type="dpmsolver",
+                             lower_order_final=True, denoise_to_zero=False, t_T=1.0, t_0=1e-3)
+        nst = len(plan.stages)
+        sets = BN.make_sets(8, dtype, dev, 1)
+        rbs = (L.RunBuffers * 8)(*[s["rb"] for s in sets])
+        n_el = 256 * 4 * 64 * 64
+        esz = 2 if dname == "fp16" else 4
+        alg = 5 * n_el * esz
+        for U in (1, 2, 4):
+            for NT in (0, 1):
+                for bpc in (2, 4, 8, 16):
+                    L.check(L.lib.dpm_tuning_set(L.TUNE_UNROLL, U))
+                    L.check(L.lib.dpm_tuning_set(L.TUNE_NONTEMPORAL, NT))
+                    L.check(L.lib.dpm_tuning_set(L.TUNE_BLOCKS_PER_CU, bpc))
+                    # --- sequential trajectories
+                    for i in range(8):
+                        L.check(L.lib.dpm_plan_run(plan.handle, C.byref(sets[i % 8]["rb"]), None, None, sptr, C.byref(res)))
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    K = 64
+                    for i in range(K):
+                        L.check(L.lib.dpm_plan_run(plan.handle, C.byref(sets[i % 8]["rb"]), None, None, sptr, C.byref(res)))
+                    torch.cuda.synchronize()
+                    wall_seq = (time.perf_counter() - t0) / (K * nst) * 1e6
+                    buf = (C.c_float * nst)()
+                    ks = []
+                    for i in range(16):
+                        L.check(L.lib.dpm_plan_run_timed(plan.handle, C.byref(sets[i % 8]["rb"]), sptr, buf, C.byref(res)))
+                        ks.append(np.frombuffer(buf, dtype=np.float32)[1:nst - 1].copy())
+                    k_seq = float(np.mean(ks) * 1e3)
+                    # --- stage-interleaved requests (HBM cold)
+                    resm = (C.c_int * 8)()
+                    for i in range(2):
+                        L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, 8, sptr, None, resm))
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    K2 = 8
+                    for i in range(K2):
+                        L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, 8, sptr, None, resm))
+                    torch.cuda.synchronize()
+                    wall_cold = (time.perf_counter() - t0) / (K2 * 8 * nst) * 1e6
+                    msb = (C.c_float * (8 * nst))()
+                    kc = []
+                    for i in range(3):
+                        L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, 8, sptr, msb, resm))
+                        a = np.frombuffer(msb, dtype=np.float32).reshape(8, nst)
+                        kc.append(a[:, 1:nst - 1].copy())
+                    k_cold = float(np.mean(kc) * 1e3)
+                    row = dict(dtype=dname, U=U, NT=NT, bpc=bpc, k_seq_us=round(k_seq, 3), wall_seq_us=round(wall_seq, 3),
+                               k_cold_us=round(k_cold, 3), wall_cold_us=round(wall_cold, 3),
+                               seq_GBs=round(alg / k_seq / 1e3, 0), cold_GBs=round(alg / k_cold / 1e3, 0))
+                    rows.append(row)
+                    print(json.dumps(row), flush=True)
+        del sets, rbs
+        torch.cuda.empty_cache()
+    best = {}
+    for r in rows:
+        k = r["dtype"]
+        if k not in best or r["k_cold_us"] < best[k]["k_cold_us"]:
+            best[k] = r
+    print("BEST(cold):", json.dumps(best))
+
+
+if __name__ == "__main__":
+    main()
