@@ -177,13 +177,48 @@ def main():
             traffic = json.load(open(tpath)).get(args.dtype, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # HBM-cold variant of the same kernel: the 8 requests are advanced stage by stage (dpm_plan_run_multi), so between
+    # two stages of one request 7 x 40 MiB of other traffic has gone through the 256 MiB Infinity Cache -- what
+    # happens in real use, where a UNet runs between two solver stages.
+    nreq = len(sets)
+    rbs = (L.RunBuffers * nreq)(*[s_["rb"] for s_ in sets])
+    resm = (C.c_int * nreq)()
+    msb = (C.c_float * (nreq * n_stages))()
+    cold = []
+    for r in range(3):
+        L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, nreq, sptr, msb, resm))
+        cold.append(np.frombuffer(msb, dtype=np.float32).reshape(nreq, n_stages)[:, 1:n_stages - 1].copy())
+    cold_us = float(np.mean(cold) * 1e3)
+    # what the memory system sustains for this pattern and size with no arithmetic at all (3 read + 2 write streams)
+    cal = {}
+    msv = C.c_float()
+    for mode in ("warm", "cold"):
+        ts = []
+        for it in range(24):
+            s_ = sets[0] if mode == "warm" else sets[it % nreq]
+            L.check(L.lib.dpm_calib_launch(1, 256, 8, L.lib.dpm_tuning_get(L.TUNE_NONTEMPORAL) if L.lib.dpm_tuning_get(L.TUNE_NONTEMPORAL) >= 0
+                                           else (5 if esz == 2 else 0),
+                                           s_["x"][1].data_ptr(), s_["x"][2].data_ptr(), s_["x"][3].data_ptr(),
+                                           s_["h"][0].data_ptr(), s_["h"][1].data_ptr(), n_el * esz, sptr, C.byref(msv)))
+            if it >= 8:
+                ts.append(msv.value)
+        cal[mode] = float(np.mean(ts) * 1e3)
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     kernel="stage_kernel<%s,%s,FORM_TWO,GUIDE_NONE> (2M steady state)" % (args.dtype, args.dtype),
                     kernel_us=round(k_us, 3), kernel_us_min=round(float(steady.min() * 1e3), 3),
                     algorithmic_bytes_per_launch=alg_bytes,
                     first_last_stage_us=[round(float(ms[:, 0].mean() * 1e3), 3), round(float(ms[:, -1].mean() * 1e3), 3)],
-                    trajectory_kernel_sum_us=round(float(ms.sum(axis=1).mean() * 1e3), 2))
+                    trajectory_kernel_sum_us=round(float(ms.sum(axis=1).mean() * 1e3), 2),
+                    incl_launch_gaps=dict(achieved=round(traj_alg_bytes * args.steps / wall / 1e9, 1),
+                                          frac=round(traj_alg_bytes * args.steps / wall / 1e9 / HBM_PEAK_GBS, 4)),
+                    hbm_cold=dict(kernel_us=round(cold_us, 3), achieved=round(alg_bytes / cold_us / 1e3, 1),
+                                  frac=round(alg_bytes / cold_us / 1e3 / HBM_PEAK_GBS, 4),
+                                  how="%d requests advanced stage by stage (dpm_plan_run_multi)" % nreq),
+                    no_arithmetic_ceiling=dict(pattern="3 read + 2 write streams, same bytes, 256-thread blocks",
+                                               warm_us=round(cal["warm"], 3), cold_us=round(cal["cold"], 3),
+                                               frac_of_ceiling_warm=round(cal["warm"] / k_us, 3),
+                                               frac_of_ceiling_cold=round(cal["cold"] / cold_us, 3)))
 
     # ---- the single end-of-sampling collective of the sharded path: all-gather of the final x (timed apart) ---
     gather_ms = None
@@ -212,7 +247,6 @@ def main():
                        "batch_per_gpu": B, "solver_stages_per_step": n_stages, "buffer_sets": len(sets),
                        "parallelism": "batch-sharded x%d, no data-path collective" % world},
             "msample_steps_per_s": round(samples * n_stages / wall / 1e6, 3),
-            "effective_GBps_incl_launch_gaps": round(traj_alg_bytes * args.steps / wall / 1e9, 1),
             "roofline": roofline,
             "gather_ms": None if gather_ms is None else round(gather_ms, 4),
         }
