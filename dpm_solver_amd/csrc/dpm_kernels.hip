@@ -19,6 +19,7 @@
 #include <hip/hip_ext.h>
 
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <new>
 
@@ -436,6 +437,150 @@ __global__ __launch_bounds__(THR_THREADS) void stage_thresh_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// dynamic thresholding for samples that do not fit in LDS (e.g. 3x256x256 pixel samples): the same exact
+// selection, spread over many workgroups per sample.  x0 is materialised once in an fp32 workspace; three
+// radix levels (12 + 12 + 7 bits of the |x0| bit pattern) each take one histogram pass (LDS-private histogram
+// per workgroup, flushed with global atomics) and one tiny per-sample scan; one more pass finds the smallest
+// value above the selected one; the final pass clamps, scales and applies the update.
+// ------------------------------------------------------------------------------------------------
+struct ThrSel {        // per-sample selection state in the workspace
+  uint32_t prefix;     // bits of the lo-th smallest |x0| decided so far
+  uint32_t mask;       // which bits those are
+  uint32_t k;          // rank still to resolve inside the prefix group
+  uint32_t cnt;        // size of the selected bin (after the last level: multiplicity of the value)
+  uint32_t min_above;  // smallest bit pattern strictly above the selected value
+  uint32_t pad[3];
+};
+constexpr int THR_BINS = 4096;
+
+template <typename TS, typename TE, int GUIDE, bool XE>
+__global__ __launch_bounds__(256) void thr_big_x0_kernel(const TS* __restrict__ x, const TS* __restrict__ xe,
+                                                         const TE* __restrict__ e0, const TE* __restrict__ e1,
+                                                         const TE* __restrict__ g, float* __restrict__ w,
+                                                         uint32_t* __restrict__ hist, KParams p, int64_t per_sample) {
+  __shared__ uint32_t lh[THR_BINS];
+  for (int i = threadIdx.x; i < THR_BINS; i += 256) lh[i] = 0u;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.y * per_sample;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
+    const int64_t gi = base + i;
+    const float xev = to_f32(XE ? xe[gi] : x[gi]);
+    const float x0 = prologue<GUIDE>(xev, to_f32(e0[gi]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[gi]) : 0.f,
+                                     GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[gi]) : 0.f, p);
+    w[gi] = x0;
+    atomicAdd(&lh[(__float_as_uint(x0) & 0x7fffffffu) >> 19], 1u);
+  }
+  __syncthreads();
+  uint32_t* gh = hist + (int64_t)blockIdx.y * THR_BINS;
+  for (int i = threadIdx.x; i < THR_BINS; i += 256)
+    if (lh[i]) atomicAdd(&gh[i], lh[i]);
+}
+
+__global__ __launch_bounds__(256) void thr_big_hist_kernel(const float* __restrict__ w, uint32_t* __restrict__ hist,
+                                                           const ThrSel* __restrict__ sel, int shift, uint32_t dmask,
+                                                           int64_t per_sample) {
+  __shared__ uint32_t lh[THR_BINS];
+  for (int i = threadIdx.x; i < THR_BINS; i += 256) lh[i] = 0u;
+  __syncthreads();
+  const uint32_t prefix = sel[blockIdx.y].prefix, mask = sel[blockIdx.y].mask;
+  const int64_t base = (int64_t)blockIdx.y * per_sample;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
+    const uint32_t u = __float_as_uint(w[base + i]) & 0x7fffffffu;
+    if ((u & mask) == prefix) atomicAdd(&lh[(u >> shift) & dmask], 1u);
+  }
+  __syncthreads();
+  uint32_t* gh = hist + (int64_t)blockIdx.y * THR_BINS;
+  for (int i = threadIdx.x; i <= (int)dmask; i += 256)
+    if (lh[i]) atomicAdd(&gh[i], lh[i]);
+}
+
+// one workgroup per sample: find the bin holding rank k, fold it into the prefix, clear the histogram
+__global__ __launch_bounds__(1024) void thr_big_scan_kernel(uint32_t* __restrict__ hist, ThrSel* __restrict__ sel,
+                                                            int shift, uint32_t dmask, int first, uint32_t lo) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t res[3];
+  uint32_t* gh = hist + (int64_t)blockIdx.x * THR_BINS;
+  ThrSel& s = sel[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint32_t k = first ? lo : s.k;
+  uint32_t c[4], tot = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    c[j] = gh[tid * 4 + j];
+    tot += c[j];
+  }
+  const uint32_t incl_w = wave_incl_scan(tot, lane);
+  if (lane == 63) wave_tot[wv] = incl_w;
+  __syncthreads();
+  uint32_t before_wave = 0;
+  for (int q = 0; q < wv; ++q) before_wave += wave_tot[q];
+  const uint32_t incl = before_wave + incl_w, excl = incl - tot;
+  if (excl <= k && k < incl) {  // exactly one thread
+    uint32_t before = excl;
+    int j = 0;
+    while (j < 3 && before + c[j] <= k) {
+      before += c[j];
+      ++j;
+    }
+    res[0] = (uint32_t)(tid * 4 + j);
+    res[1] = k - before;
+    res[2] = c[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) gh[tid * 4 + j] = 0u;  // ready for the next level
+  if (tid == 0) {
+    const uint32_t pre = first ? 0u : s.prefix, msk = first ? 0u : s.mask;
+    s.prefix = pre | (res[0] << shift);
+    s.mask = msk | (dmask << shift);
+    s.k = res[1];
+    s.cnt = res[2];
+    if (first) s.min_above = 0x7fffffffu;
+  }
+}
+
+__global__ __launch_bounds__(256) void thr_big_minabove_kernel(const float* __restrict__ w, ThrSel* __restrict__ sel,
+                                                               int64_t per_sample) {
+  const uint32_t a_bits = sel[blockIdx.y].prefix;
+  const int64_t base = (int64_t)blockIdx.y * per_sample;
+  uint32_t m = 0x7fffffffu;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
+    const uint32_t u = __float_as_uint(w[base + i]) & 0x7fffffffu;
+    if (u > a_bits && u < m) m = u;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t o = __shfl_xor(m, d, 64);
+    m = o < m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m != 0x7fffffffu) atomicMin(&sel[blockIdx.y].min_above, m);
+}
+
+template <typename TS, int FORM>
+__global__ __launch_bounds__(256) void thr_big_finish_kernel(const TS* __restrict__ x, const TS* __restrict__ h1,
+                                                             const TS* __restrict__ h2, const float* __restrict__ w,
+                                                             const ThrSel* __restrict__ sel, TS* __restrict__ xo,
+                                                             TS* __restrict__ mo, KParams p, ThrParams tp) {
+  using FT = FormTraits<FORM>;
+  const ThrSel s_ = sel[blockIdx.y];
+  const float a = __uint_as_float(s_.prefix);
+  float b = a;
+  if (tp.hi != tp.lo && s_.k + 1u >= s_.cnt) b = __uint_as_float(s_.min_above);
+  const float diff = b - a;
+  const float q = tp.w < 0.5f ? a + tp.w * diff : b - diff * (1.f - tp.w);
+  const float s = fmaxf(q, tp.max_val);
+  const bool store_m = p.flags & DPM_F_STORE_M;
+  const int64_t base = (int64_t)blockIdx.y * tp.per_sample;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tp.per_sample; i += (int64_t)gridDim.x * 256) {
+    const int64_t gi = base + i;
+    const float mn = fminf(fmaxf(w[gi], -s), s) / s;
+    const float xv = FT::needs_x ? to_f32(x[gi]) : 0.f;
+    xo[gi] = from_f32<TS>(combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[gi]) : 0.f, FT::needs_h2 ? to_f32(h2[gi]) : 0.f, p));
+    if (store_m) mo[gi] = from_f32<TS>(mn);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // add_noise (ref :1012-1030):  out = alpha*x + sigma*noise
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -526,6 +671,12 @@ KParams make_params(const dpm_stage* st) {
 
 constexpr int64_t THR_LDS_EXTRA = (256 + 8) * 4;
 
+inline int64_t round256(int64_t v) { return (v + 255) / 256 * 256; }
+// global workspace of the large-sample thresholding path: [x0 fp32: n][hist: batch x 4096 u32][sel: batch x 32 B]
+inline int64_t thr_ws_bytes(int64_t batch, int64_t per_sample) {
+  return round256(batch * per_sample * 4) + round256(batch * THR_BINS * 4) + round256(batch * (int64_t)sizeof(ThrSel));
+}
+
 // launch-shape defaults (chosen on MI355X) and the run-time tuning hooks
 // nt mask: bit 0 = nt loads, bit 1 = nt x_out store, bit 2 = nt m_out store.  Measured on [256,4,64,64]
 // (tools/tune2.py, profiles/r01_tuning.md): 2-byte states are fastest with streaming (nt) loads and an nt store of
@@ -580,10 +731,6 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
     const int64_t per_sample = b->n / b->batch;
     const int64_t lds_bytes = per_sample * 4 + THR_LDS_EXTRA;
     const int64_t lds_cap = di.lds > 0 ? di.lds : 160 * 1024;
-    if (lds_bytes > lds_cap)
-      return dpm_set_error(DPM_ERR_UNSUPPORTED,
-                           "dynamic thresholding: sample of %lld elements exceeds the LDS-resident path (max %lld)",
-                           (long long)per_sample, (long long)((lds_cap - THR_LDS_EXTRA) / 4));
     ThrParams tp;
     tp.per_sample = per_sample;
     // torch.quantile: rank = q * (n - 1) evaluated in fp32 (q is an fp32 tensor)
@@ -592,14 +739,46 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
     tp.hi = (int32_t)ceilf(rank);
     tp.w = rank - (float)tp.lo;
     tp.max_val = st->thr_max;
-    auto kern = stage_thresh_kernel<TS, TE, FORM, GUIDE, XE>;
-    if (lds_bytes > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)lds_bytes);
-      if (e != hipSuccess) return dpm_set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    if (lds_bytes <= lds_cap) {
+      auto kern = stage_thresh_kernel<TS, TE, FORM, GUIDE, XE>;
+      if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes);
+        if (e != hipSuccess) return dpm_set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+      }
+      launch(kern, dim3((unsigned)b->batch), dim3(THR_THREADS), (size_t)lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo,
+             p, tp);
+    } else {
+      // large samples: multi-workgroup exact selection through a caller-provided workspace
+      if (!b->workspace)
+        return dpm_set_error(DPM_ERR_ARG,
+                             "dynamic thresholding of %lld-element samples needs a workspace of "
+                             "dpm_threshold_workspace_bytes() = %lld bytes",
+                             (long long)per_sample, (long long)thr_ws_bytes(b->batch, per_sample));
+      if (b->batch > 65535) return dpm_set_error(DPM_ERR_UNSUPPORTED, "thresholding: batch > 65535 with large samples");
+      unsigned char* ws = static_cast<unsigned char*>(b->workspace);
+      float* w = reinterpret_cast<float*>(ws);
+      uint32_t* hist = reinterpret_cast<uint32_t*>(ws + round256(b->n * 4));
+      ThrSel* sel = reinterpret_cast<ThrSel*>(ws + round256(b->n * 4) + round256(b->batch * THR_BINS * 4));
+      hipError_t me = hipMemsetAsync(hist, 0, (size_t)b->batch * THR_BINS * 4, stream.stream);
+      if (me != hipSuccess) return dpm_set_error((int)me, "hipMemsetAsync: %s", hipGetErrorString(me));
+      int64_t chunks = (per_sample + 256 * 16 - 1) / (256 * 16);
+      const int64_t max_chunks = std::max<int64_t>(1, ((int64_t)n_cu * 8) / b->batch);
+      if (chunks > max_chunks) chunks = max_chunks;
+      const dim3 grid((unsigned)chunks, (unsigned)b->batch);
+      const LaunchCtx plain{stream.stream, nullptr, nullptr};
+      const LaunchCtx first{stream.stream, stream.start, nullptr}, last{stream.stream, nullptr, stream.stop};
+      launch(thr_big_x0_kernel<TS, TE, GUIDE, XE>, grid, dim3(256), 0, stream.start ? first : plain, x, xe, e0, e1, g, w, hist, p,
+             per_sample);
+      launch(thr_big_scan_kernel, dim3((unsigned)b->batch), dim3(1024), 0, plain, hist, sel, 19, 0xfffu, 1, (uint32_t)tp.lo);
+      launch(thr_big_hist_kernel, grid, dim3(256), 0, plain, (const float*)w, hist, (const ThrSel*)sel, 7, 0xfffu, per_sample);
+      launch(thr_big_scan_kernel, dim3((unsigned)b->batch), dim3(1024), 0, plain, hist, sel, 7, 0xfffu, 0, 0u);
+      launch(thr_big_hist_kernel, grid, dim3(256), 0, plain, (const float*)w, hist, (const ThrSel*)sel, 0, 0x7fu, per_sample);
+      launch(thr_big_scan_kernel, dim3((unsigned)b->batch), dim3(1024), 0, plain, hist, sel, 0, 0x7fu, 0, 0u);
+      launch(thr_big_minabove_kernel, grid, dim3(256), 0, plain, (const float*)w, sel, per_sample);
+      launch(thr_big_finish_kernel<TS, FORM>, grid, dim3(256), 0, stream.stop ? last : plain, x, h1, h2, (const float*)w,
+             (const ThrSel*)sel, xo, mo, p, tp);
     }
-    launch(kern, dim3((unsigned)b->batch), dim3(THR_THREADS), (size_t)lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo, p,
-           tp);
   } else {
     const size_t as = sizeof(TS) * EPT, ae = sizeof(TE) * EPT;
     const bool vec = aligned(x, as) && aligned(xe, as) && aligned(h1, as) && aligned(h2, as) && aligned(xo, as) &&
@@ -766,9 +945,11 @@ extern "C" int dpm_stage_launch_timed(const dpm_stage* st, const dpm_buffers* b,
 }
 
 extern "C" size_t dpm_threshold_workspace_bytes(int64_t batch, int64_t per_sample) {
-  (void)batch;
-  (void)per_sample;
-  return 0;  // the LDS-resident path needs no global scratch
+  if (batch < 1 || per_sample < 1) return 0;
+  const DeviceInfo& di = device_info();
+  const int64_t lds_cap = di.lds > 0 ? di.lds : 160 * 1024;
+  if (per_sample * 4 + THR_LDS_EXTRA <= lds_cap) return 0;  // the LDS-resident path needs no global scratch
+  return (size_t)thr_ws_bytes(batch, per_sample);
 }
 
 extern "C" int dpm_add_noise_launch(const dpm_schedule* s, const float* t_host, int nt, const void* x, const void* noise,

@@ -75,7 +75,12 @@ def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None):
     b = L.Buffers()
     b.x, b.xe, b.e0, b.e1, b.g = _ptr(x), _ptr(xe), _ptr(e0), _ptr(e1), _ptr(g)
     b.h1, b.h2, b.x_out, b.m_out = _ptr(h1), _ptr(h2), _ptr(x_out), _ptr(m_out)
-    b.workspace = None
+    ws = None
+    if st.flags & L.F_THRESH:
+        nb = L.lib.dpm_threshold_workspace_bytes(max(int(shape[0]), 1), ref_t.numel() // max(int(shape[0]), 1))
+        if nb:
+            ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    b.workspace = _ptr(ws)
     b.n = ref_t.numel()
     b.batch = max(int(shape[0]), 1) if len(shape) > 0 else 1
     b.state_dtype = _DT[sd]

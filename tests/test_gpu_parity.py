@@ -121,11 +121,36 @@ def test_dynamic_thresholding_bit_exact(golden):
         np.testing.assert_array_equal(y.cpu().numpy(), O.dynamic_threshold(x0, p, 1.0))
 
 
-def test_dynamic_thresholding_sample_too_large_fails_loudly():
+def test_dynamic_thresholding_large_samples(golden):
+    """Samples beyond the LDS-resident path (config-3 sized rows, 3x256x256) take the multi-workgroup selection:
+    still exact order statistics."""
     ns = make_schedule("ddpm")
+    g = lambda k: golden.get("quantile", "quant/f/%s" % k)
+    rng = np.random.default_rng(3)
+    for shape in [(4, 3, 64, 64), (3, 3, 8, 8), (2, 1, 5, 7), (2, 3, 16, 16), (2, 2, 2, 2)]:
+        rng.standard_normal(shape)                                   # replay the generator of make_golden.py
+    x0 = (rng.standard_normal((2, 3, 256, 256)) * 2.5).astype(F32)
     dpm = D.DPM_Solver(lambda x, t: x, ns, correcting_x0_fn="dynamic_thresholding")
-    with pytest.raises(NotImplementedError, match="LDS-resident"):
-        dpm.dynamic_thresholding_fn(torch.zeros(1, 3, 256, 256, device=DEV), None)
+    y = dpm.dynamic_thresholding_fn(torch.from_numpy(x0).to(DEV), None).cpu().numpy()
+    np.testing.assert_array_equal(y.reshape(2, -1)[:, :256], g("y_head"))        # vs torch.quantile in the reference
+    np.testing.assert_array_equal(y, O.dynamic_threshold(x0, 0.995, 1.0))
+    for shape, p in [((3, 1, 300, 200), 0.5), ((2, 3, 128, 128), 0.999), ((5, 1, 41000, 1), 0.25), ((1, 3, 512, 512), 1.0),
+                     ((2, 1, 1, 50000), 0.0)]:
+        x0 = (rng.standard_normal(shape) * 2.0).astype(F32)
+        x0.reshape(shape[0], -1)[0, ::3] = np.float32(1.25)
+        x0.reshape(shape[0], -1)[-1, 100:] = np.float32(-0.75)
+        dpm = D.DPM_Solver(lambda x, t: x, ns, correcting_x0_fn="dynamic_thresholding", dynamic_thresholding_ratio=p)
+        y = dpm.dynamic_thresholding_fn(torch.from_numpy(x0).to(DEV), None)
+        np.testing.assert_array_equal(y.cpu().numpy(), O.dynamic_threshold(x0, p, 1.0))
+
+
+def test_cfg3_sized_thresholded_sampling():
+    """[4,3,256,256] pixel-space 2M++ with dynamic thresholding and CFG: the large-sample path inside sample()."""
+    case = dict(C.E2E_BY_NAME["cfg5_thresh"], shape=(4, 3, 256, 256), steps=10, model="cond",
+                guidance_type="classifier-free", guidance_scale=3.0)
+    xo, _ = TO.run_oracle_case(case)
+    xf, _ = run_case(case, DEV)
+    assert rel_err(xf.cpu().numpy(), xo) < TOL
 
 
 # ------------------------------------------------------------------------------------------------
