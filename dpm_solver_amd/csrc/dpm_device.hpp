@@ -1,0 +1,875 @@
+// dpm_device.hpp -- gfx950 (MI355X, CDNA4) device code of the DPM-Solver engine: element types, the fused stage
+// kernels (streaming + dynamic thresholding) and their launch plumbing.  Included by one translation unit per
+// (state dtype, eps dtype) pair (dpm_stage_*.hip) so the instantiation matrix compiles in parallel, and by
+// dpm_kernels.hip (C ABI entry points, add_noise, adaptive error norm, calibration).
+//
+// One fused, HBM-streaming kernel per solver stage:
+//
+//   raw network output(s) --CFG blend / classifier term--> --x_start|v|score -> eps--> --eps -> x0-->
+//   --dynamic thresholding--> mn   ;   x_out = exponential-integrator combination of x, mn, h1, h2
+//
+// Memory-bound (~0.5 flop/B): no MFMA.  What matters is (i) 16-byte coalesced accesses -- each lane moves
+// 8 consecutive elements per tensor per iteration, a wavefront 512 contiguous elements, (ii) all loads of
+// an iteration issued before the first use, (iii) >= 2048 workgroups of 256 threads so every CU holds 8
+// waves per SIMD, (iv) the per-stage scalars arrive as kernel arguments, i.e. in SGPRs via the scalar
+// cache, so the vector pipeline only ever sees the five streams.  The arithmetic keeps the reference's
+// association and is compiled with -ffp-contract=off: given equal coefficients the result is bit-identical
+// to the reference's chain of ATen kernels (no fused multiply-adds there either).
+//
+// `ref :NNN` = line in the reference's dpm_solver_pytorch.py.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_ext.h>
+
+#include <cstdint>
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+#include "dpm_hip.h"
+
+int dpm_set_error(int code, const char* fmt, ...);  // dpm_host.cpp
+
+namespace dpmk {
+struct Tuning {
+  int unroll = 0;           // tiles per workgroup iteration: 1, 2;  0 = default
+  int nontemporal = -1;     // nt mask; -1 = per-dtype default
+  int blocks_per_cu = 8;    // grid cap = CUs x this (8 x 256 threads = every SIMD holds 8 waves)
+};
+extern Tuning g_tuning;     // defined in dpm_kernels.hip
+}  // namespace dpmk
+using dpmk::Tuning;
+using dpmk::g_tuning;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// element types
+// ------------------------------------------------------------------------------------------------
+struct bf16_t {
+  uint16_t v;
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(__half v) { return __half2float(v); }
+__device__ __forceinline__ float to_f32(bf16_t v) { return __uint_as_float((uint32_t)v.v << 16); }
+
+template <typename T>
+__device__ __forceinline__ T from_f32(float v);
+template <>
+__device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ __half from_f32<__half>(float v) { return __float2half_rn(v); }
+template <>
+__device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) {
+  uint32_t u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return bf16_t{(uint16_t)((u >> 16) | 0x40)};  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                                   // round to nearest even
+  return bf16_t{(uint16_t)(u >> 16)};
+}
+
+constexpr int EPT = 8;  // elements per lane per access group: 2 x 16 B (fp32) or 1 x 16 B (fp16/bf16)
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ __forceinline__ u32x4 ld16(const u32x4* p) {
+  return NT ? __builtin_nontemporal_load(p) : *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st16(u32x4* p, u32x4 v) {
+  if (NT)
+    __builtin_nontemporal_store(v, p);
+  else
+    *p = v;
+}
+
+// 8 consecutive elements of group `group` -> fp32.  Always global_load_dwordx4 (x2 for fp32).
+template <bool NT>
+__device__ __forceinline__ void load_pack(const float* __restrict__ p, int64_t group, float (&out)[EPT]) {
+  const u32x4* q = reinterpret_cast<const u32x4*>(p) + group * 2;
+  const u32x4 a = ld16<NT>(q), b = ld16<NT>(q + 1);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    out[j] = __uint_as_float(a[j]);
+    out[4 + j] = __uint_as_float(b[j]);
+  }
+}
+template <bool NT>
+__device__ __forceinline__ void load_pack(const __half* __restrict__ p, int64_t group, float (&out)[EPT]) {
+  const u32x4 a = ld16<NT>(reinterpret_cast<const u32x4*>(p) + group);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    out[2 * j] = __half2float(__ushort_as_half((unsigned short)(a[j] & 0xffffu)));
+    out[2 * j + 1] = __half2float(__ushort_as_half((unsigned short)(a[j] >> 16)));
+  }
+}
+template <bool NT>
+__device__ __forceinline__ void load_pack(const bf16_t* __restrict__ p, int64_t group, float (&out)[EPT]) {
+  const u32x4 a = ld16<NT>(reinterpret_cast<const u32x4*>(p) + group);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    out[2 * j] = __uint_as_float(a[j] << 16);
+    out[2 * j + 1] = __uint_as_float(a[j] & 0xffff0000u);
+  }
+}
+
+template <bool NT>
+__device__ __forceinline__ void store_pack(float* __restrict__ p, int64_t group, const float (&in)[EPT]) {
+  u32x4 a, b;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    a[j] = __float_as_uint(in[j]);
+    b[j] = __float_as_uint(in[4 + j]);
+  }
+  u32x4* q = reinterpret_cast<u32x4*>(p) + group * 2;
+  st16<NT>(q, a);
+  st16<NT>(q + 1, b);
+}
+template <bool NT>
+__device__ __forceinline__ void store_pack(__half* __restrict__ p, int64_t group, const float (&in)[EPT]) {
+  u32x4 a;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    a[j] = (uint32_t)__half_as_ushort(__float2half_rn(in[2 * j])) |
+           ((uint32_t)__half_as_ushort(__float2half_rn(in[2 * j + 1])) << 16);
+  st16<NT>(reinterpret_cast<u32x4*>(p) + group, a);
+}
+template <bool NT>
+__device__ __forceinline__ void store_pack(bf16_t* __restrict__ p, int64_t group, const float (&in)[EPT]) {
+  u32x4 a;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    a[j] = (uint32_t)from_f32<bf16_t>(in[2 * j]).v | ((uint32_t)from_f32<bf16_t>(in[2 * j + 1]).v << 16);
+  st16<NT>(reinterpret_cast<u32x4*>(p) + group, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-stage scalars (kernel argument => SGPRs)
+// ------------------------------------------------------------------------------------------------
+struct KParams {
+  float alpha_e, sigma_e, cfg_scale, cg_scale;
+  float cx, c0, c1, c2;
+  float k0, k1, k2, k3, k4;
+  uint32_t flags;
+  int32_t model_type;
+};
+
+// Compile-time knowledge about the prologue.  SPEC_GENERIC reads model_type / TO_X0 from the stage record at
+// run time (wave-uniform scalar branches); the two hot specialisations fix them so the inner loop is
+// branch-free: SPEC_NOISE_X0 = noise-prediction network + eps -> x0 (dpmsolver++), SPEC_NOISE_EPS = noise
+// prediction kept (dpmsolver).
+enum { SPEC_GENERIC = 0, SPEC_NOISE_X0 = 1, SPEC_NOISE_EPS = 2 };
+
+template <int SPEC>
+__device__ __forceinline__ bool spec_to_x0(const KParams& p) {
+  return SPEC == SPEC_GENERIC ? (p.flags & DPM_F_TO_X0) != 0 : SPEC == SPEC_NOISE_X0;
+}
+template <int SPEC>
+__device__ __forceinline__ bool spec_need_xe(const KParams& p) {
+  if (SPEC != SPEC_GENERIC) return SPEC == SPEC_NOISE_X0;
+  return (p.flags & DPM_F_TO_X0) || p.model_type == DPM_MODEL_X_START || p.model_type == DPM_MODEL_V;
+}
+
+// raw network output -> noise prediction (noise_pred_fn, ref :288-298)
+template <int SPEC>
+__device__ __forceinline__ float to_noise(float o, float xe, const KParams& p) {
+  if (SPEC != SPEC_GENERIC) return o;
+  switch (p.model_type) {
+    case DPM_MODEL_X_START: return (xe - p.alpha_e * o) / p.sigma_e;
+    case DPM_MODEL_V: return p.alpha_e * o + p.sigma_e * xe;
+    case DPM_MODEL_SCORE: return (-p.sigma_e) * o;
+    default: return o;
+  }
+}
+
+// everything up to (not including) thresholding: returns eps, or x0 when the stage converts (DPM_F_TO_X0)
+template <int GUIDE, int SPEC = SPEC_GENERIC>
+__device__ __forceinline__ float prologue(float xe, float o0, float o1, float gg, const KParams& p) {
+  float eps;
+  if (GUIDE == DPM_GUIDE_CFG) {  // ref :326-330: uncond + scale * (cond - uncond)
+    float nu = to_noise<SPEC>(o1, xe, p), nc = to_noise<SPEC>(o0, xe, p);
+    eps = nu + p.cfg_scale * (nc - nu);
+  } else if (GUIDE == DPM_GUIDE_CLASSIFIER) {  // ref :321
+    eps = to_noise<SPEC>(o0, xe, p) - p.cg_scale * gg;
+  } else {
+    eps = to_noise<SPEC>(o0, xe, p);
+  }
+  if (spec_to_x0<SPEC>(p)) return (xe - p.sigma_e * eps) / p.alpha_e;  // ref :439
+  return eps;
+}
+
+// the exponential-integrator combination, reference association
+template <int FORM>
+__device__ __forceinline__ float combine(float x, float mn, float h1, float h2, const KParams& p) {
+  if (FORM == DPM_FORM_LIN1) {
+    return p.cx * x - p.c0 * mn;  // ref :573-576, :585-588
+  } else if (FORM == DPM_FORM_TWO) {
+    float D = p.k0 * (mn - h1);
+    float P = (p.flags & DPM_F_BASE_HIST) ? h1 : mn;
+    return (p.cx * x - p.c0 * P) - p.c1 * D;  // ref :827-851 (multistep), :636-669, :728-778 (singlestep)
+  } else if (FORM == DPM_FORM_MS3) {
+    float D1_0 = p.k0 * (mn - h1);  // ref :880-883
+    float D1_1 = p.k1 * (h1 - h2);
+    float dd = D1_0 - D1_1;
+    float D1 = D1_0 + p.k2 * dd;
+    float D2 = p.k3 * dd;
+    return ((p.cx * x - p.c0 * mn) - p.c1 * D1) - p.c2 * D2;  // ref :888-903
+  } else if (FORM == DPM_FORM_SS3T) {
+    float D1_0 = p.k0 * (h2 - h1);  // h1 = model_s, h2 = model_s1, mn = model_s2; ref :741-750, :780-789
+    float D1_1 = p.k1 * (mn - h1);
+    float D1 = (p.k2 * D1_0 - p.k3 * D1_1) / p.k4;
+    float D2 = (2.f * (D1_1 - D1_0)) / p.k4;
+    return ((p.cx * x - p.c0 * h1) - p.c1 * D1) - p.c2 * D2;
+  } else {
+    return mn;  // DPM_FORM_DENOISE, ref :541-545
+  }
+}
+
+template <int FORM>
+struct FormTraits {
+  static constexpr bool needs_x = FORM != DPM_FORM_DENOISE;
+  static constexpr bool needs_h1 = FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3 || FORM == DPM_FORM_SS3T;
+  static constexpr bool needs_h2 = FORM == DPM_FORM_MS3 || FORM == DPM_FORM_SS3T;
+};
+
+// ------------------------------------------------------------------------------------------------
+// the streaming stage kernel
+// ------------------------------------------------------------------------------------------------
+template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int SPEC, int U, int NT>
+__global__ __launch_bounds__(256) void stage_kernel(const TS* __restrict__ x, const TS* __restrict__ xe,
+                                                    const TE* __restrict__ e0, const TE* __restrict__ e1,
+                                                    const TE* __restrict__ g, const TS* __restrict__ h1,
+                                                    const TS* __restrict__ h2, TS* __restrict__ xo,
+                                                    TS* __restrict__ mo, int64_t n, KParams p) {
+  using FT = FormTraits<FORM>;
+  const bool need_xe = spec_need_xe<SPEC>(p);
+  const bool store_m = p.flags & DPM_F_STORE_M;
+  const int64_t ngroups = n / EPT;
+  // a tile = 256 consecutive groups (one per lane of the workgroup); a workgroup iteration covers U tiles and
+  // issues the loads of all of them before the first use
+  const int64_t ntiles = (ngroups + 255) / 256;
+  for (int64_t t0 = (int64_t)blockIdx.x * U; t0 < ntiles; t0 += (int64_t)gridDim.x * U) {
+    float vx[U][EPT], vxe[U][EPT], v0[U][EPT], v1[U][EPT], vg[U][EPT], vh1[U][EPT], vh2[U][EPT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t gi = (t0 + u) * 256 + threadIdx.x;
+      if (gi < ngroups) {
+        if (FT::needs_x || (!XE && need_xe)) load_pack<(NT & 1) != 0>(x, gi, vx[u]);
+        if (XE && need_xe) load_pack<(NT & 1) != 0>(xe, gi, vxe[u]);
+        load_pack<(NT & 1) != 0>(e0, gi, v0[u]);
+        if (GUIDE == DPM_GUIDE_CFG) load_pack<(NT & 1) != 0>(e1, gi, v1[u]);
+        if (GUIDE == DPM_GUIDE_CLASSIFIER) load_pack<(NT & 1) != 0>(g, gi, vg[u]);
+        if (FT::needs_h1) load_pack<(NT & 1) != 0>(h1, gi, vh1[u]);
+        if (FT::needs_h2) load_pack<(NT & 1) != 0>(h2, gi, vh2[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t gi = (t0 + u) * 256 + threadIdx.x;
+      if (gi < ngroups) {
+        float ox[EPT], om[EPT];
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+          const float xej = XE ? vxe[u][j] : vx[u][j];
+          const float mn = prologue<GUIDE, SPEC>(xej, v0[u][j], GUIDE == DPM_GUIDE_CFG ? v1[u][j] : 0.f,
+                                                 GUIDE == DPM_GUIDE_CLASSIFIER ? vg[u][j] : 0.f, p);
+          om[j] = mn;
+          ox[j] = combine<FORM>(FT::needs_x ? vx[u][j] : 0.f, mn, FT::needs_h1 ? vh1[u][j] : 0.f,
+                                FT::needs_h2 ? vh2[u][j] : 0.f, p);
+        }
+        store_pack<(NT & 2) != 0>(xo, gi, ox);
+        if (store_m) store_pack<(NT & 4) != 0>(mo, gi, om);
+      }
+    }
+  }
+  // ragged tail (n % 8 elements): first lanes of block 0, scalar
+  const int64_t tail0 = ngroups * EPT;
+  if (blockIdx.x == 0 && tail0 + threadIdx.x < n) {
+    const int64_t i = tail0 + threadIdx.x;
+    const float xv = (FT::needs_x || (!XE && need_xe)) ? to_f32(x[i]) : 0.f;
+    const float xev = XE ? (need_xe ? to_f32(xe[i]) : 0.f) : xv;
+    const float mn = prologue<GUIDE, SPEC>(xev, to_f32(e0[i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[i]) : 0.f,
+                                           GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[i]) : 0.f, p);
+    xo[i] = from_f32<TS>(combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[i]) : 0.f, FT::needs_h2 ? to_f32(h2[i]) : 0.f, p));
+    if (store_m) mo[i] = from_f32<TS>(mn);
+  }
+}
+
+// same arithmetic, one element per lane: used when a pointer is not 16/32-byte aligned (views with offsets)
+template <typename TS, typename TE, int FORM, int GUIDE, bool XE>
+__global__ __launch_bounds__(256) void stage_kernel_scalar(const TS* __restrict__ x, const TS* __restrict__ xe,
+                                                           const TE* __restrict__ e0, const TE* __restrict__ e1,
+                                                           const TE* __restrict__ g, const TS* __restrict__ h1,
+                                                           const TS* __restrict__ h2, TS* __restrict__ xo,
+                                                           TS* __restrict__ mo, int64_t n, KParams p) {
+  using FT = FormTraits<FORM>;
+  const bool need_xe = (p.flags & DPM_F_TO_X0) || p.model_type == DPM_MODEL_X_START || p.model_type == DPM_MODEL_V;
+  const bool store_m = p.flags & DPM_F_STORE_M;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float xv = (FT::needs_x || (!XE && need_xe)) ? to_f32(x[i]) : 0.f;
+    const float xev = XE ? (need_xe ? to_f32(xe[i]) : 0.f) : xv;
+    const float mn = prologue<GUIDE>(xev, to_f32(e0[i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[i]) : 0.f,
+                                     GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[i]) : 0.f, p);
+    xo[i] = from_f32<TS>(combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[i]) : 0.f, FT::needs_h2 ? to_f32(h2[i]) : 0.f, p));
+    if (store_m) mo[i] = from_f32<TS>(mn);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dynamic thresholding (ref :416-425): one workgroup per sample, x0 resident in LDS.
+//
+//   s = quantile(|x0|, ratio) over the sample  -> exact order statistics by an 8/8/8/7-bit radix select on
+//       the bit pattern of |x0| (non-negative floats order like their bit patterns), histogram in LDS,
+//       bin search by wavefront prefix sums; the fractional rank is the reference's fp32 `ratio*(n-1)`.
+//   s = max(s, max_val);  x0 <- clamp(x0, -s, s) / s;  then the same combine as the streaming kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int THR_THREADS = 1024;
+
+struct ThrParams {
+  int64_t per_sample;
+  int32_t lo, hi;  // floor / ceil of the fp32 rank (ascending order)
+  float w;         // fractional part
+  float max_val;
+};
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+template <typename TS, typename TE, int FORM, int GUIDE, bool XE>
+__global__ __launch_bounds__(THR_THREADS) void stage_thresh_kernel(
+    const TS* __restrict__ x, const TS* __restrict__ xe, const TE* __restrict__ e0, const TE* __restrict__ e1,
+    const TE* __restrict__ g, const TS* __restrict__ h1, const TS* __restrict__ h2, TS* __restrict__ xo,
+    TS* __restrict__ mo, KParams p, ThrParams tp) {
+  using FT = FormTraits<FORM>;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  float* sx0 = reinterpret_cast<float*>(lds_raw);                 // [per_sample]
+  uint32_t* hist = reinterpret_cast<uint32_t*>(sx0 + tp.per_sample);  // [256]
+  uint32_t* misc = hist + 256;                                    // [4]: prefix, k, count, min-above
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int64_t base = (int64_t)blockIdx.x * tp.per_sample;
+  const int n = (int)tp.per_sample;
+  const bool store_m = p.flags & DPM_F_STORE_M;
+
+  // phase 1: x0 for the whole sample -> LDS
+  for (int i = tid; i < n; i += THR_THREADS) {
+    const int64_t gi = base + i;
+    const float xev = to_f32(XE ? xe[gi] : x[gi]);
+    sx0[i] = prologue<GUIDE>(xev, to_f32(e0[gi]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[gi]) : 0.f,
+                             GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[gi]) : 0.f, p);
+  }
+  if (tid == 0) {
+    misc[0] = 0u;               // prefix bits decided so far
+    misc[1] = (uint32_t)tp.lo;  // rank still to resolve inside the prefix group
+  }
+  __syncthreads();
+
+  // phase 2: radix select of the lo-th smallest |x0|
+  uint32_t known_mask = 0u;
+#pragma unroll 1
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = pass == 0 ? 23 : pass == 1 ? 15 : pass == 2 ? 7 : 0;
+    const uint32_t dmask = pass == 3 ? 0x7fu : 0xffu;
+    if (tid < 256) hist[tid] = 0u;
+    __syncthreads();
+    const uint32_t prefix = misc[0];
+    for (int i = tid; i < n; i += THR_THREADS) {
+      const uint32_t u = __float_as_uint(sx0[i]) & 0x7fffffffu;
+      if ((u & known_mask) == prefix) atomicAdd(&hist[(u >> shift) & dmask], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {  // wavefront 0: locate the bin holding rank k
+      const uint32_t k = misc[1];
+      uint32_t c[4], tot = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        c[j] = hist[lane * 4 + j];
+        tot += c[j];
+      }
+      const uint32_t incl = wave_incl_scan(tot, lane);
+      const uint64_t ball = __ballot(incl > k);
+      const int owner = __ffsll((long long)ball) - 1;
+      if (lane == owner) {
+        uint32_t before = incl - tot;
+        int j = 0;
+        while (j < 3 && before + c[j] <= k) {
+          before += c[j];
+          ++j;
+        }
+        misc[0] = prefix | ((uint32_t)(lane * 4 + j) << shift);
+        misc[1] = k - before;
+        misc[2] = c[j];
+      }
+    }
+    known_mask |= dmask << shift;
+    __syncthreads();
+  }
+  const uint32_t a_bits = misc[0];
+  float a = __uint_as_float(a_bits), b = a;
+  if (tp.hi != tp.lo && misc[1] + 1u >= misc[2]) {
+    // the next order statistic is the smallest value above a: wavefront min, then one LDS atomic per wave
+    __syncthreads();
+    if (tid == 0) misc[3] = 0x7fffffffu;
+    __syncthreads();
+    uint32_t m = 0x7fffffffu;
+    for (int i = tid; i < n; i += THR_THREADS) {
+      const uint32_t u = __float_as_uint(sx0[i]) & 0x7fffffffu;
+      if (u > a_bits && u < m) m = u;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint32_t o = __shfl_xor(m, d, 64);
+      m = o < m ? o : m;
+    }
+    if (lane == 0) atomicMin(&misc[3], m);
+    __syncthreads();
+    b = __uint_as_float(misc[3]);
+  }
+  // torch.quantile 'linear' = ATen lerp(a, b, w)
+  const float diff = b - a;
+  const float q = tp.w < 0.5f ? a + tp.w * diff : b - diff * (1.f - tp.w);
+  const float s = fmaxf(q, tp.max_val);  // ref :423
+
+  // phase 3: clamp, scale, combine, store
+  for (int i = tid; i < n; i += THR_THREADS) {
+    const int64_t gi = base + i;
+    const float x0 = sx0[i];
+    const float mn = fminf(fmaxf(x0, -s), s) / s;  // ref :424
+    const float xv = FT::needs_x ? to_f32(x[gi]) : 0.f;
+    xo[gi] = from_f32<TS>(combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[gi]) : 0.f,
+                                        FT::needs_h2 ? to_f32(h2[gi]) : 0.f, p));
+    if (store_m) mo[gi] = from_f32<TS>(mn);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dynamic thresholding for samples that do not fit in LDS (e.g. 3x256x256 pixel samples): the same exact
+// selection, spread over many workgroups per sample.  x0 is materialised once in an fp32 workspace; three
+// radix levels (12 + 12 + 7 bits of the |x0| bit pattern) each take one histogram pass (LDS-private histogram
+// per workgroup, flushed with global atomics) and one tiny per-sample scan; one more pass finds the smallest
+// value above the selected one; the final pass clamps, scales and applies the update.
+// ------------------------------------------------------------------------------------------------
+struct ThrSel {        // per-sample selection state in the workspace
+  uint32_t prefix;     // bits of the lo-th smallest |x0| decided so far
+  uint32_t mask;       // which bits those are
+  uint32_t k;          // rank still to resolve inside the prefix group
+  uint32_t cnt;        // size of the selected bin (after the last level: multiplicity of the value)
+  uint32_t min_above;  // smallest bit pattern strictly above the selected value
+  uint32_t pad[3];
+};
+constexpr int THR_BINS = 4096;
+
+template <typename TS, typename TE, int GUIDE, bool XE>
+__global__ __launch_bounds__(256) void thr_big_x0_kernel(const TS* __restrict__ x, const TS* __restrict__ xe,
+                                                         const TE* __restrict__ e0, const TE* __restrict__ e1,
+                                                         const TE* __restrict__ g, float* __restrict__ w,
+                                                         uint32_t* __restrict__ hist, KParams p, int64_t per_sample) {
+  __shared__ uint32_t lh[THR_BINS];
+  for (int i = threadIdx.x; i < THR_BINS; i += 256) lh[i] = 0u;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.y * per_sample;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
+    const int64_t gi = base + i;
+    const float xev = to_f32(XE ? xe[gi] : x[gi]);
+    const float x0 = prologue<GUIDE>(xev, to_f32(e0[gi]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[gi]) : 0.f,
+                                     GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[gi]) : 0.f, p);
+    w[gi] = x0;
+    atomicAdd(&lh[(__float_as_uint(x0) & 0x7fffffffu) >> 19], 1u);
+  }
+  __syncthreads();
+  uint32_t* gh = hist + (int64_t)blockIdx.y * THR_BINS;
+  for (int i = threadIdx.x; i < THR_BINS; i += 256)
+    if (lh[i]) atomicAdd(&gh[i], lh[i]);
+}
+
+__global__ __launch_bounds__(256) void thr_big_hist_kernel(const float* __restrict__ w, uint32_t* __restrict__ hist,
+                                                           const ThrSel* __restrict__ sel, int shift, uint32_t dmask,
+                                                           int64_t per_sample) {
+  __shared__ uint32_t lh[THR_BINS];
+  for (int i = threadIdx.x; i < THR_BINS; i += 256) lh[i] = 0u;
+  __syncthreads();
+  const uint32_t prefix = sel[blockIdx.y].prefix, mask = sel[blockIdx.y].mask;
+  const int64_t base = (int64_t)blockIdx.y * per_sample;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
+    const uint32_t u = __float_as_uint(w[base + i]) & 0x7fffffffu;
+    if ((u & mask) == prefix) atomicAdd(&lh[(u >> shift) & dmask], 1u);
+  }
+  __syncthreads();
+  uint32_t* gh = hist + (int64_t)blockIdx.y * THR_BINS;
+  for (int i = threadIdx.x; i <= (int)dmask; i += 256)
+    if (lh[i]) atomicAdd(&gh[i], lh[i]);
+}
+
+// one workgroup per sample: find the bin holding rank k, fold it into the prefix, clear the histogram
+__global__ __launch_bounds__(1024) void thr_big_scan_kernel(uint32_t* __restrict__ hist, ThrSel* __restrict__ sel,
+                                                            int shift, uint32_t dmask, int first, uint32_t lo) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t res[3];
+  uint32_t* gh = hist + (int64_t)blockIdx.x * THR_BINS;
+  ThrSel& s = sel[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint32_t k = first ? lo : s.k;
+  uint32_t c[4], tot = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    c[j] = gh[tid * 4 + j];
+    tot += c[j];
+  }
+  const uint32_t incl_w = wave_incl_scan(tot, lane);
+  if (lane == 63) wave_tot[wv] = incl_w;
+  __syncthreads();
+  uint32_t before_wave = 0;
+  for (int q = 0; q < wv; ++q) before_wave += wave_tot[q];
+  const uint32_t incl = before_wave + incl_w, excl = incl - tot;
+  if (excl <= k && k < incl) {  // exactly one thread
+    uint32_t before = excl;
+    int j = 0;
+    while (j < 3 && before + c[j] <= k) {
+      before += c[j];
+      ++j;
+    }
+    res[0] = (uint32_t)(tid * 4 + j);
+    res[1] = k - before;
+    res[2] = c[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) gh[tid * 4 + j] = 0u;  // ready for the next level
+  if (tid == 0) {
+    const uint32_t pre = first ? 0u : s.prefix, msk = first ? 0u : s.mask;
+    s.prefix = pre | (res[0] << shift);
+    s.mask = msk | (dmask << shift);
+    s.k = res[1];
+    s.cnt = res[2];
+    if (first) s.min_above = 0x7fffffffu;
+  }
+}
+
+__global__ __launch_bounds__(256) void thr_big_minabove_kernel(const float* __restrict__ w, ThrSel* __restrict__ sel,
+                                                               int64_t per_sample) {
+  const uint32_t a_bits = sel[blockIdx.y].prefix;
+  const int64_t base = (int64_t)blockIdx.y * per_sample;
+  uint32_t m = 0x7fffffffu;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
+    const uint32_t u = __float_as_uint(w[base + i]) & 0x7fffffffu;
+    if (u > a_bits && u < m) m = u;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t o = __shfl_xor(m, d, 64);
+    m = o < m ? o : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m != 0x7fffffffu) atomicMin(&sel[blockIdx.y].min_above, m);
+}
+
+template <typename TS, int FORM>
+__global__ __launch_bounds__(256) void thr_big_finish_kernel(const TS* __restrict__ x, const TS* __restrict__ h1,
+                                                             const TS* __restrict__ h2, const float* __restrict__ w,
+                                                             const ThrSel* __restrict__ sel, TS* __restrict__ xo,
+                                                             TS* __restrict__ mo, KParams p, ThrParams tp) {
+  using FT = FormTraits<FORM>;
+  const ThrSel s_ = sel[blockIdx.y];
+  const float a = __uint_as_float(s_.prefix);
+  float b = a;
+  if (tp.hi != tp.lo && s_.k + 1u >= s_.cnt) b = __uint_as_float(s_.min_above);
+  const float diff = b - a;
+  const float q = tp.w < 0.5f ? a + tp.w * diff : b - diff * (1.f - tp.w);
+  const float s = fmaxf(q, tp.max_val);
+  const bool store_m = p.flags & DPM_F_STORE_M;
+  const int64_t base = (int64_t)blockIdx.y * tp.per_sample;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tp.per_sample; i += (int64_t)gridDim.x * 256) {
+    const int64_t gi = base + i;
+    const float mn = fminf(fmaxf(w[gi], -s), s) / s;
+    const float xv = FT::needs_x ? to_f32(x[gi]) : 0.f;
+    xo[gi] = from_f32<TS>(combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[gi]) : 0.f, FT::needs_h2 ? to_f32(h2[gi]) : 0.f, p));
+    if (store_m) mo[gi] = from_f32<TS>(mn);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// add_noise (ref :1012-1030):  out = alpha*x + sigma*noise
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void add_noise_kernel(const T* __restrict__ x, const T* __restrict__ nz,
+                                                        T* __restrict__ out, int64_t n, float alpha, float sigma) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = from_f32<T>(alpha * to_f32(x[i]) + sigma * to_f32(nz[i]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// adaptive solver error norm (ref :999-1001): one workgroup per sample
+//   delta = max(atol, rtol*max(|x_lower|, |x_prev|));  E_b = sqrt(mean(((x_higher - x_lower)/delta)^2))
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void adaptive_error_kernel(const T* __restrict__ xl, const T* __restrict__ xh,
+                                                              const T* __restrict__ xp, float atol, float rtol,
+                                                              float* __restrict__ e_out, int64_t per_sample) {
+  __shared__ double part[16];
+  const int64_t base = (int64_t)blockIdx.x * per_sample;
+  double acc = 0.;
+  for (int64_t i = threadIdx.x; i < per_sample; i += blockDim.x) {
+    const float l = to_f32(xl[base + i]), h = to_f32(xh[base + i]), pv = to_f32(xp[base + i]);
+    const float delta = fmaxf(atol, rtol * fmaxf(fabsf(l), fabsf(pv)));
+    const float v = (h - l) / delta;
+    acc += (double)(v * v);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
+    e_out[blockIdx.x] = sqrtf((float)(t / (double)per_sample));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch plumbing
+// ------------------------------------------------------------------------------------------------
+struct DeviceInfo {
+  int n_cu = 0;
+  int lds = 0;
+  char arch[64] = {0};
+  bool ok = false;
+};
+
+inline const DeviceInfo& device_info() {
+  static thread_local int cached_dev = -1;
+  static thread_local DeviceInfo info;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return info;
+  if (dev != cached_dev || !info.ok) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+      info.n_cu = prop.multiProcessorCount;
+      info.lds = (int)prop.maxSharedMemoryPerMultiProcessor;
+      std::strncpy(info.arch, prop.gcnArchName, sizeof(info.arch) - 1);
+      info.ok = true;
+      cached_dev = dev;
+    }
+  }
+  return info;
+}
+
+inline bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+inline KParams make_params(const dpm_stage* st) {
+  KParams p;
+  p.alpha_e = st->alpha_e;
+  p.sigma_e = st->sigma_e;
+  p.cfg_scale = st->cfg_scale;
+  p.cg_scale = st->cg_scale;
+  p.cx = st->cx;
+  p.c0 = st->c0;
+  p.c1 = st->c1;
+  p.c2 = st->c2;
+  p.k0 = st->k[0];
+  p.k1 = st->k[1];
+  p.k2 = st->k[2];
+  p.k3 = st->k[3];
+  p.k4 = st->k[4];
+  p.flags = st->flags;
+  p.model_type = st->model_type;
+  return p;
+}
+
+constexpr int64_t THR_LDS_EXTRA = (256 + 8) * 4;
+
+inline int64_t round256(int64_t v) { return (v + 255) / 256 * 256; }
+// global workspace of the large-sample thresholding path: [x0 fp32: n][hist: batch x 4096 u32][sel: batch x 32 B]
+inline int64_t thr_ws_bytes(int64_t batch, int64_t per_sample) {
+  return round256(batch * per_sample * 4) + round256(batch * THR_BINS * 4) + round256(batch * (int64_t)sizeof(ThrSel));
+}
+
+// launch-shape defaults (chosen on MI355X) and the run-time tuning hooks
+// nt mask: bit 0 = nt loads, bit 1 = nt x_out store, bit 2 = nt m_out store.  Measured on [256,4,64,64]
+// (tools/tune2.py, profiles/r01_tuning.md): 2-byte states are fastest with streaming (nt) loads and an nt store of
+// the model value, both when the buffers are warm in the Infinity Cache and when they come from HBM; 4-byte states
+// are fastest with the default cache policy.
+constexpr int DEF_U = 1;
+template <typename TS>
+struct DefNT {
+  static constexpr int value = sizeof(TS) == 2 ? 5 : 0;
+};
+
+template <int FORM, int GUIDE, bool XE>
+struct HotCombo {
+  static constexpr bool value = (FORM == DPM_FORM_TWO || FORM == DPM_FORM_LIN1) && GUIDE == DPM_GUIDE_NONE && !XE;
+};
+
+struct LaunchCtx {
+  hipStream_t stream;
+  hipEvent_t start, stop;  // both null: plain launch; else hipExtLaunchKernelGGL brackets the kernel itself
+};
+
+template <typename K, typename... Args>
+void launch(K kern, dim3 grid, dim3 block, size_t lds, const LaunchCtx& c, Args... args) {
+  if (c.start || c.stop)
+    hipExtLaunchKernelGGL(kern, grid, block, lds, c.stream, c.start, c.stop, 0, args...);
+  else
+    hipLaunchKernelGGL(kern, grid, block, lds, c.stream, args...);
+}
+
+template <typename TS, typename TE, int FORM, int GUIDE, bool XE>
+int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& stream) {
+  const KParams p = make_params(st);
+  const TS* x = static_cast<const TS*>(b->x);
+  const TS* xe = static_cast<const TS*>(b->xe);
+  const TE* e0 = static_cast<const TE*>(b->e0);
+  const TE* e1 = static_cast<const TE*>(b->e1);
+  const TE* g = static_cast<const TE*>(b->g);
+  const TS* h1 = static_cast<const TS*>(b->h1);
+  const TS* h2 = static_cast<const TS*>(b->h2);
+  TS* xo = static_cast<TS*>(b->x_out);
+  TS* mo = static_cast<TS*>(b->m_out);
+  const DeviceInfo& di = device_info();
+  const int n_cu = di.n_cu > 0 ? di.n_cu : 256;
+
+  if (st->flags & DPM_F_THRESH) {
+    const int64_t per_sample = b->n / b->batch;
+    const int64_t lds_bytes = per_sample * 4 + THR_LDS_EXTRA;
+    const int64_t lds_cap = di.lds > 0 ? di.lds : 160 * 1024;
+    ThrParams tp;
+    tp.per_sample = per_sample;
+    // torch.quantile: rank = q * (n - 1) evaluated in fp32 (q is an fp32 tensor)
+    const float rank = st->thr_ratio * (float)(per_sample - 1);
+    tp.lo = (int32_t)floorf(rank);
+    tp.hi = (int32_t)ceilf(rank);
+    tp.w = rank - (float)tp.lo;
+    tp.max_val = st->thr_max;
+    if (lds_bytes <= lds_cap) {
+      auto kern = stage_thresh_kernel<TS, TE, FORM, GUIDE, XE>;
+      if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes);
+        if (e != hipSuccess) return dpm_set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+      }
+      launch(kern, dim3((unsigned)b->batch), dim3(THR_THREADS), (size_t)lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo,
+             p, tp);
+    } else {
+      // large samples: multi-workgroup exact selection through a caller-provided workspace
+      if (!b->workspace)
+        return dpm_set_error(DPM_ERR_ARG,
+                             "dynamic thresholding of %lld-element samples needs a workspace of "
+                             "dpm_threshold_workspace_bytes() = %lld bytes",
+                             (long long)per_sample, (long long)thr_ws_bytes(b->batch, per_sample));
+      if (b->batch > 65535) return dpm_set_error(DPM_ERR_UNSUPPORTED, "thresholding: batch > 65535 with large samples");
+      unsigned char* ws = static_cast<unsigned char*>(b->workspace);
+      float* w = reinterpret_cast<float*>(ws);
+      uint32_t* hist = reinterpret_cast<uint32_t*>(ws + round256(b->n * 4));
+      ThrSel* sel = reinterpret_cast<ThrSel*>(ws + round256(b->n * 4) + round256(b->batch * THR_BINS * 4));
+      hipError_t me = hipMemsetAsync(hist, 0, (size_t)b->batch * THR_BINS * 4, stream.stream);
+      if (me != hipSuccess) return dpm_set_error((int)me, "hipMemsetAsync: %s", hipGetErrorString(me));
+      int64_t chunks = (per_sample + 256 * 16 - 1) / (256 * 16);
+      const int64_t max_chunks = std::max<int64_t>(1, ((int64_t)n_cu * 8) / b->batch);
+      if (chunks > max_chunks) chunks = max_chunks;
+      const dim3 grid((unsigned)chunks, (unsigned)b->batch);
+      const LaunchCtx plain{stream.stream, nullptr, nullptr};
+      const LaunchCtx first{stream.stream, stream.start, nullptr}, last{stream.stream, nullptr, stream.stop};
+      launch(thr_big_x0_kernel<TS, TE, GUIDE, XE>, grid, dim3(256), 0, stream.start ? first : plain, x, xe, e0, e1, g, w, hist, p,
+             per_sample);
+      launch(thr_big_scan_kernel, dim3((unsigned)b->batch), dim3(1024), 0, plain, hist, sel, 19, 0xfffu, 1, (uint32_t)tp.lo);
+      launch(thr_big_hist_kernel, grid, dim3(256), 0, plain, (const float*)w, hist, (const ThrSel*)sel, 7, 0xfffu, per_sample);
+      launch(thr_big_scan_kernel, dim3((unsigned)b->batch), dim3(1024), 0, plain, hist, sel, 7, 0xfffu, 0, 0u);
+      launch(thr_big_hist_kernel, grid, dim3(256), 0, plain, (const float*)w, hist, (const ThrSel*)sel, 0, 0x7fu, per_sample);
+      launch(thr_big_scan_kernel, dim3((unsigned)b->batch), dim3(1024), 0, plain, hist, sel, 0, 0x7fu, 0, 0u);
+      launch(thr_big_minabove_kernel, grid, dim3(256), 0, plain, (const float*)w, sel, per_sample);
+      launch(thr_big_finish_kernel<TS, FORM>, grid, dim3(256), 0, stream.stop ? last : plain, x, h1, h2, (const float*)w,
+             (const ThrSel*)sel, xo, mo, p, tp);
+    }
+  } else {
+    const size_t as = sizeof(TS) * EPT, ae = sizeof(TE) * EPT;
+    const bool vec = aligned(x, as) && aligned(xe, as) && aligned(h1, as) && aligned(h2, as) && aligned(xo, as) &&
+                     aligned(mo, as) && aligned(e0, ae) && aligned(e1, ae) && aligned(g, ae);
+    if (!vec) {
+      int64_t blocks = (b->n + 255) / 256;
+      const int64_t cap = (int64_t)n_cu * 16;
+      if (blocks > cap) blocks = cap;
+      launch(stage_kernel_scalar<TS, TE, FORM, GUIDE, XE>, dim3((unsigned)blocks), dim3(256), 0, stream, x, xe, e0, e1, g,
+             h1, h2, xo, mo, b->n, p);
+    } else {
+      // specialise the prologue when the stage allows it (noise-prediction network: the common case)
+      const bool noise = st->model_type == DPM_MODEL_NOISE;
+      const int spec = !noise ? SPEC_GENERIC : ((st->flags & DPM_F_TO_X0) ? SPEC_NOISE_X0 : SPEC_NOISE_EPS);
+      const int64_t ntiles = ((b->n / EPT) + 255) / 256;
+      const Tuning tn = g_tuning;
+      auto grid_for = [&](int u) {
+        int64_t blocks = (ntiles + u - 1) / u;
+        const int64_t cap = (int64_t)n_cu * tn.blocks_per_cu;
+        if (blocks > cap) blocks = cap;
+        return dim3((unsigned)(blocks < 1 ? 1 : blocks));
+      };
+#define DPM_LAUNCH(SPEC_, U_, NT_)                                                                                  \
+  launch(stage_kernel<TS, TE, FORM, GUIDE, XE, SPEC_, U_, NT_>, grid_for(U_), dim3(256), 0, stream, x, xe, e0, e1, g, \
+         h1, h2, xo, mo, b->n, p)
+      if (spec == SPEC_GENERIC) {
+        DPM_LAUNCH(SPEC_GENERIC, 1, DefNT<TS>::value);
+      } else if (spec == SPEC_NOISE_EPS) {
+        DPM_LAUNCH(SPEC_NOISE_EPS, DEF_U, DefNT<TS>::value);
+      } else if (HotCombo<FORM, GUIDE, XE>::value) {
+        // tuning variants exist only for the north-star kernels (2M / 1st-order update, no guidance)
+        const int key = (tn.unroll <= 0 || tn.nontemporal < 0) ? -1 : tn.unroll * 8 + (tn.nontemporal & 7);
+        switch (key) {
+          case 8 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 1, 0); break;
+          case 8 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 1, 1); break;
+          case 8 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 1, 5); break;
+          case 8 + 6: DPM_LAUNCH(SPEC_NOISE_X0, 1, 6); break;
+          case 8 + 7: DPM_LAUNCH(SPEC_NOISE_X0, 1, 7); break;
+          case 16 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 2, 0); break;
+          case 16 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 2, 1); break;
+          case 16 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 2, 5); break;
+          case 16 + 6: DPM_LAUNCH(SPEC_NOISE_X0, 2, 6); break;
+          case 16 + 7: DPM_LAUNCH(SPEC_NOISE_X0, 2, 7); break;
+          default: DPM_LAUNCH(SPEC_NOISE_X0, DEF_U, DefNT<TS>::value); break;
+        }
+      } else {
+        DPM_LAUNCH(SPEC_NOISE_X0, DEF_U, DefNT<TS>::value);
+      }
+#undef DPM_LAUNCH
+    }
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return dpm_set_error((int)e, "stage kernel launch failed: %s", hipGetErrorString(e));
+  return DPM_OK;
+}
+
+template <typename TS, typename TE, int FORM, int GUIDE>
+int launch_xe(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& s) {
+  return (b->xe != nullptr && b->xe != b->x) ? launch_typed<TS, TE, FORM, GUIDE, true>(st, b, s)
+                                            : launch_typed<TS, TE, FORM, GUIDE, false>(st, b, s);
+}
+
+template <typename TS, typename TE, int FORM>
+int launch_guide(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& s) {
+  switch (st->guidance) {
+    case DPM_GUIDE_NONE: return launch_xe<TS, TE, FORM, DPM_GUIDE_NONE>(st, b, s);
+    case DPM_GUIDE_CFG: return launch_xe<TS, TE, FORM, DPM_GUIDE_CFG>(st, b, s);
+    case DPM_GUIDE_CLASSIFIER: return launch_xe<TS, TE, FORM, DPM_GUIDE_CLASSIFIER>(st, b, s);
+  }
+  return dpm_set_error(DPM_ERR_ARG, "unknown guidance %d", st->guidance);
+}
+
+template <typename TS, typename TE>
+int launch_form(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& s) {
+  switch (st->form) {
+    case DPM_FORM_LIN1: return launch_guide<TS, TE, DPM_FORM_LIN1>(st, b, s);
+    case DPM_FORM_TWO: return launch_guide<TS, TE, DPM_FORM_TWO>(st, b, s);
+    case DPM_FORM_MS3: return launch_guide<TS, TE, DPM_FORM_MS3>(st, b, s);
+    case DPM_FORM_SS3T: return launch_guide<TS, TE, DPM_FORM_SS3T>(st, b, s);
+    case DPM_FORM_DENOISE: return launch_guide<TS, TE, DPM_FORM_DENOISE>(st, b, s);
+  }
+  return dpm_set_error(DPM_ERR_ARG, "unknown update form %d", st->form);
+}
+
+}  // namespace
