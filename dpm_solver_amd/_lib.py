@@ -27,7 +27,7 @@ GUIDE = {"uncond": 0, "classifier-free": 1, "classifier": 2}
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
 EVAL_LOG_ALPHA, EVAL_ALPHA, EVAL_STD, EVAL_LAMBDA, EVAL_INV_LAMBDA = 0, 1, 2, 3, 4
 FORM_LIN1, FORM_TWO, FORM_MS3, FORM_SS3T, FORM_DENOISE = 0, 1, 2, 3, 4
-F_TO_X0, F_STORE_M, F_BASE_HIST, F_THRESH, F_USER_X0 = 1, 2, 4, 8, 16
+F_TO_X0, F_STORE_M, F_BASE_HIST, F_THRESH, F_USER_X0, F_BLEND = 1, 2, 4, 8, 16, 32
 SRC_STATE, SRC_TMP = 0, 1
 TUNE_UNROLL, TUNE_NONTEMPORAL, TUNE_BLOCKS_PER_CU = 0, 1, 2
 
@@ -42,6 +42,7 @@ class Stage(C.Structure):
         ("alpha_e", C.c_float), ("sigma_e", C.c_float), ("cfg_scale", C.c_float), ("cg_scale", C.c_float),
         ("cx", C.c_float), ("c0", C.c_float), ("c1", C.c_float), ("c2", C.c_float),
         ("k", C.c_float * 5), ("thr_ratio", C.c_float), ("thr_max", C.c_float),
+        ("blend_alpha", C.c_float), ("blend_sigma", C.c_float),
     ]
 
     def copy(self):
@@ -56,6 +57,8 @@ class Buffers(C.Structure):
         ("h1", C.c_void_p), ("h2", C.c_void_p), ("x_out", C.c_void_p), ("m_out", C.c_void_p),
         ("workspace", C.c_void_p), ("n", C.c_int64), ("batch", C.c_int64),
         ("state_dtype", C.c_int32), ("eps_dtype", C.c_int32),
+        ("x_out2", C.c_void_p), ("eps_stride", C.c_int64), ("mask", C.c_void_p), ("blend_a", C.c_void_p),
+        ("blend_b", C.c_void_p), ("mask_period", C.c_int64),
     ]
 
 
@@ -113,17 +116,25 @@ _SIGNATURES = [
     ("dpm_threshold_workspace_bytes", C.c_size_t, [C.c_int64, C.c_int64]),
     ("dpm_add_noise_launch", C.c_int, [C.c_void_p, _P(C.c_float), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int64, C.c_int, C.c_void_p]),
+    ("dpm_blend_launch", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p,
+                                   C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     ("dpm_adaptive_error_launch", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p,
                                             C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     ("dpm_plan_run", C.c_int, [C.c_void_p, _P(RunBuffers), C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int)]),
     ("dpm_stage_launch_timed", C.c_int, [_P(Stage), _P(Buffers), C.c_void_p, _P(C.c_float)]),
     ("dpm_plan_run_timed", C.c_int, [C.c_void_p, _P(RunBuffers), C.c_void_p, _P(C.c_float), _P(C.c_int)]),
     ("dpm_plan_run_multi", C.c_int, [C.c_void_p, _P(RunBuffers), C.c_int, C.c_void_p, _P(C.c_float), _P(C.c_int)]),
+    ("dpm_graph_create", C.c_int, [C.c_void_p, _P(RunBuffers), C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
+    ("dpm_graph_launch", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("dpm_graph_result", C.c_int, [C.c_void_p]),
+    ("dpm_graph_num_nodes", C.c_int, [C.c_void_p]),
+    ("dpm_graph_destroy", None, [C.c_void_p]),
     ("dpm_tuning_set", C.c_int, [C.c_int, C.c_int]),
     ("dpm_tuning_get", C.c_int, [C.c_int]),
     ("dpm_calib_launch", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int64, C.c_void_p, _P(C.c_float)]),
     ("dpm_version", C.c_int, []),
+    ("dpm_sizeof", C.c_size_t, [C.c_int]),
     ("dpm_last_error", C.c_char_p, []),
     ("dpm_device_info", C.c_int, [_P(C.c_int), _P(C.c_int), C.c_char_p, C.c_int]),
 ]
@@ -144,6 +155,10 @@ def _load():
 
 
 lib = _load()
+for _i, _t in enumerate((Stage, Buffers, PlanDesc, RunBuffers)):  # the ctypes mirrors must match the compiled structs
+    if lib.dpm_sizeof(_i) != C.sizeof(_t):
+        raise ImportError("dpm_solver_amd: %s is %d bytes in _lib.py but %d in libdpm_hip.so -- stale library, rebuild"
+                          % (_t.__name__, C.sizeof(_t), lib.dpm_sizeof(_i)))
 
 
 class DpmError(RuntimeError):

@@ -235,6 +235,34 @@ struct FormTraits {
 };
 
 // ------------------------------------------------------------------------------------------------
+// extensions around the update: all optional, all wave-uniform
+//   * eps_stride: the network output is a channel slice of a wider tensor (learned-variance models return
+//     [B,2C,H,W] and the solver uses out[:, :C], runners/diffusion.py:596-603): sample b of e0/e1 starts at
+//     b*eps_stride instead of b*per_sample, so no .contiguous() copy is needed;
+//   * xo2: second copy of x_out -- the other half of the [2B,...] network input of classifier-free guidance
+//     (replaces torch.cat([x] * 2), ref :326);
+//   * mask / ba / bb: the mask blend the DiffEdit / inpainting callers run as correcting_xt_fn after every update
+//     (scripts/diffedit_inpaint.ipynb cell 6):  x <- x*mask + (1 - mask)*(blend_alpha*ba + blend_sigma*bb)
+//     (bb null: x <- x*mask + (1 - mask)*ba), mask indexed modulo mask_period (broadcast [H,W] / [C,H,W] masks).
+// ------------------------------------------------------------------------------------------------
+struct KExt {
+  void* xo2;
+  const void* mask;
+  const void* ba;
+  const void* bb;
+  int64_t mask_period;  // elements
+  int64_t per_sample;   // elements of one sample (eps_stride != 0 only)
+  int64_t eps_stride;   // elements between samples of e0 / e1; 0 = contiguous
+  float blend_alpha, blend_sigma;
+};
+
+// reference association of the blend: x * mask + (1 - mask) * (alpha * a + sigma * b), one rounding per operation
+__device__ __forceinline__ float blend_ref(float v, float m, float a, float b, bool has_b, const KExt& e) {
+  const float r = has_b ? e.blend_alpha * a + e.blend_sigma * b : a;
+  return v * m + (1.f - m) * r;
+}
+
+// ------------------------------------------------------------------------------------------------
 // the streaming stage kernel
 // ------------------------------------------------------------------------------------------------
 template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int SPEC, int U, int NT>
@@ -303,18 +331,92 @@ __global__ __launch_bounds__(256) void stage_kernel_scalar(const TS* __restrict_
                                                            const TE* __restrict__ e0, const TE* __restrict__ e1,
                                                            const TE* __restrict__ g, const TS* __restrict__ h1,
                                                            const TS* __restrict__ h2, TS* __restrict__ xo,
-                                                           TS* __restrict__ mo, int64_t n, KParams p) {
+                                                           TS* __restrict__ mo, int64_t n, KParams p, KExt ext) {
   using FT = FormTraits<FORM>;
   const bool need_xe = (p.flags & DPM_F_TO_X0) || p.model_type == DPM_MODEL_X_START || p.model_type == DPM_MODEL_V;
   const bool store_m = p.flags & DPM_F_STORE_M;
+  const TS* mask = static_cast<const TS*>(ext.mask);
+  const TS* ba = static_cast<const TS*>(ext.ba);
+  const TS* bb = static_cast<const TS*>(ext.bb);
+  TS* xo2 = static_cast<TS*>(ext.xo2);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t ie = ext.eps_stride ? (i / ext.per_sample) * ext.eps_stride + i % ext.per_sample : i;
     const float xv = (FT::needs_x || (!XE && need_xe)) ? to_f32(x[i]) : 0.f;
     const float xev = XE ? (need_xe ? to_f32(xe[i]) : 0.f) : xv;
-    const float mn = prologue<GUIDE>(xev, to_f32(e0[i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[i]) : 0.f,
+    const float mn = prologue<GUIDE>(xev, to_f32(e0[ie]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[ie]) : 0.f,
                                      GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[i]) : 0.f, p);
-    xo[i] = from_f32<TS>(combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[i]) : 0.f, FT::needs_h2 ? to_f32(h2[i]) : 0.f, p));
+    float o = combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[i]) : 0.f, FT::needs_h2 ? to_f32(h2[i]) : 0.f, p);
+    if (mask) {
+      o = to_f32(from_f32<TS>(o));  // the reference blends the stored state
+      o = blend_ref(o, to_f32(mask[i % ext.mask_period]), to_f32(ba[i]), bb ? to_f32(bb[i]) : 0.f, bb != nullptr, ext);
+    }
+    const TS ov = from_f32<TS>(o);
+    xo[i] = ov;
+    if (xo2) xo2[i] = ov;
     if (store_m) mo[i] = from_f32<TS>(mn);
+  }
+}
+
+// the streaming kernel with the extensions of KExt (vector path: per_sample, eps_stride and mask_period are
+// multiples of 8 and every pointer is 16/32-byte aligned; otherwise the scalar kernel runs)
+template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int SPEC, int NT>
+__global__ __launch_bounds__(256) void stage_kernel_ext(const TS* __restrict__ x, const TS* __restrict__ xe,
+                                                        const TE* __restrict__ e0, const TE* __restrict__ e1,
+                                                        const TE* __restrict__ g, const TS* __restrict__ h1,
+                                                        const TS* __restrict__ h2, TS* __restrict__ xo,
+                                                        TS* __restrict__ mo, int64_t n, KParams p, KExt ext) {
+  using FT = FormTraits<FORM>;
+  const bool need_xe = spec_need_xe<SPEC>(p);
+  const bool store_m = p.flags & DPM_F_STORE_M;
+  const TS* mask = static_cast<const TS*>(ext.mask);
+  const TS* ba = static_cast<const TS*>(ext.ba);
+  const TS* bb = static_cast<const TS*>(ext.bb);
+  TS* xo2 = static_cast<TS*>(ext.xo2);
+  const int64_t ngroups = n / EPT;
+  const int64_t gps = ext.per_sample / EPT, sgroups = ext.eps_stride / EPT, mgroups = ext.mask_period / EPT;
+  const bool small = ngroups < (int64_t)0x7fffffff;  // 32-bit index arithmetic is enough (n < 2^34 elements)
+  for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < ngroups; gi += (int64_t)gridDim.x * 256) {
+    int64_t ge = gi;
+    if (ext.eps_stride) {
+      if (small) {
+        const uint32_t q = (uint32_t)gi / (uint32_t)gps;
+        ge = (int64_t)q * sgroups + ((uint32_t)gi - q * (uint32_t)gps);
+      } else {
+        ge = (gi / gps) * sgroups + gi % gps;
+      }
+    }
+    float vx[EPT], vxe[EPT], v0[EPT], v1[EPT], vg[EPT], vh1[EPT], vh2[EPT], vm[EPT], va[EPT], vb[EPT];
+    if (FT::needs_x || (!XE && need_xe)) load_pack<(NT & 1) != 0>(x, gi, vx);
+    if (XE && need_xe) load_pack<(NT & 1) != 0>(xe, gi, vxe);
+    load_pack<(NT & 1) != 0>(e0, ge, v0);
+    if (GUIDE == DPM_GUIDE_CFG) load_pack<(NT & 1) != 0>(e1, ge, v1);
+    if (GUIDE == DPM_GUIDE_CLASSIFIER) load_pack<(NT & 1) != 0>(g, gi, vg);
+    if (FT::needs_h1) load_pack<(NT & 1) != 0>(h1, gi, vh1);
+    if (FT::needs_h2) load_pack<(NT & 1) != 0>(h2, gi, vh2);
+    if (mask) {
+      const int64_t gm = small ? (int64_t)((uint32_t)gi % (uint32_t)mgroups) : gi % mgroups;
+      load_pack<false>(mask, gm, vm);
+      load_pack<false>(ba, gi, va);
+      if (bb) load_pack<(NT & 1) != 0>(bb, gi, vb);
+    }
+    float ox[EPT], om[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+      const float xej = XE ? vxe[j] : vx[j];
+      const float mn = prologue<GUIDE, SPEC>(xej, v0[j], GUIDE == DPM_GUIDE_CFG ? v1[j] : 0.f,
+                                             GUIDE == DPM_GUIDE_CLASSIFIER ? vg[j] : 0.f, p);
+      om[j] = mn;
+      ox[j] = combine<FORM>(FT::needs_x ? vx[j] : 0.f, mn, FT::needs_h1 ? vh1[j] : 0.f, FT::needs_h2 ? vh2[j] : 0.f, p);
+    }
+    if (mask) {
+#pragma unroll
+      for (int j = 0; j < EPT; ++j)
+        ox[j] = blend_ref(to_f32(from_f32<TS>(ox[j])), vm[j], va[j], bb ? vb[j] : 0.f, bb != nullptr, ext);
+    }
+    store_pack<(NT & 2) != 0>(xo, gi, ox);
+    if (xo2) store_pack<(NT & 2) != 0>(xo2, gi, ox);
+    if (store_m) store_pack<(NT & 4) != 0>(mo, gi, om);
   }
 }
 
@@ -348,7 +450,7 @@ template <typename TS, typename TE, int FORM, int GUIDE, bool XE>
 __global__ __launch_bounds__(THR_THREADS) void stage_thresh_kernel(
     const TS* __restrict__ x, const TS* __restrict__ xe, const TE* __restrict__ e0, const TE* __restrict__ e1,
     const TE* __restrict__ g, const TS* __restrict__ h1, const TS* __restrict__ h2, TS* __restrict__ xo,
-    TS* __restrict__ mo, KParams p, ThrParams tp) {
+    TS* __restrict__ mo, KParams p, ThrParams tp, KExt ext) {
   using FT = FormTraits<FORM>;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   float* sx0 = reinterpret_cast<float*>(lds_raw);                 // [per_sample]
@@ -357,6 +459,7 @@ __global__ __launch_bounds__(THR_THREADS) void stage_thresh_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int64_t base = (int64_t)blockIdx.x * tp.per_sample;
+  const int64_t ebase = (int64_t)blockIdx.x * (ext.eps_stride ? ext.eps_stride : tp.per_sample);
   const int n = (int)tp.per_sample;
   const bool store_m = p.flags & DPM_F_STORE_M;
 
@@ -364,7 +467,7 @@ __global__ __launch_bounds__(THR_THREADS) void stage_thresh_kernel(
   for (int i = tid; i < n; i += THR_THREADS) {
     const int64_t gi = base + i;
     const float xev = to_f32(XE ? xe[gi] : x[gi]);
-    sx0[i] = prologue<GUIDE>(xev, to_f32(e0[gi]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[gi]) : 0.f,
+    sx0[i] = prologue<GUIDE>(xev, to_f32(e0[ebase + i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[ebase + i]) : 0.f,
                              GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[gi]) : 0.f, p);
   }
   if (tid == 0) {
@@ -440,13 +543,22 @@ __global__ __launch_bounds__(THR_THREADS) void stage_thresh_kernel(
   const float s = fmaxf(q, tp.max_val);  // ref :423
 
   // phase 3: clamp, scale, combine, store
+  const TS* mask = static_cast<const TS*>(ext.mask);
+  const TS* ba = static_cast<const TS*>(ext.ba);
+  const TS* bb = static_cast<const TS*>(ext.bb);
+  TS* xo2 = static_cast<TS*>(ext.xo2);
   for (int i = tid; i < n; i += THR_THREADS) {
     const int64_t gi = base + i;
     const float x0 = sx0[i];
     const float mn = fminf(fmaxf(x0, -s), s) / s;  // ref :424
     const float xv = FT::needs_x ? to_f32(x[gi]) : 0.f;
-    xo[gi] = from_f32<TS>(combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[gi]) : 0.f,
-                                        FT::needs_h2 ? to_f32(h2[gi]) : 0.f, p));
+    float o = combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[gi]) : 0.f, FT::needs_h2 ? to_f32(h2[gi]) : 0.f, p);
+    if (mask)
+      o = blend_ref(to_f32(from_f32<TS>(o)), to_f32(mask[gi % ext.mask_period]), to_f32(ba[gi]),
+                    bb ? to_f32(bb[gi]) : 0.f, bb != nullptr, ext);
+    const TS ov = from_f32<TS>(o);
+    xo[gi] = ov;
+    if (xo2) xo2[gi] = ov;
     if (store_m) mo[gi] = from_f32<TS>(mn);
   }
 }
@@ -472,15 +584,17 @@ template <typename TS, typename TE, int GUIDE, bool XE>
 __global__ __launch_bounds__(256) void thr_big_x0_kernel(const TS* __restrict__ x, const TS* __restrict__ xe,
                                                          const TE* __restrict__ e0, const TE* __restrict__ e1,
                                                          const TE* __restrict__ g, float* __restrict__ w,
-                                                         uint32_t* __restrict__ hist, KParams p, int64_t per_sample) {
+                                                         uint32_t* __restrict__ hist, KParams p, int64_t per_sample,
+                                                         int64_t eps_stride) {
   __shared__ uint32_t lh[THR_BINS];
   for (int i = threadIdx.x; i < THR_BINS; i += 256) lh[i] = 0u;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.y * per_sample;
+  const int64_t ebase = (int64_t)blockIdx.y * (eps_stride ? eps_stride : per_sample);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
     const int64_t gi = base + i;
     const float xev = to_f32(XE ? xe[gi] : x[gi]);
-    const float x0 = prologue<GUIDE>(xev, to_f32(e0[gi]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[gi]) : 0.f,
+    const float x0 = prologue<GUIDE>(xev, to_f32(e0[ebase + i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[ebase + i]) : 0.f,
                                      GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[gi]) : 0.f, p);
     w[gi] = x0;
     atomicAdd(&lh[(__float_as_uint(x0) & 0x7fffffffu) >> 19], 1u);
@@ -575,8 +689,12 @@ template <typename TS, int FORM>
 __global__ __launch_bounds__(256) void thr_big_finish_kernel(const TS* __restrict__ x, const TS* __restrict__ h1,
                                                              const TS* __restrict__ h2, const float* __restrict__ w,
                                                              const ThrSel* __restrict__ sel, TS* __restrict__ xo,
-                                                             TS* __restrict__ mo, KParams p, ThrParams tp) {
+                                                             TS* __restrict__ mo, KParams p, ThrParams tp, KExt ext) {
   using FT = FormTraits<FORM>;
+  const TS* mask = static_cast<const TS*>(ext.mask);
+  const TS* ba = static_cast<const TS*>(ext.ba);
+  const TS* bb = static_cast<const TS*>(ext.bb);
+  TS* xo2 = static_cast<TS*>(ext.xo2);
   const ThrSel s_ = sel[blockIdx.y];
   const float a = __uint_as_float(s_.prefix);
   float b = a;
@@ -590,7 +708,13 @@ __global__ __launch_bounds__(256) void thr_big_finish_kernel(const TS* __restric
     const int64_t gi = base + i;
     const float mn = fminf(fmaxf(w[gi], -s), s) / s;
     const float xv = FT::needs_x ? to_f32(x[gi]) : 0.f;
-    xo[gi] = from_f32<TS>(combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[gi]) : 0.f, FT::needs_h2 ? to_f32(h2[gi]) : 0.f, p));
+    float o = combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[gi]) : 0.f, FT::needs_h2 ? to_f32(h2[gi]) : 0.f, p);
+    if (mask)
+      o = blend_ref(to_f32(from_f32<TS>(o)), to_f32(mask[gi % ext.mask_period]), to_f32(ba[gi]),
+                    bb ? to_f32(bb[gi]) : 0.f, bb != nullptr, ext);
+    const TS ov = from_f32<TS>(o);
+    xo[gi] = ov;
+    if (xo2) xo2[gi] = ov;
     if (store_m) mo[gi] = from_f32<TS>(mn);
   }
 }
@@ -598,12 +722,37 @@ __global__ __launch_bounds__(256) void thr_big_finish_kernel(const TS* __restric
 // ------------------------------------------------------------------------------------------------
 // add_noise (ref :1012-1030):  out = alpha*x + sigma*noise
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void add_noise_kernel(const T* __restrict__ x, const T* __restrict__ nz,
                                                         T* __restrict__ out, int64_t n, float alpha, float sigma) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (VEC) {  // n % 8 == 0, pointers 16/32-byte aligned: one 8-element group per lane and iteration
+    for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < n / EPT; gi += stride) {
+      float a[EPT], b[EPT], o[EPT];
+      load_pack<false>(x, gi, a);
+      load_pack<true>(nz, gi, b);
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) o[j] = alpha * a[j] + sigma * b[j];
+      store_pack<false>(out, gi, o);
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+      out[i] = from_f32<T>(alpha * to_f32(x[i]) + sigma * to_f32(nz[i]));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone mask blend (the epilogue of KExt as its own launch: callable use of the corrector, and the
+// correction of x_T before the first multistep update, ref :1180)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void blend_kernel(const T* __restrict__ x, const T* __restrict__ mask,
+                                                    const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
+                                                    int64_t n, KExt ext) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    out[i] = from_f32<T>(alpha * to_f32(x[i]) + sigma * to_f32(nz[i]));
+    out[i] = from_f32<T>(blend_ref(to_f32(x[i]), to_f32(mask[i % ext.mask_period]), to_f32(a[i]), b ? to_f32(b[i]) : 0.f,
+                                   b != nullptr, ext));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -735,6 +884,19 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
   TS* mo = static_cast<TS*>(b->m_out);
   const DeviceInfo& di = device_info();
   const int n_cu = di.n_cu > 0 ? di.n_cu : 256;
+  KExt ext;
+  std::memset(&ext, 0, sizeof ext);
+  const bool blend = (st->flags & DPM_F_BLEND) != 0;
+  ext.xo2 = b->x_out2;
+  ext.mask = blend ? b->mask : nullptr;
+  ext.ba = blend ? b->blend_a : nullptr;
+  ext.bb = blend ? b->blend_b : nullptr;
+  ext.mask_period = blend ? b->mask_period : 0;
+  ext.per_sample = b->n / b->batch;
+  ext.eps_stride = (b->eps_stride == ext.per_sample) ? 0 : b->eps_stride;
+  ext.blend_alpha = st->blend_alpha;
+  ext.blend_sigma = st->blend_sigma;
+  const bool use_ext = ext.xo2 || ext.mask || ext.eps_stride;
 
   if (st->flags & DPM_F_THRESH) {
     const int64_t per_sample = b->n / b->batch;
@@ -751,12 +913,21 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
     if (lds_bytes <= lds_cap) {
       auto kern = stage_thresh_kernel<TS, TE, FORM, GUIDE, XE>;
       if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds_bytes);
-        if (e != hipSuccess) return dpm_set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        // once per kernel, device and size: keeps repeated launches (and stream capture) free of attribute calls
+        static thread_local int set_dev = -1;
+        static thread_local int64_t set_bytes = 0;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev != set_dev || lds_bytes > set_bytes) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+          if (e != hipSuccess) return dpm_set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+          set_dev = dev;
+          set_bytes = lds_bytes;
+        }
       }
       launch(kern, dim3((unsigned)b->batch), dim3(THR_THREADS), (size_t)lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo,
-             p, tp);
+             p, tp, ext);
     } else {
       // large samples: multi-workgroup exact selection through a caller-provided workspace
       if (!b->workspace)
@@ -778,7 +949,7 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
       const LaunchCtx plain{stream.stream, nullptr, nullptr};
       const LaunchCtx first{stream.stream, stream.start, nullptr}, last{stream.stream, nullptr, stream.stop};
       launch(thr_big_x0_kernel<TS, TE, GUIDE, XE>, grid, dim3(256), 0, stream.start ? first : plain, x, xe, e0, e1, g, w, hist, p,
-             per_sample);
+             per_sample, ext.eps_stride);
       launch(thr_big_scan_kernel, dim3((unsigned)b->batch), dim3(1024), 0, plain, hist, sel, 19, 0xfffu, 1, (uint32_t)tp.lo);
       launch(thr_big_hist_kernel, grid, dim3(256), 0, plain, (const float*)w, hist, (const ThrSel*)sel, 7, 0xfffu, per_sample);
       launch(thr_big_scan_kernel, dim3((unsigned)b->batch), dim3(1024), 0, plain, hist, sel, 7, 0xfffu, 0, 0u);
@@ -786,18 +957,40 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
       launch(thr_big_scan_kernel, dim3((unsigned)b->batch), dim3(1024), 0, plain, hist, sel, 0, 0x7fu, 0, 0u);
       launch(thr_big_minabove_kernel, grid, dim3(256), 0, plain, (const float*)w, sel, per_sample);
       launch(thr_big_finish_kernel<TS, FORM>, grid, dim3(256), 0, stream.stop ? last : plain, x, h1, h2, (const float*)w,
-             (const ThrSel*)sel, xo, mo, p, tp);
+             (const ThrSel*)sel, xo, mo, p, tp, ext);
     }
   } else {
     const size_t as = sizeof(TS) * EPT, ae = sizeof(TE) * EPT;
-    const bool vec = aligned(x, as) && aligned(xe, as) && aligned(h1, as) && aligned(h2, as) && aligned(xo, as) &&
-                     aligned(mo, as) && aligned(e0, ae) && aligned(e1, ae) && aligned(g, ae);
+    bool vec = aligned(x, as) && aligned(xe, as) && aligned(h1, as) && aligned(h2, as) && aligned(xo, as) &&
+               aligned(mo, as) && aligned(e0, ae) && aligned(e1, ae) && aligned(g, ae);
+    if (use_ext)  // the extended vector kernel has no ragged tail and indexes whole 8-element groups
+      vec = vec && aligned(ext.xo2, as) && aligned(ext.mask, as) && aligned(ext.ba, as) && aligned(ext.bb, as) &&
+            b->n % EPT == 0 && ext.mask_period % EPT == 0 &&
+            (!ext.eps_stride || (ext.per_sample % EPT == 0 && ext.eps_stride % EPT == 0));
     if (!vec) {
       int64_t blocks = (b->n + 255) / 256;
       const int64_t cap = (int64_t)n_cu * 16;
       if (blocks > cap) blocks = cap;
       launch(stage_kernel_scalar<TS, TE, FORM, GUIDE, XE>, dim3((unsigned)blocks), dim3(256), 0, stream, x, xe, e0, e1, g,
-             h1, h2, xo, mo, b->n, p);
+             h1, h2, xo, mo, b->n, p, ext);
+    } else if (use_ext) {
+      const bool noise = st->model_type == DPM_MODEL_NOISE;
+      const int64_t ntiles = ((b->n / EPT) + 255) / 256;
+      int64_t blocks = ntiles;
+      const int64_t cap = (int64_t)n_cu * g_tuning.blocks_per_cu;
+      if (blocks > cap) blocks = cap;
+      const dim3 grid((unsigned)(blocks < 1 ? 1 : blocks));
+      // the duplicated x_out is the next network input: keep it cacheable (no nt store of x_out)
+      constexpr int NT = DefNT<TS>::value & ~2;
+      if (!noise)
+        launch(stage_kernel_ext<TS, TE, FORM, GUIDE, XE, SPEC_GENERIC, NT>, grid, dim3(256), 0, stream, x, xe, e0, e1, g, h1,
+               h2, xo, mo, b->n, p, ext);
+      else if (st->flags & DPM_F_TO_X0)
+        launch(stage_kernel_ext<TS, TE, FORM, GUIDE, XE, SPEC_NOISE_X0, NT>, grid, dim3(256), 0, stream, x, xe, e0, e1, g, h1,
+               h2, xo, mo, b->n, p, ext);
+      else
+        launch(stage_kernel_ext<TS, TE, FORM, GUIDE, XE, SPEC_NOISE_EPS, NT>, grid, dim3(256), 0, stream, x, xe, e0, e1, g, h1,
+               h2, xo, mo, b->n, p, ext);
     } else {
       // specialise the prologue when the stage allows it (noise-prediction network: the common case)
       const bool noise = st->model_type == DPM_MODEL_NOISE;

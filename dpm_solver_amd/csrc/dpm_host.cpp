@@ -36,6 +36,15 @@ int dpm_set_error(int code, const char* fmt, ...) {
 
 extern "C" const char* dpm_last_error(void) { return g_err.c_str(); }
 extern "C" int dpm_version(void) { return DPM_HIP_VERSION; }
+extern "C" size_t dpm_sizeof(int which) {
+  switch (which) {
+    case DPM_SIZEOF_STAGE: return sizeof(dpm_stage);
+    case DPM_SIZEOF_BUFFERS: return sizeof(dpm_buffers);
+    case DPM_SIZEOF_PLAN_DESC: return sizeof(dpm_plan_desc);
+    case DPM_SIZEOF_RUN_BUFFERS: return sizeof(dpm_run_buffers);
+  }
+  return 0;
+}
 
 // ------------------------------------------------------------------------------------------------
 // correctly rounded fp32 elementary functions

@@ -36,6 +36,16 @@ int dpm_stage_launch_ev(const dpm_stage* st, const dpm_buffers* b, void* stream,
   if ((st->flags & DPM_F_STORE_M) && !b->m_out) return dpm_set_error(DPM_ERR_ARG, "stage_launch: STORE_M without m_out");
   if (st->guidance == DPM_GUIDE_CFG && !b->e1) return dpm_set_error(DPM_ERR_ARG, "stage_launch: CFG needs e1");
   if (st->guidance == DPM_GUIDE_CLASSIFIER && !b->g) return dpm_set_error(DPM_ERR_ARG, "stage_launch: classifier guidance needs g");
+  if (st->flags & DPM_F_BLEND) {
+    if (!b->mask || !b->blend_a || b->mask_period < 1)
+      return dpm_set_error(DPM_ERR_ARG, "stage_launch: DPM_F_BLEND needs mask, blend_a and mask_period >= 1");
+    if (b->n % b->mask_period != 0)
+      return dpm_set_error(DPM_ERR_ARG, "stage_launch: n=%lld is not a multiple of mask_period=%lld", (long long)b->n,
+                           (long long)b->mask_period);
+  }
+  if (b->eps_stride != 0 && b->eps_stride < b->n / b->batch)
+    return dpm_set_error(DPM_ERR_ARG, "stage_launch: eps_stride=%lld is smaller than a sample (%lld elements)",
+                         (long long)b->eps_stride, (long long)(b->n / b->batch));
   dpm_buffers bb = *b;
   if (!bb.x) bb.x = bb.xe;  // DENOISE form: only the evaluation state exists
   const int sd = bb.state_dtype, ed = bb.eps_dtype;
@@ -111,29 +121,70 @@ extern "C" int dpm_add_noise_launch(const dpm_schedule* s, const float* t_host, 
   int64_t blocks = (n + 255) / 256;
   const int64_t cap = (int64_t)(di.n_cu > 0 ? di.n_cu : 256) * 16;
   if (blocks > cap) blocks = cap;
+  const bool v2 = n % EPT == 0;
   for (int j = 0; j < nt; ++j) {
     float a = 0.f, sg = 0.f;
     dpm_schedule_eval(s, DPM_EVAL_ALPHA, &t_host[j], 1, &a);
     dpm_schedule_eval(s, DPM_EVAL_STD, &t_host[j], 1, &sg);
     const int64_t off = (int64_t)j * n;
+#define DPM_AN(T)                                                                                                       \
+  do {                                                                                                                  \
+    const T* xp = (const T*)x;                                                                                          \
+    const T* np_ = (const T*)noise + off;                                                                               \
+    T* op = (T*)out + off;                                                                                              \
+    const size_t al = sizeof(T) * EPT;                                                                                  \
+    if (v2 && aligned(xp, al) && aligned(np_, al) && aligned(op, al)) {                                                 \
+      int64_t bl = (n / EPT + 255) / 256;                                                                               \
+      if (bl > cap) bl = cap;                                                                                           \
+      hipLaunchKernelGGL((add_noise_kernel<T, true>), dim3((unsigned)bl), dim3(256), 0, st, xp, np_, op, n, a, sg);     \
+    } else {                                                                                                            \
+      hipLaunchKernelGGL((add_noise_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, st, xp, np_, op, n, a, sg); \
+    }                                                                                                                   \
+  } while (0)
     switch (dtype) {
-      case DPM_DTYPE_F32:
-        hipLaunchKernelGGL(add_noise_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x,
-                           (const float*)noise + off, (float*)out + off, n, a, sg);
-        break;
-      case DPM_DTYPE_F16:
-        hipLaunchKernelGGL(add_noise_kernel<__half>, dim3((unsigned)blocks), dim3(256), 0, st, (const __half*)x,
-                           (const __half*)noise + off, (__half*)out + off, n, a, sg);
-        break;
-      case DPM_DTYPE_BF16:
-        hipLaunchKernelGGL(add_noise_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x,
-                           (const bf16_t*)noise + off, (bf16_t*)out + off, n, a, sg);
-        break;
+      case DPM_DTYPE_F32: DPM_AN(float); break;
+      case DPM_DTYPE_F16: DPM_AN(__half); break;
+      case DPM_DTYPE_BF16: DPM_AN(bf16_t); break;
       default: return dpm_set_error(DPM_ERR_UNSUPPORTED, "add_noise: unsupported dtype %d", dtype);
     }
+#undef DPM_AN
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return dpm_set_error((int)e, "add_noise launch failed: %s", hipGetErrorString(e));
+  return DPM_OK;
+}
+
+extern "C" int dpm_blend_launch(const void* x, const void* mask, const void* a, const void* b, float alpha, float sigma,
+                                void* out, int64_t n, int64_t mask_period, int dtype, void* stream) {
+  if (!x || !mask || !a || !out || n < 0 || mask_period < 1) return dpm_set_error(DPM_ERR_ARG, "blend: bad arguments");
+  if (n == 0) return DPM_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const DeviceInfo& di = device_info();
+  int64_t blocks = (n + 255) / 256;
+  const int64_t cap = (int64_t)(di.n_cu > 0 ? di.n_cu : 256) * 16;
+  if (blocks > cap) blocks = cap;
+  KExt ext;
+  std::memset(&ext, 0, sizeof ext);
+  ext.mask_period = mask_period;
+  ext.blend_alpha = alpha;
+  ext.blend_sigma = sigma;
+  switch (dtype) {
+    case DPM_DTYPE_F32:
+      hipLaunchKernelGGL(blend_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)x, (const float*)mask,
+                         (const float*)a, (const float*)b, (float*)out, n, ext);
+      break;
+    case DPM_DTYPE_F16:
+      hipLaunchKernelGGL(blend_kernel<__half>, dim3((unsigned)blocks), dim3(256), 0, st, (const __half*)x,
+                         (const __half*)mask, (const __half*)a, (const __half*)b, (__half*)out, n, ext);
+      break;
+    case DPM_DTYPE_BF16:
+      hipLaunchKernelGGL(blend_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)x,
+                         (const bf16_t*)mask, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n, ext);
+      break;
+    default: return dpm_set_error(DPM_ERR_UNSUPPORTED, "blend: unsupported dtype %d", dtype);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return dpm_set_error((int)e, "blend launch failed: %s", hipGetErrorString(e));
   return DPM_OK;
 }
 
@@ -157,6 +208,69 @@ extern "C" int dpm_adaptive_error_launch(const void* x_lower, const void* x_high
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return dpm_set_error((int)e, "adaptive_error launch failed: %s", hipGetErrorString(e));
   return DPM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// hipGraph capture of a trajectory (dpm_plan_run under stream capture)
+// ------------------------------------------------------------------------------------------------
+struct dpm_graph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  int result = -1;
+  int nodes = 0;
+};
+
+extern "C" int dpm_graph_create(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model_cb model, void* user, void* stream,
+                                dpm_graph** out) {
+  if (!p || !rb || !out) return dpm_set_error(DPM_ERR_ARG, "graph_create: null pointer");
+  if (!stream) return dpm_set_error(DPM_ERR_ARG, "graph_create: capture needs a non-null stream");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  (void)device_info();  // query device properties before the capture starts
+  dpm_graph* g = new (std::nothrow) dpm_graph;
+  if (!g) return dpm_set_error(DPM_ERR_NOMEM, "out of memory");
+  hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+  if (e != hipSuccess) {
+    delete g;
+    return dpm_set_error((int)e, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+  }
+  const int rc = dpm_plan_run(p, rb, model, user, stream, &g->result);
+  e = hipStreamEndCapture(st, &g->graph);  // always end the capture, also after a failed launch
+  if (rc) {
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return rc;
+  }
+  if (e != hipSuccess) {
+    delete g;
+    return dpm_set_error((int)e, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  }
+  size_t nn = 0;
+  if (hipGraphGetNodes(g->graph, nullptr, &nn) == hipSuccess) g->nodes = (int)nn;
+  e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+    return dpm_set_error((int)e, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  }
+  *out = g;
+  return DPM_OK;
+}
+
+extern "C" int dpm_graph_launch(dpm_graph* g, void* stream) {
+  if (!g || !g->exec) return dpm_set_error(DPM_ERR_ARG, "graph_launch: null graph");
+  hipError_t e = hipGraphLaunch(g->exec, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return dpm_set_error((int)e, "hipGraphLaunch: %s", hipGetErrorString(e));
+  return DPM_OK;
+}
+
+extern "C" int dpm_graph_result(const dpm_graph* g) { return g ? g->result : -1; }
+extern "C" int dpm_graph_num_nodes(const dpm_graph* g) { return g ? g->nodes : 0; }
+
+extern "C" void dpm_graph_destroy(dpm_graph* g) {
+  if (!g) return;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from .correctors import MaskBlend
 from .wrapper import WrappedModel
 
 _DT = {torch.float32: L.DTYPE_F32, torch.float16: L.DTYPE_F16, torch.bfloat16: L.DTYPE_BF16}
@@ -35,9 +36,20 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None):
+def _sample_strided(t):
+    """True when every sample of `t` is a contiguous block but consecutive samples are spaced wider apart: the
+    channel slice out[:, :C] of a learned-variance network's [B,2C,H,W] output (runners/diffusion.py:596-603)."""
+    return (not t.is_contiguous()) and t.dim() >= 2 and t.shape[0] >= 1 and t[0].is_contiguous() \
+        and t.stride(0) > t[0].numel()
+
+
+def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=None):
     """One `dpm_stage_launch` on the current stream.  Allocates x_out (and m_out when the stage stores
-    its model value) through torch's caching allocator; returns (x_out, m_out)."""
+    its model value) through torch's caching allocator; returns (x_out, m_out).
+
+    ext (optional dict): 'dup' -> write x_out twice into one [2B,...] buffer (returned as ext['x2'], x_out is its
+    first half): the network input of classifier-free guidance; 'blend' -> (mask, period, a, b, alpha, sigma), the
+    MaskBlend epilogue."""
     ref_t = x if x is not None else xe
     dev = ref_t.device
     sd = state_dtype
@@ -61,11 +73,23 @@ def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None):
             t = t.to(ed)
         return t if t.is_contiguous() else t.contiguous()
 
-    e0, e1, g = E(e0), E(e1), E(g)
+    eps_stride = 0
+    if e0.dtype == ed and _sample_strided(e0) and tuple(e0.shape) == tuple(ref_t.shape) and (
+            e1 is None or (e1.dtype == ed and _sample_strided(e1) and e1.stride(0) == e0.stride(0))):
+        eps_stride = int(e0.stride(0))          # read the slice in place: no .contiguous() copy
+        g = E(g)
+    else:
+        e0, e1, g = E(e0), E(e1), E(g)
     if xe is not None and x is not None and xe.data_ptr() == x.data_ptr():
         xe = None
     shape = ref_t.shape
-    x_out = torch.empty(shape, dtype=sd, device=dev)
+    x2 = None
+    if ext is not None and ext.get("dup") and len(shape) > 0:
+        x2 = torch.empty((2 * shape[0],) + tuple(shape[1:]), dtype=sd, device=dev)
+        x_out = x2[:shape[0]]
+        ext["x2"] = x2
+    else:
+        x_out = torch.empty(shape, dtype=sd, device=dev)
     store = bool(st.flags & L.F_STORE_M) if want_m is None else want_m
     m_out = torch.empty(shape, dtype=sd, device=dev) if store else None
     if store:
@@ -81,6 +105,14 @@ def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None):
         if nb:
             ws = torch.empty(nb, dtype=torch.uint8, device=dev)
     b.workspace = _ptr(ws)
+    b.eps_stride = eps_stride
+    if x2 is not None:
+        b.x_out2 = _ptr(x2[shape[0]:])
+    if ext is not None and ext.get("blend") is not None:
+        mask, period, ba, bb, alpha, sigma = ext["blend"]
+        st.flags |= L.F_BLEND
+        st.blend_alpha, st.blend_sigma = alpha, sigma
+        b.mask, b.blend_a, b.blend_b, b.mask_period = _ptr(mask), _ptr(ba), _ptr(bb), period
     b.n = ref_t.numel()
     b.batch = max(int(shape[0]), 1) if len(shape) > 0 else 1
     b.state_dtype = _DT[sd]
@@ -202,13 +234,14 @@ class DPM_Solver:
             return self._user_x0(x0)
         return self._user_x0(x0, t)
 
-    def _network(self, x_eval, t_eval_t, t_input_t):
-        """the opaque call: raw output(s) of the network at (x_eval, t)"""
+    def _network(self, x_eval, t_eval_t, t_input_t, x_in2=None):
+        """the opaque call: raw output(s) of the network at (x_eval, t).  x_in2: [2B,...] buffer both halves of
+        which already hold x_eval (written by the previous stage kernel) -- the CFG network input."""
         B = x_eval.shape[0]
         if self._wrapped is not None:
             w = self._wrapped
             t2 = t_input_t.expand(2 * B) if w.effective_guidance == "classifier-free" else None
-            return w.raw_outputs(x_eval, t_eval_t.expand(B), t_input_t.expand(B), t2)
+            return w.raw_outputs(x_eval, t_eval_t.expand(B), t_input_t.expand(B), t2, x_in2=x_in2)
         return self._model_fn(x_eval, t_eval_t.expand(B)), None, None
 
     def _prep_stage(self, st):
@@ -220,7 +253,7 @@ class DPM_Solver:
                 st.thr_max = float(self.thresholding_max_val)
         return st
 
-    def _run_stage(self, st, x, xe, outs, h1, h2, sd, t_eval_t, want_m=None):
+    def _run_stage(self, st, x, xe, outs, h1, h2, sd, t_eval_t, want_m=None, ext=None):
         """outs = (e0, e1, g) fresh network outputs.  Handles a *callable* correcting_x0_fn by splitting the
         stage: prologue kernel -> user function (opaque torch) -> combination kernel."""
         e0, e1, g = outs
@@ -230,17 +263,17 @@ class DPM_Solver:
             s1.flags = L.F_TO_X0
             x0, _ = _launch_stage(s1, None, xe if xe is not None else x, e0, e1, g, None, None, sd, want_m=False)
             x0 = self._call_x0(x0, t_eval_t)                                             # ref :440-441
-            return self._run_given(st, x, x0, h1, h2, sd, want_m)
-        return _launch_stage(st, x, xe, e0, e1, g, h1, h2, sd, want_m=want_m)
+            return self._run_given(st, x, x0, h1, h2, sd, want_m, ext=ext)
+        return _launch_stage(st, x, xe, e0, e1, g, h1, h2, sd, want_m=want_m, ext=ext)
 
-    def _run_given(self, st, x, m, h1, h2, sd, want_m=None):
+    def _run_given(self, st, x, m, h1, h2, sd, want_m=None, ext=None):
         """the update of `st` with the model value already known (no prologue)"""
         s2 = st.copy()
         s2.flags = st.flags & L.F_BASE_HIST
         s2.model_type = L.MODEL["noise"]
         s2.guidance = L.GUIDE["uncond"]
         store = bool(st.flags & L.F_STORE_M) if want_m is None else want_m
-        x_out, _ = _launch_stage(s2, x if x is not None else m, None, m, None, None, h1, h2, sd, want_m=False)
+        x_out, _ = _launch_stage(s2, x if x is not None else m, None, m, None, None, h1, h2, sd, want_m=False, ext=ext)
         return x_out, (m if store else None)
 
     # ------------------------------------------------------------------------------------------
@@ -594,26 +627,59 @@ class DPM_Solver:
         else:
             return x
 
+    def capture(self, x, warmup=2, **sample_kwargs):
+        """hipGraph-capture `sample(x, **sample_kwargs)` for a fixed shape (extension).
+
+        The step loop is launch-bound between network calls -- a stage kernel runs for microseconds -- so the whole
+        trajectory (network calls included) is recorded once into a HIP graph and replayed with one launch:
+
+            g = dpm_solver.capture(x_T, steps=20, order=2)     # warm-up runs + capture (on a side stream)
+            out = g(x_T_new)                                    # copy into the static input, replay
+
+        Requirements are those of torch.cuda.graph: the wrapped network must be capturable (no host
+        synchronisation, no data-dependent control flow), shapes are frozen, and the returned tensors are static
+        buffers that the next replay overwrites.  Not available for method='adaptive' (host control loop)."""
+        if sample_kwargs.get("method", "multistep") == "adaptive":
+            raise NotImplementedError("the adaptive solver's control loop synchronises with the host every iteration; "
+                                      "it cannot be captured into a graph")
+        return GraphedSample(self, x, warmup, sample_kwargs)
+
     def _run_plan(self, plan, x, method, cxt, keep, intermediates):
         device = x.device
         sd = self._sdtype(x)
         T = plan.times(device)            # [3, n_stages]: t_eval, t_input, t_out
-        state = x
-        tmp = None
+        blend = cxt if isinstance(cxt, MaskBlend) else None      # folded into the stage kernels' epilogue
+        if blend is not None:
+            cxt = None
+        # classifier-free guidance evaluates the network on cat([x] * 2) (ref :326): let the stage kernel that
+        # produces x write both halves of that buffer instead (not possible when an opaque corrector edits x after it)
+        dup = (self._wrapped is not None and self._wrapped.effective_guidance == "classifier-free" and cxt is None
+               and x.dim() > 0)
+        n_st = len(plan.stages)
+        state, state2 = x, None
+        tmp, tmp2 = None, None
         hist = [None] * max(plan.slots, 1)
         for i, ps in enumerate(plan.stages):
             st = ps.copy()                # launches may edit flags
-            xe = tmp if st.xe_src == L.SRC_TMP else state
-            outs = self._network(xe, T[0, i], T[1, i])
+            from_tmp = st.xe_src == L.SRC_TMP
+            xe = tmp if from_tmp else state
+            outs = self._network(xe, T[0, i], T[1, i], x_in2=tmp2 if from_tmp else state2)
             if i == 0 and method == 'multistep':
                 # ref :1179-1183: the model sees the caller's x_T; the corrector and the list see it afterwards
                 if cxt is not None:
                     state = cxt(state, T[0, 0], 0)
+                elif blend is not None:
+                    state = blend.apply(state if state.dtype == sd else state.to(sd), ps.t_eval, 0)
                 if keep:
                     intermediates.append(state)
             h1 = hist[st.h1_slot] if st.h1_slot >= 0 else None
             h2 = hist[st.h2_slot] if st.h2_slot >= 0 else None
-            x_out, m_out = self._run_stage(st, state, xe, outs, h1, h2, sd, T[0, i])
+            ext = {}
+            if dup and i + 1 < n_st:
+                ext["dup"] = True
+            if blend is not None and st.emits_state:
+                ext["blend"] = blend.operands(x.shape, sd, device, ps.t_out, st.outer_step)
+            x_out, m_out = self._run_stage(st, state, xe, outs, h1, h2, sd, T[0, i], ext=ext or None)
             if st.m_slot >= 0:
                 hist[st.m_slot] = m_out
             if st.emits_state:
@@ -622,8 +688,36 @@ class DPM_Solver:
                     x_out = cxt(x_out, t_cb, st.outer_step)
                 if keep:
                     intermediates.append(x_out)
-                state = x_out
-                tmp = None
+                state, state2 = x_out, ext.get("x2")
+                tmp, tmp2 = None, None
             else:
-                tmp = x_out
+                tmp, tmp2 = x_out, ext.get("x2")
         return state
+
+
+class GraphedSample:
+    """A captured `DPM_Solver.sample()` call (see DPM_Solver.capture)."""
+
+    def __init__(self, solver, x, warmup, sample_kwargs):
+        _require_gpu(x)
+        self.solver = solver
+        self.kwargs = dict(sample_kwargs)
+        self.static_x = x.clone()
+        dev = x.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                     # plans, time tensors, allocator pools: all warm before capture
+            for _ in range(max(int(warmup), 1)):
+                solver.sample(self.static_x, **self.kwargs)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = solver.sample(self.static_x, **self.kwargs)
+
+    def replay(self):
+        self.graph.replay()
+        return self.static_out
+
+    def __call__(self, x):
+        self.static_x.copy_(x)
+        return self.replay()

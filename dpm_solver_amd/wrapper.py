@@ -52,7 +52,7 @@ class WrappedModel:
             log_prob = self.classifier_fn(x_in, t_input, self.condition, **self.classifier_kwargs)
             return torch.autograd.grad(log_prob.sum(), x_in)[0]
 
-    def raw_outputs(self, x, t_continuous, t_input=None, t_input2=None):
+    def raw_outputs(self, x, t_continuous, t_input=None, t_input2=None, x_in2=None):
         """Run the network(s) exactly as the reference does and return (e0, e1, g):
         e0 raw output (conditional half under CFG), e1 raw unconditional output or None, g classifier
         gradient or None.  No conversion or blending is applied here -- the stage kernel does that."""
@@ -68,7 +68,8 @@ class WrappedModel:
         if self.guidance_type == "classifier-free":
             if self.guidance_scale == 1. or self.unconditional_condition is None:
                 return self.model(x, t_input, self.condition, **kw), None, None
-            x_in = torch.cat([x] * 2)
+            # x_in2: the stage kernel that produced x already wrote it into both halves of one [2B,...] buffer
+            x_in = x_in2 if x_in2 is not None else torch.cat([x] * 2)
             t_in = t_input2 if t_input2 is not None else torch.cat([t_input] * 2)
             if self._c_in is None:  # the conditioning does not change between steps: concatenate once
                 self._c_in = torch.cat([self.unconditional_condition, self.condition])

@@ -72,6 +72,9 @@ enum {
 #define DPM_F_BASE_HIST 4u  /* FORM_TWO: first-order term uses h1 (singlestep) instead of mn (multistep)      */
 #define DPM_F_THRESH 8u     /* dynamic thresholding of x0 (ref :416-425)                                      */
 #define DPM_F_USER_X0 16u   /* host applies a callable correcting_x0_fn: stage is split by the host shim       */
+#define DPM_F_BLEND 32u     /* epilogue: x_out <- x_out*mask + (1-mask)*(blend_alpha*blend_a + blend_sigma*blend_b),
+                               the mask blend DiffEdit / inpainting callers run as correcting_xt_fn after every
+                               update (scripts/diffedit_inpaint.ipynb cell 6; hook: ref :1180,:1188,:1203,:1229)     */
 
 /* buffer roles for the host-side loop */
 enum { DPM_SRC_STATE = 0, DPM_SRC_TMP = 1 };
@@ -101,6 +104,8 @@ typedef struct dpm_stage {
   float k[5];          /* difference-quotient scalars: 1/r0, 1/r1, ...                           */
   float thr_ratio;     /* dynamic_thresholding_ratio                                             */
   float thr_max;       /* thresholding_max_val                                                   */
+  float blend_alpha;   /* DPM_F_BLEND: alpha at the time the known image is noised to (add_noise, ref :1028)  */
+  float blend_sigma;   /* DPM_F_BLEND: sigma at that time                                        */
 } dpm_stage;
 
 /* ---- buffers of one launch ------------------------------------------------------------- */
@@ -119,6 +124,16 @@ typedef struct dpm_buffers {
   int64_t batch;      /* number of independent samples                                           */
   int32_t state_dtype; /* DPM_DTYPE_* of x, xe, h1, h2, x_out, m_out                             */
   int32_t eps_dtype;   /* DPM_DTYPE_* of e0, e1, g                                               */
+  /* ---- optional extensions (zero / NULL = off) ---- */
+  void* x_out2;        /* second copy of x_out: the other half of the [2B,...] network input under
+                          classifier-free guidance (replaces torch.cat([x]*2), ref :326)   [n] state dtype */
+  int64_t eps_stride;  /* elements between consecutive samples of e0 / e1 (0 = contiguous): the network output
+                          is a channel slice out[:, :C] of a learned-variance model's [B,2C,H,W] output
+                          (runners/diffusion.py:596-603); a sample's C*H*W elements stay contiguous      */
+  const void* mask;    /* DPM_F_BLEND: mask, state dtype, mask_period elements, indexed i % mask_period  */
+  const void* blend_a; /* DPM_F_BLEND: known image (or, with blend_b NULL, the state to blend in)  [n]   */
+  const void* blend_b; /* DPM_F_BLEND: noise [n], NULL = blend_a is used as is                          */
+  int64_t mask_period; /* n for a full mask, H*W for a [H,W] mask, C*H*W for a [1,C,H,W] mask           */
 } dpm_buffers;
 
 /* ---- noise schedule (NoiseScheduleVP, ref :6-167) --------------------------------------- */
@@ -197,6 +212,10 @@ size_t dpm_threshold_workspace_bytes(int64_t batch, int64_t per_sample);
 /* x_t = alpha_t*x + sigma_t*noise for nt times (add_noise, ref :1012-1030); out is [nt, n] */
 int dpm_add_noise_launch(const dpm_schedule* s, const float* t_host, int nt, const void* x, const void* noise,
                          void* out, int64_t n, int dtype, void* stream);
+/* stand-alone mask blend  out = x*mask + (1-mask)*(alpha*a + sigma*b)  (b NULL: (1-mask)*a): the DPM_F_BLEND
+   epilogue as its own launch, for callable use of the corrector and for x_T before the first update (ref :1180) */
+int dpm_blend_launch(const void* x, const void* mask, const void* a, const void* b, float alpha, float sigma, void* out,
+                     int64_t n, int64_t mask_period, int dtype, void* stream);
 /* per-sample error norm of the adaptive solver (ref :999-1001): E_b = sqrt(mean(((xh-xl)/delta)^2)) */
 int dpm_adaptive_error_launch(const void* x_lower, const void* x_higher, const void* x_prev, float atol, float rtol,
                               float* e_out /* [batch] device */, int64_t batch, int64_t per_sample, int dtype,
@@ -232,6 +251,19 @@ int dpm_plan_run_timed(const dpm_plan* p, const dpm_run_buffers* rb, void* strea
    Infinity Cache.  ms (optional, [n_req * num_stages], request-major) receives kernel-only durations. */
 int dpm_plan_run_multi(const dpm_plan* p, const dpm_run_buffers* rbs, int n_req, void* stream, float* ms, int* results);
 
+/* ---- hipGraph capture of a whole trajectory ------------------------------------------------------------
+   The step loop is launch-bound between network calls (a stage kernel runs for microseconds): capture the plan's
+   launches over fixed buffers once, replay with a single hipGraphLaunch per trajectory.  `stream` must be a real
+   (non-null) stream; `model` as in dpm_plan_run -- everything it does must be capturable (enqueue-only on `stream`);
+   NULL = frozen outputs already staged in e0/e1.  The buffers named by `rb` are baked into the graph. */
+typedef struct dpm_graph dpm_graph;
+int dpm_graph_create(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model_cb model, void* user, void* stream,
+                     dpm_graph** out);
+int dpm_graph_launch(dpm_graph* g, void* stream);
+int dpm_graph_result(const dpm_graph* g);    /* index of the xbuf that holds the final sample            */
+int dpm_graph_num_nodes(const dpm_graph* g); /* kernel / memset nodes captured                           */
+void dpm_graph_destroy(dpm_graph* g);
+
 /* ---- launch-shape tuning hooks (autotuning / benchmarking; defaults are the measured best) --------- */
 enum { DPM_TUNE_UNROLL = 0, DPM_TUNE_NONTEMPORAL = 1, DPM_TUNE_BLOCKS_PER_CU = 2 };
 int dpm_tuning_set(int knob, int value);
@@ -243,6 +275,9 @@ int dpm_calib_launch(int kind, int block, int blocks_per_cu, int nt, const void*
 
 /* ---- misc ---------------------------------------------------------------------------------- */
 int dpm_version(void);
+/* sizeof() of the ABI structs as compiled, so a binding can verify its own layout at load time */
+enum { DPM_SIZEOF_STAGE = 0, DPM_SIZEOF_BUFFERS = 1, DPM_SIZEOF_PLAN_DESC = 2, DPM_SIZEOF_RUN_BUFFERS = 3 };
+size_t dpm_sizeof(int which);
 const char* dpm_last_error(void); /* thread-local text of the last non-zero return */
 int dpm_device_info(int* n_cu, int* lds_bytes, char* arch, int arch_len);
 

@@ -71,7 +71,15 @@ def combine(st, x, mn, h1, h2):
     raise AssertionError(st.form)
 
 
-def launch_stage_double(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None):
+def blend(st_alpha, st_sigma, v, mask, a, b):
+    """KExt epilogue / dpm_blend_launch: x*mask + (1 - mask)*(alpha*a + sigma*b), fp32, one rounding per op"""
+    m = np.broadcast_to(mask.reshape((1,) * (v.ndim - mask.ndim) + mask.shape), v.shape) if mask.size != v.size \
+        else mask.reshape(v.shape)
+    r = a if b is None else F32(st_alpha) * a + F32(st_sigma) * b
+    return (v * m + (F32(1.0) - m) * r).astype(F32)
+
+
+def launch_stage_double(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=None):
     ref_t = x if x is not None else xe
     xn, xen = _np(x), _np(xe)
     if xen is None:
@@ -84,4 +92,18 @@ def launch_stage_double(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None):
     out = combine(st, xn, mn, _np(h1), _np(h2)).astype(F32)
     store = bool(st.flags & L.F_STORE_M) if want_m is None else want_m
     conv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(state_dtype).reshape(ref_t.shape)
-    return conv(out), (conv(mn) if store else None)
+    if ext is not None and ext.get("blend") is not None:
+        mask, period, ba, bb, alpha, sigma = ext["blend"]
+        out = blend(alpha, sigma, conv(out).float().numpy(), _np(mask), _np(ba), _np(bb))
+    x_out = conv(out)
+    if ext is not None and ext.get("dup"):
+        ext["x2"] = torch.cat([x_out, x_out])
+        x_out = ext["x2"][:x_out.shape[0]]
+    return x_out, (conv(mn) if store else None)
+
+
+def maskblend_apply_double(self, x, t_host, step):
+    """numpy double of MaskBlend.apply (dpm_blend_launch)"""
+    mask, period, ba, bb, alpha, sigma = self.operands(x.shape, x.dtype, x.device, t_host, step)
+    out = blend(alpha, sigma, _np(x), _np(mask), _np(ba), _np(bb))
+    return torch.from_numpy(np.ascontiguousarray(out)).to(x.dtype).reshape(x.shape)

@@ -26,11 +26,12 @@ def test_header_functions_are_exported_and_bound():
 
 
 def test_struct_layouts_match_header():
-    # sizes are part of the ABI: Stage = 12 int32 + 18 float, Buffers = 10 ptr + 2 int64 + 2 int32
-    assert ctypes.sizeof(L.Stage) == 12 * 4 + 18 * 4
-    assert ctypes.sizeof(L.Buffers) == 10 * 8 + 2 * 8 + 2 * 4
+    # sizes are part of the ABI: the ctypes mirrors against sizeof() as compiled, and against the header by count
+    for i, t in enumerate((L.Stage, L.Buffers, L.PlanDesc, L.RunBuffers)):
+        assert L.lib.dpm_sizeof(i) == ctypes.sizeof(t), t.__name__
+    assert ctypes.sizeof(L.Stage) == 12 * 4 + 20 * 4                       # 12 int32 + 20 float
+    assert ctypes.sizeof(L.Buffers) == 14 * 8 + 4 * 8 + 2 * 4              # 14 pointers, 4 int64, 2 int32
     assert ctypes.sizeof(L.PlanDesc) == 12 * 4 + 5 * 8
-    assert ctypes.sizeof(L.RunBuffers) == 4 * 8 + 3 * 8 + 3 * 8 + 2 * 8 + 2 * 4
 
 
 def test_version_and_error_text():

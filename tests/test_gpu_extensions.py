@@ -1,0 +1,310 @@
+"""GPU tests of the SURVEY 8f rows built around the stage kernel: the CFG input producer (x_out written into both
+halves of the [2B,...] network input), in-place reads of channel-sliced network outputs (learned-variance models),
+the fused mask-blend corrector (DiffEdit / inpainting) and hipGraph capture.  Each is checked bit for bit against
+the same computation done the reference's way (torch.cat / .contiguous() / a Python closure / eager launches), and
+the end-to-end cases against the oracle.  Run on an MI355X:  pytest -m gpu
+"""
+import ctypes as C_
+
+import numpy as np
+import pytest
+import torch
+
+import cases as C
+import dpm_solver_amd as D
+import dpm_solver_amd.solver as S
+from conftest import rel_err
+from dpm_solver_amd import _lib as L
+from engine_cases import build_solver, make_schedule, run_case, sample_kwargs, tt
+import test_oracle_golden as TO
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+TOL = 1e-5
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert torch.cuda.is_available(), "these tests need a GPU; run with -m 'not gpu' elsewhere"
+    yield
+    torch.cuda.synchronize()
+
+
+class LaunchSpy:
+    """records the dpm_buffers of every dpm_stage_launch"""
+
+    def __init__(self, monkeypatch):
+        self.calls = []
+        real = L.lib.dpm_stage_launch
+
+        def spy(st, b, stream):
+            bo, so = b._obj, st._obj
+            self.calls.append(dict(x_out2=bo.x_out2, eps_stride=bo.eps_stride, mask=bo.mask, flags=so.flags, form=so.form))
+            return real(st, b, stream)
+
+        monkeypatch.setattr(S.L.lib, "dpm_stage_launch", spy)
+
+
+# ------------------------------------------------------------------------------------------------
+# classifier-free guidance: the stage kernel writes the network's [2B,...] input itself
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["cfg_ms2", "cfg3_dpmsolver", "cfg3_pp", "cfg_v"])
+def test_cfg_network_input_is_produced_by_the_stage_kernel(name, monkeypatch):
+    case = C.E2E_BY_NAME[name]
+    seen = []
+    cats = []
+    real_cat = torch.cat
+
+    def counting_cat(ts, *a, **k):
+        if len(ts) == 2 and ts[0] is ts[1]:
+            cats.append(1)
+        return real_cat(ts, *a, **k)
+
+    ns = make_schedule(case["schedule"])
+    base = C.MODELS[case["model"]]
+
+    def net(x, t, cond=None):
+        B = x.shape[0] // 2
+        assert torch.equal(x[:B], x[B:])                       # both halves hold the same state
+        seen.append((x.data_ptr(), x.is_contiguous()))
+        return base(x, t, cond)
+
+    cond, uncond = C.cond_for(case)
+    fn = D.model_wrapper(net, ns, model_type=case["model_type"], guidance_type="classifier-free",
+                         guidance_scale=case["guidance_scale"], condition=tt(cond, DEV), unconditional_condition=tt(uncond, DEV))
+    dpm = D.DPM_Solver(fn, ns, algorithm_type=case["algorithm_type"])
+    spy = LaunchSpy(monkeypatch)
+    monkeypatch.setattr(torch, "cat", counting_cat)
+    x = tt(C.x_T_for(case), DEV)
+    xf, inter = dpm.sample(x, **sample_kwargs(case))
+    monkeypatch.setattr(torch, "cat", real_cat)
+    assert len(cats) == 1, "only x_T (the caller's tensor) is duplicated with torch.cat"
+    assert all(c for _, c in seen)
+    n_dup = sum(1 for c in spy.calls if c["x_out2"])
+    assert n_dup == len(spy.calls) - 1                         # every stage but the last feeds a network call
+    xo, _ = TO.run_oracle_case(case)
+    assert rel_err(xf.cpu().numpy(), xo) < TOL
+    # and bit-identical to the torch.cat path (an opaque corrector forces it)
+    dpm_cat = D.DPM_Solver(fn, ns, algorithm_type=case["algorithm_type"], correcting_xt_fn=lambda xt, t, step: xt)
+    seen.clear()
+    xc, _ = dpm_cat.sample(x, **sample_kwargs(case))
+    assert torch.equal(xf, xc)
+
+
+# ------------------------------------------------------------------------------------------------
+# learned-variance networks: out[:, :C] of a [B,2C,H,W] output is read in place (runners/diffusion.py:596-603)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("guidance,thresh,shape", [("uncond", False, (4, 3, 32, 32)), ("classifier-free", False, (4, 3, 32, 32)),
+                                                   ("uncond", True, (4, 3, 32, 32)), ("classifier", True, (3, 3, 16, 16)),
+                                                   ("uncond", True, (2, 3, 256, 256)), ("uncond", False, (3, 3, 5, 7))])
+def test_channel_sliced_network_output_is_read_in_place(guidance, thresh, shape, monkeypatch):
+    ns = make_schedule("ddpm")
+    B, Cc = shape[0], shape[1]
+    rng = np.random.default_rng(11)
+    x = torch.from_numpy(rng.standard_normal(shape).astype(F32)).to(DEV)
+    cond = torch.arange(B, device=DEV, dtype=torch.float32) * 0.25
+    junk = torch.from_numpy(rng.standard_normal((2 * B,) + shape[1:]).astype(F32)).to(DEV)
+
+    def mean_of(xx, t, c=None):
+        out = xx * 0.5 if c is None else xx * (c * 0.1 + 1.0).reshape(-1, 1, 1, 1)
+        return out
+
+    def net6(xx, t, c=None, **kw):        # [B, 2C, H, W]: mean and variance channels; the solver uses the mean
+        out = torch.cat([mean_of(xx, t, c), junk[:xx.shape[0]]], dim=1)
+        return torch.split(out, Cc, dim=1)[0]
+
+    def net3(xx, t, c=None, **kw):
+        return mean_of(xx, t, c).contiguous()
+
+    def solver(net):
+        kw = dict(guidance_type=guidance)
+        if guidance == "classifier-free":
+            kw.update(condition=cond, unconditional_condition=torch.zeros_like(cond), guidance_scale=3.0)
+        elif guidance == "classifier":
+            kw.update(condition=cond, guidance_scale=2.0, classifier_fn=C.classifier_logp_torch)
+        return D.DPM_Solver(D.model_wrapper(net, ns, **kw), ns,
+                            correcting_x0_fn="dynamic_thresholding" if thresh else None)
+
+    want = solver(net3).sample(x, steps=8, order=2)
+    spy = LaunchSpy(monkeypatch)
+    got = solver(net6).sample(x, steps=8, order=2)
+    assert torch.equal(got, want)
+    per_sample = int(np.prod(shape[1:]))
+    assert all(c["eps_stride"] == 2 * per_sample for c in spy.calls), [c["eps_stride"] for c in spy.calls]
+
+
+# ------------------------------------------------------------------------------------------------
+# MaskBlend: the DiffEdit / inpainting corrector folded into the stage kernel's epilogue
+# ------------------------------------------------------------------------------------------------
+def _blend_setup(shape, mask_shape, seed=3):
+    rng = np.random.default_rng(seed)
+    x = torch.from_numpy(rng.standard_normal(shape).astype(F32)).to(DEV)
+    x0 = torch.from_numpy(rng.standard_normal(shape).astype(F32)).to(DEV)
+    noise = torch.from_numpy(rng.standard_normal(shape).astype(F32)).to(DEV)
+    mask = torch.from_numpy(rng.random(mask_shape).astype(F32)).to(DEV)        # soft mask: exercises the arithmetic
+    return x, x0, noise, mask
+
+
+@pytest.mark.parametrize("method,order,steps", [("multistep", 2, 10), ("singlestep", 3, 9), ("multistep", 3, 8)])
+@pytest.mark.parametrize("mask_shape", [(16, 16), (1, 4, 16, 16), (2, 4, 16, 16), (2, 1, 16, 16)])
+def test_maskblend_fused_equals_closure_stochastic(method, order, steps, mask_shape, monkeypatch):
+    shape = (2, 4, 16, 16)
+    ns = make_schedule("sd")
+    x, x0, noise, mask = _blend_setup(shape, mask_shape)
+    fn = D.model_wrapper(lambda xx, t: xx * 0.5, ns)
+    helper = D.DPM_Solver(fn, ns)
+
+    def closure(xt, t, step):            # what the notebook passes (diffedit_inpaint.ipynb cell 6)
+        return xt * mask + (1 - mask) * helper.add_noise(x0, t.reshape(1), noise=noise.unsqueeze(0))
+
+    kw = dict(steps=steps, order=order, method=method, return_intermediate=True, denoise_to_zero=True)
+    want, wi = D.DPM_Solver(fn, ns, correcting_xt_fn=closure).sample(x, **kw)
+    spy = LaunchSpy(monkeypatch)
+    got, gi = D.DPM_Solver(fn, ns, correcting_xt_fn=D.MaskBlend(ns, mask, x0=x0, noise=noise)).sample(x, **kw)
+    assert torch.equal(got, want)
+    assert len(gi) == len(wi) and all(torch.equal(a, b) for a, b in zip(gi, wi))
+    assert sum(1 for c in spy.calls if c["flags"] & L.F_BLEND) >= steps // order     # folded into the stage kernels
+    # the object is also a plain callable (stand-alone kernel)
+    t = torch.tensor(0.37, device=DEV)
+    assert torch.equal(D.MaskBlend(ns, mask, x0=x0, noise=noise)(x, t, 3), closure(x, t, 3))
+
+
+def test_maskblend_against_reference_callback_goldens(golden):
+    """goldens produced by the real reference with the closure xt*mask + (1-mask)*(0.25*step) as correcting_xt_fn"""
+    case = C.E2E_BY_NAME["cfg1_small"]
+    ns = make_schedule("sd")
+    x = tt(C.x_T_for(case), DEV)
+    mask = torch.from_numpy(golden.get("callbacks", "cb/mask")).to(DEV)
+    levels = [torch.full(x.shape, 0.25 * step, device=DEV) for step in range(12)]
+    fn = D.model_wrapper(lambda xx, t: C.model_half(xx, t), ns)
+    for method, order, steps in [("multistep", 2, 8), ("singlestep", 3, 8)]:
+        dpm = D.DPM_Solver(fn, ns, correcting_xt_fn=D.MaskBlend(ns, mask, intermediates=levels))
+        xf, inter = dpm.sample(x, steps=steps, order=order, method=method, denoise_to_zero=True, return_intermediate=True)
+        pre = "cb/xt/%s/" % method
+        assert rel_err(xf.cpu().numpy(), golden.get("callbacks", pre + "final")) < TOL
+        ri = golden.get("callbacks", pre + "intermediates")
+        assert len(inter) == ri.shape[0]
+        for i, v in enumerate(inter):
+            assert rel_err(v.cpu().numpy(), ri[i]) < TOL
+
+
+def test_maskblend_fresh_noise_follows_the_same_random_stream():
+    shape = (2, 4, 16, 16)
+    ns = make_schedule("sd")
+    x, x0, _, mask = _blend_setup(shape, (16, 16))
+    fn = D.model_wrapper(lambda xx, t: xx * 0.5, ns)
+    helper = D.DPM_Solver(fn, ns)
+    closure = lambda xt, t, step: xt * mask + (1 - mask) * helper.add_noise(x0, t.reshape(1))
+    torch.manual_seed(7)
+    want = D.DPM_Solver(fn, ns, correcting_xt_fn=closure).sample(x, steps=10, t_start=0.6)
+    torch.manual_seed(7)
+    got = D.DPM_Solver(fn, ns, correcting_xt_fn=D.MaskBlend(ns, mask, x0=x0)).sample(x, steps=10, t_start=0.6)
+    assert torch.equal(got, want)
+
+
+def test_maskblend_deterministic_intermediates_and_time_fn():
+    """the notebook's 'deterministic' variant: encode with inverse(), then blend reversed intermediates back in"""
+    shape = (2, 4, 16, 16)
+    ns = make_schedule("sd")
+    x, x0, noise, mask = _blend_setup(shape, (16, 16), seed=5)
+    fn = D.model_wrapper(lambda xx, t: xx * 0.5, ns)
+    dpm = D.DPM_Solver(fn, ns)
+    enc, inter = dpm.inverse(x0, steps=10, t_end=0.6, lower_order_final=False, return_intermediate=True)
+    inter = list(reversed(inter))
+    closure = lambda xt, t, step: xt * mask + (1 - mask) * inter[step]
+    kw = dict(steps=10, t_start=0.6, lower_order_final=False)
+    want = D.DPM_Solver(fn, ns, correcting_xt_fn=closure).sample(enc, **kw)
+    got = D.DPM_Solver(fn, ns, correcting_xt_fn=D.MaskBlend(ns, mask, intermediates=inter)).sample(enc, **kw)
+    assert torch.equal(got, want)
+    # time_fn: the noise level is looked up at a remapped time
+    tf = lambda t: 0.5 * t + 0.1
+    helper = D.DPM_Solver(fn, ns)
+    closure2 = lambda xt, t, step: xt * mask + (1 - mask) * helper.add_noise(
+        x0, torch.tensor([tf(float(t))], device=DEV), noise=noise.unsqueeze(0))
+    want2 = D.DPM_Solver(fn, ns, correcting_xt_fn=closure2).sample(x, steps=6)
+    got2 = D.DPM_Solver(fn, ns, correcting_xt_fn=D.MaskBlend(ns, mask, x0=x0, noise=noise, time_fn=tf)).sample(x, steps=6)
+    assert torch.equal(got2, want2)
+
+
+def test_maskblend_with_cfg_thresholding_and_half_state():
+    shape = (4, 3, 32, 32)
+    ns = make_schedule("ddpm")
+    x, x0, noise, mask = _blend_setup(shape, (32, 32), seed=9)
+    cond = torch.arange(4, device=DEV, dtype=torch.float32)
+    fn = D.model_wrapper(lambda xx, t, c: xx * (c * 0.1 + 1.0).reshape(-1, 1, 1, 1), ns, guidance_type="classifier-free",
+                         condition=cond, unconditional_condition=torch.zeros_like(cond), guidance_scale=3.0)
+    helper = D.DPM_Solver(fn, ns)
+    closure = lambda xt, t, step: xt * mask + (1 - mask) * helper.add_noise(x0, t.reshape(1), noise=noise.unsqueeze(0))
+    kw = dict(correcting_x0_fn="dynamic_thresholding")
+    want = D.DPM_Solver(fn, ns, correcting_xt_fn=closure, **kw).sample(x, steps=8)
+    got = D.DPM_Solver(fn, ns, correcting_xt_fn=D.MaskBlend(ns, mask, x0=x0, noise=noise), **kw).sample(x, steps=8)
+    assert torch.equal(got, want)
+    # fp16 state: same values up to the half-precision rounding of the intermediate products
+    gh = D.DPM_Solver(fn, ns, correcting_xt_fn=D.MaskBlend(ns, mask, x0=x0, noise=noise), state_dtype=torch.float16,
+                      **kw).sample(x.half(), steps=8)
+    assert gh.dtype == torch.float16
+    assert rel_err(gh.float().cpu().numpy(), want.cpu().numpy()) < 4e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# hipGraph capture
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["cfg1_small", "cfg_ms2", "cfg3_dpmsolver", "cfg5_thresh_small"])
+def test_captured_sample_equals_eager(name):
+    case = C.E2E_BY_NAME[name]
+    dpm = build_solver(case, DEV)
+    x = tt(C.x_T_for(case), DEV)
+    kw = sample_kwargs(case, False)
+    want = dpm.sample(x, **kw)
+    g = dpm.capture(x, **kw)
+    assert torch.equal(g(x), want)
+    x2 = x * 0.5 + 0.25
+    want2 = dpm.sample(x2, **kw)
+    assert torch.equal(g(x2), want2)          # replay on new input
+    xo, _ = TO.run_oracle_case(case)
+    assert rel_err(g(x).cpu().numpy(), xo) < TOL
+
+
+def test_capture_rejects_adaptive():
+    ns = make_schedule("sd")
+    dpm = D.DPM_Solver(D.model_wrapper(lambda x, t: x, ns), ns)
+    with pytest.raises(NotImplementedError, match="adaptive"):
+        dpm.capture(torch.zeros(2, 4, 8, 8, device=DEV), method="adaptive")
+
+
+@pytest.mark.parametrize("sdt", [torch.float32, torch.float16])
+def test_native_graph_equals_native_loop(sdt):
+    """C ABI: dpm_graph_create / dpm_graph_launch replay the 20 launches of dpm_plan_run"""
+    ns = make_schedule("sd")
+    shape = (16, 4, 64, 64)
+    rng = np.random.default_rng(13)
+    x = torch.from_numpy(rng.standard_normal(shape).astype(F32)).to(DEV).to(sdt)
+    eps = torch.from_numpy(rng.standard_normal(shape).astype(F32)).to(DEV).to(sdt)
+    dpm = D.DPM_Solver(D.model_wrapper(lambda xx, t: eps, ns), ns, state_dtype=sdt)
+    want = dpm.sample(x, steps=20, order=2)
+    plan = dpm._get_plan(method="multistep", order=2, steps=20, skip_type="time_uniform", solver_type="dpmsolver",
+                         lower_order_final=True, denoise_to_zero=False, t_T=1.0, t_0=1.0 / ns.total_N)
+    xb = [x.clone()] + [torch.empty_like(x) for _ in range(3)]
+    hb = [torch.empty_like(x) for _ in range(3)]
+    rb = L.RunBuffers()
+    for i in range(4):
+        rb.xbuf[i] = xb[i].data_ptr()
+    for i in range(3):
+        rb.hist[i] = hb[i].data_ptr()
+    rb.e0 = eps.data_ptr()
+    dt = {torch.float32: L.DTYPE_F32, torch.float16: L.DTYPE_F16}[sdt]
+    rb.n, rb.batch, rb.state_dtype, rb.eps_dtype = x.numel(), shape[0], dt, dt
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = C_.c_void_p()
+    with pytest.raises(ValueError, match="non-null stream"):
+        L.check(L.lib.dpm_graph_create(plan.handle, C_.byref(rb), None, None, None, C_.byref(g)))
+    L.check(L.lib.dpm_graph_create(plan.handle, C_.byref(rb), None, None, C_.c_void_p(side.cuda_stream), C_.byref(g)))
+    assert L.lib.dpm_graph_num_nodes(g) == len(plan.stages)
+    for _ in range(3):
+        L.check(L.lib.dpm_graph_launch(g, C_.c_void_p(side.cuda_stream)))
+    side.synchronize()
+    assert torch.equal(xb[L.lib.dpm_graph_result(g)], want)
+    assert torch.equal(xb[0], x)
+    L.lib.dpm_graph_destroy(g)

@@ -18,7 +18,7 @@ import dpm_solver_amd.wrapper as W
 from conftest import rel_err
 from dpm_solver_amd import _lib as L
 from engine_cases import build_solver, make_schedule, run_case, sample_kwargs, tt
-from kernel_double import launch_stage_double
+from kernel_double import launch_stage_double, maskblend_apply_double
 from oracle import dpm_oracle as O
 
 F32 = np.float32
@@ -29,6 +29,7 @@ TOL = 1e-5
 def cpu_double(monkeypatch):
     monkeypatch.setattr(S, "_launch_stage", launch_stage_double)
     monkeypatch.setattr(S, "_require_gpu", lambda x: None)
+    monkeypatch.setattr(D.MaskBlend, "apply", maskblend_apply_double)
 
 
 def test_linspace_and_time_grids_bitwise_vs_torch_and_golden(golden):
@@ -135,6 +136,73 @@ def test_callbacks(golden):
                 steps_seen = [s for s, _ in seen]
                 assert steps_seen == (list(range(0, 10)) if method == "multistep" else list(range(0, 4)))   # orders [3,3,2] + denoise
                 assert seen[-1][1] == (1,)          # denoise_to_zero hands a (1,)-shaped t (ref :1236)
+
+
+def test_maskblend_against_reference_callback_goldens(golden):
+    """The reference's correcting_xt_fn hook with the mask-blend closure of the goldens (cb/xt:
+    xt*mask + (1-mask)*(0.25*step)) expressed as a MaskBlend object, i.e. folded into the stage epilogue."""
+    case = C.E2E_BY_NAME["cfg1_small"]
+    ns = make_schedule("sd")
+    x = tt(C.x_T_for(case), "cpu")
+    mask = torch.from_numpy(golden.get("callbacks", "cb/mask"))
+    levels = [torch.full(x.shape, 0.25 * step) for step in range(12)]
+    fn = D.model_wrapper(lambda xx, t: C.model_half(xx, t), ns)
+    for method, order, steps in [("multistep", 2, 8), ("singlestep", 3, 8)]:
+        dpm = D.DPM_Solver(fn, ns, correcting_xt_fn=D.MaskBlend(ns, mask, intermediates=levels))
+        xf, inter = dpm.sample(x, steps=steps, order=order, method=method, denoise_to_zero=True, return_intermediate=True)
+        pre = "cb/xt/%s/" % method
+        assert rel_err(xf.numpy(), golden.get("callbacks", pre + "final")) < TOL
+        ri = golden.get("callbacks", pre + "intermediates")
+        assert len(inter) == ri.shape[0]
+        for i, v in enumerate(inter):
+            assert rel_err(v.numpy(), ri[i]) < TOL
+
+
+def test_maskblend_host_logic_equals_closure():
+    shape = (2, 4, 8, 8)
+    ns = make_schedule("sd")
+    rng = np.random.default_rng(2)
+    x, x0, noise = [torch.from_numpy(rng.standard_normal(shape).astype(F32)) for _ in range(3)]
+    mask = torch.from_numpy(rng.random((8, 8)).astype(F32))
+    fn = D.model_wrapper(lambda xx, t: xx * 0.5, ns)
+    a_s = lambda t: (F32(ns.marginal_alpha(t.reshape(1))[0].item()), F32(ns.marginal_std(t.reshape(1))[0].item()))
+
+    def closure(xt, t, step):
+        a, s = a_s(t)
+        return xt * mask + (1 - mask) * (float(a) * x0 + float(s) * noise)
+
+    for method, order, steps in [("multistep", 2, 8), ("singlestep", 3, 9)]:
+        kw = dict(steps=steps, order=order, method=method, return_intermediate=True, denoise_to_zero=True)
+        want, wi = D.DPM_Solver(fn, ns, correcting_xt_fn=closure).sample(x, **kw)
+        got, gi = D.DPM_Solver(fn, ns, correcting_xt_fn=D.MaskBlend(ns, mask, x0=x0, noise=noise)).sample(x, **kw)
+        assert torch.equal(got, want)
+        assert len(gi) == len(wi) and all(torch.equal(p, q) for p, q in zip(gi, wi))
+
+
+def test_cfg_input_buffer_host_logic():
+    """classifier-free guidance: every network call after the first receives the [2B,...] buffer the previous stage
+    produced (both halves equal), torch.cat([x]*2) is used for the caller's x_T only."""
+    case = C.E2E_BY_NAME["cfg3_pp"]
+    seen = []
+
+    def net(xx, t, c):
+        B = xx.shape[0] // 2
+        assert torch.equal(xx[:B], xx[B:])
+        seen.append(xx)
+        return C.model_cond(xx, t, c)
+
+    ns = make_schedule(case["schedule"])
+    cond, uncond = C.cond_for(case)
+    fn = D.model_wrapper(net, ns, guidance_type="classifier-free", guidance_scale=case["guidance_scale"],
+                         condition=tt(cond, "cpu"), unconditional_condition=tt(uncond, "cpu"))
+    dpm = D.DPM_Solver(fn, ns, algorithm_type=case["algorithm_type"])
+    x = tt(C.x_T_for(case), "cpu")
+    xf, inter = dpm.sample(x, **sample_kwargs(case))
+    xo, _ = run_case(case, "cpu")
+    assert torch.equal(xf, xo)
+    assert len(seen) == case["steps"]
+    for v in inter[1:-1]:       # solver states are first halves of the network-input buffers
+        assert v._base is not None and v._base.shape[0] == 2 * v.shape[0]
 
 
 @pytest.mark.parametrize("sname", ["sd", "vp_linear", "cosine4000"])
