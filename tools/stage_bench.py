@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Kernel-only timing of every stage-kernel variant the BASELINE configs use (MI355X).
+
+Runs DPM_Solver.sample() with a frozen network and replaces dpm_stage_launch by dpm_stage_launch_timed
+(hipExtLaunchKernelGGL start/stop events around the kernel itself), then groups the launches by kernel signature
+and prints algorithmic bytes, median microseconds and GB/s against the 8 TB/s HBM peak.
+
+    python tools/stage_bench.py [--md profiles/rNN_stage_table.md]
+"""
+import argparse
+import collections
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import dpm_solver_amd as D  # noqa: E402
+import dpm_solver_amd.solver as S  # noqa: E402
+from dpm_solver_amd import _lib as L  # noqa: E402
+
+DEV = "cuda:0"
+PEAK = 8000.0
+FORM = {0: "LIN1", 1: "TWO", 2: "MS3", 3: "SS3T", 4: "DENOISE"}
+GUIDE = {0: "-", 1: "cfg", 2: "clsg"}
+
+
+def sd_schedule():
+    betas = np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=np.float64) ** 2
+    return D.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(np.cumprod(1.0 - betas).astype(np.float32)))
+
+
+def ddpm_schedule():
+    return D.NoiseScheduleVP("discrete", betas=torch.from_numpy(np.linspace(1e-4, 0.02, 1000, dtype=np.float64).astype(np.float32)))
+
+
+class Timed:
+    def __init__(self):
+        self.rows = []
+        self.real = L.lib.dpm_stage_launch
+
+    def __call__(self, st, b, stream):
+        so, bo = st._obj, b._obj
+        ms = C.c_float()
+        rc = L.lib.dpm_stage_launch_timed(st, b, stream, C.byref(ms))
+        ss = {L.DTYPE_F32: 4, L.DTYPE_F16: 2, L.DTYPE_BF16: 2}[bo.state_dtype]
+        es = {L.DTYPE_F32: 4, L.DTYPE_F16: 2, L.DTYPE_BF16: 2}[bo.eps_dtype]
+        n = bo.n
+        needs_x = so.form != L.FORM_DENOISE
+        need_xe = bool(so.flags & L.F_TO_X0) or so.model_type in (1, 2)
+        rd = 0
+        if needs_x:
+            rd += ss
+        if need_xe and (bo.xe and bo.xe != bo.x or not needs_x):
+            rd += ss
+        rd += es * (1 + (1 if so.guidance == 1 else 0) + (1 if so.guidance == 2 else 0))
+        rd += ss * ((1 if so.form in (1, 2, 3) else 0) + (1 if so.form in (2, 3) else 0))
+        if so.flags & L.F_BLEND:
+            rd += ss * (1 + (1 if bo.blend_b else 0)) + ss * bo.mask_period / n
+        wr = ss * (1 + (1 if bo.x_out2 else 0) + (1 if so.flags & L.F_STORE_M else 0))
+        sig = "%s %s%s%s%s%s%s" % (FORM[so.form], GUIDE[so.guidance], " thr" if so.flags & L.F_THRESH else "",
+                                  " +m" if so.flags & L.F_STORE_M else "", " dup" if bo.x_out2 else "",
+                                  " strided" if bo.eps_stride else "", " blend" if so.flags & L.F_BLEND else "")
+        self.rows.append((sig, n * (rd + wr), ms.value * 1e3))
+        return rc
+
+
+def run(name, solver, x, reps=5, **kw):
+    t = Timed()
+    L.lib.dpm_stage_launch = t
+    try:
+        for _ in range(reps):
+            solver.sample(x, **kw)
+    finally:
+        L.lib.dpm_stage_launch = t.real
+    groups = collections.OrderedDict()
+    per = len(t.rows) // reps
+    for sig, by, us in t.rows[per:]:          # first repetition = warm-up
+        groups.setdefault((sig, by), []).append(us)
+    out = []
+    for (sig, by), v in groups.items():
+        us = float(np.median(v))
+        out.append((name, sig, len(v) // (reps - 1), by, us, by / us / 1e3))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--md", default=None)
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    rows = []
+    sd, dd = sd_schedule(), ddpm_schedule()
+
+    def frozen(shape, dtype, n=1):
+        outs = [torch.randn(shape, device=DEV).to(dtype) for _ in range(n)]
+        return outs
+
+    # cfg2: 2M++, [256,4,64,64], fp16 / fp32 state
+    for dt in (torch.float16, torch.float32):
+        shape = (256, 4, 64, 64)
+        e, = frozen(shape, dt)
+        s = D.DPM_Solver(D.model_wrapper(lambda x, t: e, sd), sd, state_dtype=dt)
+        rows += run("cfg2 2M++ %s" % str(dt)[6:], s, torch.randn(shape, device=DEV).to(dt), steps=20, order=2)
+    # 3M++
+    shape = (256, 4, 64, 64)
+    e, = frozen(shape, torch.float16)
+    s = D.DPM_Solver(D.model_wrapper(lambda x, t: e, sd), sd, state_dtype=torch.float16)
+    rows += run("3M++ float16", s, torch.randn(shape, device=DEV).half(), steps=20, order=3)
+    # SD-like: 2M++ with CFG, fp32 state + fp16 network output, [64,4,64,64]
+    shape = (64, 4, 64, 64)
+    e2, = frozen((128, 4, 64, 64), torch.float16)
+    c = torch.zeros(64, device=DEV)
+    s = D.DPM_Solver(D.model_wrapper(lambda x, t, cc: e2, sd, guidance_type="classifier-free", condition=c,
+                                     unconditional_condition=c, guidance_scale=7.5), sd)
+    rows += run("SD 2M++ cfg, f32 state / f16 eps", s, torch.randn(shape, device=DEV), steps=20, order=2)
+    # cfg3: DPM-Solver-3 singlestep, 15 NFE, [64,3,256,256] fp32, CFG 7.5
+    shape = (64, 3, 256, 256)
+    e2, = frozen((128, 3, 256, 256), torch.float32)
+    c = torch.zeros(64, device=DEV)
+    for algo in ("dpmsolver", "dpmsolver++"):
+        s = D.DPM_Solver(D.model_wrapper(lambda x, t, cc: e2, dd, guidance_type="classifier-free", condition=c,
+                                         unconditional_condition=c, guidance_scale=7.5), dd, algorithm_type=algo)
+        rows += run("cfg3 3S %s" % algo, s, torch.randn(shape, device=DEV), reps=3, steps=15, order=3, method="singlestep")
+    del e2
+    # cfg5: 2M++ with dynamic thresholding, pixel space; batch 32 (BASELINE) and 1024
+    for B in (32, 1024):
+        shape = (B, 3, 64, 64)
+        e, = frozen(shape, torch.float32)
+        s = D.DPM_Solver(D.model_wrapper(lambda x, t: e, dd), dd, correcting_x0_fn="dynamic_thresholding")
+        rows += run("cfg5 2M++ thr B=%d" % B, s, torch.randn(shape, device=DEV), steps=25, order=2)
+    # learned-variance output (6 channels) + thresholding, B=1024
+    shape = (1024, 3, 64, 64)
+    e6 = torch.randn((1024, 6, 64, 64), device=DEV)
+    s = D.DPM_Solver(D.model_wrapper(lambda x, t: e6[:, :3], dd), dd, correcting_x0_fn="dynamic_thresholding")
+    rows += run("guided-diffusion 2M++ thr 6ch B=1024", s, torch.randn(shape, device=DEV), steps=25, order=2)
+    s = D.DPM_Solver(D.model_wrapper(lambda x, t: e6[:, :3], dd), dd)
+    rows += run("guided-diffusion 2M++ 6ch B=1024", s, torch.randn(shape, device=DEV), steps=25, order=2)
+    del e6
+    # large-sample thresholding [64,3,256,256]
+    shape = (64, 3, 256, 256)
+    e, = frozen(shape, torch.float32)
+    s = D.DPM_Solver(D.model_wrapper(lambda x, t: e, dd), dd, correcting_x0_fn="dynamic_thresholding")
+    rows += run("2M++ thr [64,3,256,256]", s, torch.randn(shape, device=DEV), reps=3, steps=10, order=2)
+    # inpainting: 2M++ + MaskBlend, [64,4,64,64] fp32
+    shape = (64, 4, 64, 64)
+    e, = frozen(shape, torch.float32)
+    mb = D.MaskBlend(sd, torch.rand(64, 64, device=DEV), x0=torch.randn(shape, device=DEV), noise=torch.randn(shape, device=DEV))
+    s = D.DPM_Solver(D.model_wrapper(lambda x, t: e, sd), sd, correcting_xt_fn=mb)
+    rows += run("inpaint 2M++ MaskBlend f32", s, torch.randn(shape, device=DEV), steps=20, order=2)
+
+    # Python host loop: eager sample() vs DPM_Solver.capture() replay (frozen network), wall per trajectory
+    import time
+    loop = []
+    for label, shape, dt, kw in [("cfg2 [256,4,64,64] f16 2M++ 20 steps", (256, 4, 64, 64), torch.float16, dict(steps=20, order=2)),
+                                 ("cfg1 [8,4,64,64] f32 2M++ 20 steps", (8, 4, 64, 64), torch.float32, dict(steps=20, order=2))]:
+        e, = frozen(shape, dt)
+        s = D.DPM_Solver(D.model_wrapper(lambda x, t: e, sd), sd, state_dtype=dt)
+        x = torch.randn(shape, device=DEV).to(dt)
+        g = s.capture(x, **kw)
+        res = {}
+        for mode, fn in (("eager", lambda: s.sample(x, **kw)), ("graph", lambda: g(x))):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                fn()
+            torch.cuda.synchronize()
+            res[mode] = (time.perf_counter() - t0) / 50 * 1e6
+        loop.append((label, res["eager"], res["graph"]))
+
+    hdr = "| scenario | kernel (form guidance flags) | launches | alg. MB | median us | GB/s | % of 8 TB/s |\n|---|---|---|---|---|---|---|"
+    lines = [hdr]
+    for name, sig, cnt, by, us, gbs in rows:
+        lines.append("| %s | %s | %d | %.2f | %.2f | %.0f | %.1f |" % (name, sig, cnt, by / 1e6, us, gbs, 100 * gbs / PEAK))
+    txt = "\n".join(lines)
+    print(txt)
+    if args.md:
+        with open(args.md, "w") as f:
+            f.write("# Stage-kernel table (kernel-only, hipExtLaunchKernelGGL events; tools/stage_bench.py)\n\n"
+                    "Thresholding rows on large samples are several kernels per stage; the time is first-start to last-stop.\n\n")
+            f.write(txt + "\n")
+            f.write("\n## Python host loop (DPM_Solver.sample, frozen network): eager vs hipGraph replay (DPM_Solver.capture)\n\n"
+                    "| workload | eager us / trajectory | captured us / trajectory |\n|---|---|---|\n")
+            for label, a, b in loop:
+                f.write("| %s | %.1f | %.1f |\n" % (label, a, b))
+    for label, a, b in loop:
+        print("python loop %s: eager %.1f us, captured %.1f us" % (label, a, b))
+
+
+if __name__ == "__main__":
+    main()
