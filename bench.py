@@ -96,8 +96,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--sets", type=int, default=8, help="independent buffer sets cycled through (cache defeat)")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32", "bf16"])
-    ap.add_argument("--mode", default="graph", choices=["graph", "eager"],
-                    help="graph: one hipGraph replay per trajectory (default); eager: 20 launches per trajectory")
+    ap.add_argument("--mode", default="eager", choices=["graph", "eager"],
+                    help="eager: 20 launches per trajectory through dpm_plan_run (default, measured fastest); graph: one hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     dtype = {"fp16": torch.float16, "fp32": torch.float32, "bf16": torch.bfloat16}[args.dtype]

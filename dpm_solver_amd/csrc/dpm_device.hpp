@@ -421,20 +421,41 @@ __global__ __launch_bounds__(256) void stage_kernel_ext(const TS* __restrict__ x
 }
 
 // ------------------------------------------------------------------------------------------------
-// dynamic thresholding (ref :416-425): one workgroup per sample, x0 resident in LDS.
+// dynamic thresholding (ref :416-425)
 //
-//   s = quantile(|x0|, ratio) over the sample  -> exact order statistics by an 8/8/8/7-bit radix select on
-//       the bit pattern of |x0| (non-negative floats order like their bit patterns), histogram in LDS,
-//       bin search by wavefront prefix sums; the fractional rank is the reference's fp32 `ratio*(n-1)`.
-//   s = max(s, max_val);  x0 <- clamp(x0, -s, s) / s;  then the same combine as the streaming kernel.
+//   s = quantile(|x0|, ratio) over the sample;  s = max(s, max_val);  x0 <- clamp(x0, -s, s) / s;
+//   then the same combine / epilogue as the streaming kernel.
+//
+// A *cluster* of k workgroups owns one sample at a time (k = 1 when a sample fits one workgroup's LDS and the batch
+// alone fills the chip; k > 1 spreads small batches and large samples -- 3x256x256 pixels -- over many CUs).  Each
+// workgroup computes x0 for its chunk of the sample ONCE into LDS, so HBM sees every stream exactly once (5N for the
+// 2M stage).  The quantile needs two exact order statistics: an 11/11/9-bit radix select over the bit pattern of
+// |x0| (non-negative floats order like their bit patterns).  Per level: LDS histogram by atomics -> (k > 1: merged
+// into the sample's global histogram, cluster barrier, read back) -> every workgroup locates the bin of the wanted
+// rank by wavefront prefix sums (__shfl_up) over 2 bins per lane.  The next order statistic, when it is not a
+// duplicate, is the smallest value above the selected one: wavefront min (__shfl_xor) + one atomic per wave.  The
+// fractional rank is the reference's fp32 `ratio*(n-1)` and the interpolation is ATen's lerp.
+//
+// Cluster barriers are single-use counters in a zeroed workspace (agent-scope atomics); the launch keeps the grid
+// within the number of co-resident workgroups, so waiting workgroups can always be joined by their peers.
 // ------------------------------------------------------------------------------------------------
-constexpr int THR_THREADS = 1024;
+constexpr int THR_THREADS = 512;
+constexpr int THR_NB = 2048;                 // bins per radix level
+constexpr int THR_WS_WORDS = 3 * THR_NB + 64;  // per sample: 3 level histograms + counters (256-byte multiple)
+constexpr int THR_CHUNK_MAX = 12288;         // elements of a sample one workgroup keeps in LDS (48 KiB)
 
 struct ThrParams {
   int64_t per_sample;
   int32_t lo, hi;  // floor / ceil of the fp32 rank (ascending order)
   float w;         // fractional part
   float max_val;
+  int32_t chunk;   // elements per workgroup of a cluster (multiple of 4 when the vector path is on)
+  int32_t k;       // workgroups per cluster
+  int32_t groups;  // clusters in the grid
+  int32_t batch;
+  int32_t vec;     // 1: 4-element vector accesses are legal for every tensor of this launch
+  int32_t pad;
+  uint32_t* ws;    // k > 1: batch x THR_WS_WORDS zeroed words
 };
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
@@ -446,276 +467,252 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
   return v;
 }
 
-template <typename TS, typename TE, int FORM, int GUIDE, bool XE>
-__global__ __launch_bounds__(THR_THREADS) void stage_thresh_kernel(
+// 4 consecutive elements (one 16-byte / 8-byte access)
+__device__ __forceinline__ void load4(const float* __restrict__ p, int64_t i, float (&o)[4]) {
+  const u32x4 a = *reinterpret_cast<const u32x4*>(p + i);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = __uint_as_float(a[j]);
+}
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void load4(const __half* __restrict__ p, int64_t i, float (&o)[4]) {
+  const u32x2 a = *reinterpret_cast<const u32x2*>(p + i);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    o[2 * j] = __half2float(__ushort_as_half((unsigned short)(a[j] & 0xffffu)));
+    o[2 * j + 1] = __half2float(__ushort_as_half((unsigned short)(a[j] >> 16)));
+  }
+}
+__device__ __forceinline__ void load4(const bf16_t* __restrict__ p, int64_t i, float (&o)[4]) {
+  const u32x2 a = *reinterpret_cast<const u32x2*>(p + i);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    o[2 * j] = __uint_as_float(a[j] << 16);
+    o[2 * j + 1] = __uint_as_float(a[j] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void store4(float* __restrict__ p, int64_t i, const float (&v)[4]) {
+  u32x4 a;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a[j] = __float_as_uint(v[j]);
+  *reinterpret_cast<u32x4*>(p + i) = a;
+}
+__device__ __forceinline__ void store4(__half* __restrict__ p, int64_t i, const float (&v)[4]) {
+  u32x2 a;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    a[j] = (uint32_t)__half_as_ushort(__float2half_rn(v[2 * j])) | ((uint32_t)__half_as_ushort(__float2half_rn(v[2 * j + 1])) << 16);
+  *reinterpret_cast<u32x2*>(p + i) = a;
+}
+__device__ __forceinline__ void store4(bf16_t* __restrict__ p, int64_t i, const float (&v)[4]) {
+  u32x2 a;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) a[j] = (uint32_t)from_f32<bf16_t>(v[2 * j]).v | ((uint32_t)from_f32<bf16_t>(v[2 * j + 1]).v << 16);
+  *reinterpret_cast<u32x2*>(p + i) = a;
+}
+
+// all workgroups of a cluster meet here; `cnt` is a zero-initialised single-use counter.  Everything the cluster
+// shares travels as agent-scope atomics and sc1 loads, so no cache write-back / invalidate is needed: drain this
+// wave's atomics, arrive with a relaxed atomic, poll with relaxed sc1 loads (MI355X_MICROARCH.md, barrier-counter).
+__device__ __forceinline__ void cluster_barrier(uint32_t* cnt, uint32_t k) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t spins = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 26)) __builtin_trap();  // peers are co-resident by construction: never expected
+    }
+  }
+  __syncthreads();
+}
+
+template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int T>
+__global__ __launch_bounds__(T) void stage_thresh_kernel(
     const TS* __restrict__ x, const TS* __restrict__ xe, const TE* __restrict__ e0, const TE* __restrict__ e1,
     const TE* __restrict__ g, const TS* __restrict__ h1, const TS* __restrict__ h2, TS* __restrict__ xo,
     TS* __restrict__ mo, KParams p, ThrParams tp, KExt ext) {
   using FT = FormTraits<FORM>;
+  constexpr int BPT = THR_NB / T;  // histogram bins per thread when all threads touch the histogram
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  float* sx0 = reinterpret_cast<float*>(lds_raw);                 // [per_sample]
-  uint32_t* hist = reinterpret_cast<uint32_t*>(sx0 + tp.per_sample);  // [256]
-  uint32_t* misc = hist + 256;                                    // [4]: prefix, k, count, min-above
+  float* sx0 = reinterpret_cast<float*>(lds_raw);                    // [chunk]
+  uint32_t* hist = reinterpret_cast<uint32_t*>(sx0 + tp.chunk);      // [THR_NB]
+  uint32_t* misc = hist + THR_NB;                                    // [32]: selection result [3], min-above
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int64_t base = (int64_t)blockIdx.x * tp.per_sample;
-  const int64_t ebase = (int64_t)blockIdx.x * (ext.eps_stride ? ext.eps_stride : tp.per_sample);
-  const int n = (int)tp.per_sample;
   const bool store_m = p.flags & DPM_F_STORE_M;
+  const bool vec = tp.vec != 0;
+  const uint32_t k = (uint32_t)tp.k;
+  const int grp = k == 1 ? (int)blockIdx.x : (int)(blockIdx.x / k);
+  const int c = k == 1 ? 0 : (int)(blockIdx.x % k);
+  const TS* mask = static_cast<const TS*>(ext.mask);
+  const TS* ba = static_cast<const TS*>(ext.ba);
+  const TS* bb = static_cast<const TS*>(ext.bb);
+  TS* xo2 = static_cast<TS*>(ext.xo2);
 
-  // phase 1: x0 for the whole sample -> LDS
-  for (int i = tid; i < n; i += THR_THREADS) {
-    const int64_t gi = base + i;
-    const float xev = to_f32(XE ? xe[gi] : x[gi]);
-    sx0[i] = prologue<GUIDE>(xev, to_f32(e0[ebase + i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[ebase + i]) : 0.f,
-                             GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[gi]) : 0.f, p);
-  }
-  if (tid == 0) {
-    misc[0] = 0u;               // prefix bits decided so far
-    misc[1] = (uint32_t)tp.lo;  // rank still to resolve inside the prefix group
-  }
-  __syncthreads();
+  for (int s_idx = grp; s_idx < tp.batch; s_idx += tp.groups) {
+    const int64_t base = (int64_t)s_idx * tp.per_sample + (int64_t)c * tp.chunk;
+    const int64_t ebase = (int64_t)s_idx * (ext.eps_stride ? ext.eps_stride : tp.per_sample) + (int64_t)c * tp.chunk;
+    const int64_t left = tp.per_sample - (int64_t)c * tp.chunk;
+    const int n = left <= 0 ? 0 : (left < tp.chunk ? (int)left : tp.chunk);
+    uint32_t* ws = k == 1 ? nullptr : tp.ws + (int64_t)s_idx * THR_WS_WORDS;
+    // mask index of element base + i without a 64-bit division per element (launch: period < 2^31 or period == n)
+    const bool mfull = ext.mask_period >= ((int64_t)1 << 31);
+    const uint32_t mbase = (mask && !mfull) ? (uint32_t)(base % ext.mask_period) : 0u;
+    const uint32_t mper = (uint32_t)ext.mask_period;
 
-  // phase 2: radix select of the lo-th smallest |x0|
-  uint32_t known_mask = 0u;
+    // phase 1: x0 of this workgroup's chunk -> LDS
+    if (vec) {
+#pragma unroll 2
+      for (int i = tid * 4; i < n; i += T * 4) {
+        float vx[4], v0[4], v1[4], vg[4], o[4];
+        load4(XE ? xe : x, base + i, vx);
+        load4(e0, ebase + i, v0);
+        if (GUIDE == DPM_GUIDE_CFG) load4(e1, ebase + i, v1);
+        if (GUIDE == DPM_GUIDE_CLASSIFIER) load4(g, base + i, vg);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          o[j] = prologue<GUIDE>(vx[j], v0[j], GUIDE == DPM_GUIDE_CFG ? v1[j] : 0.f, GUIDE == DPM_GUIDE_CLASSIFIER ? vg[j] : 0.f, p);
+        store4(sx0, i, o);
+      }
+    } else {
+#pragma unroll 4
+      for (int i = tid; i < n; i += T) {
+        const float xev = to_f32(XE ? xe[base + i] : x[base + i]);
+        sx0[i] = prologue<GUIDE>(xev, to_f32(e0[ebase + i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[ebase + i]) : 0.f,
+                                 GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[base + i]) : 0.f, p);
+      }
+    }
+
+    // phase 2: radix select of the lo-th smallest |x0| of the whole sample, 11 + 11 + 9 bits
+    uint32_t prefix = 0u, known = 0u, rank = (uint32_t)tp.lo, cnt_sel = 0u;
 #pragma unroll 1
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = pass == 0 ? 23 : pass == 1 ? 15 : pass == 2 ? 7 : 0;
-    const uint32_t dmask = pass == 3 ? 0x7fu : 0xffu;
-    if (tid < 256) hist[tid] = 0u;
-    __syncthreads();
-    const uint32_t prefix = misc[0];
-    for (int i = tid; i < n; i += THR_THREADS) {
-      const uint32_t u = __float_as_uint(sx0[i]) & 0x7fffffffu;
-      if ((u & known_mask) == prefix) atomicAdd(&hist[(u >> shift) & dmask], 1u);
-    }
-    __syncthreads();
-    if (tid < 64) {  // wavefront 0: locate the bin holding rank k
-      const uint32_t k = misc[1];
-      uint32_t c[4], tot = 0;
+    for (int pass = 0; pass < 3; ++pass) {
+      const int shift = pass == 0 ? 20 : pass == 1 ? 9 : 0;
+      const uint32_t dmask = pass == 2 ? 0x1ffu : 0x7ffu;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        c[j] = hist[lane * 4 + j];
-        tot += c[j];
+      for (int j = 0; j < BPT; ++j) hist[j * T + tid] = 0u;
+      __syncthreads();  // also orders phase 1's LDS writes before the first read
+#pragma unroll 4
+      for (int i = tid; i < n; i += T) {
+        const uint32_t u = __float_as_uint(sx0[i]) & 0x7fffffffu;
+        if ((u & known) == prefix) atomicAdd(&hist[(u >> shift) & dmask], 1u);
       }
-      const uint32_t incl = wave_incl_scan(tot, lane);
-      const uint64_t ball = __ballot(incl > k);
-      const int owner = __ffsll((long long)ball) - 1;
-      if (lane == owner) {
-        uint32_t before = incl - tot;
-        int j = 0;
-        while (j < 3 && before + c[j] <= k) {
-          before += c[j];
-          ++j;
+      __syncthreads();
+      if (k > 1) {  // merge into the sample's histogram of this level, wait for the peers, read the sum back
+        uint32_t* gh = ws + pass * THR_NB;
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) {
+          const uint32_t v = hist[j * T + tid];
+          if (v) __hip_atomic_fetch_add(&gh[j * T + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        misc[0] = prefix | ((uint32_t)(lane * 4 + j) << shift);
-        misc[1] = k - before;
-        misc[2] = c[j];
+        cluster_barrier(ws + 3 * THR_NB + pass, k);
+#pragma unroll
+        for (int j = 0; j < BPT; ++j)
+          hist[j * T + tid] = __hip_atomic_load(&gh[j * T + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+      }
+      // wavefront 0 locates the bin holding `rank`: two levels of wavefront prefix sums (64 x 32 bins)
+      if (tid < 64) {
+        const u32x4* h4 = reinterpret_cast<const u32x4*>(hist) + lane * 8;
+        uint32_t tot = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const u32x4 v = h4[j];
+          tot += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        const uint32_t incl = wave_incl_scan(tot, lane);
+        const int owner = __ffsll((long long)__ballot(incl > rank)) - 1;  // first 32-bin group reaching the rank
+        const uint32_t before_grp = __shfl(incl - tot, owner, 64);
+        const uint32_t cbin = lane < 32 ? hist[owner * 32 + lane] : 0u;
+        const uint32_t incl2 = wave_incl_scan(cbin, lane) + before_grp;
+        const int ob = __ffsll((long long)__ballot(lane < 32 && incl2 > rank)) - 1;
+        if (lane == ob) {
+          misc[0] = (uint32_t)(owner * 32 + ob);
+          misc[1] = rank - (incl2 - cbin);
+          misc[2] = cbin;
+        }
+      }
+      __syncthreads();
+      prefix |= misc[0] << shift;
+      known |= dmask << shift;
+      rank = misc[1];
+      cnt_sel = misc[2];
+    }
+    const uint32_t a_bits = prefix;
+    float a = __uint_as_float(a_bits), b = a;
+    if (tp.hi != tp.lo && rank + 1u >= cnt_sel) {
+      // the next order statistic is the smallest value above a: wavefront min, one atomic per wave
+      if (tid == 0) misc[3] = 0x7fffffffu;
+      __syncthreads();
+      uint32_t m = 0x7fffffffu;
+#pragma unroll 4
+      for (int i = tid; i < n; i += T) {
+        const uint32_t u = __float_as_uint(sx0[i]) & 0x7fffffffu;
+        if (u > a_bits && u < m) m = u;
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = __shfl_xor(m, d, 64);
+        m = o < m ? o : m;
+      }
+      if (lane == 0) atomicMin(&misc[3], m);
+      __syncthreads();
+      if (k > 1) {  // workspace words start at zero: keep the minimum as a maximum of the complement
+        uint32_t* gm = ws + 3 * THR_NB + 8;
+        if (tid == 0) __hip_atomic_fetch_max(gm, 0x7fffffffu - misc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cluster_barrier(ws + 3 * THR_NB + 3, k);
+        b = __uint_as_float(0x7fffffffu - __hip_atomic_load(gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      } else {
+        b = __uint_as_float(misc[3]);
       }
     }
-    known_mask |= dmask << shift;
-    __syncthreads();
-  }
-  const uint32_t a_bits = misc[0];
-  float a = __uint_as_float(a_bits), b = a;
-  if (tp.hi != tp.lo && misc[1] + 1u >= misc[2]) {
-    // the next order statistic is the smallest value above a: wavefront min, then one LDS atomic per wave
-    __syncthreads();
-    if (tid == 0) misc[3] = 0x7fffffffu;
-    __syncthreads();
-    uint32_t m = 0x7fffffffu;
-    for (int i = tid; i < n; i += THR_THREADS) {
-      const uint32_t u = __float_as_uint(sx0[i]) & 0x7fffffffu;
-      if (u > a_bits && u < m) m = u;
+    // torch.quantile 'linear' = ATen lerp(a, b, w)
+    const float diff = b - a;
+    const float q = tp.w < 0.5f ? a + tp.w * diff : b - diff * (1.f - tp.w);
+    const float s = fmaxf(q, tp.max_val);  // ref :423
+
+    // phase 3: clamp, scale, combine, epilogue, store
+    if (vec) {
+#pragma unroll 2
+      for (int i = tid * 4; i < n; i += T * 4) {
+        const int64_t gi = base + i;
+        float vx[4], vh1[4], vh2[4], vm[4], va[4], vb[4], o[4], om[4];
+        if (FT::needs_x) load4(x, gi, vx);
+        if (FT::needs_h1) load4(h1, gi, vh1);
+        if (FT::needs_h2) load4(h2, gi, vh2);
+        if (mask) {
+          load4(mask, mfull ? gi : (int64_t)((mbase + (uint32_t)i) % mper), vm);
+          load4(ba, gi, va);
+          if (bb) load4(bb, gi, vb);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          om[j] = fminf(fmaxf(sx0[i + j], -s), s) / s;  // ref :424
+          o[j] = combine<FORM>(FT::needs_x ? vx[j] : 0.f, om[j], FT::needs_h1 ? vh1[j] : 0.f, FT::needs_h2 ? vh2[j] : 0.f, p);
+          if (mask) o[j] = blend_ref(to_f32(from_f32<TS>(o[j])), vm[j], va[j], bb ? vb[j] : 0.f, bb != nullptr, ext);
+        }
+        store4(xo, gi, o);
+        if (xo2) store4(xo2, gi, o);
+        if (store_m) store4(mo, gi, om);
+      }
+    } else {
+#pragma unroll 2
+      for (int i = tid; i < n; i += T) {
+        const int64_t gi = base + i;
+        const float mn = fminf(fmaxf(sx0[i], -s), s) / s;  // ref :424
+        const float xv = FT::needs_x ? to_f32(x[gi]) : 0.f;
+        float o = combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[gi]) : 0.f, FT::needs_h2 ? to_f32(h2[gi]) : 0.f, p);
+        if (mask)
+          o = blend_ref(to_f32(from_f32<TS>(o)), to_f32(mask[mfull ? gi : (int64_t)((mbase + (uint32_t)i) % mper)]),
+                        to_f32(ba[gi]), bb ? to_f32(bb[gi]) : 0.f, bb != nullptr, ext);
+        const TS ov = from_f32<TS>(o);
+        xo[gi] = ov;
+        if (xo2) xo2[gi] = ov;
+        if (store_m) mo[gi] = from_f32<TS>(mn);
+      }
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      const uint32_t o = __shfl_xor(m, d, 64);
-      m = o < m ? o : m;
-    }
-    if (lane == 0) atomicMin(&misc[3], m);
-    __syncthreads();
-    b = __uint_as_float(misc[3]);
-  }
-  // torch.quantile 'linear' = ATen lerp(a, b, w)
-  const float diff = b - a;
-  const float q = tp.w < 0.5f ? a + tp.w * diff : b - diff * (1.f - tp.w);
-  const float s = fmaxf(q, tp.max_val);  // ref :423
-
-  // phase 3: clamp, scale, combine, store
-  const TS* mask = static_cast<const TS*>(ext.mask);
-  const TS* ba = static_cast<const TS*>(ext.ba);
-  const TS* bb = static_cast<const TS*>(ext.bb);
-  TS* xo2 = static_cast<TS*>(ext.xo2);
-  for (int i = tid; i < n; i += THR_THREADS) {
-    const int64_t gi = base + i;
-    const float x0 = sx0[i];
-    const float mn = fminf(fmaxf(x0, -s), s) / s;  // ref :424
-    const float xv = FT::needs_x ? to_f32(x[gi]) : 0.f;
-    float o = combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[gi]) : 0.f, FT::needs_h2 ? to_f32(h2[gi]) : 0.f, p);
-    if (mask)
-      o = blend_ref(to_f32(from_f32<TS>(o)), to_f32(mask[gi % ext.mask_period]), to_f32(ba[gi]),
-                    bb ? to_f32(bb[gi]) : 0.f, bb != nullptr, ext);
-    const TS ov = from_f32<TS>(o);
-    xo[gi] = ov;
-    if (xo2) xo2[gi] = ov;
-    if (store_m) mo[gi] = from_f32<TS>(mn);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// dynamic thresholding for samples that do not fit in LDS (e.g. 3x256x256 pixel samples): the same exact
-// selection, spread over many workgroups per sample.  x0 is materialised once in an fp32 workspace; three
-// radix levels (12 + 12 + 7 bits of the |x0| bit pattern) each take one histogram pass (LDS-private histogram
-// per workgroup, flushed with global atomics) and one tiny per-sample scan; one more pass finds the smallest
-// value above the selected one; the final pass clamps, scales and applies the update.
-// ------------------------------------------------------------------------------------------------
-struct ThrSel {        // per-sample selection state in the workspace
-  uint32_t prefix;     // bits of the lo-th smallest |x0| decided so far
-  uint32_t mask;       // which bits those are
-  uint32_t k;          // rank still to resolve inside the prefix group
-  uint32_t cnt;        // size of the selected bin (after the last level: multiplicity of the value)
-  uint32_t min_above;  // smallest bit pattern strictly above the selected value
-  uint32_t pad[3];
-};
-constexpr int THR_BINS = 4096;
-
-template <typename TS, typename TE, int GUIDE, bool XE>
-__global__ __launch_bounds__(256) void thr_big_x0_kernel(const TS* __restrict__ x, const TS* __restrict__ xe,
-                                                         const TE* __restrict__ e0, const TE* __restrict__ e1,
-                                                         const TE* __restrict__ g, float* __restrict__ w,
-                                                         uint32_t* __restrict__ hist, KParams p, int64_t per_sample,
-                                                         int64_t eps_stride) {
-  __shared__ uint32_t lh[THR_BINS];
-  for (int i = threadIdx.x; i < THR_BINS; i += 256) lh[i] = 0u;
-  __syncthreads();
-  const int64_t base = (int64_t)blockIdx.y * per_sample;
-  const int64_t ebase = (int64_t)blockIdx.y * (eps_stride ? eps_stride : per_sample);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
-    const int64_t gi = base + i;
-    const float xev = to_f32(XE ? xe[gi] : x[gi]);
-    const float x0 = prologue<GUIDE>(xev, to_f32(e0[ebase + i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[ebase + i]) : 0.f,
-                                     GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[gi]) : 0.f, p);
-    w[gi] = x0;
-    atomicAdd(&lh[(__float_as_uint(x0) & 0x7fffffffu) >> 19], 1u);
-  }
-  __syncthreads();
-  uint32_t* gh = hist + (int64_t)blockIdx.y * THR_BINS;
-  for (int i = threadIdx.x; i < THR_BINS; i += 256)
-    if (lh[i]) atomicAdd(&gh[i], lh[i]);
-}
-
-__global__ __launch_bounds__(256) void thr_big_hist_kernel(const float* __restrict__ w, uint32_t* __restrict__ hist,
-                                                           const ThrSel* __restrict__ sel, int shift, uint32_t dmask,
-                                                           int64_t per_sample) {
-  __shared__ uint32_t lh[THR_BINS];
-  for (int i = threadIdx.x; i < THR_BINS; i += 256) lh[i] = 0u;
-  __syncthreads();
-  const uint32_t prefix = sel[blockIdx.y].prefix, mask = sel[blockIdx.y].mask;
-  const int64_t base = (int64_t)blockIdx.y * per_sample;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
-    const uint32_t u = __float_as_uint(w[base + i]) & 0x7fffffffu;
-    if ((u & mask) == prefix) atomicAdd(&lh[(u >> shift) & dmask], 1u);
-  }
-  __syncthreads();
-  uint32_t* gh = hist + (int64_t)blockIdx.y * THR_BINS;
-  for (int i = threadIdx.x; i <= (int)dmask; i += 256)
-    if (lh[i]) atomicAdd(&gh[i], lh[i]);
-}
-
-// one workgroup per sample: find the bin holding rank k, fold it into the prefix, clear the histogram
-__global__ __launch_bounds__(1024) void thr_big_scan_kernel(uint32_t* __restrict__ hist, ThrSel* __restrict__ sel,
-                                                            int shift, uint32_t dmask, int first, uint32_t lo) {
-  __shared__ uint32_t wave_tot[16];
-  __shared__ uint32_t res[3];
-  uint32_t* gh = hist + (int64_t)blockIdx.x * THR_BINS;
-  ThrSel& s = sel[blockIdx.x];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const uint32_t k = first ? lo : s.k;
-  uint32_t c[4], tot = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    c[j] = gh[tid * 4 + j];
-    tot += c[j];
-  }
-  const uint32_t incl_w = wave_incl_scan(tot, lane);
-  if (lane == 63) wave_tot[wv] = incl_w;
-  __syncthreads();
-  uint32_t before_wave = 0;
-  for (int q = 0; q < wv; ++q) before_wave += wave_tot[q];
-  const uint32_t incl = before_wave + incl_w, excl = incl - tot;
-  if (excl <= k && k < incl) {  // exactly one thread
-    uint32_t before = excl;
-    int j = 0;
-    while (j < 3 && before + c[j] <= k) {
-      before += c[j];
-      ++j;
-    }
-    res[0] = (uint32_t)(tid * 4 + j);
-    res[1] = k - before;
-    res[2] = c[j];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < 4; ++j) gh[tid * 4 + j] = 0u;  // ready for the next level
-  if (tid == 0) {
-    const uint32_t pre = first ? 0u : s.prefix, msk = first ? 0u : s.mask;
-    s.prefix = pre | (res[0] << shift);
-    s.mask = msk | (dmask << shift);
-    s.k = res[1];
-    s.cnt = res[2];
-    if (first) s.min_above = 0x7fffffffu;
-  }
-}
-
-__global__ __launch_bounds__(256) void thr_big_minabove_kernel(const float* __restrict__ w, ThrSel* __restrict__ sel,
-                                                               int64_t per_sample) {
-  const uint32_t a_bits = sel[blockIdx.y].prefix;
-  const int64_t base = (int64_t)blockIdx.y * per_sample;
-  uint32_t m = 0x7fffffffu;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
-    const uint32_t u = __float_as_uint(w[base + i]) & 0x7fffffffu;
-    if (u > a_bits && u < m) m = u;
-  }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    const uint32_t o = __shfl_xor(m, d, 64);
-    m = o < m ? o : m;
-  }
-  if ((threadIdx.x & 63) == 0 && m != 0x7fffffffu) atomicMin(&sel[blockIdx.y].min_above, m);
-}
-
-template <typename TS, int FORM>
-__global__ __launch_bounds__(256) void thr_big_finish_kernel(const TS* __restrict__ x, const TS* __restrict__ h1,
-                                                             const TS* __restrict__ h2, const float* __restrict__ w,
-                                                             const ThrSel* __restrict__ sel, TS* __restrict__ xo,
-                                                             TS* __restrict__ mo, KParams p, ThrParams tp, KExt ext) {
-  using FT = FormTraits<FORM>;
-  const TS* mask = static_cast<const TS*>(ext.mask);
-  const TS* ba = static_cast<const TS*>(ext.ba);
-  const TS* bb = static_cast<const TS*>(ext.bb);
-  TS* xo2 = static_cast<TS*>(ext.xo2);
-  const ThrSel s_ = sel[blockIdx.y];
-  const float a = __uint_as_float(s_.prefix);
-  float b = a;
-  if (tp.hi != tp.lo && s_.k + 1u >= s_.cnt) b = __uint_as_float(s_.min_above);
-  const float diff = b - a;
-  const float q = tp.w < 0.5f ? a + tp.w * diff : b - diff * (1.f - tp.w);
-  const float s = fmaxf(q, tp.max_val);
-  const bool store_m = p.flags & DPM_F_STORE_M;
-  const int64_t base = (int64_t)blockIdx.y * tp.per_sample;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tp.per_sample; i += (int64_t)gridDim.x * 256) {
-    const int64_t gi = base + i;
-    const float mn = fminf(fmaxf(w[gi], -s), s) / s;
-    const float xv = FT::needs_x ? to_f32(x[gi]) : 0.f;
-    float o = combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[gi]) : 0.f, FT::needs_h2 ? to_f32(h2[gi]) : 0.f, p);
-    if (mask)
-      o = blend_ref(to_f32(from_f32<TS>(o)), to_f32(mask[gi % ext.mask_period]), to_f32(ba[gi]),
-                    bb ? to_f32(bb[gi]) : 0.f, bb != nullptr, ext);
-    const TS ov = from_f32<TS>(o);
-    xo[gi] = ov;
-    if (xo2) xo2[gi] = ov;
-    if (store_m) mo[gi] = from_f32<TS>(mn);
+    __syncthreads();  // the next sample of this cluster reuses the LDS
   }
 }
 
@@ -833,12 +830,23 @@ inline KParams make_params(const dpm_stage* st) {
   return p;
 }
 
-constexpr int64_t THR_LDS_EXTRA = (256 + 8) * 4;
-
-inline int64_t round256(int64_t v) { return (v + 255) / 256 * 256; }
-// global workspace of the large-sample thresholding path: [x0 fp32: n][hist: batch x 4096 u32][sel: batch x 32 B]
-inline int64_t thr_ws_bytes(int64_t batch, int64_t per_sample) {
-  return round256(batch * per_sample * 4) + round256(batch * THR_BINS * 4) + round256(batch * (int64_t)sizeof(ThrSel));
+// cluster shape of the thresholding kernel: k workgroups per sample, `chunk` elements each.  Depends only on the
+// batch, the sample size and the CU count, so dpm_threshold_workspace_bytes() and the launch agree.
+struct ThrPlan {
+  int64_t k, chunk;
+};
+inline ThrPlan thr_plan(int64_t batch, int64_t per_sample, int n_cu) {
+  const int64_t kmin = (per_sample + THR_CHUNK_MAX - 1) / THR_CHUNK_MAX;        // what LDS allows
+  const int64_t kfill = (2 * (int64_t)n_cu) / (batch < 1 ? 1 : batch);          // spread a small batch over the chip
+  const int64_t kmax = std::max<int64_t>(1, per_sample / 2048);                 // but keep >= 2 elements per lane
+  int64_t k = std::max(kmin, std::min(std::min(kfill, kmax), (int64_t)n_cu));
+  if (k < 1) k = 1;
+  int64_t chunk = (per_sample + k - 1) / k;
+  chunk = (chunk + 3) / 4 * 4;
+  return ThrPlan{k, chunk};
+}
+inline int64_t thr_ws_bytes(int64_t batch, int64_t per_sample, int n_cu) {
+  return thr_plan(batch, per_sample, n_cu).k > 1 ? batch * (int64_t)THR_WS_WORDS * 4 : 0;
 }
 
 // launch-shape defaults (chosen on MI355X) and the run-time tuning hooks
@@ -900,9 +908,11 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
 
   if (st->flags & DPM_F_THRESH) {
     const int64_t per_sample = b->n / b->batch;
-    const int64_t lds_bytes = per_sample * 4 + THR_LDS_EXTRA;
-    const int64_t lds_cap = di.lds > 0 ? di.lds : 160 * 1024;
+    if (b->batch > 0x7fffffff || per_sample > ((int64_t)1 << 40))
+      return dpm_set_error(DPM_ERR_UNSUPPORTED, "thresholding: batch / sample size out of range");
+    const ThrPlan pl = thr_plan(b->batch, per_sample, n_cu);
     ThrParams tp;
+    std::memset(&tp, 0, sizeof tp);
     tp.per_sample = per_sample;
     // torch.quantile: rank = q * (n - 1) evaluated in fp32 (q is an fp32 tensor)
     const float rank = st->thr_ratio * (float)(per_sample - 1);
@@ -910,55 +920,50 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
     tp.hi = (int32_t)ceilf(rank);
     tp.w = rank - (float)tp.lo;
     tp.max_val = st->thr_max;
-    if (lds_bytes <= lds_cap) {
-      auto kern = stage_thresh_kernel<TS, TE, FORM, GUIDE, XE>;
-      if (lds_bytes > 64 * 1024) {
-        // once per kernel, device and size: keeps repeated launches (and stream capture) free of attribute calls
-        static thread_local int set_dev = -1;
-        static thread_local int64_t set_bytes = 0;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev != set_dev || lds_bytes > set_bytes) {
-          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-          if (e != hipSuccess) return dpm_set_error((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-          set_dev = dev;
-          set_bytes = lds_bytes;
-        }
+    tp.chunk = (int32_t)pl.chunk;
+    tp.k = (int32_t)pl.k;
+    tp.batch = (int32_t)b->batch;
+    const size_t a4s = sizeof(TS) * 4, a4e = sizeof(TE) * 4;
+    tp.vec = per_sample % 4 == 0 && ext.eps_stride % 4 == 0 && ext.mask_period % 4 == 0 && aligned(x, a4s) &&
+             aligned(xe, a4s) && aligned(h1, a4s) && aligned(h2, a4s) && aligned(xo, a4s) && aligned(mo, a4s) &&
+             aligned(ext.xo2, a4s) && aligned(ext.mask, a4s) && aligned(ext.ba, a4s) && aligned(ext.bb, a4s) &&
+             aligned(e0, a4e) && aligned(e1, a4e) && aligned(g, a4e);
+    const size_t lds_bytes = (size_t)pl.chunk * 4 + THR_NB * 4 + 32 * 4;
+    auto kern = stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS>;
+    int64_t grid = b->batch;
+    tp.groups = (int32_t)b->batch;
+    if (pl.k > 1) {
+      // clusters synchronise through spin barriers: every workgroup of the grid must be resident at once
+      static thread_local int occ_dev = -1, occ = 0;
+      static thread_local size_t occ_lds = 0;
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (dev != occ_dev || lds_bytes != occ_lds) {
+        int nb = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), THR_THREADS,
+                                                                    lds_bytes);
+        if (e != hipSuccess) return dpm_set_error((int)e, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s", hipGetErrorString(e));
+        occ_dev = dev;
+        occ_lds = lds_bytes;
+        occ = nb;
       }
-      launch(kern, dim3((unsigned)b->batch), dim3(THR_THREADS), (size_t)lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo,
-             p, tp, ext);
-    } else {
-      // large samples: multi-workgroup exact selection through a caller-provided workspace
+      const int64_t cap = (int64_t)n_cu * (occ < 1 ? 1 : (occ > 2 ? 2 : occ));
+      if (pl.k > cap)
+        return dpm_set_error(DPM_ERR_UNSUPPORTED, "dynamic thresholding: a sample of %lld elements needs %lld co-resident "
+                             "workgroups, the device holds %lld", (long long)per_sample, (long long)pl.k, (long long)cap);
       if (!b->workspace)
         return dpm_set_error(DPM_ERR_ARG,
-                             "dynamic thresholding of %lld-element samples needs a workspace of "
+                             "dynamic thresholding of %lld samples x %lld elements needs a workspace of "
                              "dpm_threshold_workspace_bytes() = %lld bytes",
-                             (long long)per_sample, (long long)thr_ws_bytes(b->batch, per_sample));
-      if (b->batch > 65535) return dpm_set_error(DPM_ERR_UNSUPPORTED, "thresholding: batch > 65535 with large samples");
-      unsigned char* ws = static_cast<unsigned char*>(b->workspace);
-      float* w = reinterpret_cast<float*>(ws);
-      uint32_t* hist = reinterpret_cast<uint32_t*>(ws + round256(b->n * 4));
-      ThrSel* sel = reinterpret_cast<ThrSel*>(ws + round256(b->n * 4) + round256(b->batch * THR_BINS * 4));
-      hipError_t me = hipMemsetAsync(hist, 0, (size_t)b->batch * THR_BINS * 4, stream.stream);
+                             (long long)b->batch, (long long)per_sample, (long long)thr_ws_bytes(b->batch, per_sample, n_cu));
+      const int64_t groups = std::min<int64_t>(b->batch, cap / pl.k);
+      tp.groups = (int32_t)groups;
+      tp.ws = static_cast<uint32_t*>(b->workspace);
+      grid = groups * pl.k;
+      hipError_t me = hipMemsetAsync(b->workspace, 0, (size_t)thr_ws_bytes(b->batch, per_sample, n_cu), stream.stream);
       if (me != hipSuccess) return dpm_set_error((int)me, "hipMemsetAsync: %s", hipGetErrorString(me));
-      int64_t chunks = (per_sample + 256 * 16 - 1) / (256 * 16);
-      const int64_t max_chunks = std::max<int64_t>(1, ((int64_t)n_cu * 8) / b->batch);
-      if (chunks > max_chunks) chunks = max_chunks;
-      const dim3 grid((unsigned)chunks, (unsigned)b->batch);
-      const LaunchCtx plain{stream.stream, nullptr, nullptr};
-      const LaunchCtx first{stream.stream, stream.start, nullptr}, last{stream.stream, nullptr, stream.stop};
-      launch(thr_big_x0_kernel<TS, TE, GUIDE, XE>, grid, dim3(256), 0, stream.start ? first : plain, x, xe, e0, e1, g, w, hist, p,
-             per_sample, ext.eps_stride);
-      launch(thr_big_scan_kernel, dim3((unsigned)b->batch), dim3(1024), 0, plain, hist, sel, 19, 0xfffu, 1, (uint32_t)tp.lo);
-      launch(thr_big_hist_kernel, grid, dim3(256), 0, plain, (const float*)w, hist, (const ThrSel*)sel, 7, 0xfffu, per_sample);
-      launch(thr_big_scan_kernel, dim3((unsigned)b->batch), dim3(1024), 0, plain, hist, sel, 7, 0xfffu, 0, 0u);
-      launch(thr_big_hist_kernel, grid, dim3(256), 0, plain, (const float*)w, hist, (const ThrSel*)sel, 0, 0x7fu, per_sample);
-      launch(thr_big_scan_kernel, dim3((unsigned)b->batch), dim3(1024), 0, plain, hist, sel, 0, 0x7fu, 0, 0u);
-      launch(thr_big_minabove_kernel, grid, dim3(256), 0, plain, (const float*)w, sel, per_sample);
-      launch(thr_big_finish_kernel<TS, FORM>, grid, dim3(256), 0, stream.stop ? last : plain, x, h1, h2, (const float*)w,
-             (const ThrSel*)sel, xo, mo, p, tp, ext);
     }
+    launch(kern, dim3((unsigned)grid), dim3(THR_THREADS), lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo, p, tp, ext);
   } else {
     const size_t as = sizeof(TS) * EPT, ae = sizeof(TE) * EPT;
     bool vec = aligned(x, as) && aligned(xe, as) && aligned(h1, as) && aligned(h2, as) && aligned(xo, as) &&

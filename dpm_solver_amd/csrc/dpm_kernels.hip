@@ -42,6 +42,8 @@ int dpm_stage_launch_ev(const dpm_stage* st, const dpm_buffers* b, void* stream,
     if (b->n % b->mask_period != 0)
       return dpm_set_error(DPM_ERR_ARG, "stage_launch: n=%lld is not a multiple of mask_period=%lld", (long long)b->n,
                            (long long)b->mask_period);
+    if (b->mask_period >= ((int64_t)1 << 31) && b->mask_period != b->n)
+      return dpm_set_error(DPM_ERR_UNSUPPORTED, "stage_launch: a broadcast mask of 2^31 or more elements");
   }
   if (b->eps_stride != 0 && b->eps_stride < b->n / b->batch)
     return dpm_set_error(DPM_ERR_ARG, "stage_launch: eps_stride=%lld is smaller than a sample (%lld elements)",
@@ -107,9 +109,9 @@ extern "C" int dpm_stage_launch_timed(const dpm_stage* st, const dpm_buffers* b,
 extern "C" size_t dpm_threshold_workspace_bytes(int64_t batch, int64_t per_sample) {
   if (batch < 1 || per_sample < 1) return 0;
   const DeviceInfo& di = device_info();
-  const int64_t lds_cap = di.lds > 0 ? di.lds : 160 * 1024;
-  if (per_sample * 4 + THR_LDS_EXTRA <= lds_cap) return 0;  // the LDS-resident path needs no global scratch
-  return (size_t)thr_ws_bytes(batch, per_sample);
+  // 0 when one workgroup per sample is the plan (the sample lives in that workgroup's LDS); else the zeroed
+  // per-sample histograms and barrier counters the clusters merge through
+  return (size_t)thr_ws_bytes(batch, per_sample, di.n_cu > 0 ? di.n_cu : 256);
 }
 
 extern "C" int dpm_add_noise_launch(const dpm_schedule* s, const float* t_host, int nt, const void* x, const void* noise,

@@ -68,7 +68,12 @@ class Timed:
         return rc
 
 
+ONLY = None
+
+
 def run(name, solver, x, reps=5, **kw):
+    if ONLY and ONLY not in name:
+        return []
     t = Timed()
     L.lib.dpm_stage_launch = t
     try:
@@ -90,8 +95,11 @@ def run(name, solver, x, reps=5, **kw):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--md", default=None)
+    ap.add_argument("--only", default=None, help="substring filter on scenario names (skips the others and the loop timing)")
     args = ap.parse_args()
     torch.manual_seed(0)
+    global ONLY
+    ONLY = args.only
     rows = []
     sd, dd = sd_schedule(), ddpm_schedule()
 
@@ -155,8 +163,9 @@ def main():
     # Python host loop: eager sample() vs DPM_Solver.capture() replay (frozen network), wall per trajectory
     import time
     loop = []
-    for label, shape, dt, kw in [("cfg2 [256,4,64,64] f16 2M++ 20 steps", (256, 4, 64, 64), torch.float16, dict(steps=20, order=2)),
-                                 ("cfg1 [8,4,64,64] f32 2M++ 20 steps", (8, 4, 64, 64), torch.float32, dict(steps=20, order=2))]:
+    for label, shape, dt, kw in [] if ONLY else [
+            ("cfg2 [256,4,64,64] f16 2M++ 20 steps", (256, 4, 64, 64), torch.float16, dict(steps=20, order=2)),
+            ("cfg1 [8,4,64,64] f32 2M++ 20 steps", (8, 4, 64, 64), torch.float32, dict(steps=20, order=2))]:
         e, = frozen(shape, dt)
         s = D.DPM_Solver(D.model_wrapper(lambda x, t: e, sd), sd, state_dtype=dt)
         x = torch.randn(shape, device=DEV).to(dt)
