@@ -78,6 +78,7 @@ class RunBuffers(C.Structure):
         ("xbuf", C.c_void_p * 4), ("hist", C.c_void_p * 3), ("e0", C.c_void_p), ("e1", C.c_void_p),
         ("workspace", C.c_void_p), ("n", C.c_int64), ("batch", C.c_int64),
         ("state_dtype", C.c_int32), ("eps_dtype", C.c_int32),
+        ("eps_stride", C.c_int64), ("dup_state", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

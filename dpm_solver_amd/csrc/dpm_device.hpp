@@ -776,7 +776,10 @@ __global__ __launch_bounds__(1024) void adaptive_error_kernel(const T* __restric
   if (threadIdx.x == 0) {
     double t = 0.;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
-    e_out[blockIdx.x] = sqrtf((float)(t / (double)per_sample));
+    const float e = sqrtf((float)(t / (double)per_sample));
+    e_out[blockIdx.x] = e;
+    // batch maximum (ref :1001) in the extra slot: E >= 0, so the bit patterns order like the values
+    atomicMax(reinterpret_cast<unsigned int*>(e_out + gridDim.x), __float_as_uint(e));
   }
 }
 

@@ -865,6 +865,9 @@ static int plan_run_impl(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model
     b.batch = rb->batch;
     b.state_dtype = rb->state_dtype;
     b.eps_dtype = rb->eps_dtype;
+    b.eps_stride = rb->eps_stride;
+    if (rb->dup_state && &st != &p->stages.back())  // the last stage's output feeds no network call
+      b.x_out2 = static_cast<char*>(rb->xbuf[out]) + rb->n * (rb->state_dtype == DPM_DTYPE_F32 ? 4 : 2);
     int rc = dpm_stage_launch_ev(&st, &b, stream, ev_start ? ev_start[st.index] : nullptr,
                                  ev_stop ? ev_stop[st.index] : nullptr);
     if (rc) return rc;

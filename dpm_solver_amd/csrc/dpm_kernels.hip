@@ -196,6 +196,8 @@ extern "C" int dpm_adaptive_error_launch(const void* x_lower, const void* x_high
   if (!x_lower || !x_higher || !x_prev || !e_out || batch < 1 || per_sample < 1)
     return dpm_set_error(DPM_ERR_ARG, "adaptive_error: bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t me = hipMemsetAsync(e_out + batch, 0, sizeof(float), st);  // the batch-maximum slot
+  if (me != hipSuccess) return dpm_set_error((int)me, "hipMemsetAsync: %s", hipGetErrorString(me));
   switch (dtype) {
     case DPM_DTYPE_F32:
       hipLaunchKernelGGL(adaptive_error_kernel<float>, dim3((unsigned)batch), dim3(1024), 0, st, (const float*)x_lower,

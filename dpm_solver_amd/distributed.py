@@ -6,7 +6,8 @@ each rank owns a contiguous slice of the batch, its own plan copy and network re
 ranks until the single all-gather of the finished samples.  (The reference itself never moves a tensor between
 ranks: examples/ddpm_and_guided-diffusion/main.py:249-265 spawns one process per GPU with seed + rank and each
 writes its own PNGs.)  The 'adaptive' method is the one exception -- its error norm takes a max over the batch
-(dpm_solver_pytorch.py:1001) -- and is rejected here.
+(dpm_solver_pytorch.py:1001): there one 4-byte MAX all-reduce per iteration keeps the sharded run identical to
+the unsharded one.
 """
 import torch
 import torch.distributed as dist
@@ -65,12 +66,24 @@ def gather_samples(x_local, batch=None, group=None):
 def sample_sharded(solver, x_T, group=None, gather=True, **sample_kwargs):
     """DPM_Solver.sample() on this rank's shard of x_T (a full-batch tensor present on every rank, or already a
     shard when `gather=False`), followed by the all-gather of the results."""
-    if sample_kwargs.get("method", "multistep") == "adaptive":
-        raise NotImplementedError("adaptive step sizes couple the whole batch (cross-batch max of the error norm); "
-                                  "batch sharding would change the result")
+    adaptive = sample_kwargs.get("method", "multistep") == "adaptive"
     if sample_kwargs.get("return_intermediate"):
         raise NotImplementedError("return_intermediate is per-rank state; gather the shards yourself")
     full = x_T.shape[0]
     xs = shard_batch(x_T, group=group) if gather else x_T
-    out = solver.sample(xs, **sample_kwargs)
+    if adaptive:
+        # the adaptive controller reads E = max over the WHOLE batch of the per-sample error norm (ref :1001): one
+        # 4-byte MAX all-reduce per iteration makes every rank take the same accept / reject and step-size decisions
+        # as the unsharded run (same number of iterations on every rank, so the collectives pair up)
+        def reduce_max(e):
+            e = e.clone()
+            dist.all_reduce(e, op=dist.ReduceOp.MAX, group=group)
+            return e
+        prev, solver.error_reduce = solver.error_reduce, reduce_max
+        try:
+            out = solver.sample(xs, **sample_kwargs)
+        finally:
+            solver.error_reduce = prev
+    else:
+        out = solver.sample(xs, **sample_kwargs)
     return gather_samples(out, batch=full, group=group) if gather else out

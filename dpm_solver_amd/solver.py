@@ -123,6 +123,21 @@ def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=No
     return x_out, m_out
 
 
+def _adaptive_error(x_lower, x_higher, x_prev, atol, rtol):
+    """max over the batch of the adaptive solver's per-sample error norm (ref :999-1001) as a 0-dim device tensor:
+    one kernel (per-sample RMS + atomic max), no host synchronisation here."""
+    B = x_lower.shape[0]
+    per_sample = x_lower.numel() // max(B, 1)
+    e_dev = torch.empty((B + 1,), dtype=torch.float32, device=x_lower.device)
+    xp = x_prev if x_prev.dtype == x_lower.dtype else x_prev.to(x_lower.dtype)
+    with torch.cuda.device(x_lower.device):
+        L.check(L.lib.dpm_adaptive_error_launch(
+            _ptr(x_lower.contiguous()), _ptr(x_higher.contiguous()), _ptr(xp.contiguous()), float(atol), float(rtol),
+            _ptr(e_dev), B, per_sample, _DT[x_lower.dtype],
+            C.c_void_p(torch.cuda.current_stream(x_lower.device).cuda_stream)))
+    return e_dev[B]
+
+
 class _Plan:
     """A frozen `dpm_plan` plus the per-device time tensors handed to the network / callbacks."""
 
@@ -191,6 +206,8 @@ class DPM_Solver:
         self.thresholding_max_val = thresholding_max_val
         self._state_dtype = state_dtype
         self._plans = {}
+        # adaptive solver: optional hook applied to the 0-dim batch-maximum error before the controller reads it
+        self.error_reduce = None
 
     # ------------------------------------------------------------------------------------------
     # helpers
@@ -505,19 +522,14 @@ class DPM_Solver:
                 x, s, t, r1=r1, r2=r2, solver_type=solver_type, **kw)
         else:
             raise ValueError("For adaptive step size solver, order must be 2 or 3, got {}".format(order))
-        B = x.shape[0]
-        per_sample = x.numel() // max(B, 1)
-        e_dev = torch.empty((B,), dtype=torch.float32, device=x.device)
         while abs(_F32(s - _F32(t_0))) > t_err:
             t = _F32(ns._eval_np(L.EVAL_INV_LAMBDA, [_F32(lambda_s + h)])[0])
             x_lower, lower_noise_kwargs = lower_update(x, float(s), float(t))
             x_higher = higher_update(x, float(s), float(t), **lower_noise_kwargs)
-            xp = x_prev if x_prev.dtype == x_lower.dtype else x_prev.to(x_lower.dtype)
-            with torch.cuda.device(x.device):
-                L.check(L.lib.dpm_adaptive_error_launch(
-                    _ptr(x_lower), _ptr(x_higher), _ptr(xp.contiguous()), float(atol), float(rtol), _ptr(e_dev), B,
-                    per_sample, _DT[x_lower.dtype], C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
-            E = _F32(e_dev.max().item())             # the one host sync per iteration, as in the reference (ref :1002)
+            E_dev = _adaptive_error(x_lower, x_higher, x_prev, atol, rtol)
+            if self.error_reduce is not None:
+                E_dev = self.error_reduce(E_dev)     # batch-sharded runs: MAX all-reduce over the ranks
+            E = _F32(E_dev.item())                   # the one host sync per iteration, as in the reference (ref :1002)
             if E <= 1.:
                 x = x_higher
                 s = t

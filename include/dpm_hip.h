@@ -216,9 +216,10 @@ int dpm_add_noise_launch(const dpm_schedule* s, const float* t_host, int nt, con
    epilogue as its own launch, for callable use of the corrector and for x_T before the first update (ref :1180) */
 int dpm_blend_launch(const void* x, const void* mask, const void* a, const void* b, float alpha, float sigma, void* out,
                      int64_t n, int64_t mask_period, int dtype, void* stream);
-/* per-sample error norm of the adaptive solver (ref :999-1001): E_b = sqrt(mean(((xh-xl)/delta)^2)) */
+/* error norm of the adaptive solver (ref :999-1001): E_b = sqrt(mean(((xh-xl)/delta)^2)) per sample in e_out[0..batch),
+   and their maximum over the batch (the value the step-size controller reads) in e_out[batch] */
 int dpm_adaptive_error_launch(const void* x_lower, const void* x_higher, const void* x_prev, float atol, float rtol,
-                              float* e_out /* [batch] device */, int64_t batch, int64_t per_sample, int dtype,
+                              float* e_out /* [batch + 1] device */, int64_t batch, int64_t per_sample, int dtype,
                               void* stream);
 
 /* native sample loop for non-Python hosts and for the solver-only benchmark.
@@ -235,6 +236,12 @@ typedef struct dpm_run_buffers {
   void* workspace;
   int64_t n, batch;
   int32_t state_dtype, eps_dtype;
+  /* ---- optional (zero = off) ---- */
+  int64_t eps_stride;  /* as dpm_buffers.eps_stride: e0 / e1 are channel slices of a wider network output        */
+  int32_t dup_state;   /* 1: every xbuf holds 2n elements and each state is written to both halves, so the model
+                          callback of a classifier-free-guidance network receives its [2B,...] input ready-made
+                          (xbuf[0] must already hold x_T twice)                                                  */
+  int32_t reserved;
 } dpm_run_buffers;
 int dpm_plan_run(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model_cb model, void* user, void* stream,
                  int* result);

@@ -107,3 +107,14 @@ def maskblend_apply_double(self, x, t_host, step):
     mask, period, ba, bb, alpha, sigma = self.operands(x.shape, x.dtype, x.device, t_host, step)
     out = blend(alpha, sigma, _np(x), _np(mask), _np(ba), _np(bb))
     return torch.from_numpy(np.ascontiguousarray(out)).to(x.dtype).reshape(x.shape)
+
+
+def adaptive_error_double(x_lower, x_higher, x_prev, atol, rtol):
+    """numpy double of dpm_adaptive_error_launch: per-sample RMS of (xh - xl)/delta (fp32 terms, double accumulation),
+    then the batch maximum, returned as a 0-dim tensor"""
+    l, h, p = _np(x_lower), _np(x_higher), _np(x_prev)
+    delta = np.maximum(F32(atol), F32(rtol) * np.maximum(np.abs(l), np.abs(p))).astype(F32)
+    v = ((h - l) / delta).astype(F32)
+    sq = (v * v).astype(F32).reshape(v.shape[0], -1).astype(np.float64)
+    e = np.sqrt((sq.sum(axis=1) / sq.shape[1]).astype(F32)).astype(F32)
+    return torch.tensor(float(e.max()), dtype=torch.float32)

@@ -37,8 +37,18 @@ def _worker(rank, world, port, batch, q):
         out = DD.sample_sharded(dpm, x, **kw)
         full = build_solver(case, "cpu").sample(x, **kw)
         ok = bool(torch.equal(out, full)) and out.shape[0] == batch
-        with pytest.raises(NotImplementedError):
-            DD.sample_sharded(dpm, x, method="adaptive")
+        # adaptive step sizes couple the batch through max_b E_b (ref :1001): one MAX all-reduce per iteration keeps
+        # every rank on the unsharded run's accept / reject sequence
+        from kernel_double import adaptive_error_double
+        import dpm_solver_amd as D
+        from engine_cases import make_schedule
+        S._adaptive_error = adaptive_error_double
+        ns = make_schedule("vp_linear")
+        xa = x * torch.linspace(0.5, 2.0, batch).reshape(-1, 1, 1, 1)          # samples with different error norms
+        mk = lambda: D.DPM_Solver(D.model_wrapper(lambda xx, t: C.model_half(xx, t), ns), ns, algorithm_type="dpmsolver")
+        oa = DD.sample_sharded(mk(), xa, method="adaptive", order=2, t_end=1e-3)
+        fa = mk().sample(xa, method="adaptive", order=2, t_end=1e-3)
+        ok = ok and bool(torch.equal(oa, fa))
         assert DD.rank_seed(7) == 7 + rank
         q.put((rank, ok, tuple(out.shape)))
     finally:

@@ -308,3 +308,48 @@ def test_native_graph_equals_native_loop(sdt):
     assert torch.equal(xb[L.lib.dpm_graph_result(g)], want)
     assert torch.equal(xb[0], x)
     L.lib.dpm_graph_destroy(g)
+
+
+def test_native_loop_with_cfg_callback_and_duplicated_state():
+    """C ABI for non-Python hosts: dpm_plan_run with a model callback under classifier-free guidance; dup_state makes
+    every stage write the callback's [2B,...] input itself.  Must equal the Python loop bit for bit."""
+    case = C.E2E_BY_NAME["cfg3_pp"]
+    ns = make_schedule(case["schedule"])
+    cond, uncond = C.cond_for(case)
+    c_in = torch.cat([tt(uncond, DEV), tt(cond, DEV)])
+    dpm = build_solver(case, DEV)
+    x = tt(C.x_T_for(case), DEV)
+    want = dpm.sample(x, **sample_kwargs(case, False))
+    plan = dpm._get_plan(method=case["method"], order=case["order"], steps=case["steps"], skip_type=case["skip_type"],
+                         solver_type=case["solver_type"], lower_order_final=case["lower_order_final"],
+                         denoise_to_zero=case["denoise_to_zero"], t_T=1.0, t_0=1.0 / ns.total_N)
+    B = x.shape[0]
+    xb = [torch.cat([x, x])] + [torch.empty((2 * B,) + tuple(x.shape[1:]), device=DEV) for _ in range(3)]
+    hb = [torch.empty_like(x) for _ in range(3)]
+    out2 = torch.empty((2 * B,) + tuple(x.shape[1:]), device=DEV)            # [uncond half | cond half]
+    by_ptr = {t.data_ptr(): t for t in xb}
+    calls = []
+
+    def model_cb(user, st, xptr, e0, e1, stream):
+        xin = by_ptr[xptr]
+        assert torch.equal(xin[:B], xin[B:])
+        t_in = torch.full((2 * B,), st.contents.t_input, device=DEV)
+        out2.copy_(C.model_cond(xin, t_in, c_in))
+        calls.append(st.contents.index)
+        return 0
+
+    cb = L.MODEL_CB(model_cb)
+    rb = L.RunBuffers()
+    for i in range(4):
+        rb.xbuf[i] = xb[i].data_ptr()
+    for i in range(3):
+        rb.hist[i] = hb[i].data_ptr()
+    rb.e1, rb.e0 = out2[:B].data_ptr(), out2[B:].data_ptr()
+    rb.n, rb.batch, rb.state_dtype, rb.eps_dtype = x.numel(), B, L.DTYPE_F32, L.DTYPE_F32
+    rb.dup_state = 1
+    res = C_.c_int(-1)
+    L.check(L.lib.dpm_plan_run(plan.handle, C_.byref(rb), C_.cast(cb, C_.c_void_p), None,
+                               C_.c_void_p(torch.cuda.current_stream().cuda_stream), C_.byref(res)))
+    torch.cuda.synchronize()
+    assert calls == list(range(len(plan.stages)))
+    assert torch.equal(xb[res.value][:B], want)

@@ -18,7 +18,7 @@ import dpm_solver_amd.wrapper as W
 from conftest import rel_err
 from dpm_solver_amd import _lib as L
 from engine_cases import build_solver, make_schedule, run_case, sample_kwargs, tt
-from kernel_double import launch_stage_double, maskblend_apply_double
+from kernel_double import adaptive_error_double, launch_stage_double, maskblend_apply_double
 from oracle import dpm_oracle as O
 
 F32 = np.float32
@@ -30,6 +30,7 @@ def cpu_double(monkeypatch):
     monkeypatch.setattr(S, "_launch_stage", launch_stage_double)
     monkeypatch.setattr(S, "_require_gpu", lambda x: None)
     monkeypatch.setattr(D.MaskBlend, "apply", maskblend_apply_double)
+    monkeypatch.setattr(S, "_adaptive_error", adaptive_error_double)
 
 
 def test_linspace_and_time_grids_bitwise_vs_torch_and_golden(golden):
@@ -136,6 +137,18 @@ def test_callbacks(golden):
                 steps_seen = [s for s, _ in seen]
                 assert steps_seen == (list(range(0, 10)) if method == "multistep" else list(range(0, 4)))   # orders [3,3,2] + denoise
                 assert seen[-1][1] == (1,)          # denoise_to_zero hands a (1,)-shaped t (ref :1236)
+
+
+@pytest.mark.parametrize("name,sname,order,algo", [("a12", "vp_linear", 2, "dpmsolver"), ("a23", "vp_linear", 3, "dpmsolver"),
+                                                   ("a23pp", "sd", 3, "dpmsolver++")])
+def test_adaptive_control_loop_against_reference_goldens(golden, capsys, name, sname, order, algo):
+    """DPM-Solver-12 / -23 (ref :956-1010): same accept / reject sequence (NFE) and result as the reference"""
+    ns = make_schedule(sname)
+    dpm = D.DPM_Solver(D.model_wrapper(lambda xx, t: C.model_half(xx, t), ns), ns, algorithm_type=algo)
+    g = lambda k: golden.get("adaptive", "adaptive/%s/%s" % (name, k))
+    xf = dpm.sample(tt(g("x"), "cpu"), method="adaptive", order=order, t_end=1e-3)
+    assert capsys.readouterr().out.strip() == "adaptive solver nfe %d" % int(g("nfe"))
+    assert rel_err(xf.numpy(), g("final")) < 5e-5
 
 
 def test_maskblend_against_reference_callback_goldens(golden):
