@@ -123,6 +123,17 @@ def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=No
     return x_out, m_out
 
 
+def _add_noise(sched_handle, x, noise, t_host):
+    """out[j] = alpha(t_j) * x + sigma(t_j) * noise[j] for the host times t_host (fp32 numpy): one kernel per time"""
+    nt = int(t_host.shape[0])
+    out = torch.empty((nt, *x.shape), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib.dpm_add_noise_launch(sched_handle, t_host.ctypes.data_as(C.POINTER(C.c_float)), nt, _ptr(x),
+                                           _ptr(noise), _ptr(out), x.numel(), _DT[x.dtype],
+                                           C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+    return out
+
+
 def _adaptive_error(x_lower, x_higher, x_prev, atol, rtol):
     """max over the batch of the adaptive solver's per-sample error norm (ref :999-1001) as a 0-dim device tensor:
     one kernel (per-sample RMS + atomic max), no host synchronisation here."""
@@ -550,15 +561,9 @@ class DPM_Solver:
         nt = int(th.shape[0])
         if noise is None:
             noise = torch.randn((nt, *x.shape), device=x.device)
-        xd = x.contiguous()
-        if xd.dtype not in _DT:
-            raise NotImplementedError("add_noise: dtype %s" % xd.dtype)
-        nz = noise.to(xd.dtype).contiguous()
-        out = torch.empty((nt, *x.shape), dtype=xd.dtype, device=x.device)
-        with torch.cuda.device(x.device):
-            L.check(L.lib.dpm_add_noise_launch(self._h, th.ctypes.data_as(C.POINTER(C.c_float)), nt, _ptr(xd), _ptr(nz),
-                                               _ptr(out), xd.numel(), _DT[xd.dtype],
-                                               C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        if x.dtype not in _DT:
+            raise NotImplementedError("add_noise: dtype %s" % x.dtype)
+        out = _add_noise(self._h, x.contiguous(), noise.to(x.dtype).contiguous(), th)
         return out.squeeze(0) if nt == 1 else out
 
     def inverse(self, x, steps=20, t_start=None, t_end=None, order=2, skip_type='time_uniform',

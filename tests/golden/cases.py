@@ -204,3 +204,34 @@ def cond_for(case):
     """(condition, unconditional_condition) per-sample scalars for guided cases."""
     b = case["shape"][0]
     return np.ones((b,), dtype=F32), np.zeros((b,), dtype=F32)
+
+
+# --------------------------------------------------------------------------------------
+# Stable-Diffusion adapter (examples/stable-diffusion/ldm/models/diffusion/dpm_solver/sampler.py):
+# a stand-in for the latent-diffusion model object.  The adapter touches only `alphas_cumprod`,
+# `betas.device`, `device` and `apply_model(x, t, c)`.
+# --------------------------------------------------------------------------------------
+SAMPLER_SHAPE = (2, 4, 8, 8)
+
+
+def sampler_inputs():
+    rng = np.random.default_rng(21)
+    sh = SAMPLER_SHAPE
+    return dict(x_T=rng.standard_normal(sh).astype(F32), x0=rng.standard_normal(sh).astype(F32),
+                noise=rng.standard_normal(sh).astype(F32), mask=rng.random(sh[2:]).astype(F32),
+                cond=np.array([1.0, 2.0], dtype=F32), uncond=np.zeros(2, dtype=F32))
+
+
+class FakeLatentDiffusion:
+    """`lib` = torch; tensors live on `device`"""
+
+    def __init__(self, torch, device):
+        si = schedule_inputs("sd")
+        self.alphas_cumprod = torch.from_numpy(si["alphas_cumprod"]).to(device)
+        self.betas = torch.zeros(1, device=device)
+        self.device = torch.device(device)
+        self.calls = []
+
+    def apply_model(self, x, t, c):
+        self.calls.append((tuple(x.shape), float(t.reshape(-1)[0])))
+        return x * _bshape(c * F32(0.1).item() + 0.5, x)

@@ -278,10 +278,58 @@ def gen_adaptive(out):
         print("  adaptive %-6s nfe=%d" % (name, nfe))
 
 
+def gen_sampler(out):
+    """The reference's Stable-Diffusion adapter (DPMSolverSampler) driven by a stand-in model on CPU: txt2img-style
+    sampling, stochastic / deterministic encoding and both DiffEdit variants of scripts/diffedit_inpaint.ipynb
+    (cell 6).  The class is imported unmodified; only its `register_buffer` -- which insists on a CUDA device --
+    is replaced at run time so that the goldens can be produced in this CPU-only container."""
+    sd_dir = os.path.join(REF_DIR, "examples", "stable-diffusion", "ldm", "models", "diffusion")
+    sys.path.insert(0, sd_dir)
+    import dpm_solver.sampler as RS  # the reference package ldm/models/diffusion/dpm_solver
+    RS.DPMSolverSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)
+    inp = C.sampler_inputs()
+    model = C.FakeLatentDiffusion(torch, "cpu")
+    smp = RS.DPMSolverSampler(model)
+    x_T, x0, noise, mask = tt(inp["x_T"]), tt(inp["x0"]), tt(inp["noise"]), tt(inp["mask"])
+    cond, uncond = tt(inp["cond"]), tt(inp["uncond"])
+    B = x_T.shape[0]
+    x, inter = smp.sample(10, B, x_T.shape[1:], conditioning=cond, unconditional_guidance_scale=7.5,
+                          unconditional_conditioning=uncond, x_T=x_T, verbose=False)
+    out["sampler/sample/final"] = x.numpy()
+    out["sampler/sample/intermediates"] = np.stack([v.numpy() for v in inter])
+    out["sampler/sample/calls_t"] = np.array([t for _, t in model.calls], dtype=np.float64)
+    out["sampler/stochastic_encode"] = smp.stochastic_encode(x0, 0.6, noise=noise.unsqueeze(0)).numpy()
+    enc, einter = smp.encode(10, x0, 0.6, conditioning=cond, unconditional_guidance_scale=7.5,
+                             unconditional_conditioning=uncond)
+    out["sampler/encode/final"] = enc.numpy()
+    out["sampler/encode/intermediates"] = np.stack([v.numpy() for v in einter])
+    tv = torch.tensor([0.001, 0.25, 0.6004, 1.0])
+    out["sampler/times"] = np.stack([smp.time_discrete_to_continuous(tv * 999).numpy(),
+                                     smp.time_continuous_to_discrete(tv).numpy(), smp.ratio_to_time(tv).numpy(),
+                                     smp.time_to_ratio(tv).numpy()])
+    # DiffEdit, deterministic: reversed encode() intermediates are blended back in at every step
+    rev = list(reversed(einter))
+    det = lambda xt, t, step: xt * mask + (1 - mask) * rev[step]
+    x, _ = smp.sample(10, B, x_T.shape[1:], conditioning=cond * 0.5, unconditional_guidance_scale=7.5,
+                      unconditional_conditioning=uncond, lower_order_final=False, t_start=smp.ratio_to_time(0.6),
+                      x_T=enc, correcting_xt_fn=det)
+    out["sampler/diffedit_det"] = x.numpy()
+    # DiffEdit, stochastic (noise fixed so that the golden does not depend on a random stream)
+    noised = smp.stochastic_encode(x0, 0.6, noise=noise.unsqueeze(0))
+
+    def sto(xt, t, step):
+        return xt * mask + (1 - mask) * smp.stochastic_encode(x0, smp.time_to_ratio(t), noise=noise.unsqueeze(0))
+    x, _ = smp.sample(10, B, x_T.shape[1:], conditioning=cond * 0.5, unconditional_guidance_scale=7.5,
+                      unconditional_conditioning=uncond, lower_order_final=False, t_start=smp.ratio_to_time(0.6),
+                      x_T=noised, correcting_xt_fn=sto)
+    out["sampler/diffedit_sto"] = x.numpy()
+    print("  sampler: %d network calls" % len(model.calls))
+
+
 def main():
     groups = dict(schedules=gen_schedules, timesteps=gen_timesteps, updates=gen_updates,
                   quantile=gen_quantile, add_noise=gen_add_noise, e2e=gen_e2e,
-                  callbacks=gen_callbacks, adaptive=gen_adaptive)
+                  callbacks=gen_callbacks, adaptive=gen_adaptive, sampler=gen_sampler)
     only = sys.argv[1:]
     for gname, fn in groups.items():
         if only and gname not in only:

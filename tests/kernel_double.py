@@ -118,3 +118,21 @@ def adaptive_error_double(x_lower, x_higher, x_prev, atol, rtol):
     sq = (v * v).astype(F32).reshape(v.shape[0], -1).astype(np.float64)
     e = np.sqrt((sq.sum(axis=1) / sq.shape[1]).astype(F32)).astype(F32)
     return torch.tensor(float(e.max()), dtype=torch.float32)
+
+
+def add_noise_double(sched_handle, x, noise, t_host):
+    """numpy double of dpm_add_noise_launch (ref :1012-1030): alpha*x + sigma*noise, fp32, no fused multiply-add"""
+    import ctypes as C
+    ev = lambda what: np.array([_eval1(sched_handle, what, t) for t in t_host], dtype=F32)
+    a, s = ev(L.EVAL_ALPHA), ev(L.EVAL_STD)
+    xn, nz = _np(x), _np(noise)
+    out = np.stack([(a[j] * xn).astype(F32) + (s[j] * nz[j]).astype(F32) for j in range(len(t_host))]).astype(F32)
+    return torch.from_numpy(out).to(x.dtype)
+
+
+def _eval1(h, what, t):
+    import ctypes as C
+    i = np.array([t], dtype=F32)
+    o = np.empty(1, dtype=F32)
+    L.check(L.lib.dpm_schedule_eval(h, what, i.ctypes.data_as(C.POINTER(C.c_float)), 1, o.ctypes.data_as(C.POINTER(C.c_float))))
+    return o[0]

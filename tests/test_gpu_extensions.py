@@ -353,3 +353,10 @@ def test_native_loop_with_cfg_callback_and_duplicated_state():
     torch.cuda.synchronize()
     assert calls == list(range(len(plan.stages)))
     assert torch.equal(xb[res.value][:B], want)
+
+
+def test_stable_diffusion_adapter_against_reference_goldens(golden):
+    """DPMSolverSampler (sampler.py) on the HIP path vs goldens produced by the reference's class: txt2img-style
+    sampling, stochastic / deterministic encoding, both DiffEdit variants (closures and fused MaskBlend objects)"""
+    import test_host_logic as TH
+    TH.sampler_checks(golden, DEV, TOL)

@@ -18,7 +18,7 @@ import dpm_solver_amd.wrapper as W
 from conftest import rel_err
 from dpm_solver_amd import _lib as L
 from engine_cases import build_solver, make_schedule, run_case, sample_kwargs, tt
-from kernel_double import adaptive_error_double, launch_stage_double, maskblend_apply_double
+from kernel_double import add_noise_double, adaptive_error_double, launch_stage_double, maskblend_apply_double
 from oracle import dpm_oracle as O
 
 F32 = np.float32
@@ -31,6 +31,7 @@ def cpu_double(monkeypatch):
     monkeypatch.setattr(S, "_require_gpu", lambda x: None)
     monkeypatch.setattr(D.MaskBlend, "apply", maskblend_apply_double)
     monkeypatch.setattr(S, "_adaptive_error", adaptive_error_double)
+    monkeypatch.setattr(S, "_add_noise", add_noise_double)
 
 
 def test_linspace_and_time_grids_bitwise_vs_torch_and_golden(golden):
@@ -328,3 +329,57 @@ def test_no_cpu_fallback(monkeypatch):
     dpm = D.DPM_Solver(D.model_wrapper(lambda x, t: x, ns), ns)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         dpm.sample(torch.zeros(2, 4, 8, 8), steps=5)
+
+
+# ------------------------------------------------------------------------------------------------
+# the Stable-Diffusion adapter (sampler.py) against goldens produced by the reference's DPMSolverSampler
+# ------------------------------------------------------------------------------------------------
+def sampler_checks(golden, device, tol):
+    from dpm_solver_amd.adapters import DPMSolverSampler
+    g = lambda k: golden.get("sampler", "sampler/" + k)
+    inp = C.sampler_inputs()
+    model = C.FakeLatentDiffusion(torch, device)
+    smp = DPMSolverSampler(model)
+    T = lambda k: tt(inp[k], device)
+    x_T, x0, noise, mask, cond, uncond = T("x_T"), T("x0"), T("noise"), T("mask"), T("cond"), T("uncond")
+    B = x_T.shape[0]
+    x, inter = smp.sample(10, B, x_T.shape[1:], conditioning=cond, unconditional_guidance_scale=7.5,
+                          unconditional_conditioning=uncond, x_T=x_T, verbose=False)
+    assert rel_err(x.cpu().numpy(), g("sample/final")) < tol
+    ri = g("sample/intermediates")
+    assert len(inter) == ri.shape[0] and all(rel_err(v.cpu().numpy(), ri[i]) < tol for i, v in enumerate(inter))
+    np.testing.assert_allclose(np.array([t for _, t in model.calls]), g("sample/calls_t"), rtol=1e-6)
+    assert all(s == (2 * B,) + tuple(x_T.shape[1:]) for s, _ in model.calls)       # one batched CFG call per step
+    assert rel_err(smp.stochastic_encode(x0, 0.6, noise=noise.unsqueeze(0)).cpu().numpy(), g("stochastic_encode")) < tol
+    enc, einter = smp.encode(10, x0, 0.6, conditioning=cond, unconditional_guidance_scale=7.5, unconditional_conditioning=uncond)
+    assert rel_err(enc.cpu().numpy(), g("encode/final")) < tol
+    ri = g("encode/intermediates")
+    assert len(einter) == ri.shape[0] and all(rel_err(v.cpu().numpy(), ri[i]) < tol for i, v in enumerate(einter))
+    tv = torch.tensor([0.001, 0.25, 0.6004, 1.0])
+    got = np.stack([smp.time_discrete_to_continuous(tv * 999).numpy(), smp.time_continuous_to_discrete(tv).numpy(),
+                    smp.ratio_to_time(tv).numpy(), smp.time_to_ratio(tv).numpy()])
+    np.testing.assert_allclose(got, g("times"), rtol=1e-6)
+    # DiffEdit (diffedit_inpaint.ipynb cell 6), both as the notebook's closures and as fused MaskBlend objects
+    N = smp.noise_schedule.total_N
+    rev = list(reversed(einter))
+    noised = smp.stochastic_encode(x0, 0.6, noise=noise.unsqueeze(0))
+    f32 = np.float32
+
+    def remap(t):      # ratio_to_time(time_to_ratio(t)) in the reference's fp32 tensor arithmetic
+        r = (f32(t) - f32(1. / N)) / f32(1. - N)
+        return float(f32(f32(1. - 1. / N) * r) + f32(1. / N))
+
+    det_c = lambda xt, t, step: xt * mask + (1 - mask) * rev[step]
+    sto_c = lambda xt, t, step: xt * mask + (1 - mask) * smp.stochastic_encode(x0, smp.time_to_ratio(t), noise=noise.unsqueeze(0))
+    det_f = D.MaskBlend(smp.noise_schedule, mask, intermediates=rev)
+    sto_f = D.MaskBlend(smp.noise_schedule, mask, x0=x0, noise=noise, time_fn=remap)
+    for key, start, fns in [("diffedit_det", enc, (det_c, det_f)), ("diffedit_sto", noised, (sto_c, sto_f))]:
+        for fn in fns:
+            x, _ = smp.sample(10, B, x_T.shape[1:], conditioning=cond * 0.5, unconditional_guidance_scale=7.5,
+                              unconditional_conditioning=uncond, lower_order_final=False, t_start=smp.ratio_to_time(0.6),
+                              x_T=start, correcting_xt_fn=fn)
+            assert rel_err(x.cpu().numpy(), g(key)) < tol, (key, type(fn).__name__)
+
+
+def test_stable_diffusion_adapter_against_reference_goldens(golden):
+    sampler_checks(golden, "cpu", TOL)
