@@ -93,6 +93,7 @@ _SIGNATURES = [
     ("dpm_schedule_create_alphas_cumprod_f64", C.c_int, [_P(C.c_double), C.c_int, C.c_int, _P(C.c_void_p)]),
     ("dpm_schedule_create_log_alpha", C.c_int, [_P(C.c_float), C.c_int, _P(C.c_void_p)]),
     ("dpm_schedule_create_linear", C.c_int, [C.c_double, C.c_double, _P(C.c_void_p)]),
+    ("dpm_schedule_create_cosine", C.c_int, [_P(C.c_void_p)]),
     ("dpm_schedule_destroy", None, [C.c_void_p]),
     ("dpm_schedule_is_discrete", C.c_int, [C.c_void_p]),
     ("dpm_schedule_total_N", C.c_int, [C.c_void_p]),

@@ -55,6 +55,8 @@ inline float f_log(float x) { return (float)std::log((double)x); }
 inline float f_expm1(float x) { return (float)std::expm1((double)x); }
 inline float f_log1p(float x) { return (float)std::log1p((double)x); }
 inline float f_sqrt(float x) { return std::sqrt(x); }
+inline float f_cos(float x) { return (float)std::cos((double)x); }
+inline float f_acos(float x) { return (float)std::acos((double)x); }
 // torch.logaddexp
 inline float f_logaddexp(float a, float b) {
   float m = a > b ? a : b;
@@ -94,9 +96,17 @@ struct dpm_schedule {
   std::vector<float> la, t;        // log_alpha_array, t_array (ref :105,:107)
   std::vector<float> la_rev, t_rev;  // flipped copies for inverse_lambda (ref :166)
   double beta0 = 0.1, beta1 = 20.0;
+  // 'cosine' continuous-time schedule of the older vendored revision (examples/score_sde_pytorch/dpm_solver.py
+  // :114-124, :134-137, :171-175); `legacy :N` below = line N of that file
+  bool cosine = false;
+  double cos_s = 0.008, cos_la0 = 0.;
 
   float log_alpha(float tt) const {  // marginal_log_mean_coeff, ref :127-134
     if (discrete) return interp32(tt, t.data(), la.data(), total_N);
+    if (cosine) {  // legacy :135-137, one fp32 rounding per tensor-scalar operation
+      const float a = (((tt + (float)cos_s) / (float)(1. + cos_s)) * (float)M_PI) / 2.f;
+      return f_log(f_cos(a)) - (float)cos_la0;
+    }
     return -0.25f * (tt * tt) * (float)(beta1 - beta0) - 0.5f * tt * (float)beta0;
   }
   float alpha(float tt) const { return f_exp(log_alpha(tt)); }                                  // ref :140
@@ -106,6 +116,11 @@ struct dpm_schedule {
     return l - 0.5f * f_log(1.f - f_exp(2.f * l));
   }
   float inv_lambda(float lam) const {  // ref :156-167
+    if (cosine) {  // legacy :171-175
+      const float l = -0.5f * f_logaddexp(-2.f * lam, 0.f);
+      const float ac = f_acos(f_exp(l + (float)cos_la0));
+      return (((ac * 2.f) * (float)(1. + cos_s)) / (float)M_PI) - (float)cos_s;
+    }
     if (!discrete) {
       float tmp = (float)(2. * (beta1 - beta0)) * f_logaddexp(-2.f * lam, 0.f);
       float delta = (float)(beta0 * beta0) + tmp;
@@ -206,6 +221,19 @@ extern "C" int dpm_schedule_create_linear(double beta_0, double beta_1, dpm_sche
   s->total_N = 1000;  // ref :110
   s->beta0 = beta_0;
   s->beta1 = beta_1;
+  *out = s;
+  return DPM_OK;
+}
+
+extern "C" int dpm_schedule_create_cosine(dpm_schedule** out) {
+  if (!out) return dpm_set_error(DPM_ERR_ARG, "null out");
+  dpm_schedule* s = new (std::nothrow) dpm_schedule;
+  if (!s) return dpm_set_error(DPM_ERR_NOMEM, "out of memory");
+  s->discrete = false;
+  s->cosine = true;
+  s->total_N = 1000;  // legacy :111
+  s->cos_s = 0.008;   // legacy :114
+  s->cos_la0 = std::log(std::cos(s->cos_s / (1. + s->cos_s) * M_PI / 2.));  // legacy :117 (Python float arithmetic)
   *out = s;
   return DPM_OK;
 }

@@ -14,14 +14,17 @@ from . import _lib as L
 
 
 class NoiseScheduleVP:
+    _SCHEDULES = ['discrete', 'linear']
+    _clip = True            # numerical_clip_alpha at lambda = -5.1 (ref :114-125)
+
     def __init__(self, schedule='discrete', betas=None, alphas_cumprod=None, continuous_beta_0=0.1,
                  continuous_beta_1=20., dtype=torch.float32):
-        if schedule not in ['discrete', 'linear']:
-            raise ValueError("Unsupported noise schedule {}. The schedule needs to be 'discrete' or 'linear'".format(schedule))
+        if schedule not in self._SCHEDULES:
+            raise ValueError("Unsupported noise schedule {}. The schedule needs to be {}".format(
+                schedule, " or ".join("'%s'" % v for v in self._SCHEDULES)))
         self.schedule = schedule
         self.T = 1.
         self._h = C.c_void_p()
-        self._clip = getattr(self, "_clip", True)
         if schedule == 'discrete':
             src = betas if betas is not None else alphas_cumprod
             assert src is not None
@@ -39,6 +42,14 @@ class NoiseScheduleVP:
             self.total_N = K.value
             self.log_alpha_array = torch.from_numpy(np.ctypeslib.as_array(la, (K.value,)).copy()).reshape((1, -1)).to(dtype=dtype)
             self.t_array = torch.from_numpy(np.ctypeslib.as_array(ta, (K.value,)).copy()).reshape((1, -1)).to(dtype=dtype)
+        elif schedule == 'cosine':
+            # older vendored revision only (LegacyNoiseScheduleVP): T = 1 has numerical issues, so T = 0.9946
+            self.total_N = 1000
+            self.beta_0 = continuous_beta_0
+            self.beta_1 = continuous_beta_1
+            self.cosine_s = 0.008
+            self.T = 0.9946
+            L.check(L.lib.dpm_schedule_create_cosine(C.byref(self._h)))
         else:
             self.total_N = 1000
             self.beta_0 = continuous_beta_0
@@ -95,3 +106,12 @@ class NoiseScheduleVP:
         if self.schedule != 'discrete':
             out = out.reshape(lamb.shape)
         return out.to(device=lamb.device)
+
+
+class LegacyNoiseScheduleVP(NoiseScheduleVP):
+    """NoiseScheduleVP of the older revision the reference still vendors for the ScoreSDE example
+    (examples/score_sde_pytorch/dpm_solver.py:6-176): it additionally offers the continuous-time 'cosine' schedule
+    (:114-124, T = 0.9946) and does NOT clip discrete schedules (total_N = len(log_alphas), :106).  The solver classes
+    of the two revisions are otherwise identical, so `DPM_Solver` serves both."""
+    _SCHEDULES = ['discrete', 'linear', 'cosine']
+    _clip = False

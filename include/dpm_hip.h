@@ -146,6 +146,9 @@ int dpm_schedule_create_alphas_cumprod_f32(const float* ac, int n, int clip, dpm
 int dpm_schedule_create_alphas_cumprod_f64(const double* ac, int n, int clip, dpm_schedule** out);
 int dpm_schedule_create_log_alpha(const float* log_alpha, int n, dpm_schedule** out);                  /* ready table */
 int dpm_schedule_create_linear(double beta_0, double beta_1, dpm_schedule** out);                      /* ref :109-112 */
+/* the continuous-time 'cosine' schedule of the older vendored revision (examples/score_sde_pytorch/dpm_solver.py
+   :114-124,:134-137,:171-175): s = 0.008, T = 0.9946 (the caller's default end time) */
+int dpm_schedule_create_cosine(dpm_schedule** out);
 void dpm_schedule_destroy(dpm_schedule* s);
 int dpm_schedule_is_discrete(const dpm_schedule* s);
 int dpm_schedule_total_N(const dpm_schedule* s);                                                       /* ref :106,:110 */

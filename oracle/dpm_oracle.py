@@ -52,6 +52,14 @@ def log1p_32(v):
     return np.log1p(_f(v).astype(F64)).astype(F32)
 
 
+def cos32(v):
+    return np.cos(_f(v).astype(F64)).astype(F32)
+
+
+def arccos32(v):
+    return np.arccos(_f(v).astype(F64)).astype(F32)
+
+
 def sqrt32(v):
     return np.sqrt(_f(v))  # IEEE sqrt is correctly rounded in fp32 already
 
@@ -108,25 +116,34 @@ class Schedule:
         else:
             self.total_N = 1000                                              # ref:110
             self.beta_0, self.beta_1 = beta_0, beta_1
+            if kind == "cosine":
+                # older vendored revision (examples/score_sde_pytorch/dpm_solver.py:114-124 = "legacy:N" below)
+                self.cosine_s = 0.008
+                self.cosine_log_alpha_0 = math.log(math.cos(self.cosine_s / (1. + self.cosine_s) * math.pi / 2.))
+                self.T = 0.9946
 
     # ---- constructors ---------------------------------------------------------------
     @staticmethod
-    def from_betas(betas):
+    def from_betas(betas, clip=True):
         """ref:100  log_alphas = 0.5 * log(1 - betas).cumsum(0); torch's CPU cumsum accumulates
-        fp32 inputs in double and rounds each prefix to fp32."""
+        fp32 inputs in double and rounds each prefix to fp32.  clip=False: the older vendored revision (legacy:106)."""
         b = np.asarray(betas)
         if b.dtype == np.float64:
             la = 0.5 * np.cumsum(np.log(1.0 - b))
         else:
             l = log32(F32(1.0) - b.astype(F32))
             la = F32(0.5) * np.cumsum(l.astype(F64)).astype(F32)
-        return Schedule("discrete", Schedule._clip(la).astype(F32))
+        return Schedule("discrete", (Schedule._clip(la) if clip else la).astype(F32))
 
     @staticmethod
-    def from_alphas_cumprod(ac):
+    def from_alphas_cumprod(ac, clip=True):
         a = np.asarray(ac)                                                   # ref:103
         la = 0.5 * np.log(a) if a.dtype == np.float64 else F32(0.5) * log32(a.astype(F32))
-        return Schedule("discrete", Schedule._clip(la).astype(F32))
+        return Schedule("discrete", (Schedule._clip(la) if clip else la).astype(F32))
+
+    @staticmethod
+    def cosine():
+        return Schedule("cosine")
 
     @staticmethod
     def linear(beta_0=0.1, beta_1=20.0):
@@ -151,6 +168,9 @@ class Schedule:
         t = _f(t)
         if self.kind == "discrete":
             return interp32(t.reshape(-1), self.t_arr, self.log_alpha)
+        if self.kind == "cosine":                                            # legacy:135-137
+            a = (((t + F32(self.cosine_s)) / F32(1. + self.cosine_s)) * F32(math.pi)) / F32(2.0)
+            return (log32(cos32(a)) - F32(self.cosine_log_alpha_0)).astype(F32)
         b0, b1 = self.beta_0, self.beta_1
         return (F32(-0.25) * (t * t) * F32(b1 - b0) - F32(0.5) * t * F32(b0)).astype(F32)
 
@@ -172,6 +192,10 @@ class Schedule:
             tmp = F32(2.0 * (b1 - b0)) * logaddexp32(F32(-2.0) * lam, F32(0.0))
             delta = F32(b0 ** 2) + tmp
             return (tmp / (sqrt32(delta) + F32(b0)) / F32(b1 - b0)).astype(F32)
+        if self.kind == "cosine":                                            # legacy:171-175
+            la = F32(-0.5) * logaddexp32(F32(-2.0) * lam, F32(0.0))
+            ac = arccos32(exp32(la + F32(self.cosine_log_alpha_0)))
+            return ((((ac * F32(2.0)) * F32(1. + self.cosine_s)) / F32(math.pi)) - F32(self.cosine_s)).astype(F32)
         la = F32(-0.5) * logaddexp32(F32(0.0), F32(-2.0) * lam)
         return interp32(la.reshape(-1), self.log_alpha[::-1].copy(), self.t_arr[::-1].copy())
 

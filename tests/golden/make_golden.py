@@ -326,8 +326,47 @@ def gen_sampler(out):
     print("  sampler: %d network calls" % len(model.calls))
 
 
+def gen_legacy(out):
+    """The older revision the reference vendors for the ScoreSDE example (examples/score_sde_pytorch/dpm_solver.py),
+    imported unmodified: its continuous-time 'cosine' schedule (T = 0.9946) and its unclipped discrete schedules."""
+    import importlib.util
+    path = os.path.join(REF_DIR, "examples", "score_sde_pytorch", "dpm_solver.py")
+    spec = importlib.util.spec_from_file_location("dpm_solver_legacy", path)
+    LG = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(LG)
+    rng = np.random.default_rng(17)
+    ns = LG.NoiseScheduleVP("cosine")
+    out["legacy/cosine/T"] = np.float64(ns.T)
+    t = np.concatenate([rng.uniform(1e-4, ns.T, size=64).astype(np.float32), np.array([1e-3, 0.5, ns.T], dtype=np.float32)])
+    out["legacy/cosine/t"] = t
+    tt_ = tt(t)
+    out["legacy/cosine/log_alpha"] = ns.marginal_log_mean_coeff(tt_).numpy()
+    out["legacy/cosine/alpha"] = ns.marginal_alpha(tt_).numpy()
+    out["legacy/cosine/std"] = ns.marginal_std(tt_).numpy()
+    lam = ns.marginal_lambda(tt_)
+    out["legacy/cosine/lambda"] = lam.numpy()
+    out["legacy/cosine/inv_lambda"] = ns.inverse_lambda(lam).numpy()
+    x = rng.standard_normal((2, 3, 8, 8)).astype(np.float32)
+    out["legacy/x"] = x
+    for tag, kw in [("ms2", dict(steps=10, order=2, method="multistep")),
+                    ("ss3_logsnr", dict(steps=9, order=3, method="singlestep", skip_type="logSNR")),
+                    ("ms3_noise", dict(steps=8, order=3, method="multistep"))]:
+        algo = "dpmsolver" if tag == "ms3_noise" else "dpmsolver++"
+        fn = LG.model_wrapper(lambda xx, t: C.model_tdep(xx, t), ns)
+        xf = LG.DPM_Solver(fn, ns, algorithm_type=algo).sample(tt(x), t_end=1e-3, **kw)
+        out["legacy/cosine/%s" % tag] = xf.numpy()
+    # unclipped discrete schedule: cosine-4000 betas keep all 4000 entries (the root file clips to 3984)
+    si = C.schedule_inputs("cosine4000")
+    nd = LG.NoiseScheduleVP("discrete", betas=tt(si["betas"]))
+    out["legacy/noclip/total_N"] = np.int64(nd.total_N)
+    out["legacy/noclip/log_alpha_tail"] = nd.log_alpha_array.numpy()[0, -32:]
+    fn = LG.model_wrapper(lambda xx, t: C.model_tdep(xx, t), nd)
+    out["legacy/noclip/ms2"] = LG.DPM_Solver(fn, nd).sample(tt(x), steps=10, order=2, t_start=0.9).numpy()
+    print("  legacy: cosine T=%.4f, noclip total_N=%d" % (ns.T, nd.total_N))
+
+
 def main():
-    groups = dict(schedules=gen_schedules, timesteps=gen_timesteps, updates=gen_updates,
+    groups = dict(legacy=gen_legacy, schedules=gen_schedules, timesteps=gen_timesteps, updates=gen_updates,
                   quantile=gen_quantile, add_noise=gen_add_noise, e2e=gen_e2e,
                   callbacks=gen_callbacks, adaptive=gen_adaptive, sampler=gen_sampler)
     only = sys.argv[1:]

@@ -360,3 +360,9 @@ def test_stable_diffusion_adapter_against_reference_goldens(golden):
     sampling, stochastic / deterministic encoding, both DiffEdit variants (closures and fused MaskBlend objects)"""
     import test_host_logic as TH
     TH.sampler_checks(golden, DEV, TOL)
+
+
+def test_legacy_revision_cosine_schedule_and_unclipped_tables(golden):
+    """LegacyNoiseScheduleVP (the revision vendored under examples/score_sde_pytorch) on the HIP path"""
+    import test_host_logic as TH
+    TH.legacy_checks(golden, DEV)

@@ -383,3 +383,36 @@ def sampler_checks(golden, device, tol):
 
 def test_stable_diffusion_adapter_against_reference_goldens(golden):
     sampler_checks(golden, "cpu", TOL)
+
+
+# ------------------------------------------------------------------------------------------------
+# the older vendored revision (examples/score_sde_pytorch/dpm_solver.py): 'cosine' schedule, unclipped tables
+# ------------------------------------------------------------------------------------------------
+def legacy_checks(golden, device):
+    from test_oracle_golden import LEGACY_RUNS
+    g = lambda k: golden.get("legacy", "legacy/" + k)
+    with pytest.raises(ValueError, match="Unsupported noise schedule cosine"):
+        D.NoiseScheduleVP("cosine")                          # the root revision does not know it (ref :94-95)
+    ns = D.LegacyNoiseScheduleVP("cosine")
+    assert ns.T == float(g("cosine/T")) and ns.total_N == 1000
+    osch = O.Schedule.cosine()
+    t = g("cosine/t")
+    # planner == oracle bit for bit (both round the elementary functions correctly); oracle vs reference: test_oracle_golden
+    np.testing.assert_array_equal(ns.marginal_log_mean_coeff(torch.from_numpy(t)).numpy(), osch.log_alpha_t(t))
+    np.testing.assert_array_equal(ns.marginal_lambda(torch.from_numpy(t)).numpy(), osch.lam(t))
+    lam = g("cosine/lambda")
+    np.testing.assert_array_equal(ns.inverse_lambda(torch.from_numpy(lam)).numpy(), osch.inv_lam(lam))
+    x = tt(g("x"), device)
+    for tag, algo, kw in LEGACY_RUNS:
+        dpm = D.DPM_Solver(D.model_wrapper(lambda xx, tv: C.model_tdep(xx, tv), ns), ns, algorithm_type=algo)
+        assert rel_err(dpm.sample(x, t_end=1e-3, **kw).cpu().numpy(), g("cosine/" + tag)) < TOL, tag
+    nd = D.LegacyNoiseScheduleVP("discrete", betas=torch.from_numpy(C.schedule_inputs("cosine4000")["betas"]))
+    assert nd.total_N == int(g("noclip/total_N")) == 4000
+    assert make_schedule("cosine4000").total_N == 3984          # the root revision clips (ref :114-125)
+    np.testing.assert_allclose(nd.log_alpha_array.numpy()[0, -32:], g("noclip/log_alpha_tail"), rtol=2e-6)
+    dpm = D.DPM_Solver(D.model_wrapper(lambda xx, tv: C.model_tdep(xx, tv), nd), nd)
+    assert rel_err(dpm.sample(x, steps=10, order=2, t_start=0.9).cpu().numpy(), g("noclip/ms2")) < TOL
+
+
+def test_legacy_revision_cosine_schedule_and_unclipped_tables(golden):
+    legacy_checks(golden, "cpu")
