@@ -43,6 +43,21 @@ def _sample_strided(t):
         and t.stride(0) > t[0].numel()
 
 
+def _raw_stream(dev):
+    """hipStream_t of torch's current stream on `dev` as an int (what dpm_* entry points take as void*)"""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(idx), idx
+
+
+def _conv(t, dt):
+    """`t` as a contiguous tensor of dtype `dt` (no copy when it already is one)"""
+    if t is None:
+        return None
+    if t.dtype != dt:
+        t = t.to(dt)
+    return t if t.is_contiguous() else t.contiguous()
+
+
 def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=None):
     """One `dpm_stage_launch` on the current stream.  Allocates x_out (and m_out when the stage stores
     its model value) through torch's caching allocator; returns (x_out, m_out).
@@ -53,73 +68,74 @@ def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=No
     ref_t = x if x is not None else xe
     dev = ref_t.device
     sd = state_dtype
-
-    def S(t):  # state-typed, contiguous
-        if t is None:
-            return None
-        if t.dtype != sd:
-            t = t.to(sd)
-        return t if t.is_contiguous() else t.contiguous()
-
-    x, xe, h1, h2 = S(x), S(xe), S(h1), S(h2)
+    x, xe, h1, h2 = _conv(x, sd), _conv(xe, sd), _conv(h1, sd), _conv(h2, sd)
     ed = e0.dtype
     if ed not in _DT or (sd != torch.float32 and ed != sd):
         ed = sd  # only (fp32 state, any eps) and equal low-precision pairs have kernels
-
-    def E(t):
-        if t is None:
-            return None
-        if t.dtype != ed:
-            t = t.to(ed)
-        return t if t.is_contiguous() else t.contiguous()
-
     eps_stride = 0
-    if e0.dtype == ed and _sample_strided(e0) and tuple(e0.shape) == tuple(ref_t.shape) and (
+    if e0.dtype == ed and not e0.is_contiguous() and _sample_strided(e0) and e0.shape == ref_t.shape and (
             e1 is None or (e1.dtype == ed and _sample_strided(e1) and e1.stride(0) == e0.stride(0))):
         eps_stride = int(e0.stride(0))          # read the slice in place: no .contiguous() copy
-        g = E(g)
+        g = _conv(g, ed)
     else:
-        e0, e1, g = E(e0), E(e1), E(g)
-    if xe is not None and x is not None and xe.data_ptr() == x.data_ptr():
-        xe = None
+        e0, e1, g = _conv(e0, ed), _conv(e1, ed), _conv(g, ed)
     shape = ref_t.shape
+    B = int(shape[0]) if len(shape) > 0 else 1
+    b = L.Buffers()                               # zero-initialised
     x2 = None
     if ext is not None and ext.get("dup") and len(shape) > 0:
-        x2 = torch.empty((2 * shape[0],) + tuple(shape[1:]), dtype=sd, device=dev)
-        x_out = x2[:shape[0]]
+        x2 = torch.empty((2 * B,) + tuple(shape[1:]), dtype=sd, device=dev)
+        x_out = x2[:B]
         ext["x2"] = x2
+        b.x_out2 = x2.data_ptr() + x_out.numel() * x_out.element_size()
     else:
         x_out = torch.empty(shape, dtype=sd, device=dev)
     store = bool(st.flags & L.F_STORE_M) if want_m is None else want_m
-    m_out = torch.empty(shape, dtype=sd, device=dev) if store else None
+    m_out = None
     if store:
         st.flags |= L.F_STORE_M
+        m_out = torch.empty(shape, dtype=sd, device=dev)
+        b.m_out = m_out.data_ptr()
     else:
         st.flags &= ~L.F_STORE_M
-    b = L.Buffers()
-    b.x, b.xe, b.e0, b.e1, b.g = _ptr(x), _ptr(xe), _ptr(e0), _ptr(e1), _ptr(g)
-    b.h1, b.h2, b.x_out, b.m_out = _ptr(h1), _ptr(h2), _ptr(x_out), _ptr(m_out)
+    if x is not None:
+        b.x = x.data_ptr()
+    if xe is not None and (x is None or xe.data_ptr() != x.data_ptr()):
+        b.xe = xe.data_ptr()
+    b.e0 = e0.data_ptr()
+    if e1 is not None:
+        b.e1 = e1.data_ptr()
+    if g is not None:
+        b.g = g.data_ptr()
+    if h1 is not None:
+        b.h1 = h1.data_ptr()
+    if h2 is not None:
+        b.h2 = h2.data_ptr()
+    b.x_out = x_out.data_ptr()
+    b.n = ref_t.numel()
+    b.batch = max(B, 1)
+    b.state_dtype = _DT[sd]
+    b.eps_dtype = _DT[ed]
+    b.eps_stride = eps_stride
     ws = None
     if st.flags & L.F_THRESH:
-        nb = L.lib.dpm_threshold_workspace_bytes(max(int(shape[0]), 1), ref_t.numel() // max(int(shape[0]), 1))
+        nb = L.lib.dpm_threshold_workspace_bytes(b.batch, b.n // b.batch)
         if nb:
             ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-    b.workspace = _ptr(ws)
-    b.eps_stride = eps_stride
-    if x2 is not None:
-        b.x_out2 = _ptr(x2[shape[0]:])
+            b.workspace = ws.data_ptr()
     if ext is not None and ext.get("blend") is not None:
         mask, period, ba, bb, alpha, sigma = ext["blend"]
         st.flags |= L.F_BLEND
         st.blend_alpha, st.blend_sigma = alpha, sigma
-        b.mask, b.blend_a, b.blend_b, b.mask_period = _ptr(mask), _ptr(ba), _ptr(bb), period
-    b.n = ref_t.numel()
-    b.batch = max(int(shape[0]), 1) if len(shape) > 0 else 1
-    b.state_dtype = _DT[sd]
-    b.eps_dtype = _DT[ed]
-    with torch.cuda.device(dev):
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        L.check(L.lib.dpm_stage_launch(C.byref(st), C.byref(b), C.c_void_p(stream)))
+        b.mask, b.blend_a, b.mask_period = mask.data_ptr(), ba.data_ptr(), period
+        if bb is not None:
+            b.blend_b = bb.data_ptr()
+    stream, idx = _raw_stream(dev)
+    if idx == torch.cuda.current_device():
+        L.check(L.lib.dpm_stage_launch(C.byref(st), C.byref(b), stream))
+    else:
+        with torch.cuda.device(idx):
+            L.check(L.lib.dpm_stage_launch(C.byref(st), C.byref(b), stream))
     return x_out, m_out
 
 
@@ -163,6 +179,7 @@ class _Plan:
             L.check(L.lib.dpm_plan_stage(self.handle, i, C.byref(st)))
             self.stages.append(st)
         self._dev = {}
+        self._views = {}
 
     def times(self, device):
         """(t_eval, t_input, t_out) as fp32 device vectors, one host-to-device copy per plan and device."""
@@ -172,6 +189,21 @@ class _Plan:
                             [s.t_out for s in self.stages]], dtype=np.float32)
             self._dev[key] = torch.from_numpy(arr).to(device)
         return self._dev[key]
+
+    def time_views(self, device, batch, cfg):
+        """per stage: 0-dim t_eval / t_out, t_eval and t_input expanded to (batch,) and, under classifier-free
+        guidance, t_input expanded to (2*batch,) -- views of times(), built once per (device, batch)"""
+        key = (str(device), int(batch), bool(cfg))
+        hit = self._views.get(key)
+        if hit is None:
+            T = self.times(device)
+            n = len(self.stages)
+            hit = dict(t_eval=[T[0, i] for i in range(n)], t_out=[T[2, i] for i in range(n)],
+                       t_eval_b=[T[0, i].expand(batch) for i in range(n)],
+                       t_input_b=[T[1, i].expand(batch) for i in range(n)],
+                       t_input_2b=[T[1, i].expand(2 * batch) for i in range(n)] if cfg else None)
+            self._views[key] = hit
+        return hit
 
     def __del__(self):
         if getattr(self, "handle", None):
@@ -262,15 +294,20 @@ class DPM_Solver:
             return self._user_x0(x0)
         return self._user_x0(x0, t)
 
-    def _network(self, x_eval, t_eval_t, t_input_t, x_in2=None):
+    def _network(self, x_eval, t_eval_t, t_input_t, x_in2=None, pre=None):
         """the opaque call: raw output(s) of the network at (x_eval, t).  x_in2: [2B,...] buffer both halves of
-        which already hold x_eval (written by the previous stage kernel) -- the CFG network input."""
+        which already hold x_eval (written by the previous stage kernel) -- the CFG network input.  pre: the
+        time tensors already expanded to the batch (t_eval_b, t_input_b, t_input_2b)."""
         B = x_eval.shape[0]
+        if pre is not None:
+            te, ti, t2 = pre
+        else:
+            te, ti = t_eval_t.expand(B), t_input_t.expand(B)
+            t2 = t_input_t.expand(2 * B) if (self._wrapped is not None and
+                                             self._wrapped.effective_guidance == "classifier-free") else None
         if self._wrapped is not None:
-            w = self._wrapped
-            t2 = t_input_t.expand(2 * B) if w.effective_guidance == "classifier-free" else None
-            return w.raw_outputs(x_eval, t_eval_t.expand(B), t_input_t.expand(B), t2, x_in2=x_in2)
-        return self._model_fn(x_eval, t_eval_t.expand(B)), None, None
+            return self._wrapped.raw_outputs(x_eval, te, ti, t2, x_in2=x_in2)
+        return self._model_fn(x_eval, te), None, None
 
     def _prep_stage(self, st):
         """stage flags that depend on this solver's correctors"""
@@ -664,14 +701,14 @@ class DPM_Solver:
     def _run_plan(self, plan, x, method, cxt, keep, intermediates):
         device = x.device
         sd = self._sdtype(x)
-        T = plan.times(device)            # [3, n_stages]: t_eval, t_input, t_out
+        cfg = self._wrapped is not None and self._wrapped.effective_guidance == "classifier-free"
+        V = plan.time_views(device, x.shape[0] if x.dim() > 0 else 1, cfg)
         blend = cxt if isinstance(cxt, MaskBlend) else None      # folded into the stage kernels' epilogue
         if blend is not None:
             cxt = None
         # classifier-free guidance evaluates the network on cat([x] * 2) (ref :326): let the stage kernel that
         # produces x write both halves of that buffer instead (not possible when an opaque corrector edits x after it)
-        dup = (self._wrapped is not None and self._wrapped.effective_guidance == "classifier-free" and cxt is None
-               and x.dim() > 0)
+        dup = cfg and cxt is None and x.dim() > 0
         n_st = len(plan.stages)
         state, state2 = x, None
         tmp, tmp2 = None, None
@@ -680,11 +717,12 @@ class DPM_Solver:
             st = ps.copy()                # launches may edit flags
             from_tmp = st.xe_src == L.SRC_TMP
             xe = tmp if from_tmp else state
-            outs = self._network(xe, T[0, i], T[1, i], x_in2=tmp2 if from_tmp else state2)
+            outs = self._network(xe, None, None, x_in2=tmp2 if from_tmp else state2,
+                                 pre=(V["t_eval_b"][i], V["t_input_b"][i], V["t_input_2b"][i] if cfg else None))
             if i == 0 and method == 'multistep':
                 # ref :1179-1183: the model sees the caller's x_T; the corrector and the list see it afterwards
                 if cxt is not None:
-                    state = cxt(state, T[0, 0], 0)
+                    state = cxt(state, V["t_eval"][0], 0)
                 elif blend is not None:
                     state = blend.apply(state if state.dtype == sd else state.to(sd), ps.t_eval, 0)
                 if keep:
@@ -696,12 +734,12 @@ class DPM_Solver:
                 ext["dup"] = True
             if blend is not None and st.emits_state:
                 ext["blend"] = blend.operands(x.shape, sd, device, ps.t_out, st.outer_step)
-            x_out, m_out = self._run_stage(st, state, xe, outs, h1, h2, sd, T[0, i], ext=ext or None)
+            x_out, m_out = self._run_stage(st, state, xe, outs, h1, h2, sd, V["t_eval"][i], ext=ext or None)
             if st.m_slot >= 0:
                 hist[st.m_slot] = m_out
             if st.emits_state:
                 if cxt is not None:
-                    t_cb = T[2, i].reshape(1) if st.form == L.FORM_DENOISE else T[2, i]
+                    t_cb = V["t_out"][i].reshape(1) if st.form == L.FORM_DENOISE else V["t_out"][i]
                     x_out = cxt(x_out, t_cb, st.outer_step)
                 if keep:
                     intermediates.append(x_out)
