@@ -25,6 +25,7 @@
 #include <cstdint>
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 #include <new>
 
 #include "dpm_hip.h"
@@ -145,6 +146,65 @@ __device__ __forceinline__ void store_pack(bf16_t* __restrict__ p, int64_t group
   st16<NT>(reinterpret_cast<u32x4*>(p) + group, a);
 }
 
+// Tile-level access for the streaming kernel.  A tile is the 2048 elements of one workgroup iteration (256 lanes x 8).
+// `split` (4-byte state, tile complete): lane t takes elements [4t, 4t+4) and [1024+4t, 1024+4t+4) of the tile, so
+// each of the two global_load_dwordx4 of a wavefront covers 1 KiB of consecutive addresses; otherwise lane t takes the
+// 8 consecutive elements [8t, 8t+8) (one 16-byte access for 2-byte types, two adjacent ones for fp32).  The op is
+// elementwise, so any mapping that is the same for every tensor of the launch is correct.
+template <bool NT, typename T>
+__device__ __forceinline__ void load_tile(const T* __restrict__ p, int64_t gi, bool split, float (&out)[EPT]) {
+  if constexpr (sizeof(T) == 4) {
+    if (split) {
+      const u32x4* q = reinterpret_cast<const u32x4*>(p) + (gi + (gi & ~(int64_t)255));
+      const u32x4 a = ld16<NT>(q), b = ld16<NT>(q + 256);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        out[j] = __uint_as_float(a[j]);
+        out[4 + j] = __uint_as_float(b[j]);
+      }
+      return;
+    }
+  } else {
+    if (split) {  // 2-byte network output next to a 4-byte state: the same elements as two 8-byte accesses
+      typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+      const u32x2_t* q = reinterpret_cast<const u32x2_t*>(p) + (gi + (gi & ~(int64_t)255));
+      const u32x2_t a = NT ? __builtin_nontemporal_load(q) : *q;
+      const u32x2_t b = NT ? __builtin_nontemporal_load(q + 256) : *(q + 256);
+      const uint32_t w[4] = {a[0], a[1], b[0], b[1]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (std::is_same<T, __half>::value) {
+          out[2 * j] = __half2float(__ushort_as_half((unsigned short)(w[j] & 0xffffu)));
+          out[2 * j + 1] = __half2float(__ushort_as_half((unsigned short)(w[j] >> 16)));
+        } else {
+          out[2 * j] = __uint_as_float(w[j] << 16);
+          out[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+        }
+      }
+      return;
+    }
+  }
+  load_pack<NT>(p, gi, out);
+}
+template <bool NT, typename T>
+__device__ __forceinline__ void store_tile(T* __restrict__ p, int64_t gi, bool split, const float (&in)[EPT]) {
+  if constexpr (sizeof(T) == 4) {
+    if (split) {
+      u32x4 a, b;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a[j] = __float_as_uint(in[j]);
+        b[j] = __float_as_uint(in[4 + j]);
+      }
+      u32x4* q = reinterpret_cast<u32x4*>(p) + (gi + (gi & ~(int64_t)255));
+      st16<NT>(q, a);
+      st16<NT>(q + 256, b);
+      return;
+    }
+  }
+  store_pack<NT>(p, gi, in);
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-stage scalars (kernel argument => SGPRs)
 // ------------------------------------------------------------------------------------------------
@@ -154,7 +214,19 @@ struct KParams {
   float k0, k1, k2, k3, k4;
   uint32_t flags;
   int32_t model_type;
+  float inv_alpha;  // RN(1 / alpha_e), used by the specialised prologue (see div_by_alpha)
 };
+
+// x / alpha_e for a wave-uniform divisor whose correctly rounded reciprocal r = RN(1/alpha) is known: q = RN(x*r),
+// then one exact-residual correction q' = RN(q + RN(x - q*alpha) * r) (both fused: the residual is exact).  This is
+// the correctly rounded quotient -- bit-identical to IEEE division, which the reference uses -- for every finite
+// x whose quotient is a normal number, provided alpha's significand is not all ones (Markstein's theorem; the launch
+// falls back to the generic prologue with a true division when that guard fails).  3 VALU ops instead of ~12.
+__device__ __forceinline__ float div_by_alpha(float x, const KParams& p) {
+  const float q = x * p.inv_alpha;
+  const float e = __builtin_fmaf(-q, p.alpha_e, x);
+  return __builtin_fmaf(e, p.inv_alpha, q);
+}
 
 // Compile-time knowledge about the prologue.  SPEC_GENERIC reads model_type / TO_X0 from the stage record at
 // run time (wave-uniform scalar branches); the two hot specialisations fix them so the inner loop is
@@ -196,7 +268,8 @@ __device__ __forceinline__ float prologue(float xe, float o0, float o1, float gg
   } else {
     eps = to_noise<SPEC>(o0, xe, p);
   }
-  if (spec_to_x0<SPEC>(p)) return (xe - p.sigma_e * eps) / p.alpha_e;  // ref :439
+  if (SPEC == SPEC_NOISE_X0) return div_by_alpha(xe - p.sigma_e * eps, p);  // ref :439, division by invariant
+  if (spec_to_x0<SPEC>(p)) return (xe - p.sigma_e * eps) / p.alpha_e;         // ref :439
   return eps;
 }
 
@@ -272,6 +345,7 @@ __global__ __launch_bounds__(256) void stage_kernel(const TS* __restrict__ x, co
                                                     const TS* __restrict__ h2, TS* __restrict__ xo,
                                                     TS* __restrict__ mo, int64_t n, KParams p) {
   using FT = FormTraits<FORM>;
+  constexpr bool SPLIT = sizeof(TS) == 4;  // see load_tile
   const bool need_xe = spec_need_xe<SPEC>(p);
   const bool store_m = p.flags & DPM_F_STORE_M;
   const int64_t ngroups = n / EPT;
@@ -283,19 +357,21 @@ __global__ __launch_bounds__(256) void stage_kernel(const TS* __restrict__ x, co
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t gi = (t0 + u) * 256 + threadIdx.x;
+      const bool split = SPLIT && (t0 + u) * 256 + 256 <= ngroups;
       if (gi < ngroups) {
-        if (FT::needs_x || (!XE && need_xe)) load_pack<(NT & 1) != 0>(x, gi, vx[u]);
-        if (XE && need_xe) load_pack<(NT & 1) != 0>(xe, gi, vxe[u]);
-        load_pack<(NT & 1) != 0>(e0, gi, v0[u]);
-        if (GUIDE == DPM_GUIDE_CFG) load_pack<(NT & 1) != 0>(e1, gi, v1[u]);
-        if (GUIDE == DPM_GUIDE_CLASSIFIER) load_pack<(NT & 1) != 0>(g, gi, vg[u]);
-        if (FT::needs_h1) load_pack<(NT & 1) != 0>(h1, gi, vh1[u]);
-        if (FT::needs_h2) load_pack<(NT & 1) != 0>(h2, gi, vh2[u]);
+        if (FT::needs_x || (!XE && need_xe)) load_tile<(NT & 1) != 0>(x, gi, split, vx[u]);
+        if (XE && need_xe) load_tile<(NT & 1) != 0>(xe, gi, split, vxe[u]);
+        load_tile<(NT & 1) != 0>(e0, gi, split, v0[u]);
+        if (GUIDE == DPM_GUIDE_CFG) load_tile<(NT & 1) != 0>(e1, gi, split, v1[u]);
+        if (GUIDE == DPM_GUIDE_CLASSIFIER) load_tile<(NT & 1) != 0>(g, gi, split, vg[u]);
+        if (FT::needs_h1) load_tile<(NT & 1) != 0>(h1, gi, split, vh1[u]);
+        if (FT::needs_h2) load_tile<(NT & 1) != 0>(h2, gi, split, vh2[u]);
       }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t gi = (t0 + u) * 256 + threadIdx.x;
+      const bool split = SPLIT && (t0 + u) * 256 + 256 <= ngroups;
       if (gi < ngroups) {
         float ox[EPT], om[EPT];
 #pragma unroll
@@ -307,8 +383,8 @@ __global__ __launch_bounds__(256) void stage_kernel(const TS* __restrict__ x, co
           ox[j] = combine<FORM>(FT::needs_x ? vx[u][j] : 0.f, mn, FT::needs_h1 ? vh1[u][j] : 0.f,
                                 FT::needs_h2 ? vh2[u][j] : 0.f, p);
         }
-        store_pack<(NT & 2) != 0>(xo, gi, ox);
-        if (store_m) store_pack<(NT & 4) != 0>(mo, gi, om);
+        store_tile<(NT & 2) != 0>(xo, gi, split, ox);
+        if (store_m) store_tile<(NT & 4) != 0>(mo, gi, split, om);
       }
     }
   }
@@ -376,7 +452,10 @@ __global__ __launch_bounds__(256) void stage_kernel_ext(const TS* __restrict__ x
   const int64_t ngroups = n / EPT;
   const int64_t gps = ext.per_sample / EPT, sgroups = ext.eps_stride / EPT, mgroups = ext.mask_period / EPT;
   const bool small = ngroups < (int64_t)0x7fffffff;  // 32-bit index arithmetic is enough (n < 2^34 elements)
+  // split tile layout (see load_tile): all-fp32 launches without per-sample / per-period index arithmetic
+  const bool can_split = sizeof(TS) == 4 && !ext.eps_stride && !mask;
   for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < ngroups; gi += (int64_t)gridDim.x * 256) {
+    const bool split = can_split && (gi | 255) < ngroups;
     int64_t ge = gi;
     if (ext.eps_stride) {
       if (small) {
@@ -387,13 +466,13 @@ __global__ __launch_bounds__(256) void stage_kernel_ext(const TS* __restrict__ x
       }
     }
     float vx[EPT], vxe[EPT], v0[EPT], v1[EPT], vg[EPT], vh1[EPT], vh2[EPT], vm[EPT], va[EPT], vb[EPT];
-    if (FT::needs_x || (!XE && need_xe)) load_pack<(NT & 1) != 0>(x, gi, vx);
-    if (XE && need_xe) load_pack<(NT & 1) != 0>(xe, gi, vxe);
-    load_pack<(NT & 1) != 0>(e0, ge, v0);
-    if (GUIDE == DPM_GUIDE_CFG) load_pack<(NT & 1) != 0>(e1, ge, v1);
-    if (GUIDE == DPM_GUIDE_CLASSIFIER) load_pack<(NT & 1) != 0>(g, gi, vg);
-    if (FT::needs_h1) load_pack<(NT & 1) != 0>(h1, gi, vh1);
-    if (FT::needs_h2) load_pack<(NT & 1) != 0>(h2, gi, vh2);
+    if (FT::needs_x || (!XE && need_xe)) load_tile<(NT & 1) != 0>(x, gi, split, vx);
+    if (XE && need_xe) load_tile<(NT & 1) != 0>(xe, gi, split, vxe);
+    load_tile<(NT & 1) != 0>(e0, ge, split, v0);
+    if (GUIDE == DPM_GUIDE_CFG) load_tile<(NT & 1) != 0>(e1, ge, split, v1);
+    if (GUIDE == DPM_GUIDE_CLASSIFIER) load_tile<(NT & 1) != 0>(g, gi, split, vg);
+    if (FT::needs_h1) load_tile<(NT & 1) != 0>(h1, gi, split, vh1);
+    if (FT::needs_h2) load_tile<(NT & 1) != 0>(h2, gi, split, vh2);
     if (mask) {
       const int64_t gm = small ? (int64_t)((uint32_t)gi % (uint32_t)mgroups) : gi % mgroups;
       load_pack<false>(mask, gm, vm);
@@ -414,9 +493,9 @@ __global__ __launch_bounds__(256) void stage_kernel_ext(const TS* __restrict__ x
       for (int j = 0; j < EPT; ++j)
         ox[j] = blend_ref(to_f32(from_f32<TS>(ox[j])), vm[j], va[j], bb ? vb[j] : 0.f, bb != nullptr, ext);
     }
-    store_pack<(NT & 2) != 0>(xo, gi, ox);
-    if (xo2) store_pack<(NT & 2) != 0>(xo2, gi, ox);
-    if (store_m) store_pack<(NT & 4) != 0>(mo, gi, om);
+    store_tile<(NT & 2) != 0>(xo, gi, split, ox);
+    if (xo2) store_tile<(NT & 2) != 0>(xo2, gi, split, ox);
+    if (store_m) store_tile<(NT & 4) != 0>(mo, gi, split, om);
   }
 }
 
@@ -813,9 +892,19 @@ inline const DeviceInfo& device_info() {
 
 inline bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+// the division-by-invariant of the specialised prologue is exact unless alpha's significand is all ones (or alpha is
+// not a normal number): then the generic prologue, with a true division, runs instead
+inline bool div_invariant_ok(float alpha) {
+  uint32_t u;
+  std::memcpy(&u, &alpha, 4);
+  const uint32_t ex = (u >> 23) & 0xffu;
+  return ex != 0u && ex != 0xffu && (u & 0x7fffffu) != 0x7fffffu && ex > 32u && ex < 222u;
+}
+
 inline KParams make_params(const dpm_stage* st) {
   KParams p;
   p.alpha_e = st->alpha_e;
+  p.inv_alpha = 1.0f / st->alpha_e;
   p.sigma_e = st->sigma_e;
   p.cfg_scale = st->cfg_scale;
   p.cg_scale = st->cg_scale;
@@ -982,7 +1071,7 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
       launch(stage_kernel_scalar<TS, TE, FORM, GUIDE, XE>, dim3((unsigned)blocks), dim3(256), 0, stream, x, xe, e0, e1, g,
              h1, h2, xo, mo, b->n, p, ext);
     } else if (use_ext) {
-      const bool noise = st->model_type == DPM_MODEL_NOISE;
+      const bool noise = st->model_type == DPM_MODEL_NOISE && (!(st->flags & DPM_F_TO_X0) || div_invariant_ok(st->alpha_e));
       const int64_t ntiles = ((b->n / EPT) + 255) / 256;
       int64_t blocks = ntiles;
       const int64_t cap = (int64_t)n_cu * g_tuning.blocks_per_cu;
@@ -1001,7 +1090,7 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
                h2, xo, mo, b->n, p, ext);
     } else {
       // specialise the prologue when the stage allows it (noise-prediction network: the common case)
-      const bool noise = st->model_type == DPM_MODEL_NOISE;
+      const bool noise = st->model_type == DPM_MODEL_NOISE && (!(st->flags & DPM_F_TO_X0) || div_invariant_ok(st->alpha_e));
       const int spec = !noise ? SPEC_GENERIC : ((st->flags & DPM_F_TO_X0) ? SPEC_NOISE_X0 : SPEC_NOISE_EPS);
       const int64_t ntiles = ((b->n / EPT) + 255) / 256;
       const Tuning tn = g_tuning;

@@ -113,6 +113,11 @@ def main():
         e, = frozen(shape, dt)
         s = D.DPM_Solver(D.model_wrapper(lambda x, t: e, sd), sd, state_dtype=dt)
         rows += run("cfg2 2M++ %s" % str(dt)[6:], s, torch.randn(shape, device=DEV).to(dt), steps=20, order=2)
+    # autocast: fp32 state, fp16 network output
+    shape = (256, 4, 64, 64)
+    e, = frozen(shape, torch.float16)
+    s = D.DPM_Solver(D.model_wrapper(lambda x, t: e, sd), sd)
+    rows += run("cfg2-size 2M++ f32 state / f16 eps", s, torch.randn(shape, device=DEV), steps=20, order=2)
     # 3M++
     shape = (256, 4, 64, 64)
     e, = frozen(shape, torch.float16)
