@@ -25,6 +25,7 @@
 #include <cstdint>
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <type_traits>
 #include <new>
 
@@ -39,9 +40,18 @@ struct Tuning {
   int blocks_per_cu = 8;    // grid cap = CUs x this (8 x 256 threads = every SIMD holds 8 waves)
 };
 extern Tuning g_tuning;     // defined in dpm_kernels.hip
+// device-wide chain of clustered thresholding launches (see launch_typed): one instance per device for the library
+struct ClusterChain {
+  std::mutex mu;
+  hipEvent_t ev = nullptr;
+  bool recorded = false;
+};
+ClusterChain& cluster_chain(int dev);  // defined in dpm_kernels.hip
 }  // namespace dpmk
 using dpmk::Tuning;
 using dpmk::g_tuning;
+using dpmk::ClusterChain;
+using dpmk::cluster_chain;
 
 namespace {
 
@@ -1054,6 +1064,25 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
       grid = groups * pl.k;
       hipError_t me = hipMemsetAsync(b->workspace, 0, (size_t)thr_ws_bytes(b->batch, per_sample, n_cu), stream.stream);
       if (me != hipSuccess) return dpm_set_error((int)me, "hipMemsetAsync: %s", hipGetErrorString(me));
+      // Two clustered launches on different streams could each hold part of the CUs with spinning workgroups and
+      // starve the other's missing peers.  Within this process they are therefore chained device-wide: wait for the
+      // previous clustered launch (whatever its stream), record after this one.  (Not under stream capture, where an
+      // event recorded outside the capture cannot be waited on; a captured graph is the caller's to serialise.)
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      (void)hipStreamIsCapturing(stream.stream, &cs);
+      if (cs == hipStreamCaptureStatusNone) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        ClusterChain& ch = cluster_chain(dev);
+        std::lock_guard<std::mutex> lk(ch.mu);
+        if (!ch.ev && hipEventCreateWithFlags(&ch.ev, hipEventDisableTiming) != hipSuccess) ch.ev = nullptr;
+        if (ch.ev && ch.recorded) (void)hipStreamWaitEvent(stream.stream, ch.ev, 0);
+        launch(kern, dim3((unsigned)grid), dim3(THR_THREADS), lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo, p, tp, ext);
+        if (ch.ev && hipEventRecord(ch.ev, stream.stream) == hipSuccess) ch.recorded = true;
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return dpm_set_error((int)e, "stage kernel launch failed: %s", hipGetErrorString(e));
+        return DPM_OK;
+      }
     }
     launch(kern, dim3((unsigned)grid), dim3(THR_THREADS), lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo, p, tp, ext);
   } else {

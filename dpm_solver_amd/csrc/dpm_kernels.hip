@@ -6,7 +6,11 @@
 
 namespace dpmk {
 Tuning g_tuning;
+ClusterChain& cluster_chain(int dev) {
+  static ClusterChain chains[64];
+  return chains[(dev < 0 ? 0 : dev) % 64];
 }
+}  // namespace dpmk
 
 // one translation unit per (state, eps) dtype pair
 int dpm_launch_f32_f32(const dpm_stage*, const dpm_buffers*, void*, void*, void*);

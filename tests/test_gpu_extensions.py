@@ -366,3 +366,24 @@ def test_legacy_revision_cosine_schedule_and_unclipped_tables(golden):
     """LegacyNoiseScheduleVP (the revision vendored under examples/score_sde_pytorch) on the HIP path"""
     import test_host_logic as TH
     TH.legacy_checks(golden, DEV)
+
+
+def test_clustered_thresholding_launched_from_two_streams():
+    """Small batches / large samples run the thresholding kernel as clusters that synchronise through spin barriers;
+    launches from different streams are chained device-wide so two of them never starve each other's peers."""
+    ns = make_schedule("ddpm")
+    dpm = D.DPM_Solver(lambda x, t: x, ns, correcting_x0_fn="dynamic_thresholding")
+    rng = np.random.default_rng(4)
+    xs = [torch.from_numpy((rng.standard_normal(shape) * 2).astype(F32)).to(DEV)
+          for shape in [(8, 3, 64, 64), (2, 3, 256, 256)]]
+    want = [dpm.dynamic_thresholding_fn(x, None) for x in xs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for it in range(40):
+        for j, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs[j].append(dpm.dynamic_thresholding_fn(xs[j], None))
+    torch.cuda.synchronize()
+    for j in range(2):
+        assert all(torch.equal(o, want[j]) for o in outs[j])
