@@ -240,8 +240,9 @@ def main():
         ts = []
         for it in range(24):
             s_ = sets[0] if mode == "warm" else sets[it % nreq]
+            # same cache policy as the stage kernel in that situation: default when warm, streaming loads when cold
             L.check(L.lib.dpm_calib_launch(1, 256, 8, L.lib.dpm_tuning_get(L.TUNE_NONTEMPORAL) if L.lib.dpm_tuning_get(L.TUNE_NONTEMPORAL) >= 0
-                                           else (5 if esz == 2 else 0),
+                                           else (0 if mode == "warm" else 5),
                                            s_["x"][1].data_ptr(), s_["x"][2].data_ptr(), s_["x"][3].data_ptr(),
                                            s_["h"][0].data_ptr(), s_["h"][1].data_ptr(), n_el * esz, sptr, C.byref(msv)))
             if it >= 8:

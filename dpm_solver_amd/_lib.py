@@ -29,7 +29,7 @@ EVAL_LOG_ALPHA, EVAL_ALPHA, EVAL_STD, EVAL_LAMBDA, EVAL_INV_LAMBDA = 0, 1, 2, 3,
 FORM_LIN1, FORM_TWO, FORM_MS3, FORM_SS3T, FORM_DENOISE = 0, 1, 2, 3, 4
 F_TO_X0, F_STORE_M, F_BASE_HIST, F_THRESH, F_USER_X0, F_BLEND = 1, 2, 4, 8, 16, 32
 SRC_STATE, SRC_TMP = 0, 1
-TUNE_UNROLL, TUNE_NONTEMPORAL, TUNE_BLOCKS_PER_CU = 0, 1, 2
+TUNE_UNROLL, TUNE_NONTEMPORAL, TUNE_BLOCKS_PER_CU, TUNE_ASSUME_RESIDENT = 0, 1, 2, 3
 
 
 class Stage(C.Structure):
@@ -59,6 +59,7 @@ class Buffers(C.Structure):
         ("state_dtype", C.c_int32), ("eps_dtype", C.c_int32),
         ("x_out2", C.c_void_p), ("eps_stride", C.c_int64), ("mask", C.c_void_p), ("blend_a", C.c_void_p),
         ("blend_b", C.c_void_p), ("mask_period", C.c_int64),
+        ("inputs_resident", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

@@ -894,6 +894,7 @@ static int plan_run_impl(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model
     b.state_dtype = rb->state_dtype;
     b.eps_dtype = rb->eps_dtype;
     b.eps_stride = rb->eps_stride;
+    b.inputs_resident = model == nullptr;  // frozen outputs: nothing ran since the previous stage wrote x and m
     if (rb->dup_state && &st != &p->stages.back())  // the last stage's output feeds no network call
       b.x_out2 = static_cast<char*>(rb->xbuf[out]) + rb->n * (rb->state_dtype == DPM_DTYPE_F32 ? 4 : 2);
     int rc = dpm_stage_launch_ev(&st, &b, stream, ev_start ? ev_start[st.index] : nullptr,
@@ -965,6 +966,7 @@ extern "C" int dpm_plan_run_multi(const dpm_plan* p, const dpm_run_buffers* rbs,
       b.batch = rb.batch;
       b.state_dtype = rb.state_dtype;
       b.eps_dtype = rb.eps_dtype;
+      b.inputs_resident = n_req == 1;  // interleaved requests evict each other's buffers, like a network would
       const int k = r * ns + st.index;
       rc = dpm_stage_launch_ev(&st, &b, stream, starts ? starts[k] : nullptr, stops ? stops[k] : nullptr);
       if (st.emits_state) {

@@ -358,6 +358,7 @@ extern "C" int dpm_tuning_set(int knob, int value) {
       if (value < 1 || value > 64) return dpm_set_error(DPM_ERR_ARG, "blocks_per_cu must be in 1..64");
       g_tuning.blocks_per_cu = value;
       return DPM_OK;
+    case DPM_TUNE_ASSUME_RESIDENT: g_tuning.assume_resident = value != 0; return DPM_OK;
   }
   return dpm_set_error(DPM_ERR_ARG, "unknown tuning knob %d", knob);
 }
@@ -367,6 +368,7 @@ extern "C" int dpm_tuning_get(int knob) {
     case DPM_TUNE_UNROLL: return g_tuning.unroll;
     case DPM_TUNE_NONTEMPORAL: return g_tuning.nontemporal;
     case DPM_TUNE_BLOCKS_PER_CU: return g_tuning.blocks_per_cu;
+    case DPM_TUNE_ASSUME_RESIDENT: return g_tuning.assume_resident;
   }
   return -1;
 }

@@ -134,6 +134,11 @@ typedef struct dpm_buffers {
   const void* blend_a; /* DPM_F_BLEND: known image (or, with blend_b NULL, the state to blend in)  [n]   */
   const void* blend_b; /* DPM_F_BLEND: noise [n], NULL = blend_a is used as is                          */
   int64_t mask_period; /* n for a full mask, H*W for a [H,W] mask, C*H*W for a [1,C,H,W] mask           */
+  int32_t inputs_resident; /* cache-policy hint.  0 (default): a network ran since x / the cached values were
+                          written, the streams come from HBM -> streaming loads.  1: the immediately preceding launch
+                          wrote them (frozen-model loops; dpm_plan_run sets it when there is no model callback) ->
+                          default cache policy, they are expected in the 256 MiB Infinity Cache                  */
+  int32_t reserved;
 } dpm_buffers;
 
 /* ---- noise schedule (NoiseScheduleVP, ref :6-167) --------------------------------------- */
@@ -275,7 +280,7 @@ int dpm_graph_num_nodes(const dpm_graph* g); /* kernel / memset nodes captured  
 void dpm_graph_destroy(dpm_graph* g);
 
 /* ---- launch-shape tuning hooks (autotuning / benchmarking; defaults are the measured best) --------- */
-enum { DPM_TUNE_UNROLL = 0, DPM_TUNE_NONTEMPORAL = 1, DPM_TUNE_BLOCKS_PER_CU = 2 };
+enum { DPM_TUNE_UNROLL = 0, DPM_TUNE_NONTEMPORAL = 1, DPM_TUNE_BLOCKS_PER_CU = 2, DPM_TUNE_ASSUME_RESIDENT = 3 };
 int dpm_tuning_set(int knob, int value);
 int dpm_tuning_get(int knob);
 /* memory-system calibration with no arithmetic (kind 0: copy; kind 1: 3 read + 2 write streams, the 2M stage's
