@@ -557,47 +557,62 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
   return v;
 }
 
-// 4 consecutive elements (one 16-byte / 8-byte access)
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// 4 consecutive elements (one 16-byte / 8-byte access); NT = streaming (non-temporal) access for data that is dead
+// after this kernel
+template <bool NT = false>
 __device__ __forceinline__ void load4(const float* __restrict__ p, int64_t i, float (&o)[4]) {
-  const u32x4 a = *reinterpret_cast<const u32x4*>(p + i);
+  const u32x4 a = ld16<NT>(reinterpret_cast<const u32x4*>(p + i));
 #pragma unroll
   for (int j = 0; j < 4; ++j) o[j] = __uint_as_float(a[j]);
 }
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <bool NT = false>
 __device__ __forceinline__ void load4(const __half* __restrict__ p, int64_t i, float (&o)[4]) {
-  const u32x2 a = *reinterpret_cast<const u32x2*>(p + i);
+  const u32x2* q = reinterpret_cast<const u32x2*>(p + i);
+  const u32x2 a = NT ? __builtin_nontemporal_load(q) : *q;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     o[2 * j] = __half2float(__ushort_as_half((unsigned short)(a[j] & 0xffffu)));
     o[2 * j + 1] = __half2float(__ushort_as_half((unsigned short)(a[j] >> 16)));
   }
 }
+template <bool NT = false>
 __device__ __forceinline__ void load4(const bf16_t* __restrict__ p, int64_t i, float (&o)[4]) {
-  const u32x2 a = *reinterpret_cast<const u32x2*>(p + i);
+  const u32x2* q = reinterpret_cast<const u32x2*>(p + i);
+  const u32x2 a = NT ? __builtin_nontemporal_load(q) : *q;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     o[2 * j] = __uint_as_float(a[j] << 16);
     o[2 * j + 1] = __uint_as_float(a[j] & 0xffff0000u);
   }
 }
+template <bool NT = false>
 __device__ __forceinline__ void store4(float* __restrict__ p, int64_t i, const float (&v)[4]) {
   u32x4 a;
 #pragma unroll
   for (int j = 0; j < 4; ++j) a[j] = __float_as_uint(v[j]);
-  *reinterpret_cast<u32x4*>(p + i) = a;
+  st16<NT>(reinterpret_cast<u32x4*>(p + i), a);
 }
+template <bool NT = false>
 __device__ __forceinline__ void store4(__half* __restrict__ p, int64_t i, const float (&v)[4]) {
   u32x2 a;
 #pragma unroll
   for (int j = 0; j < 2; ++j)
     a[j] = (uint32_t)__half_as_ushort(__float2half_rn(v[2 * j])) | ((uint32_t)__half_as_ushort(__float2half_rn(v[2 * j + 1])) << 16);
-  *reinterpret_cast<u32x2*>(p + i) = a;
+  if (NT)
+    __builtin_nontemporal_store(a, reinterpret_cast<u32x2*>(p + i));
+  else
+    *reinterpret_cast<u32x2*>(p + i) = a;
 }
+template <bool NT = false>
 __device__ __forceinline__ void store4(bf16_t* __restrict__ p, int64_t i, const float (&v)[4]) {
   u32x2 a;
 #pragma unroll
   for (int j = 0; j < 2; ++j) a[j] = (uint32_t)from_f32<bf16_t>(v[2 * j]).v | ((uint32_t)from_f32<bf16_t>(v[2 * j + 1]).v << 16);
-  *reinterpret_cast<u32x2*>(p + i) = a;
+  if (NT)
+    __builtin_nontemporal_store(a, reinterpret_cast<u32x2*>(p + i));
+  else
+    *reinterpret_cast<u32x2*>(p + i) = a;
 }
 
 // all workgroups of a cluster meet here; `cnt` is a zero-initialised single-use counter.  Everything the cluster
@@ -657,9 +672,9 @@ __global__ __launch_bounds__(T) void stage_thresh_kernel(
       for (int i = tid * 4; i < n; i += T * 4) {
         float vx[4], v0[4], v1[4], vg[4], o[4];
         load4(XE ? xe : x, base + i, vx);
-        load4(e0, ebase + i, v0);
-        if (GUIDE == DPM_GUIDE_CFG) load4(e1, ebase + i, v1);
-        if (GUIDE == DPM_GUIDE_CLASSIFIER) load4(g, base + i, vg);
+        load4<true>(e0, ebase + i, v0);                       // the network outputs are dead after this kernel
+        if (GUIDE == DPM_GUIDE_CFG) load4<true>(e1, ebase + i, v1);
+        if (GUIDE == DPM_GUIDE_CLASSIFIER) load4<true>(g, base + i, vg);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           o[j] = prologue<GUIDE>(vx[j], v0[j], GUIDE == DPM_GUIDE_CFG ? v1[j] : 0.f, GUIDE == DPM_GUIDE_CLASSIFIER ? vg[j] : 0.f, p);
@@ -768,9 +783,9 @@ __global__ __launch_bounds__(T) void stage_thresh_kernel(
       for (int i = tid * 4; i < n; i += T * 4) {
         const int64_t gi = base + i;
         float vx[4], vh1[4], vh2[4], vm[4], va[4], vb[4], o[4], om[4];
-        if (FT::needs_x) load4(x, gi, vx);
-        if (FT::needs_h1) load4(h1, gi, vh1);
-        if (FT::needs_h2) load4(h2, gi, vh2);
+        if (FT::needs_x) load4<true>(x, gi, vx);                 // last use of x and of the cached model values
+        if (FT::needs_h1) load4<true>(h1, gi, vh1);
+        if (FT::needs_h2) load4<true>(h2, gi, vh2);
         if (mask) {
           load4(mask, mfull ? gi : (int64_t)((mbase + (uint32_t)i) % mper), vm);
           load4(ba, gi, va);
@@ -784,7 +799,7 @@ __global__ __launch_bounds__(T) void stage_thresh_kernel(
         }
         store4(xo, gi, o);
         if (xo2) store4(xo2, gi, o);
-        if (store_m) store4(mo, gi, om);
+        if (store_m) store4<true>(mo, gi, om);                  // read again only after the next network call
       }
     } else {
 #pragma unroll 2
