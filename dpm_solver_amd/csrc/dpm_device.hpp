@@ -1158,10 +1158,16 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
         DPM_LAUNCH(SPEC_NOISE_EPS, DEF_U, DefNT<TS>::value);
       } else if (HotCombo<FORM, GUIDE, XE>::value) {
         // tuning variants exist only for the north-star kernels (2M / 1st-order update, no guidance)
+        // (tiles per iteration, nt mask) by situation and dtypes, from profiles/r01_tuning_v3.txt:
+        //   inputs cache-resident: default policy; 4-byte states with two tiles per iteration
+        //   inputs from HBM:       2-byte state (1, nt loads); fp32 + fp32 (1, nt loads + nt m store);
+        //                          fp32 state + 2-byte network output (2, nt loads)  [SD under autocast: 12.3 vs 14.0 us]
         const bool resident = b->inputs_resident != 0 || tn.assume_resident != 0;
         const int key = (tn.unroll > 0 && tn.nontemporal >= 0) ? tn.unroll * 8 + (tn.nontemporal & 7)
-                        : resident                              ? (sizeof(TS) == 4 ? 16 : 8) + 0  // warm: default policy
-                                                                : -1;
+                        : resident                              ? (sizeof(TS) == 4 ? 16 : 8) + 0
+                        : sizeof(TS) == 2                       ? 8 + 1
+                        : sizeof(TE) == 4                       ? 8 + 5
+                                                                : 16 + 1;
         switch (key) {
           case 8 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 1, 0); break;
           case 8 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 1, 1); break;

@@ -18,7 +18,8 @@ from dpm_solver_amd import _lib as L
 B, N_EL = 256, 256 * 4 * 64 * 64
 
 
-def arena_sets(n_sets, dtype, dev, pad):
+def arena_sets(n_sets, dtype, dev, pad, eps_dtype=None):
+    eps_dtype = eps_dtype or dtype
     esz = torch.empty((), dtype=dtype).element_size()
     size = N_EL * esz
     slot = size + pad
@@ -32,7 +33,9 @@ def arena_sets(n_sets, dtype, dev, pad):
         off = [p - arena.data_ptr() for p in ptrs]
         ts = [arena[o:o + size].view(dtype) for o in off]
         ts[0].copy_(torch.randn(N_EL, generator=g).to(dev, dtype))
-        ts[1].copy_(torch.randn(N_EL, generator=g).to(dev, dtype))
+        if eps_dtype != dtype:       # network output narrower than the state: it occupies the front of its slot
+            ts[1] = arena[off[1]:off[1] + N_EL * torch.empty((), dtype=eps_dtype).element_size()].view(eps_dtype)
+        ts[1].copy_(torch.randn(N_EL, generator=g).to(dev, eps_dtype))
         rb = L.RunBuffers()
         rb.xbuf[0] = ptrs[0]
         rb.e0 = ptrs[1]
@@ -41,7 +44,8 @@ def arena_sets(n_sets, dtype, dev, pad):
         for i in range(2):
             rb.hist[i] = ptrs[5 + i]
         rb.n, rb.batch = N_EL, B
-        rb.state_dtype = rb.eps_dtype = {torch.float16: L.DTYPE_F16, torch.float32: L.DTYPE_F32}[dtype]
+        dmap = {torch.float16: L.DTYPE_F16, torch.float32: L.DTYPE_F32, torch.bfloat16: L.DTYPE_BF16}
+        rb.state_dtype, rb.eps_dtype = dmap[dtype], dmap[eps_dtype]
         sets.append(rb)
         views.append(ts)
     return arena, sets, views

@@ -19,14 +19,15 @@ def main():
     dev = torch.device("cuda", 0)
     ns = D.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(BN.sd_alphas_cumprod()))
     sptr = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    for dname in ["fp16", "fp32"]:
-        dtype = {"fp16": torch.float16, "fp32": torch.float32}[dname]
-        alg = 5 * T2.N_EL * (2 if dname == "fp16" else 4)
+    for dname in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["fp16", "fp32", "fp32/fp16"]):
+        dtype = {"fp16": torch.float16, "fp32": torch.float32, "fp32/fp16": torch.float32}[dname]
+        edt = torch.float16 if dname == "fp32/fp16" else dtype
+        alg = T2.N_EL * (4 * (2 if dname == "fp16" else 4) + (2 if edt == torch.float16 else 4))
         dpm = D.DPM_Solver(D.model_wrapper(lambda x, t: x, ns), ns, state_dtype=dtype)
         plan = dpm._get_plan(method="multistep", order=2, steps=20, skip_type="time_uniform", solver_type="dpmsolver",
                              lower_order_final=True, denoise_to_zero=False, t_T=1.0, t_0=1e-3)
         nst = len(plan.stages)
-        arena, sets, views = T2.arena_sets(8, dtype, dev, 0)
+        arena, sets, views = T2.arena_sets(8, dtype, dev, 0, edt)
         for U in (1, 2):
             for NT in (0, 1, 5, 6, 7):
                 for bpc in (4, 8, 16):
