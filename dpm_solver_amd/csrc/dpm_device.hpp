@@ -533,6 +533,7 @@ constexpr int THR_THREADS = 512;
 constexpr int THR_NB = 2048;                 // bins per radix level
 constexpr int THR_WS_WORDS = 3 * THR_NB + 64;  // per sample: 3 level histograms + counters (256-byte multiple)
 constexpr int THR_CHUNK_MAX = 12288;         // elements of a sample one workgroup keeps in LDS (48 KiB)
+constexpr int THR_CAP = 4096;                // candidates (elements sharing the selected top digit) kept compacted
 
 struct ThrParams {
   int64_t per_sample;
@@ -642,7 +643,8 @@ __global__ __launch_bounds__(T) void stage_thresh_kernel(
   extern __shared__ __align__(16) unsigned char lds_raw[];
   float* sx0 = reinterpret_cast<float*>(lds_raw);                    // [chunk]
   uint32_t* hist = reinterpret_cast<uint32_t*>(sx0 + tp.chunk);      // [THR_NB]
-  uint32_t* misc = hist + THR_NB;                                    // [32]: selection result [3], min-above
+  uint32_t* misc = hist + THR_NB;                                    // [32]: selection result [3], min-above, candidate count
+  uint32_t* cand = misc + 32;                                        // [THR_CAP] candidates of levels 1, 2
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const bool store_m = p.flags & DPM_F_STORE_M;
@@ -666,7 +668,12 @@ __global__ __launch_bounds__(T) void stage_thresh_kernel(
     const uint32_t mbase = (mask && !mfull) ? (uint32_t)(base % ext.mask_period) : 0u;
     const uint32_t mper = (uint32_t)ext.mask_period;
 
-    // phase 1: x0 of this workgroup's chunk -> LDS
+    // phase 1: x0 of this workgroup's chunk -> LDS, and the level-0 histogram (top 11 bits of |x0|) on the way: the
+    // LDS atomics overlap the global loads
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) hist[j * T + tid] = 0u;
+    if (tid == 0) misc[4] = 0u;  // candidate counter
+    __syncthreads();
     if (vec) {
 #pragma unroll 2
       for (int i = tid * 4; i < n; i += T * 4) {
@@ -679,31 +686,50 @@ __global__ __launch_bounds__(T) void stage_thresh_kernel(
         for (int j = 0; j < 4; ++j)
           o[j] = prologue<GUIDE>(vx[j], v0[j], GUIDE == DPM_GUIDE_CFG ? v1[j] : 0.f, GUIDE == DPM_GUIDE_CLASSIFIER ? vg[j] : 0.f, p);
         store4(sx0, i, o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(&hist[(__float_as_uint(o[j]) & 0x7fffffffu) >> 20], 1u);
       }
     } else {
 #pragma unroll 4
       for (int i = tid; i < n; i += T) {
         const float xev = to_f32(XE ? xe[base + i] : x[base + i]);
-        sx0[i] = prologue<GUIDE>(xev, to_f32(e0[ebase + i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[ebase + i]) : 0.f,
-                                 GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[base + i]) : 0.f, p);
+        const float o = prologue<GUIDE>(xev, to_f32(e0[ebase + i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[ebase + i]) : 0.f,
+                                        GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[base + i]) : 0.f, p);
+        sx0[i] = o;
+        atomicAdd(&hist[(__float_as_uint(o) & 0x7fffffffu) >> 20], 1u);
       }
     }
+    __syncthreads();
 
-    // phase 2: radix select of the lo-th smallest |x0| of the whole sample, 11 + 11 + 9 bits
+    // phase 2: radix select of the lo-th smallest |x0| of the whole sample, 11 + 11 + 9 bits.  After level 0 the
+    // elements that share the selected top digit -- the only ones levels 1, 2 and the min-above search can still
+    // care about -- are compacted into `cand` (wave-aggregated append); everything above that digit only matters
+    // through its minimum, kept per lane in `hi`.
     uint32_t prefix = 0u, known = 0u, rank = (uint32_t)tp.lo, cnt_sel = 0u;
+    uint32_t hi = 0x7fffffffu, nc = 0u;
+    bool use_cand = false;
 #pragma unroll 1
     for (int pass = 0; pass < 3; ++pass) {
       const int shift = pass == 0 ? 20 : pass == 1 ? 9 : 0;
       const uint32_t dmask = pass == 2 ? 0x1ffu : 0x7ffu;
+      if (pass > 0) {
 #pragma unroll
-      for (int j = 0; j < BPT; ++j) hist[j * T + tid] = 0u;
-      __syncthreads();  // also orders phase 1's LDS writes before the first read
+        for (int j = 0; j < BPT; ++j) hist[j * T + tid] = 0u;
+        __syncthreads();
+        if (use_cand) {
+          for (uint32_t i = tid; i < nc; i += T) {
+            const uint32_t u = cand[i];
+            if ((u & known) == prefix) atomicAdd(&hist[(u >> shift) & dmask], 1u);
+          }
+        } else {
 #pragma unroll 4
-      for (int i = tid; i < n; i += T) {
-        const uint32_t u = __float_as_uint(sx0[i]) & 0x7fffffffu;
-        if ((u & known) == prefix) atomicAdd(&hist[(u >> shift) & dmask], 1u);
+          for (int i = tid; i < n; i += T) {
+            const uint32_t u = __float_as_uint(sx0[i]) & 0x7fffffffu;
+            if ((u & known) == prefix) atomicAdd(&hist[(u >> shift) & dmask], 1u);
+          }
+        }
+        __syncthreads();
       }
-      __syncthreads();
       if (k > 1) {  // merge into the sample's histogram of this level, wait for the peers, read the sum back
         uint32_t* gh = ws + pass * THR_NB;
 #pragma unroll
@@ -743,6 +769,26 @@ __global__ __launch_bounds__(T) void stage_thresh_kernel(
       known |= dmask << shift;
       rank = misc[1];
       cnt_sel = misc[2];
+      if (pass == 0) {  // compact this chunk's candidates, remember the smallest value of the higher digits
+        const uint32_t bin0 = prefix >> 20;
+        for (int i = tid; i < n; i += T) {
+          const uint32_t u = __float_as_uint(sx0[i]) & 0x7fffffffu;
+          const uint32_t d = u >> 20;
+          const bool is_c = d == bin0;
+          const uint64_t bal = __ballot(is_c);
+          if (bal) {  // one LDS atomic per wavefront: the first candidate lane reserves slots for all of them
+            const int leader = __ffsll((long long)bal) - 1;
+            uint32_t slot = 0;
+            if (lane == leader) slot = atomicAdd(&misc[4], (uint32_t)__popcll(bal));
+            slot = __shfl(slot, leader, 64) + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (is_c && slot < (uint32_t)THR_CAP) cand[slot] = u;
+          }
+          if (d > bin0 && u < hi) hi = u;
+        }
+        __syncthreads();
+        nc = misc[4];
+        use_cand = nc <= (uint32_t)THR_CAP;
+      }
     }
     const uint32_t a_bits = prefix;
     float a = __uint_as_float(a_bits), b = a;
@@ -750,11 +796,18 @@ __global__ __launch_bounds__(T) void stage_thresh_kernel(
       // the next order statistic is the smallest value above a: wavefront min, one atomic per wave
       if (tid == 0) misc[3] = 0x7fffffffu;
       __syncthreads();
-      uint32_t m = 0x7fffffffu;
+      uint32_t m = hi;
+      if (use_cand) {
+        for (uint32_t i = tid; i < nc; i += T) {
+          const uint32_t u = cand[i];
+          if (u > a_bits && u < m) m = u;
+        }
+      } else {
 #pragma unroll 4
-      for (int i = tid; i < n; i += T) {
-        const uint32_t u = __float_as_uint(sx0[i]) & 0x7fffffffu;
-        if (u > a_bits && u < m) m = u;
+        for (int i = tid; i < n; i += T) {
+          const uint32_t u = __float_as_uint(sx0[i]) & 0x7fffffffu;
+          if (u > a_bits && u < m) m = u;
+        }
       }
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) {
@@ -1050,7 +1103,7 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
              aligned(xe, a4s) && aligned(h1, a4s) && aligned(h2, a4s) && aligned(xo, a4s) && aligned(mo, a4s) &&
              aligned(ext.xo2, a4s) && aligned(ext.mask, a4s) && aligned(ext.ba, a4s) && aligned(ext.bb, a4s) &&
              aligned(e0, a4e) && aligned(e1, a4e) && aligned(g, a4e);
-    const size_t lds_bytes = (size_t)pl.chunk * 4 + THR_NB * 4 + 32 * 4;
+    const size_t lds_bytes = (size_t)pl.chunk * 4 + THR_NB * 4 + 32 * 4 + THR_CAP * 4;
     auto kern = stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS>;
     int64_t grid = b->batch;
     tp.groups = (int32_t)b->batch;
