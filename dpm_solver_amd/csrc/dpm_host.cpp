@@ -778,13 +778,10 @@ extern "C" int dpm_plan_create(const dpm_schedule* s, const dpm_plan_desc* d, dp
       if (d->method == DPM_METHOD_SINGLESTEP) {
         rc = singlestep_grid(s, d->steps, d->order, d->skip_type, t_T, t_0, outer, orders);  // ref :1216
       } else {
-        int K = d->steps / d->order;  // ref :1218-1220
-        if (K < 1) rc = dpm_set_error(DPM_ERR_ARG, "singlestep_fixed needs steps >= order");
-        if (!rc) {
-          orders.assign(K, d->order);
-          outer.resize(K + 1);
-          rc = time_steps(s, d->skip_type, t_T, t_0, K, outer.data());
-        }
+        const int K = d->steps / d->order;  // ref :1218-1220; K = 0 (steps < order) is a no-op in the reference too
+        orders.assign(K, d->order);
+        outer.resize(K + 1);
+        rc = time_steps(s, d->skip_type, t_T, t_0, K, outer.data());
       }
     }
     if (!rc) {

@@ -387,3 +387,13 @@ def test_clustered_thresholding_launched_from_two_streams():
     torch.cuda.synchronize()
     for j in range(2):
         assert all(torch.equal(o, want[j]) for o in outs[j])
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_random_configurations_against_oracle(seed):
+    """seeded random sweep over sample() configurations (method, order, steps, schedule, skip type, solver type,
+    algorithm, parameterisation, time range): HIP path vs oracle"""
+    import test_host_logic as TH
+    for cfg in TH.random_configs(seed, 40):
+        got, want = TH.run_random_config(cfg, DEV)
+        assert rel_err(got, want) < TOL, cfg

@@ -416,3 +416,50 @@ def legacy_checks(golden, device):
 
 def test_legacy_revision_cosine_schedule_and_unclipped_tables(golden):
     legacy_checks(golden, "cpu")
+
+
+# ------------------------------------------------------------------------------------------------
+# seeded random sweep over sample() configurations: C planner + host loop (kernel double) against the oracle
+# ------------------------------------------------------------------------------------------------
+def random_configs(seed, count):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        method = str(rng.choice(["multistep", "singlestep", "singlestep_fixed"]))
+        order = int(rng.integers(1, 4))
+        steps = int(rng.integers(order if method == "multistep" else 1, 24))
+        sname = str(rng.choice(["sd", "ddpm", "vp_linear", "cosine1000"]))
+        skip = str(rng.choice(["time_uniform", "logSNR", "time_quadratic"]))
+        out.append(dict(method=method, order=order, steps=steps, schedule=sname, skip_type=skip,
+                        solver_type=str(rng.choice(["dpmsolver", "taylor"])),
+                        algorithm_type=str(rng.choice(["dpmsolver++", "dpmsolver"])),
+                        model_type=str(rng.choice(["noise", "x_start", "v", "score"])),
+                        lower_order_final=bool(rng.integers(0, 2)), denoise_to_zero=bool(rng.integers(0, 2)),
+                        t_end=float(rng.choice([1e-3, 1e-2, 0.05])), t_start=float(rng.choice([1.0, 0.8, 0.5])),
+                        seed=int(rng.integers(0, 1 << 30))))
+    return out
+
+
+def run_random_config(cfg, device):
+    """(engine result, oracle result) of one random configuration"""
+    from test_oracle_golden import make_schedule as make_oracle_schedule
+    ns, osch = make_schedule(cfg["schedule"]), make_oracle_schedule(cfg["schedule"])
+    rng = np.random.default_rng(cfg["seed"])
+    x = rng.standard_normal((2, 3, 6, 6)).astype(F32)
+    kw = dict(steps=cfg["steps"], order=cfg["order"], method=cfg["method"], skip_type=cfg["skip_type"],
+              solver_type=cfg["solver_type"], lower_order_final=cfg["lower_order_final"],
+              denoise_to_zero=cfg["denoise_to_zero"], t_start=cfg["t_start"], t_end=cfg["t_end"])
+    dpm = D.DPM_Solver(D.model_wrapper(lambda xx, t: C.model_tdep(xx, t), ns, model_type=cfg["model_type"]), ns,
+                       algorithm_type=cfg["algorithm_type"])
+    got = dpm.sample(tt(x, device), **kw).cpu().numpy()
+    sol = O.Solver(O.wrap_model(lambda xx, t: C.model_tdep(xx, t), osch, model_type=cfg["model_type"]), osch,
+                   algorithm_type=cfg["algorithm_type"])
+    return got, sol.sample(x, **kw)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_configurations_against_oracle(seed):
+    for cfg in random_configs(seed, 40):
+        got, want = run_random_config(cfg, "cpu")
+        assert np.all(np.isfinite(want)), cfg
+        assert rel_err(got, want) < TOL, cfg
