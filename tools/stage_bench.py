@@ -19,7 +19,6 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import dpm_solver_amd as D  # noqa: E402
-import dpm_solver_amd.solver as S  # noqa: E402
 from dpm_solver_amd import _lib as L  # noqa: E402
 
 DEV = "cuda:0"

@@ -2,7 +2,6 @@
 """Re-check of the launch-shape defaults after the kernel changes (division by invariant, split-tile fp32 layout):
 unroll x non-temporal mask x blocks per CU, warm (sequential trajectories) and HBM-cold (8 requests interleaved)."""
 import ctypes as C
-import json
 import sys
 
 import torch
