@@ -891,7 +891,8 @@ static int plan_run_impl(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model
     b.state_dtype = rb->state_dtype;
     b.eps_dtype = rb->eps_dtype;
     b.eps_stride = rb->eps_stride;
-    b.inputs_resident = model == nullptr;  // frozen outputs: nothing ran since the previous stage wrote x and m
+    // frozen outputs: nothing ran since the previous stage wrote x and m (the first stage reads the caller's x_T cold)
+    b.inputs_resident = model == nullptr && st.index > 0;
     if (rb->dup_state && &st != &p->stages.back())  // the last stage's output feeds no network call
       b.x_out2 = static_cast<char*>(rb->xbuf[out]) + rb->n * (rb->state_dtype == DPM_DTYPE_F32 ? 4 : 2);
     int rc = dpm_stage_launch_ev(&st, &b, stream, ev_start ? ev_start[st.index] : nullptr,
