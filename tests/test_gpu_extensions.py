@@ -397,3 +397,37 @@ def test_random_configurations_against_oracle(seed):
     for cfg in TH.random_configs(seed, 40):
         got, want = TH.run_random_config(cfg, DEV)
         assert rel_err(got, want) < TOL, cfg
+
+
+def test_plain_c_host_without_python_or_torch(tmp_path):
+    """examples/native_host.c (gcc, links libdpm_hip.so + the system HIP runtime) runs the 2M trajectory through
+    dpm_plan_run with a C model callback; its result must equal the Python host's bit for bit on the same inputs."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "native_host")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    out = tmp_path / "native.bin"
+    r = subprocess.run([exe, str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "gfx950" in r.stdout and "20 network calls" in r.stdout, r.stdout
+    got = np.fromfile(out, dtype=F32).reshape(8, 4, 64, 64)
+    # the C program's inputs: sum of four 24-bit LCG uniforms, seed 12345, x first then eps
+    n = 8 * 4 * 64 * 64
+    raw = np.empty(2 * n * 4, dtype=np.uint32)
+    s = 12345
+    for i in range(raw.shape[0]):
+        s = (s * 1664525 + 1013904223) & 0xffffffff
+        raw[i] = s
+    u = (raw >> 8).astype(F32) * F32(1.0 / 16777216.0)
+    acc = np.zeros(2 * n, dtype=F32)
+    for k in range(4):
+        acc = (acc + u[k::4]).astype(F32)
+    vals = ((acc - F32(2.0)) * F32(1.7320508)).astype(F32)
+    x = torch.from_numpy(vals[:n].reshape(8, 4, 64, 64)).to(DEV)
+    eps = torch.from_numpy(vals[n:].reshape(8, 4, 64, 64)).to(DEV)
+    b0, b1 = np.sqrt(0.00085), np.sqrt(0.012)                       # the C program's double arithmetic, op for op
+    v = b0 + (b1 - b0) * np.arange(1000, dtype=np.float64) / 999.0
+    ns = D.NoiseScheduleVP("discrete", betas=torch.from_numpy(v * v))
+    want = D.DPM_Solver(D.model_wrapper(lambda xx, t: eps, ns), ns).sample(x, steps=20, order=2)
+    np.testing.assert_array_equal(got, want.cpu().numpy())
