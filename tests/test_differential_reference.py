@@ -173,3 +173,24 @@ def test_public_update_methods_against_the_reference(R):
                 a = dr.get_time_steps(skip, 0.9, 0.01, 13, "cpu")
                 b = de.get_time_steps(skip, 0.9, 0.01, 13, "cpu")
                 np.testing.assert_allclose(b.numpy(), a.numpy(), rtol=3e-6, atol=1e-7)
+
+
+def test_adaptive_solver_against_the_reference(R, capsys):
+    """DPM-Solver-12 / -23: same number of function evaluations (= same accept / reject sequence) and same result"""
+    rng = np.random.default_rng(5)
+    for k in range(10):
+        sname = str(rng.choice(["vp_linear", "sd", "ddpm"]))
+        order = int(rng.choice([2, 3]))
+        algo = str(rng.choice(["dpmsolver", "dpmsolver++"]))
+        st = str(rng.choice(["dpmsolver", "taylor"]))
+        kw = dict(method="adaptive", order=order, solver_type=st, t_end=float(rng.choice([1e-3, 1e-2])),
+                  atol=float(rng.choice([0.0078, 0.02])), rtol=float(rng.choice([0.05, 0.1])))
+        x = torch.from_numpy(rng.standard_normal((3, 2, 5, 5)).astype(F32))
+        nr, ne = ref_schedule(R, sname), make_schedule(sname)
+        net = lambda xx, t: C.model_half(xx, t)
+        want = R.DPM_Solver(R.model_wrapper(net, nr), nr, algorithm_type=algo).sample(x, **kw)
+        nfe_ref = capsys.readouterr().out.strip()
+        got = D.DPM_Solver(D.model_wrapper(net, ne), ne, algorithm_type=algo).sample(x, **kw)
+        nfe_got = capsys.readouterr().out.strip()
+        assert nfe_got == nfe_ref, (k, sname, order, algo, st, nfe_got, nfe_ref)
+        assert rel_err(got.numpy(), want.numpy()) < 5e-5, (k, sname, order, algo, st)
