@@ -221,11 +221,14 @@ def main():
             traffic = json.load(open(tpath)).get(args.dtype, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    # HBM-cold variant of the same kernel: the 8 requests are advanced stage by stage (dpm_plan_run_multi), so between
-    # two stages of one request 7 x 40 MiB of other traffic has gone through the 256 MiB Infinity Cache -- what
-    # happens in real use, where a UNet runs between two solver stages.
-    nreq = len(sets)
-    rbs = (L.RunBuffers * nreq)(*[s_["rb"] for s_ in sets])
+    # HBM-cold variant of the same kernel: many requests are advanced stage by stage (dpm_plan_run_multi), so between
+    # two stages of one request the other requests' traffic has flushed the 256 MiB Infinity Cache -- what happens in
+    # real use, where a UNet runs between two solver stages.
+    # 32 requests: > 1 GB of other traffic between two uses of a buffer.  (With 8, part of a request's buffers survives
+    # in the cache and the figure is ~6 % too good.)
+    cold_sets = sets + make_sets(max(0, 32 - len(sets)), dtype, dev, seed=4321 + rank)
+    nreq = len(cold_sets)
+    rbs = (L.RunBuffers * nreq)(*[s_["rb"] for s_ in cold_sets])
     resm = (C.c_int * nreq)()
     msb = (C.c_float * (nreq * n_stages))()
     cold = []
@@ -239,7 +242,7 @@ def main():
     for mode in ("warm", "cold"):
         ts = []
         for it in range(24):
-            s_ = sets[0] if mode == "warm" else sets[it % nreq]
+            s_ = sets[0] if mode == "warm" else cold_sets[it % nreq]
             # same cache policy as the stage kernel in that situation: default when warm, streaming loads when cold
             L.check(L.lib.dpm_calib_launch(1, 256, 8, L.lib.dpm_tuning_get(L.TUNE_NONTEMPORAL) if L.lib.dpm_tuning_get(L.TUNE_NONTEMPORAL) >= 0
                                            else (0 if mode == "warm" else 5),

@@ -14,6 +14,9 @@ import tune2 as T2
 from dpm_solver_amd import _lib as L
 
 
+N_SETS = 32   # 32 x 8 state-sized arrays: more than 1 GB between two uses of a buffer, far beyond the 256 MiB Infinity Cache
+
+
 def main():
     dev = torch.device("cuda", 0)
     ns = D.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(BN.sd_alphas_cumprod()))
@@ -26,10 +29,10 @@ def main():
         plan = dpm._get_plan(method="multistep", order=2, steps=20, skip_type="time_uniform", solver_type="dpmsolver",
                              lower_order_final=True, denoise_to_zero=False, t_T=1.0, t_0=1e-3)
         nst = len(plan.stages)
-        arena, sets, views = T2.arena_sets(8, dtype, dev, 0, edt)
+        arena, sets, views = T2.arena_sets(N_SETS, dtype, dev, 0, edt)
         for U in (1, 2):
             for NT in (0, 1, 5, 6, 7):
-                for bpc in (4, 8, 16):
+                for bpc in (8,):
                     L.check(L.lib.dpm_tuning_set(L.TUNE_UNROLL, U))
                     L.check(L.lib.dpm_tuning_set(L.TUNE_NONTEMPORAL, NT))
                     L.check(L.lib.dpm_tuning_set(L.TUNE_BLOCKS_PER_CU, bpc))
