@@ -43,3 +43,25 @@ def test_version_and_error_text():
 
 def test_package_reports_library_path():
     assert os.path.exists(dpm_solver_amd.LIB_PATH)
+
+
+def test_reference_import_paths_resolve_to_the_engine():
+    """README.md:380 and the vendored paths of the example apps"""
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "shims"))
+    try:
+        for name in ("dpm_solver", "dpm_solver.sampler", "dpm_solver.dpm_solver", "dpm_solver.legacy"):
+            sys.modules.pop(name, None)
+        m = importlib.import_module("dpm_solver")
+        assert m.DPM_Solver is dpm_solver_amd.DPM_Solver and m.NoiseScheduleVP is dpm_solver_amd.NoiseScheduleVP
+        s = importlib.import_module("dpm_solver.sampler")
+        assert s.model_wrapper is dpm_solver_amd.model_wrapper and s.DPMSolverSampler.__name__ == "DPMSolverSampler"
+        assert importlib.import_module("dpm_solver.dpm_solver").DPM_Solver is dpm_solver_amd.DPM_Solver
+        assert importlib.import_module("dpm_solver.legacy").NoiseScheduleVP is dpm_solver_amd.LegacyNoiseScheduleVP
+        root = importlib.import_module("dpm_solver_pytorch")
+        assert root.DPM_Solver is dpm_solver_amd.DPM_Solver
+    finally:
+        sys.path.remove(os.path.join(ROOT, "shims"))
+        for name in ("dpm_solver", "dpm_solver.sampler", "dpm_solver.dpm_solver", "dpm_solver.legacy"):
+            sys.modules.pop(name, None)
