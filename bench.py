@@ -108,10 +108,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    # under torch.distributed.run (RANK is set) the process group is initialised for any world size, so the collective
+    # path of the N > 1 runs (barrier, MAX all-reduce of the time, final all-gather) is also exercised on one GPU
+    if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))     # "nccl" is RCCL on ROCm
+        # RCCL prints a version banner on stdout when NCCL_DEBUG=VERSION (set on the GPU boxes): keep stdout for the
+        # one JSON line by pointing fd 1 at stderr while the communicator is created
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
+            torch.cuda.set_device(local_rank)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
