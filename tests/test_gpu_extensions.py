@@ -434,3 +434,26 @@ def test_plain_c_host_without_python_or_torch(tmp_path):
     ns = D.NoiseScheduleVP("discrete", betas=torch.from_numpy(v * v))
     want = D.DPM_Solver(D.model_wrapper(lambda xx, t: eps, ns), ns).sample(x, steps=20, order=2)
     np.testing.assert_array_equal(got, want.cpu().numpy())
+
+
+def test_sharded_sampling_over_rccl_single_rank():
+    """dpm_solver_amd.distributed on the real backend (RCCL via torch.distributed 'nccl'), world size 1: the all-gather of
+    the finished shards and the MAX all-reduce of the adaptive solver run through RCCL and change nothing"""
+    import os
+    import torch.distributed as dist
+    from dpm_solver_amd import distributed as DD
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        ns = make_schedule("vp_linear")
+        mk = lambda: D.DPM_Solver(D.model_wrapper(lambda xx, t: C.model_half(xx, t), ns), ns, algorithm_type="dpmsolver")
+        rng = np.random.default_rng(8)
+        x = torch.from_numpy(rng.standard_normal((5, 3, 8, 8)).astype(F32)).to(DEV)
+        assert torch.equal(DD.sample_sharded(mk(), x, steps=10, order=2), mk().sample(x, steps=10, order=2))
+        a = DD.sample_sharded(mk(), x, method="adaptive", order=2, t_end=1e-3)
+        b = mk().sample(x, method="adaptive", order=2, t_end=1e-3)
+        assert torch.equal(a, b)
+        assert DD.rank_seed(3) == 3
+    finally:
+        dist.destroy_process_group()
