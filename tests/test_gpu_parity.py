@@ -337,10 +337,10 @@ def test_cfg5_full_size_thresholding():
 # ------------------------------------------------------------------------------------------------
 # the native sample loop of the C ABI (dpm_plan_run) == the Python loop
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(8, 4, 64, 64), (3, 3, 37, 41), (5, 4, 64, 65)])      # whole tiles / ragged / 2.5 tiles
 @pytest.mark.parametrize("method,order,steps", [("multistep", 2, 20), ("multistep", 3, 12), ("singlestep", 3, 14)])
-def test_plan_run_native_loop_matches_python_loop(method, order, steps):
+def test_plan_run_native_loop_matches_python_loop(method, order, steps, shape):
     ns = make_schedule("sd")
-    shape = (8, 4, 64, 64)
     rng = np.random.default_rng(9)
     x = torch.from_numpy(rng.standard_normal(shape).astype(F32)).to(DEV)
     eps = torch.from_numpy(rng.standard_normal(shape).astype(F32)).to(DEV)       # frozen network output
