@@ -457,3 +457,18 @@ def test_sharded_sampling_over_rccl_single_rank():
         assert DD.rank_seed(3) == 3
     finally:
         dist.destroy_process_group()
+
+
+def test_captured_sample_with_clustered_thresholding():
+    """hipGraph capture of a trajectory whose thresholding kernel runs as clusters (workspace memset + spin barriers
+    inside the graph): replays must keep matching eager runs"""
+    case = dict(C.E2E_BY_NAME["cfg5_thresh"], shape=(2, 3, 64, 64), steps=8)
+    dpm = build_solver(case, DEV)
+    x = tt(C.x_T_for(case), DEV)
+    kw = sample_kwargs(case, False)
+    want = dpm.sample(x, **kw)
+    g = dpm.capture(x, **kw)
+    for _ in range(3):
+        assert torch.equal(g(x), want)
+    x2 = x * 0.75
+    assert torch.equal(g(x2), dpm.sample(x2, **kw))
