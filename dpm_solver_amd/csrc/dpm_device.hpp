@@ -349,40 +349,67 @@ __device__ __forceinline__ float blend_ref(float v, float m, float a, float b, b
 // ------------------------------------------------------------------------------------------------
 // the streaming stage kernel
 // ------------------------------------------------------------------------------------------------
-template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int SPEC, int U, int NT>
+// EXT = the launch uses one of the KExt extensions (duplicate store, strided network output, mask blend): the same
+// tiling, with the extra index arithmetic and streams compiled in.  EXT launches have no ragged tail (the scalar kernel
+// takes those) and use the split layout only when no per-sample / per-period index is involved.
+template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int SPEC, int U, int NT, bool EXT>
 __global__ __launch_bounds__(256) void stage_kernel(const TS* __restrict__ x, const TS* __restrict__ xe,
                                                     const TE* __restrict__ e0, const TE* __restrict__ e1,
                                                     const TE* __restrict__ g, const TS* __restrict__ h1,
                                                     const TS* __restrict__ h2, TS* __restrict__ xo,
-                                                    TS* __restrict__ mo, int64_t n, KParams p) {
+                                                    TS* __restrict__ mo, int64_t n, KParams p, KExt ext) {
   using FT = FormTraits<FORM>;
   constexpr bool SPLIT = sizeof(TS) == 4;  // see load_tile
   const bool need_xe = spec_need_xe<SPEC>(p);
   const bool store_m = p.flags & DPM_F_STORE_M;
   const int64_t ngroups = n / EPT;
+  const TS* mask = EXT ? static_cast<const TS*>(ext.mask) : nullptr;
+  const TS* ba = EXT ? static_cast<const TS*>(ext.ba) : nullptr;
+  const TS* bb = EXT ? static_cast<const TS*>(ext.bb) : nullptr;
+  TS* xo2 = EXT ? static_cast<TS*>(ext.xo2) : nullptr;
+  const int64_t gps = EXT ? ext.per_sample / EPT : 1, sgroups = EXT ? ext.eps_stride / EPT : 0;
+  const int64_t mgroups = EXT ? ext.mask_period / EPT : 1;
+  const bool small = ngroups < (int64_t)0x7fffffff;  // 32-bit index arithmetic is enough (n < 2^34 elements)
+  const bool can_split = SPLIT && (!EXT || (!ext.eps_stride && !mask));
   // a tile = 256 consecutive groups (one per lane of the workgroup); a workgroup iteration covers U tiles and
   // issues the loads of all of them before the first use
   const int64_t ntiles = (ngroups + 255) / 256;
   for (int64_t t0 = (int64_t)blockIdx.x * U; t0 < ntiles; t0 += (int64_t)gridDim.x * U) {
     float vx[U][EPT], vxe[U][EPT], v0[U][EPT], v1[U][EPT], vg[U][EPT], vh1[U][EPT], vh2[U][EPT];
+    float vm[EXT ? U : 1][EPT], va[EXT ? U : 1][EPT], vb[EXT ? U : 1][EPT];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t gi = (t0 + u) * 256 + threadIdx.x;
-      const bool split = SPLIT && (t0 + u) * 256 + 256 <= ngroups;
+      const bool split = can_split && (t0 + u) * 256 + 256 <= ngroups;
       if (gi < ngroups) {
+        int64_t ge = gi;  // group index into the network outputs
+        if (EXT && ext.eps_stride) {
+          if (small) {
+            const uint32_t q = (uint32_t)gi / (uint32_t)gps;
+            ge = (int64_t)q * sgroups + ((uint32_t)gi - q * (uint32_t)gps);
+          } else {
+            ge = (gi / gps) * sgroups + gi % gps;
+          }
+        }
         if (FT::needs_x || (!XE && need_xe)) load_tile<(NT & 1) != 0>(x, gi, split, vx[u]);
         if (XE && need_xe) load_tile<(NT & 1) != 0>(xe, gi, split, vxe[u]);
-        load_tile<(NT & 1) != 0>(e0, gi, split, v0[u]);
-        if (GUIDE == DPM_GUIDE_CFG) load_tile<(NT & 1) != 0>(e1, gi, split, v1[u]);
+        load_tile<(NT & 1) != 0>(e0, ge, split, v0[u]);
+        if (GUIDE == DPM_GUIDE_CFG) load_tile<(NT & 1) != 0>(e1, ge, split, v1[u]);
         if (GUIDE == DPM_GUIDE_CLASSIFIER) load_tile<(NT & 1) != 0>(g, gi, split, vg[u]);
         if (FT::needs_h1) load_tile<(NT & 1) != 0>(h1, gi, split, vh1[u]);
         if (FT::needs_h2) load_tile<(NT & 1) != 0>(h2, gi, split, vh2[u]);
+        if (EXT && mask) {
+          const int64_t gm = small ? (int64_t)((uint32_t)gi % (uint32_t)mgroups) : gi % mgroups;
+          load_pack<false>(mask, gm, vm[u]);
+          load_pack<false>(ba, gi, va[u]);
+          if (bb) load_pack<(NT & 1) != 0>(bb, gi, vb[u]);
+        }
       }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t gi = (t0 + u) * 256 + threadIdx.x;
-      const bool split = SPLIT && (t0 + u) * 256 + 256 <= ngroups;
+      const bool split = can_split && (t0 + u) * 256 + 256 <= ngroups;
       if (gi < ngroups) {
         float ox[EPT], om[EPT];
 #pragma unroll
@@ -394,21 +421,30 @@ __global__ __launch_bounds__(256) void stage_kernel(const TS* __restrict__ x, co
           ox[j] = combine<FORM>(FT::needs_x ? vx[u][j] : 0.f, mn, FT::needs_h1 ? vh1[u][j] : 0.f,
                                 FT::needs_h2 ? vh2[u][j] : 0.f, p);
         }
+        if (EXT && mask) {
+#pragma unroll
+          for (int j = 0; j < EPT; ++j)
+            ox[j] = blend_ref(to_f32(from_f32<TS>(ox[j])), vm[EXT ? u : 0][j], va[EXT ? u : 0][j],
+                              bb ? vb[EXT ? u : 0][j] : 0.f, bb != nullptr, ext);
+        }
         store_tile<(NT & 2) != 0>(xo, gi, split, ox);
+        if (EXT && xo2) store_tile<(NT & 2) != 0>(xo2, gi, split, ox);
         if (store_m) store_tile<(NT & 4) != 0>(mo, gi, split, om);
       }
     }
   }
-  // ragged tail (n % 8 elements): first lanes of block 0, scalar
-  const int64_t tail0 = ngroups * EPT;
-  if (blockIdx.x == 0 && tail0 + threadIdx.x < n) {
-    const int64_t i = tail0 + threadIdx.x;
-    const float xv = (FT::needs_x || (!XE && need_xe)) ? to_f32(x[i]) : 0.f;
-    const float xev = XE ? (need_xe ? to_f32(xe[i]) : 0.f) : xv;
-    const float mn = prologue<GUIDE, SPEC>(xev, to_f32(e0[i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[i]) : 0.f,
-                                           GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[i]) : 0.f, p);
-    xo[i] = from_f32<TS>(combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[i]) : 0.f, FT::needs_h2 ? to_f32(h2[i]) : 0.f, p));
-    if (store_m) mo[i] = from_f32<TS>(mn);
+  if constexpr (!EXT) {
+    // ragged tail (n % 8 elements): first lanes of block 0, scalar
+    const int64_t tail0 = ngroups * EPT;
+    if (blockIdx.x == 0 && tail0 + threadIdx.x < n) {
+      const int64_t i = tail0 + threadIdx.x;
+      const float xv = (FT::needs_x || (!XE && need_xe)) ? to_f32(x[i]) : 0.f;
+      const float xev = XE ? (need_xe ? to_f32(xe[i]) : 0.f) : xv;
+      const float mn = prologue<GUIDE, SPEC>(xev, to_f32(e0[i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[i]) : 0.f,
+                                             GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[i]) : 0.f, p);
+      xo[i] = from_f32<TS>(combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[i]) : 0.f, FT::needs_h2 ? to_f32(h2[i]) : 0.f, p));
+      if (store_m) mo[i] = from_f32<TS>(mn);
+    }
   }
 }
 
@@ -442,71 +478,6 @@ __global__ __launch_bounds__(256) void stage_kernel_scalar(const TS* __restrict_
     xo[i] = ov;
     if (xo2) xo2[i] = ov;
     if (store_m) mo[i] = from_f32<TS>(mn);
-  }
-}
-
-// the streaming kernel with the extensions of KExt (vector path: per_sample, eps_stride and mask_period are
-// multiples of 8 and every pointer is 16/32-byte aligned; otherwise the scalar kernel runs)
-template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int SPEC, int NT>
-__global__ __launch_bounds__(256) void stage_kernel_ext(const TS* __restrict__ x, const TS* __restrict__ xe,
-                                                        const TE* __restrict__ e0, const TE* __restrict__ e1,
-                                                        const TE* __restrict__ g, const TS* __restrict__ h1,
-                                                        const TS* __restrict__ h2, TS* __restrict__ xo,
-                                                        TS* __restrict__ mo, int64_t n, KParams p, KExt ext) {
-  using FT = FormTraits<FORM>;
-  const bool need_xe = spec_need_xe<SPEC>(p);
-  const bool store_m = p.flags & DPM_F_STORE_M;
-  const TS* mask = static_cast<const TS*>(ext.mask);
-  const TS* ba = static_cast<const TS*>(ext.ba);
-  const TS* bb = static_cast<const TS*>(ext.bb);
-  TS* xo2 = static_cast<TS*>(ext.xo2);
-  const int64_t ngroups = n / EPT;
-  const int64_t gps = ext.per_sample / EPT, sgroups = ext.eps_stride / EPT, mgroups = ext.mask_period / EPT;
-  const bool small = ngroups < (int64_t)0x7fffffff;  // 32-bit index arithmetic is enough (n < 2^34 elements)
-  // split tile layout (see load_tile): all-fp32 launches without per-sample / per-period index arithmetic
-  const bool can_split = sizeof(TS) == 4 && !ext.eps_stride && !mask;
-  for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < ngroups; gi += (int64_t)gridDim.x * 256) {
-    const bool split = can_split && (gi | 255) < ngroups;
-    int64_t ge = gi;
-    if (ext.eps_stride) {
-      if (small) {
-        const uint32_t q = (uint32_t)gi / (uint32_t)gps;
-        ge = (int64_t)q * sgroups + ((uint32_t)gi - q * (uint32_t)gps);
-      } else {
-        ge = (gi / gps) * sgroups + gi % gps;
-      }
-    }
-    float vx[EPT], vxe[EPT], v0[EPT], v1[EPT], vg[EPT], vh1[EPT], vh2[EPT], vm[EPT], va[EPT], vb[EPT];
-    if (FT::needs_x || (!XE && need_xe)) load_tile<(NT & 1) != 0>(x, gi, split, vx);
-    if (XE && need_xe) load_tile<(NT & 1) != 0>(xe, gi, split, vxe);
-    load_tile<(NT & 1) != 0>(e0, ge, split, v0);
-    if (GUIDE == DPM_GUIDE_CFG) load_tile<(NT & 1) != 0>(e1, ge, split, v1);
-    if (GUIDE == DPM_GUIDE_CLASSIFIER) load_tile<(NT & 1) != 0>(g, gi, split, vg);
-    if (FT::needs_h1) load_tile<(NT & 1) != 0>(h1, gi, split, vh1);
-    if (FT::needs_h2) load_tile<(NT & 1) != 0>(h2, gi, split, vh2);
-    if (mask) {
-      const int64_t gm = small ? (int64_t)((uint32_t)gi % (uint32_t)mgroups) : gi % mgroups;
-      load_pack<false>(mask, gm, vm);
-      load_pack<false>(ba, gi, va);
-      if (bb) load_pack<(NT & 1) != 0>(bb, gi, vb);
-    }
-    float ox[EPT], om[EPT];
-#pragma unroll
-    for (int j = 0; j < EPT; ++j) {
-      const float xej = XE ? vxe[j] : vx[j];
-      const float mn = prologue<GUIDE, SPEC>(xej, v0[j], GUIDE == DPM_GUIDE_CFG ? v1[j] : 0.f,
-                                             GUIDE == DPM_GUIDE_CLASSIFIER ? vg[j] : 0.f, p);
-      om[j] = mn;
-      ox[j] = combine<FORM>(FT::needs_x ? vx[j] : 0.f, mn, FT::needs_h1 ? vh1[j] : 0.f, FT::needs_h2 ? vh2[j] : 0.f, p);
-    }
-    if (mask) {
-#pragma unroll
-      for (int j = 0; j < EPT; ++j)
-        ox[j] = blend_ref(to_f32(from_f32<TS>(ox[j])), vm[j], va[j], bb ? vb[j] : 0.f, bb != nullptr, ext);
-    }
-    store_tile<(NT & 2) != 0>(xo, gi, split, ox);
-    if (xo2) store_tile<(NT & 2) != 0>(xo2, gi, split, ox);
-    if (store_m) store_tile<(NT & 4) != 0>(mo, gi, split, om);
   }
 }
 
@@ -1173,23 +1144,33 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
       launch(stage_kernel_scalar<TS, TE, FORM, GUIDE, XE>, dim3((unsigned)blocks), dim3(256), 0, stream, x, xe, e0, e1, g,
              h1, h2, xo, mo, b->n, p, ext);
     } else if (use_ext) {
+      // (tiles per iteration, nt mask) of the inputs-from-HBM table below; x_out stays cacheable (it is the next
+      // network input), so bit 1 is never set
+      constexpr int EU = (sizeof(TS) == 4 && sizeof(TE) == 2) ? 2 : 1;
+      constexpr int ENT = sizeof(TS) == 2 ? 1 : (sizeof(TE) == 4 ? 5 : 1);
       const bool noise = st->model_type == DPM_MODEL_NOISE && (!(st->flags & DPM_F_TO_X0) || div_invariant_ok(st->alpha_e));
       const int64_t ntiles = ((b->n / EPT) + 255) / 256;
-      int64_t blocks = ntiles;
+      const bool two = EU == 2 && ntiles >= 4 * (int64_t)n_cu;  // two tiles per iteration only when there is work for it
+      int64_t blocks = two ? (ntiles + 1) / 2 : ntiles;
       const int64_t cap = (int64_t)n_cu * g_tuning.blocks_per_cu;
       if (blocks > cap) blocks = cap;
       const dim3 grid((unsigned)(blocks < 1 ? 1 : blocks));
-      // the duplicated x_out is the next network input: keep it cacheable (no nt store of x_out)
-      constexpr int NT = DefNT<TS>::value & ~2;
+#define DPM_LAUNCH_EXT(SPEC_)                                                                                           \
+  do {                                                                                                                  \
+    if (two)                                                                                                            \
+      launch(stage_kernel<TS, TE, FORM, GUIDE, XE, SPEC_, EU, ENT, true>, grid, dim3(256), 0, stream, x, xe, e0, e1, g, h1, \
+             h2, xo, mo, b->n, p, ext);                                                                                 \
+    else                                                                                                                \
+      launch(stage_kernel<TS, TE, FORM, GUIDE, XE, SPEC_, 1, ENT, true>, grid, dim3(256), 0, stream, x, xe, e0, e1, g, h1,  \
+             h2, xo, mo, b->n, p, ext);                                                                                 \
+  } while (0)
       if (!noise)
-        launch(stage_kernel_ext<TS, TE, FORM, GUIDE, XE, SPEC_GENERIC, NT>, grid, dim3(256), 0, stream, x, xe, e0, e1, g, h1,
-               h2, xo, mo, b->n, p, ext);
+        DPM_LAUNCH_EXT(SPEC_GENERIC);
       else if (st->flags & DPM_F_TO_X0)
-        launch(stage_kernel_ext<TS, TE, FORM, GUIDE, XE, SPEC_NOISE_X0, NT>, grid, dim3(256), 0, stream, x, xe, e0, e1, g, h1,
-               h2, xo, mo, b->n, p, ext);
+        DPM_LAUNCH_EXT(SPEC_NOISE_X0);
       else
-        launch(stage_kernel_ext<TS, TE, FORM, GUIDE, XE, SPEC_NOISE_EPS, NT>, grid, dim3(256), 0, stream, x, xe, e0, e1, g, h1,
-               h2, xo, mo, b->n, p, ext);
+        DPM_LAUNCH_EXT(SPEC_NOISE_EPS);
+#undef DPM_LAUNCH_EXT
     } else {
       // specialise the prologue when the stage allows it (noise-prediction network: the common case)
       const bool noise = st->model_type == DPM_MODEL_NOISE && (!(st->flags & DPM_F_TO_X0) || div_invariant_ok(st->alpha_e));
@@ -1203,8 +1184,8 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
         return dim3((unsigned)(blocks < 1 ? 1 : blocks));
       };
 #define DPM_LAUNCH(SPEC_, U_, NT_)                                                                                  \
-  launch(stage_kernel<TS, TE, FORM, GUIDE, XE, SPEC_, U_, NT_>, grid_for(U_), dim3(256), 0, stream, x, xe, e0, e1, g, \
-         h1, h2, xo, mo, b->n, p)
+  launch(stage_kernel<TS, TE, FORM, GUIDE, XE, SPEC_, U_, NT_, false>, grid_for(U_), dim3(256), 0, stream, x, xe, e0, e1, \
+         g, h1, h2, xo, mo, b->n, p, ext)
       if (spec == SPEC_GENERIC) {
         DPM_LAUNCH(SPEC_GENERIC, 1, DefNT<TS>::value);
       } else if (spec == SPEC_NOISE_EPS) {
@@ -1216,11 +1197,12 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
         //   inputs from HBM:       2-byte state (1, nt loads); fp32 + fp32 (1, nt loads + nt m store);
         //                          fp32 state + 2-byte network output (2, nt loads)  [SD under autocast: 12.3 vs 14.0 us]
         const bool resident = b->inputs_resident != 0 || tn.assume_resident != 0;
+        const bool big = ntiles >= 4 * (int64_t)n_cu;  // two tiles per iteration only when there is work for it
         const int key = (tn.unroll > 0 && tn.nontemporal >= 0) ? tn.unroll * 8 + (tn.nontemporal & 7)
-                        : resident                              ? (sizeof(TS) == 4 ? 16 : 8) + 0
+                        : resident                              ? (sizeof(TS) == 4 && big ? 16 : 8) + 0
                         : sizeof(TS) == 2                       ? 8 + 1
                         : sizeof(TE) == 4                       ? 8 + 5
-                                                                : 16 + 1;
+                                                                : (big ? 16 : 8) + 1;
         switch (key) {
           case 8 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 1, 0); break;
           case 8 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 1, 1); break;
