@@ -505,6 +505,7 @@ constexpr int THR_NB = 2048;                 // bins per radix level
 constexpr int THR_WS_WORDS = 3 * THR_NB + 64;  // per sample: 3 level histograms + counters (256-byte multiple)
 constexpr int THR_CHUNK_MAX = 12288;         // elements of a sample one workgroup keeps in LDS (48 KiB)
 constexpr int THR_CAP = 4096;                // candidates (elements sharing the selected top digit) kept compacted
+constexpr int THR_GCAP = THR_NB;             // cluster-wide candidates exchanged through the level-1 histogram's words
 
 struct ThrParams {
   int64_t per_sample;
@@ -643,7 +644,10 @@ __global__ __launch_bounds__(T) void stage_thresh_kernel(
     // LDS atomics overlap the global loads
 #pragma unroll
     for (int j = 0; j < BPT; ++j) hist[j * T + tid] = 0u;
-    if (tid == 0) misc[4] = 0u;  // candidate counter
+    if (tid == 0) {
+      misc[4] = 0u;           // candidate counter
+      misc[3] = 0x7fffffffu;  // smallest value above the selected top digit (cluster exchange)
+    }
     __syncthreads();
     if (vec) {
 #pragma unroll 2
@@ -678,7 +682,7 @@ __global__ __launch_bounds__(T) void stage_thresh_kernel(
     // through its minimum, kept per lane in `hi`.
     uint32_t prefix = 0u, known = 0u, rank = (uint32_t)tp.lo, cnt_sel = 0u;
     uint32_t hi = 0x7fffffffu, nc = 0u;
-    bool use_cand = false;
+    bool use_cand = false, local_only = k == 1;  // local_only: no further cluster-wide step is needed
 #pragma unroll 1
     for (int pass = 0; pass < 3; ++pass) {
       const int shift = pass == 0 ? 20 : pass == 1 ? 9 : 0;
@@ -701,7 +705,7 @@ __global__ __launch_bounds__(T) void stage_thresh_kernel(
         }
         __syncthreads();
       }
-      if (k > 1) {  // merge into the sample's histogram of this level, wait for the peers, read the sum back
+      if (!local_only) {  // merge into the sample's histogram of this level, wait for the peers, read the sum back
         uint32_t* gh = ws + pass * THR_NB;
 #pragma unroll
         for (int j = 0; j < BPT; ++j) {
@@ -759,6 +763,37 @@ __global__ __launch_bounds__(T) void stage_thresh_kernel(
         __syncthreads();
         nc = misc[4];
         use_cand = nc <= (uint32_t)THR_CAP;
+        if (k > 1 && cnt_sel <= (uint32_t)THR_GCAP) {
+          // The whole cluster's candidates fit one list: exchange them (and the minimum of the higher digits) once.
+          // Every workgroup then finishes levels 1, 2 and the min-above search on identical data by itself -- two
+          // cluster barriers per sample instead of four.
+          uint32_t* gl = ws + THR_NB;              // the level-1 histogram's words double as the list
+          uint32_t* ghi = ws + 3 * THR_NB + 8;     // complement of the smallest value above the selected digit
+          uint32_t* gcnt = ws + 3 * THR_NB + 9;    // list slots handed out so far
+#pragma unroll
+          for (int d = 32; d >= 1; d >>= 1) {
+            const uint32_t o = __shfl_xor(hi, d, 64);
+            hi = o < hi ? o : hi;
+          }
+          if (lane == 0) atomicMin(&misc[3], hi);
+          __syncthreads();
+          if (tid == 0) {
+            misc[5] = __hip_atomic_fetch_add(gcnt, nc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(ghi, 0x7fffffffu - misc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          __syncthreads();
+          const uint32_t slot0 = misc[5];
+          for (uint32_t i = tid; i < nc; i += T)
+            __hip_atomic_store(&gl[slot0 + i], cand[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          cluster_barrier(ws + 3 * THR_NB + 1, k);
+          nc = cnt_sel;
+          for (uint32_t i = tid; i < nc; i += T)
+            cand[i] = __hip_atomic_load(&gl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          hi = 0x7fffffffu - __hip_atomic_load(ghi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          use_cand = true;
+          local_only = true;
+          __syncthreads();
+        }
       }
     }
     const uint32_t a_bits = prefix;
@@ -787,7 +822,7 @@ __global__ __launch_bounds__(T) void stage_thresh_kernel(
       }
       if (lane == 0) atomicMin(&misc[3], m);
       __syncthreads();
-      if (k > 1) {  // workspace words start at zero: keep the minimum as a maximum of the complement
+      if (!local_only) {  // workspace words start at zero: keep the minimum as a maximum of the complement
         uint32_t* gm = ws + 3 * THR_NB + 8;
         if (tid == 0) __hip_atomic_fetch_max(gm, 0x7fffffffu - misc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         cluster_barrier(ws + 3 * THR_NB + 3, k);
