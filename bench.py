@@ -311,9 +311,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp16": "f16", "fp32": "f32", "bf16": "bf16"}[args.dtype], "data": "synthetic",
-            "config": {"workload": "DPM-Solver++ 2M, 20 steps, [256,4,64,64] %s per GPU, frozen model_fn (eps pre-staged), "
-                                   "SD-v1 scaled-linear schedule, time_uniform" % args.dtype,
+            "dtype": "f32",          # the arithmetic type of the path: fp32 whatever the storage type of the state is
+            "storage_dtype": {"fp16": "f16", "fp32": "f32", "bf16": "bf16"}[args.dtype], "data": "synthetic",
+            "config": {"workload": "DPM-Solver++ 2M, 20 steps, [256,4,64,64] %s state and network output per GPU (fp32 "
+                                   "arithmetic), frozen model_fn (eps pre-staged), SD-v1 scaled-linear schedule, "
+                                   "time_uniform" % args.dtype,
                        "batch_per_gpu": B, "solver_stages_per_step": n_stages, "buffer_sets": len(sets),
                        "launch": "hipGraph replay (dpm_graph_launch)" if args.mode == "graph" else "eager (dpm_plan_run)",
                        "parallelism": "batch-sharded x%d, no data-path collective" % world},
