@@ -46,6 +46,14 @@ def sd_alphas_cumprod():
     return np.cumprod(1.0 - betas).astype(np.float32)
 
 
+def baseline_metric():
+    """the metric string of BASELINE.json (value = its Msamples/s part; the HBM GB/s part is `roofline`)"""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "solver-update Msamples/sec + HBM GB/s, DPM-Solver++(2M) 20-step, Bx4x64x64"
+
+
 def make_sets(n_sets, dtype, dev, seed):
     """n_sets independent buffer sets: x_T, frozen eps, 3 state scratch buffers, 2 history slots."""
     from dpm_solver_amd import _lib as L
@@ -306,7 +314,7 @@ def main():
     if rank == 0:
         samples = world * args.steps * B
         line = {
-            "metric": "solver-update Msamples/sec, DPM-Solver++(2M) 20-step, Bx4x64x64",
+            "metric": baseline_metric(),
             "value": round(samples / wall / 1e6, 4), "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 5),
