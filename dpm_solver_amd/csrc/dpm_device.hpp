@@ -377,56 +377,57 @@ __global__ __launch_bounds__(256) void stage_kernel(const TS* __restrict__ x, co
   for (int64_t t0 = (int64_t)blockIdx.x * U; t0 < ntiles; t0 += (int64_t)gridDim.x * U) {
     float vx[U][EPT], vxe[U][EPT], v0[U][EPT], v1[U][EPT], vg[U][EPT], vh1[U][EPT], vh2[U][EPT];
     float vm[EXT ? U : 1][EPT], va[EXT ? U : 1][EPT], vb[EXT ? U : 1][EPT];
+    // Lanes past the end of the last tile load a clamped (valid) group and only skip the store: loads and arithmetic
+    // stay in straight-line code, so the loaded registers are consumed where they land (no copies at a join).
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t gi = (t0 + u) * 256 + threadIdx.x;
+      const int64_t gr = (t0 + u) * 256 + threadIdx.x;
+      const int64_t gi = gr < ngroups ? gr : ngroups - 1;
       const bool split = can_split && (t0 + u) * 256 + 256 <= ngroups;
-      if (gi < ngroups) {
-        int64_t ge = gi;  // group index into the network outputs
-        if (EXT && ext.eps_stride) {
-          if (small) {
-            const uint32_t q = (uint32_t)gi / (uint32_t)gps;
-            ge = (int64_t)q * sgroups + ((uint32_t)gi - q * (uint32_t)gps);
-          } else {
-            ge = (gi / gps) * sgroups + gi % gps;
-          }
+      int64_t ge = gi;  // group index into the network outputs
+      if (EXT && ext.eps_stride) {
+        if (small) {
+          const uint32_t q = (uint32_t)gi / (uint32_t)gps;
+          ge = (int64_t)q * sgroups + ((uint32_t)gi - q * (uint32_t)gps);
+        } else {
+          ge = (gi / gps) * sgroups + gi % gps;
         }
-        if (FT::needs_x || (!XE && need_xe)) load_tile<(NT & 1) != 0>(x, gi, split, vx[u]);
-        if (XE && need_xe) load_tile<(NT & 1) != 0>(xe, gi, split, vxe[u]);
-        load_tile<(NT & 1) != 0>(e0, ge, split, v0[u]);
-        if (GUIDE == DPM_GUIDE_CFG) load_tile<(NT & 1) != 0>(e1, ge, split, v1[u]);
-        if (GUIDE == DPM_GUIDE_CLASSIFIER) load_tile<(NT & 1) != 0>(g, gi, split, vg[u]);
-        if (FT::needs_h1) load_tile<(NT & 1) != 0>(h1, gi, split, vh1[u]);
-        if (FT::needs_h2) load_tile<(NT & 1) != 0>(h2, gi, split, vh2[u]);
-        if (EXT && mask) {
-          const int64_t gm = small ? (int64_t)((uint32_t)gi % (uint32_t)mgroups) : gi % mgroups;
-          load_pack<false>(mask, gm, vm[u]);
-          load_pack<false>(ba, gi, va[u]);
-          if (bb) load_pack<(NT & 1) != 0>(bb, gi, vb[u]);
-        }
+      }
+      if (FT::needs_x || (!XE && need_xe)) load_tile<(NT & 1) != 0>(x, gi, split, vx[u]);
+      if (XE && need_xe) load_tile<(NT & 1) != 0>(xe, gi, split, vxe[u]);
+      load_tile<(NT & 1) != 0>(e0, ge, split, v0[u]);
+      if (GUIDE == DPM_GUIDE_CFG) load_tile<(NT & 1) != 0>(e1, ge, split, v1[u]);
+      if (GUIDE == DPM_GUIDE_CLASSIFIER) load_tile<(NT & 1) != 0>(g, gi, split, vg[u]);
+      if (FT::needs_h1) load_tile<(NT & 1) != 0>(h1, gi, split, vh1[u]);
+      if (FT::needs_h2) load_tile<(NT & 1) != 0>(h2, gi, split, vh2[u]);
+      if (EXT && mask) {
+        const int64_t gm = small ? (int64_t)((uint32_t)gi % (uint32_t)mgroups) : gi % mgroups;
+        load_pack<false>(mask, gm, vm[u]);
+        load_pack<false>(ba, gi, va[u]);
+        if (bb) load_pack<(NT & 1) != 0>(bb, gi, vb[u]);
       }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t gi = (t0 + u) * 256 + threadIdx.x;
       const bool split = can_split && (t0 + u) * 256 + 256 <= ngroups;
+      float ox[EPT], om[EPT];
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) {
+        const float xej = XE ? vxe[u][j] : vx[u][j];
+        const float mn = prologue<GUIDE, SPEC>(xej, v0[u][j], GUIDE == DPM_GUIDE_CFG ? v1[u][j] : 0.f,
+                                               GUIDE == DPM_GUIDE_CLASSIFIER ? vg[u][j] : 0.f, p);
+        om[j] = mn;
+        ox[j] = combine<FORM>(FT::needs_x ? vx[u][j] : 0.f, mn, FT::needs_h1 ? vh1[u][j] : 0.f,
+                              FT::needs_h2 ? vh2[u][j] : 0.f, p);
+      }
+      if (EXT && mask) {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j)
+          ox[j] = blend_ref(to_f32(from_f32<TS>(ox[j])), vm[EXT ? u : 0][j], va[EXT ? u : 0][j],
+                            bb ? vb[EXT ? u : 0][j] : 0.f, bb != nullptr, ext);
+      }
       if (gi < ngroups) {
-        float ox[EPT], om[EPT];
-#pragma unroll
-        for (int j = 0; j < EPT; ++j) {
-          const float xej = XE ? vxe[u][j] : vx[u][j];
-          const float mn = prologue<GUIDE, SPEC>(xej, v0[u][j], GUIDE == DPM_GUIDE_CFG ? v1[u][j] : 0.f,
-                                                 GUIDE == DPM_GUIDE_CLASSIFIER ? vg[u][j] : 0.f, p);
-          om[j] = mn;
-          ox[j] = combine<FORM>(FT::needs_x ? vx[u][j] : 0.f, mn, FT::needs_h1 ? vh1[u][j] : 0.f,
-                                FT::needs_h2 ? vh2[u][j] : 0.f, p);
-        }
-        if (EXT && mask) {
-#pragma unroll
-          for (int j = 0; j < EPT; ++j)
-            ox[j] = blend_ref(to_f32(from_f32<TS>(ox[j])), vm[EXT ? u : 0][j], va[EXT ? u : 0][j],
-                              bb ? vb[EXT ? u : 0][j] : 0.f, bb != nullptr, ext);
-        }
         store_tile<(NT & 2) != 0>(xo, gi, split, ox);
         if (EXT && xo2) store_tile<(NT & 2) != 0>(xo2, gi, split, ox);
         if (store_m) store_tile<(NT & 4) != 0>(mo, gi, split, om);
