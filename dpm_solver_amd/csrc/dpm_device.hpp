@@ -139,13 +139,18 @@ __device__ __forceinline__ void store_pack(float* __restrict__ p, int64_t group,
   st16<NT>(q, a);
   st16<NT>(q + 1, b);
 }
+// two fp32 -> one dword of two fp16, round to nearest even (one v_cvt_pk_f16_f32)
+__device__ __forceinline__ uint32_t pack_half2(float lo, float hi) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 v = __builtin_convertvector(f2{lo, hi}, h2);
+  return __builtin_bit_cast(uint32_t, v);
+}
 template <bool NT>
 __device__ __forceinline__ void store_pack(__half* __restrict__ p, int64_t group, const float (&in)[EPT]) {
   u32x4 a;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
-    a[j] = (uint32_t)__half_as_ushort(__float2half_rn(in[2 * j])) |
-           ((uint32_t)__half_as_ushort(__float2half_rn(in[2 * j + 1])) << 16);
+  for (int j = 0; j < 4; ++j) a[j] = pack_half2(in[2 * j], in[2 * j + 1]);
   st16<NT>(reinterpret_cast<u32x4*>(p) + group, a);
 }
 template <bool NT>
@@ -233,10 +238,17 @@ struct KParams {
 // the correctly rounded quotient -- bit-identical to IEEE division, which the reference uses -- for every finite
 // x whose quotient is a normal number, provided alpha's significand is not all ones (Markstein's theorem; the launch
 // falls back to the generic prologue with a true division when that guard fails).  3 VALU ops instead of ~12.
-__device__ __forceinline__ float div_by_alpha(float x, const KParams& p) {
-  const float q = x * p.inv_alpha;
-  const float e = __builtin_fmaf(-q, p.alpha_e, x);
-  return __builtin_fmaf(e, p.inv_alpha, q);
+// The arithmetic below is written once for V = float and V = f32x2 (two adjacent elements): the streaming kernel works
+// on adjacent pairs so that the packed fp32 instructions (v_pk_mul/add/fma_f32) take their operands from the register
+// pairs the loads and conversions produce, and v_cvt_pk_f16_f32 packs the two halves of one output dword directly.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float vfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ f32x2 vfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+template <typename V>
+__device__ __forceinline__ V div_by_alpha(V x, const KParams& p) {
+  const V q = x * p.inv_alpha;
+  const V e = vfma(-q, (V)(p.alpha_e), x);
+  return vfma(e, (V)(p.inv_alpha), q);
 }
 
 // Compile-time knowledge about the prologue.  SPEC_GENERIC reads model_type / TO_X0 from the stage record at
@@ -256,8 +268,8 @@ __device__ __forceinline__ bool spec_need_xe(const KParams& p) {
 }
 
 // raw network output -> noise prediction (noise_pred_fn, ref :288-298)
-template <int SPEC>
-__device__ __forceinline__ float to_noise(float o, float xe, const KParams& p) {
+template <int SPEC, typename V>
+__device__ __forceinline__ V to_noise(V o, V xe, const KParams& p) {
   if (SPEC != SPEC_GENERIC) return o;
   switch (p.model_type) {
     case DPM_MODEL_X_START: return (xe - p.alpha_e * o) / p.sigma_e;
@@ -268,11 +280,11 @@ __device__ __forceinline__ float to_noise(float o, float xe, const KParams& p) {
 }
 
 // everything up to (not including) thresholding: returns eps, or x0 when the stage converts (DPM_F_TO_X0)
-template <int GUIDE, int SPEC = SPEC_GENERIC>
-__device__ __forceinline__ float prologue(float xe, float o0, float o1, float gg, const KParams& p) {
-  float eps;
+template <int GUIDE, int SPEC = SPEC_GENERIC, typename V = float>
+__device__ __forceinline__ V prologue(V xe, V o0, V o1, V gg, const KParams& p) {
+  V eps;
   if (GUIDE == DPM_GUIDE_CFG) {  // ref :326-330: uncond + scale * (cond - uncond)
-    float nu = to_noise<SPEC>(o1, xe, p), nc = to_noise<SPEC>(o0, xe, p);
+    V nu = to_noise<SPEC>(o1, xe, p), nc = to_noise<SPEC>(o0, xe, p);
     eps = nu + p.cfg_scale * (nc - nu);
   } else if (GUIDE == DPM_GUIDE_CLASSIFIER) {  // ref :321
     eps = to_noise<SPEC>(o0, xe, p) - p.cg_scale * gg;
@@ -285,26 +297,26 @@ __device__ __forceinline__ float prologue(float xe, float o0, float o1, float gg
 }
 
 // the exponential-integrator combination, reference association
-template <int FORM>
-__device__ __forceinline__ float combine(float x, float mn, float h1, float h2, const KParams& p) {
+template <int FORM, typename V>
+__device__ __forceinline__ V combine(V x, V mn, V h1, V h2, const KParams& p) {
   if (FORM == DPM_FORM_LIN1) {
     return p.cx * x - p.c0 * mn;  // ref :573-576, :585-588
   } else if (FORM == DPM_FORM_TWO) {
-    float D = p.k0 * (mn - h1);
-    float P = (p.flags & DPM_F_BASE_HIST) ? h1 : mn;
+    V D = p.k0 * (mn - h1);
+    V P = (p.flags & DPM_F_BASE_HIST) ? h1 : mn;
     return (p.cx * x - p.c0 * P) - p.c1 * D;  // ref :827-851 (multistep), :636-669, :728-778 (singlestep)
   } else if (FORM == DPM_FORM_MS3) {
-    float D1_0 = p.k0 * (mn - h1);  // ref :880-883
-    float D1_1 = p.k1 * (h1 - h2);
-    float dd = D1_0 - D1_1;
-    float D1 = D1_0 + p.k2 * dd;
-    float D2 = p.k3 * dd;
+    V D1_0 = p.k0 * (mn - h1);  // ref :880-883
+    V D1_1 = p.k1 * (h1 - h2);
+    V dd = D1_0 - D1_1;
+    V D1 = D1_0 + p.k2 * dd;
+    V D2 = p.k3 * dd;
     return ((p.cx * x - p.c0 * mn) - p.c1 * D1) - p.c2 * D2;  // ref :888-903
   } else if (FORM == DPM_FORM_SS3T) {
-    float D1_0 = p.k0 * (h2 - h1);  // h1 = model_s, h2 = model_s1, mn = model_s2; ref :741-750, :780-789
-    float D1_1 = p.k1 * (mn - h1);
-    float D1 = (p.k2 * D1_0 - p.k3 * D1_1) / p.k4;
-    float D2 = (2.f * (D1_1 - D1_0)) / p.k4;
+    V D1_0 = p.k0 * (h2 - h1);  // h1 = model_s, h2 = model_s1, mn = model_s2; ref :741-750, :780-789
+    V D1_1 = p.k1 * (mn - h1);
+    V D1 = (p.k2 * D1_0 - p.k3 * D1_1) / p.k4;
+    V D2 = (2.f * (D1_1 - D1_0)) / p.k4;
     return ((p.cx * x - p.c0 * h1) - p.c1 * D1) - p.c2 * D2;
   } else {
     return mn;  // DPM_FORM_DENOISE, ref :541-545
@@ -413,13 +425,19 @@ __global__ __launch_bounds__(256) void stage_kernel(const TS* __restrict__ x, co
       const bool split = can_split && (t0 + u) * 256 + 256 <= ngroups;
       float ox[EPT], om[EPT];
 #pragma unroll
-      for (int j = 0; j < EPT; ++j) {
-        const float xej = XE ? vxe[u][j] : vx[u][j];
-        const float mn = prologue<GUIDE, SPEC>(xej, v0[u][j], GUIDE == DPM_GUIDE_CFG ? v1[u][j] : 0.f,
-                                               GUIDE == DPM_GUIDE_CLASSIFIER ? vg[u][j] : 0.f, p);
-        om[j] = mn;
-        ox[j] = combine<FORM>(FT::needs_x ? vx[u][j] : 0.f, mn, FT::needs_h1 ? vh1[u][j] : 0.f,
-                              FT::needs_h2 ? vh2[u][j] : 0.f, p);
+      for (int q = 0; q < EPT; q += 2) {  // adjacent pairs: see f32x2
+        const f32x2 z = {0.f, 0.f};
+        const f32x2 x2 = FT::needs_x || (!XE && need_xe) ? f32x2{vx[u][q], vx[u][q + 1]} : z;
+        const f32x2 xe2 = XE ? f32x2{vxe[u][q], vxe[u][q + 1]} : x2;
+        const f32x2 mn = prologue<GUIDE, SPEC>(xe2, f32x2{v0[u][q], v0[u][q + 1]},
+                                               GUIDE == DPM_GUIDE_CFG ? f32x2{v1[u][q], v1[u][q + 1]} : z,
+                                               GUIDE == DPM_GUIDE_CLASSIFIER ? f32x2{vg[u][q], vg[u][q + 1]} : z, p);
+        const f32x2 o = combine<FORM>(FT::needs_x ? x2 : z, mn, FT::needs_h1 ? f32x2{vh1[u][q], vh1[u][q + 1]} : z,
+                                      FT::needs_h2 ? f32x2{vh2[u][q], vh2[u][q + 1]} : z, p);
+        om[q] = mn.x;
+        om[q + 1] = mn.y;
+        ox[q] = o.x;
+        ox[q + 1] = o.y;
       }
       if (EXT && mask) {
 #pragma unroll
@@ -572,7 +590,7 @@ __device__ __forceinline__ void store4(__half* __restrict__ p, int64_t i, const 
   u32x2 a;
 #pragma unroll
   for (int j = 0; j < 2; ++j)
-    a[j] = (uint32_t)__half_as_ushort(__float2half_rn(v[2 * j])) | ((uint32_t)__half_as_ushort(__float2half_rn(v[2 * j + 1])) << 16);
+    a[j] = pack_half2(v[2 * j], v[2 * j + 1]);
   if (NT)
     __builtin_nontemporal_store(a, reinterpret_cast<u32x2*>(p + i));
   else
