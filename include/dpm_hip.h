@@ -214,8 +214,10 @@ int dpm_coef_prologue(const dpm_schedule* s, float t_eval, int model_type, int g
 /* ---- device side --------------------------------------------------------------------------- */
 /* one fused stage kernel, asynchronous on `stream` */
 int dpm_stage_launch(const dpm_stage* st, const dpm_buffers* b, void* stream);
-/* scratch needed by stages with DPM_F_THRESH: 0 when a sample fits the LDS-resident path, else the size of the
-   multi-workgroup path's workspace (fp32 x0 + per-sample histograms); pass it as dpm_buffers.workspace */
+/* scratch needed by stages with DPM_F_THRESH on the current device: 0 when one workgroup per sample is the plan (the
+   sample lives in that workgroup's LDS), else ~24 KiB per sample of histograms / counters through which the workgroup
+   cluster of a sample synchronises (small batches, samples beyond 12288 elements); the launch zeroes it itself.
+   Pass it as dpm_buffers.workspace. */
 size_t dpm_threshold_workspace_bytes(int64_t batch, int64_t per_sample);
 /* x_t = alpha_t*x + sigma_t*noise for nt times (add_noise, ref :1012-1030); out is [nt, n] */
 int dpm_add_noise_launch(const dpm_schedule* s, const float* t_host, int nt, const void* x, const void* noise,
