@@ -146,6 +146,13 @@ __device__ __forceinline__ uint32_t pack_half2(float lo, float hi) {
   const h2 v = __builtin_convertvector(f2{lo, hi}, h2);
   return __builtin_bit_cast(uint32_t, v);
 }
+// two fp32 -> one dword of two bf16, round to nearest even (gfx950: one v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t pack_bf162(float lo, float hi) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  const b2 v = __builtin_convertvector(f2{lo, hi}, b2);
+  return __builtin_bit_cast(uint32_t, v);
+}
 template <bool NT>
 __device__ __forceinline__ void store_pack(__half* __restrict__ p, int64_t group, const float (&in)[EPT]) {
   u32x4 a;
@@ -158,7 +165,7 @@ __device__ __forceinline__ void store_pack(bf16_t* __restrict__ p, int64_t group
   u32x4 a;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
-    a[j] = (uint32_t)from_f32<bf16_t>(in[2 * j]).v | ((uint32_t)from_f32<bf16_t>(in[2 * j + 1]).v << 16);
+    a[j] = pack_bf162(in[2 * j], in[2 * j + 1]);
   st16<NT>(reinterpret_cast<u32x4*>(p) + group, a);
 }
 
@@ -600,7 +607,7 @@ template <bool NT = false>
 __device__ __forceinline__ void store4(bf16_t* __restrict__ p, int64_t i, const float (&v)[4]) {
   u32x2 a;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) a[j] = (uint32_t)from_f32<bf16_t>(v[2 * j]).v | ((uint32_t)from_f32<bf16_t>(v[2 * j + 1]).v << 16);
+  for (int j = 0; j < 2; ++j) a[j] = pack_bf162(v[2 * j], v[2 * j + 1]);
   if (NT)
     __builtin_nontemporal_store(a, reinterpret_cast<u32x2*>(p + i));
   else
