@@ -369,3 +369,23 @@ def test_plan_run_native_loop_matches_python_loop(method, order, steps, shape):
                                      ms, C_.byref(res)))
     assert torch.equal(xb[res.value], want)
     assert all(0.0 < v < 5.0 for v in ms), list(ms)
+
+
+@pytest.mark.parametrize("sdt", [torch.float16, torch.bfloat16])
+def test_half_precision_stores_round_to_nearest_even(sdt):
+    """the packed conversions on the store path (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32) against torch's rounding, ties and
+    subnormals included: one first-order stage x_out = cx * x, computed in fp32 and rounded once"""
+    rng = np.random.default_rng(12)
+    n = 1 << 16
+    base = torch.from_numpy(rng.standard_normal(n).astype(F32)).to(DEV)
+    tiny = torch.from_numpy((rng.standard_normal(4096) * 1e-6).astype(F32)).to(DEV)          # fp16 subnormal range
+    x = torch.cat([base, tiny, torch.tensor([0.0, -0.0, 1.0, 65000.0, -3e-8], device=DEV)]).to(sdt)
+    x = torch.cat([x, x[: (-x.numel()) % 8]]).reshape(1, -1)                                  # whole 8-element groups
+    for cx in (1.0 + 2.0 ** -9, 1.0 + 2.0 ** -11, 0.3333333432674408, 1.5):                  # 1 + 2^-9 / 2^-11: ties
+        st = L.Stage()
+        st.h1_slot = st.h2_slot = st.m_slot = -1
+        st.form, st.flags, st.model_type, st.guidance = L.FORM_LIN1, 0, L.MODEL["noise"], L.GUIDE["uncond"]
+        st.cx, st.c0, st.alpha_e, st.sigma_e, st.cfg_scale = cx, 0.0, 1.0, 0.0, 1.0
+        out, _ = S._launch_stage(st, x, None, torch.zeros_like(x), None, None, None, None, sdt, want_m=False)
+        want = (x.float() * np.float32(cx)).to(sdt)
+        assert torch.equal(out.view(torch.int16), want.view(torch.int16)), cx
