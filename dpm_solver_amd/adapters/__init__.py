@@ -1,2 +1,3 @@
 """Host-side mirrors of the reference's caller adapters (the code on the caller's side of the solver path)."""
 from .stable_diffusion import DPMSolverSampler  # noqa: F401
+from .guided_diffusion import sample_image as guided_diffusion_sample_image  # noqa: F401

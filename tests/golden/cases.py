@@ -235,3 +235,42 @@ class FakeLatentDiffusion:
     def apply_model(self, x, t, c):
         self.calls.append((tuple(x.shape), float(t.reshape(-1)[0])))
         return x * _bshape(c * F32(0.1).item() + 0.5, x)
+
+
+# --------------------------------------------------------------------------------------
+# guided-diffusion runner wiring (examples/ddpm_and_guided-diffusion/runners/diffusion.py:594-640): stand-ins for the
+# 6-channel (learned variance) UNet and the noisy classifier.  Weights are fixed numbers, the classifier is linear in
+# pooled features, so torch on CPU (golden) and on the GPU agree to rounding.
+# --------------------------------------------------------------------------------------
+GD_SHAPE = (4, 3, 8, 8)
+GD_CLASSES = 5
+
+
+def gd_inputs():
+    rng = np.random.default_rng(31)
+    return dict(x=rng.standard_normal(GD_SHAPE).astype(F32), y=np.array([0, 3, 1, 4], dtype=np.int64),
+                w=(rng.standard_normal((GD_CLASSES, GD_SHAPE[1])) * 0.3).astype(F32),
+                junk=rng.standard_normal((GD_SHAPE[0], 3) + GD_SHAPE[2:]).astype(F32))
+
+
+def gd_network(torch, junk):
+    """[B,3,H,W] -> [B,6,H,W]: mean half depends on x, t and the label; variance half is unrelated data"""
+    def net(x, t, y=None):
+        scale = (t * F32(0.0005).item() + 0.25) + (y.to(x.dtype) * F32(0.05).item() if y is not None else 0.0)
+        return torch.cat([x * scale.reshape(-1, 1, 1, 1), junk.to(x.device)[: x.shape[0]]], dim=1)
+    return net
+
+
+def gd_classifier(torch, w):
+    def clf(x, t):
+        feat = x.mean(dim=(2, 3))                                   # [B, C]
+        return feat @ w.to(x.device).t() + (t * F32(0.001).item()).reshape(-1, 1)
+    return clf
+
+
+GD_RUNS = [
+    ("pp_clf_thresh_denoise", dict(sample_type="dpmsolver++", use_clf=True, thresholding=True, denoise=True, scale=2.0)),
+    ("pp_uncond", dict(sample_type="dpmsolver++", use_clf=False, thresholding=False, denoise=False, scale=1.0)),
+    ("eps_clf_ss3", dict(sample_type="dpmsolver", use_clf=True, thresholding=False, denoise=False, scale=1.5,
+                         method="singlestep", order=3, timesteps=9)),
+]

@@ -365,8 +365,37 @@ def gen_legacy(out):
     print("  legacy: cosine T=%.4f, noclip total_N=%d" % (ns.T, nd.total_N))
 
 
+def gen_guided(out):
+    """The DPM-Solver branch of the guided-diffusion runner (runners/diffusion.py:594-640) wired by hand around the
+    reference solver classes: 6-channel network, classifier guidance through log_softmax + autograd, thresholding,
+    denoise.  (The Runner class itself needs the whole app's args/config machinery; the wiring is eight lines.)"""
+    inp = C.gd_inputs()
+    x, y = tt(inp["x"]), torch.from_numpy(inp["y"])
+    model = C.gd_network(torch, tt(inp["junk"]))
+    classifier = C.gd_classifier(torch, tt(inp["w"]))
+    betas = tt(C.schedule_inputs("ddpm")["betas"])
+
+    def run(sample_type, use_clf, thresholding, denoise, scale, method="multistep", order=2, timesteps=12):
+        def model_fn(xx, t, **kw):
+            return torch.split(model(xx, t, **kw), 3, dim=1)[0]
+
+        def classifier_fn(xx, t, yy, **kw):
+            log_probs = torch.nn.functional.log_softmax(classifier(xx, t), dim=-1)
+            return log_probs[range(len(log_probs)), yy.view(-1)]
+        ns = R.NoiseScheduleVP(schedule="discrete", betas=betas)
+        fn = R.model_wrapper(model_fn, ns, model_type="noise", model_kwargs={"y": y},
+                             guidance_type="classifier" if use_clf else "uncond", condition=y, guidance_scale=scale,
+                             classifier_fn=classifier_fn, classifier_kwargs={})
+        dpm = R.DPM_Solver(fn, ns, algorithm_type=sample_type,
+                           correcting_x0_fn="dynamic_thresholding" if thresholding else None)
+        return dpm.sample(x, steps=(timesteps - 1 if denoise else timesteps), order=order, skip_type="time_uniform",
+                          method=method, lower_order_final=True, denoise_to_zero=denoise, solver_type="dpmsolver")
+    for tag, kw in C.GD_RUNS:
+        out["guided/" + tag] = run(**kw).detach().numpy()
+
+
 def main():
-    groups = dict(legacy=gen_legacy, schedules=gen_schedules, timesteps=gen_timesteps, updates=gen_updates,
+    groups = dict(guided=gen_guided, legacy=gen_legacy, schedules=gen_schedules, timesteps=gen_timesteps, updates=gen_updates,
                   quantile=gen_quantile, add_noise=gen_add_noise, e2e=gen_e2e,
                   callbacks=gen_callbacks, adaptive=gen_adaptive, sampler=gen_sampler)
     only = sys.argv[1:]

@@ -472,3 +472,12 @@ def test_captured_sample_with_clustered_thresholding():
         assert torch.equal(g(x), want)
     x2 = x * 0.75
     assert torch.equal(g(x2), dpm.sample(x2, **kw))
+
+
+def test_guided_diffusion_adapter_against_reference_goldens(golden, monkeypatch):
+    """runners/diffusion.py:594-640 on the HIP path: 6-channel network read in place, classifier guidance through
+    log_softmax + autograd, thresholding, denoise -- vs goldens from the reference solver with the same wiring"""
+    import test_host_logic as TH
+    spy = LaunchSpy(monkeypatch)
+    TH.guided_checks(golden, DEV, 2 * TOL)
+    assert all(c["eps_stride"] == 2 * 3 * 8 * 8 for c in spy.calls)       # the mean half is never copied out

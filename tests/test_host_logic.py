@@ -463,3 +463,27 @@ def test_random_configurations_against_oracle(seed):
         got, want = run_random_config(cfg, "cpu")
         assert np.all(np.isfinite(want)), cfg
         assert rel_err(got, want) < TOL, cfg
+
+
+# ------------------------------------------------------------------------------------------------
+# the guided-diffusion runner's DPM-Solver branch (runners/diffusion.py:594-640) against goldens from the reference
+# ------------------------------------------------------------------------------------------------
+def guided_checks(golden, device, tol):
+    from dpm_solver_amd.adapters import guided_diffusion_sample_image
+    inp = C.gd_inputs()
+    x, y = tt(inp["x"], device), torch.from_numpy(inp["y"]).to(device)
+    model = C.gd_network(torch, tt(inp["junk"], device))
+    classifier = C.gd_classifier(torch, tt(inp["w"], device))
+    betas = torch.from_numpy(C.schedule_inputs("ddpm")["betas"])
+    for tag, kw in C.GD_RUNS:
+        got, cls = guided_diffusion_sample_image(
+            x, model, betas, classifier=classifier if kw["use_clf"] else None, classes=y,
+            classifier_scale=kw["scale"], out_channels=6, sample_type=kw["sample_type"], thresholding=kw["thresholding"],
+            timesteps=kw.get("timesteps", 12), denoise=kw["denoise"], dpm_solver_order=kw.get("order", 2),
+            dpm_solver_method=kw.get("method", "multistep"))
+        assert cls is y
+        assert rel_err(got.cpu().numpy(), golden.get("guided", "guided/" + tag)) < tol, tag
+
+
+def test_guided_diffusion_adapter_against_reference_goldens(golden):
+    guided_checks(golden, "cpu", TOL)
