@@ -516,19 +516,32 @@ __global__ __launch_bounds__(256) void stage_kernel_scalar(const TS* __restrict_
 // A *cluster* of k workgroups owns one sample at a time (k = 1 when a sample fits one workgroup's LDS and the batch
 // alone fills the chip; k > 1 spreads small batches and large samples -- 3x256x256 pixels -- over many CUs).  Each
 // workgroup computes x0 for its chunk of the sample ONCE into LDS, so HBM sees every stream exactly once (5N for the
-// 2M stage).  The quantile needs two exact order statistics: an 11/11/9-bit radix select over the bit pattern of
-// |x0| (non-negative floats order like their bit patterns).  Per level: LDS histogram by atomics -> (k > 1: merged
-// into the sample's global histogram, cluster barrier, read back) -> every workgroup locates the bin of the wanted
-// rank by wavefront prefix sums (__shfl_up) over 2 bins per lane.  The next order statistic, when it is not a
-// duplicate, is the smallest value above the selected one: wavefront min (__shfl_xor) + one atomic per wave.  The
-// fractional rank is the reference's fp32 `ratio*(n-1)` and the interpolation is ATen's lerp.
+// 2M stage).  The quantile needs two exact order statistics of |x0| (non-negative floats order like their bit
+// patterns).  Two routes to a short candidate list that provably holds them:
+//   * top-K front end (ratio close to 1: K = n - rank is a small part of the thread count): every thread keeps the
+//     largest |x0| it produced; the K-th largest element of the sample is at least the K-th largest of those maxima, so
+//     a histogram of ONE value per thread bounds the top digit, and the elements at or above it are the candidates;
+//   * otherwise the level-0 histogram (top 11 bits) of all elements, built by LDS atomics during the load phase; the
+//     candidates are the elements of the selected bin, the smallest value of the higher bins rides along.
+// The candidates are compacted (count in registers, wavefront scan, one LDS atomic per wavefront), exchanged through the
+// workspace when k > 1, and -- when there are at most T of them, the usual case -- finished by rank counting: every
+// thread counts the candidates smaller than its own one.  Longer lists (plateaus, K > T/4) run the remaining levels of
+// an 11/11/9-bit radix select and a min-above search.  Bins are located by a workgroup-wide prefix sum (16 bytes of
+// histogram per thread, DPP wavefront scan).  The fractional rank is the reference's fp32 `ratio*(n-1)` and the
+// interpolation is ATen's lerp.
 //
 // Cluster barriers are single-use counters in a zeroed workspace (agent-scope atomics); the launch keeps the grid
 // within the number of co-resident workgroups, so waiting workgroups can always be joined by their peers.
 // ------------------------------------------------------------------------------------------------
 constexpr int THR_THREADS = 512;
 constexpr int THR_NB = 2048;                 // bins per radix level
-constexpr int THR_WS_WORDS = 3 * THR_NB + 64;  // per sample: 3 level histograms + counters (256-byte multiple)
+// workspace words per sample (k > 1): 3 level histograms, the histogram of the per-thread maxima and the candidate list
+// of the top-K front end, counters (a 256-byte multiple)
+constexpr int THR_WS_WORDS = 5 * THR_NB + 64;
+constexpr int THR_WS_MAXH = 3 * THR_NB;
+constexpr int THR_WS_LIST = 4 * THR_NB;
+constexpr int THR_WS_CNT = 5 * THR_NB;  // [0..3] barriers of the radix levels / min-above, [4..5] barriers of the top-K front
+                                        // end, [8] min-above complement, [9], [10] list cursors
 constexpr int THR_CHUNK_MAX = 12288;         // elements of a sample one workgroup keeps in LDS (48 KiB)
 constexpr int THR_CAP = 4096;                // candidates (elements sharing the selected top digit) kept compacted
 constexpr int THR_GCAP = THR_NB;             // cluster-wide candidates exchanged through the level-1 histogram's words
@@ -543,16 +556,21 @@ struct ThrParams {
   int32_t groups;  // clusters in the grid
   int32_t batch;
   int32_t vec;     // 1: 4-element vector accesses are legal for every tensor of this launch
+  int32_t topk;    // > 0: K = per_sample - lo is small enough for the top-K front end of the select
+  int32_t mrank;   // top-K: ascending rank of the K-th largest per-thread maximum among the contributing threads
   int32_t pad;
   uint32_t* ws;    // k > 1: batch x THR_WS_WORDS zeroed words
 };
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(v, d, 64);
-    if (lane >= d) v += t;
-  }
+// inclusive prefix sum over the 64 lanes of a wavefront: DPP row shifts inside the rows of 16 lanes, then the two row
+// broadcasts (no LDS traffic, six VALU instructions).  Needs all 64 lanes active.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
   return v;
 }
 
@@ -631,23 +649,147 @@ __device__ __forceinline__ void cluster_barrier(uint32_t* cnt, uint32_t k) {
   __syncthreads();
 }
 
+// Every thread owns 4 consecutive bins of the workgroup's LDS histogram (THR_NB = 4 T): one conflict-free 16-byte
+// read, a wavefront scan, the wavefront totals through LDS.  The thread whose bins hold the ascending `rank`
+// publishes misc[0] = bin, misc[1] = rank inside that bin, misc[2] = the bin's count.  The histogram is left ZEROED.
+template <int T>
+__device__ __forceinline__ void locate_bin(uint32_t* hist, uint32_t* misc, uint32_t rank, int tid) {
+  static_assert(THR_NB == 4 * T, "one 16-byte histogram slice per thread");
+  u32x4* h4 = reinterpret_cast<u32x4*>(hist);
+  const u32x4 v = h4[tid];
+  h4[tid] = u32x4{0u, 0u, 0u, 0u};
+  const uint32_t tot = (v[0] + v[1]) + (v[2] + v[3]);
+  const uint32_t incl = wave_incl_scan(tot);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wavefront-uniform: scalar compares below
+  if ((tid & 63) == 63) misc[16 + wave] = incl;
+  __syncthreads();
+  static_assert(T / 64 == 8, "two 16-byte reads of the wavefront totals");
+  const u32x4 w0 = *reinterpret_cast<const u32x4*>(misc + 16), w1 = *reinterpret_cast<const u32x4*>(misc + 20);
+  uint32_t before = 0u;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) before += (w < wave ? w0[w] : 0u) + (w + 4 < wave ? w1[w] : 0u);
+  const uint32_t excl = before + incl - tot;
+  if (rank >= excl && rank - excl < tot) {
+    uint32_t r = rank - excl, cbin = v[0];
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+      if (j == q - 1 && r >= cbin) {
+        r -= cbin;
+        cbin = v[q];
+        j = q;
+      }
+    misc[0] = (uint32_t)(tid * 4 + j);
+    misc[1] = r;
+    misc[2] = cbin;
+  }
+  __syncthreads();
+}
+
+// Append the elements of sx0[0..n) whose top digit d satisfies (GE ? d >= bin : d == bin) to cand[] (capacity THR_CAP;
+// misc[4] counts all of them): count in registers, wavefront scan, ONE LDS atomic per wavefront for the base slot,
+// write -- not one atomic round trip per 64 elements.  Returns this lane's minimum of the elements above digit `bin`.
+template <int T, bool GE>
+__device__ __forceinline__ uint32_t compact_candidates(const float* sx0, int n, uint32_t bin, uint32_t* misc,
+                                                       uint32_t* cand, int tid) {
+  constexpr int NIT = THR_CHUNK_MAX / (T * 4);
+  constexpr uint32_t ABS = 0x7fffffffu;
+  u32x4 q[NIT];
+  uint32_t cnt = 0u, hi = ABS;
+  const int last = n > 0 ? ((n - 1) & ~3) : 0;  // rows beyond the end re-read the last group: all LDS reads issue at once
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = tid * 4 + it * T * 4;
+    q[it] = *reinterpret_cast<const u32x4*>(sx0 + (i < n ? i : last));
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = tid * 4 + it * T * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t u = q[it][j] & ABS;
+      const uint32_t d = u >> 20;
+      const bool in = i + j < n;
+      cnt += (in && (GE ? d >= bin : d == bin)) ? 1u : 0u;
+      if (!GE && in && d > bin && u < hi) hi = u;
+    }
+  }
+  const uint32_t incl = wave_incl_scan(cnt);
+  uint32_t slot = 0u;
+  if ((tid & 63) == 63 && incl) slot = atomicAdd(&misc[4], incl);
+  uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)slot, 63) + incl - cnt;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = tid * 4 + it * T * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t u = q[it][j] & ABS;
+      const uint32_t d = u >> 20;
+      if (i + j < n && (GE ? d >= bin : d == bin)) {
+        if (off < (uint32_t)THR_CAP) cand[off] = u;
+        ++off;
+      }
+    }
+  }
+  return hi;
+}
+
+// nc <= T candidates in cand[]: every thread counts the candidates smaller than its own one; the element of ascending
+// rank r is the largest candidate with at most r smaller ones.  misc[6] <- rank-th, misc[7] <- (rank+1)-th (or the
+// largest candidate when there is none).  One pass, two barriers -- instead of three histogram levels + a min search.
+template <int T>
+__device__ __forceinline__ void rank_select(uint32_t* cand, uint32_t nc, uint32_t rank, uint32_t* misc, int tid) {
+  if (tid == 0) {
+    misc[6] = 0u;
+    misc[7] = 0u;
+  }
+  if (tid < 32) cand[nc + tid] = 0xffffffffu;  // sentinels (never smaller than anything): the list becomes a multiple of 32
+  __syncthreads();
+  if ((uint32_t)(tid & ~63) < nc) {  // wavefronts beyond the list have nothing to do
+    const uint32_t my = (uint32_t)tid < nc ? cand[tid] : 0xffffffffu;
+    uint32_t lt = 0u;
+    for (uint32_t j = 0; j < nc; j += 32) {  // broadcast reads, eight in flight
+      u32x4 q[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) q[e] = *reinterpret_cast<const u32x4*>(cand + j + 4 * e);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        lt += (q[e][0] < my ? 1u : 0u) + (q[e][1] < my ? 1u : 0u) + (q[e][2] < my ? 1u : 0u) + (q[e][3] < my ? 1u : 0u);
+    }
+    uint32_t ma = ((uint32_t)tid < nc && lt <= rank) ? my : 0u;
+    uint32_t mb = ((uint32_t)tid < nc && lt <= rank + 1u) ? my : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint32_t oa = __shfl_xor(ma, d, 64), ob = __shfl_xor(mb, d, 64);
+      ma = oa > ma ? oa : ma;
+      mb = ob > mb ? ob : mb;
+    }
+    if ((tid & 63) == 0) {
+      atomicMax(&misc[6], ma);
+      atomicMax(&misc[7], mb);
+    }
+  }
+  __syncthreads();
+}
+
 template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int T>
-__global__ __launch_bounds__(T) void stage_thresh_kernel(
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void stage_thresh_kernel(
     const TS* __restrict__ x, const TS* __restrict__ xe, const TE* __restrict__ e0, const TE* __restrict__ e1,
     const TE* __restrict__ g, const TS* __restrict__ h1, const TS* __restrict__ h2, TS* __restrict__ xo,
     TS* __restrict__ mo, KParams p, ThrParams tp, KExt ext) {
   using FT = FormTraits<FORM>;
   constexpr int BPT = THR_NB / T;  // histogram bins per thread when all threads touch the histogram
+  constexpr uint32_t ABS = 0x7fffffffu;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   float* sx0 = reinterpret_cast<float*>(lds_raw);                    // [chunk]
   uint32_t* hist = reinterpret_cast<uint32_t*>(sx0 + tp.chunk);      // [THR_NB]
-  uint32_t* misc = hist + THR_NB;                                    // [32]: selection result [3], min-above, candidate count
-  uint32_t* cand = misc + 32;                                        // [THR_CAP] candidates of levels 1, 2
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
+  uint32_t* misc = hist + THR_NB;                                    // [32]: [0..2] locate_bin result, [3] min-above, [4] candidate
+                                                                     // count, [5] list cursor, [16..23] wavefront totals
+  uint32_t* cand = misc + 32;                                        // [THR_CAP + 32] candidates (+ sentinels)
   const bool store_m = p.flags & DPM_F_STORE_M;
   const bool vec = tp.vec != 0;
   const uint32_t k = (uint32_t)tp.k;
+  const bool topk = tp.topk > 0;
   const int grp = k == 1 ? (int)blockIdx.x : (int)(blockIdx.x / k);
   const int c = k == 1 ? 0 : (int)(blockIdx.x % k);
   const TS* mask = static_cast<const TS*>(ext.mask);
@@ -656,6 +798,11 @@ __global__ __launch_bounds__(T) void stage_thresh_kernel(
   TS* xo2 = static_cast<TS*>(ext.xo2);
 
   for (int s_idx = grp; s_idx < tp.batch; s_idx += tp.groups) {
+    // The thread index is re-materialised per sample: otherwise the compiler hoists every per-thread predicate of the
+    // body (dozens of 64-bit lane masks) out of this loop, runs out of SGPRs and pays v_readlane pairs all over the select.
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
     const int64_t base = (int64_t)s_idx * tp.per_sample + (int64_t)c * tp.chunk;
     const int64_t ebase = (int64_t)s_idx * (ext.eps_stride ? ext.eps_stride : tp.per_sample) + (int64_t)c * tp.chunk;
     const int64_t left = tp.per_sample - (int64_t)c * tp.chunk;
@@ -666,15 +813,16 @@ __global__ __launch_bounds__(T) void stage_thresh_kernel(
     const uint32_t mbase = (mask && !mfull) ? (uint32_t)(base % ext.mask_period) : 0u;
     const uint32_t mper = (uint32_t)ext.mask_period;
 
-    // phase 1: x0 of this workgroup's chunk -> LDS, and the level-0 histogram (top 11 bits of |x0|) on the way: the
-    // LDS atomics overlap the global loads
+    // phase 1: x0 of this workgroup's chunk -> LDS.  On the way: the largest |x0| of every thread (top-K front end),
+    // or the level-0 histogram (top 11 bits of |x0|) -- its LDS atomics overlap the global loads
 #pragma unroll
     for (int j = 0; j < BPT; ++j) hist[j * T + tid] = 0u;
     if (tid == 0) {
-      misc[4] = 0u;           // candidate counter
-      misc[3] = 0x7fffffffu;  // smallest value above the selected top digit (cluster exchange)
+      misc[4] = 0u;   // candidate counter
+      misc[3] = ABS;  // smallest value above the selected top digit (cluster exchange)
     }
     __syncthreads();
+    uint32_t mx = 0u;
     if (vec) {
 #pragma unroll 2
       for (int i = tid * 4; i < n; i += T * 4) {
@@ -687,8 +835,16 @@ __global__ __launch_bounds__(T) void stage_thresh_kernel(
         for (int j = 0; j < 4; ++j)
           o[j] = prologue<GUIDE>(vx[j], v0[j], GUIDE == DPM_GUIDE_CFG ? v1[j] : 0.f, GUIDE == DPM_GUIDE_CLASSIFIER ? vg[j] : 0.f, p);
         store4(sx0, i, o);
+        if (topk) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) atomicAdd(&hist[(__float_as_uint(o[j]) & 0x7fffffffu) >> 20], 1u);
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t u = __float_as_uint(o[j]) & ABS;
+            mx = u > mx ? u : mx;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) atomicAdd(&hist[(__float_as_uint(o[j]) & ABS) >> 20], 1u);
+        }
       }
     } else {
 #pragma unroll 4
@@ -697,36 +853,103 @@ __global__ __launch_bounds__(T) void stage_thresh_kernel(
         const float o = prologue<GUIDE>(xev, to_f32(e0[ebase + i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[ebase + i]) : 0.f,
                                         GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[base + i]) : 0.f, p);
         sx0[i] = o;
-        atomicAdd(&hist[(__float_as_uint(o) & 0x7fffffffu) >> 20], 1u);
+        const uint32_t u = __float_as_uint(o) & ABS;
+        if (topk)
+          mx = u > mx ? u : mx;
+        else
+          atomicAdd(&hist[u >> 20], 1u);
       }
     }
+    const bool has = (vec ? tid * 4 : tid) < n;  // this thread produced at least one element (launch: ThrParams.mrank)
     __syncthreads();
 
-    // phase 2: radix select of the lo-th smallest |x0| of the whole sample, 11 + 11 + 9 bits.  After level 0 the
-    // elements that share the selected top digit -- the only ones levels 1, 2 and the min-above search can still
-    // care about -- are compacted into `cand` (wave-aggregated append); everything above that digit only matters
-    // through its minimum, kept per lane in `hi`.
+    // phase 2: the lo-th smallest |x0| of the whole sample.
     uint32_t prefix = 0u, known = 0u, rank = (uint32_t)tp.lo, cnt_sel = 0u;
-    uint32_t hi = 0x7fffffffu, nc = 0u;
+    uint32_t hi = ABS, nc = 0u;
     bool use_cand = false, local_only = k == 1;  // local_only: no further cluster-wide step is needed
+    bool hist_ready = !topk;                     // the level-0 histogram of the whole chunk exists
+    bool fast = false;                           // the candidates are few: finish by rank counting
+
+    if (topk) {
+      // Top-K front end (the usual case: ratio close to 1, K = n - lo elements at or above the wanted one, K much smaller
+      // than the number of threads).  The K-th largest element of the sample is at least the K-th largest of the
+      // per-thread maxima (those are K distinct elements), so every element that can still matter has a top digit >=
+      // the digit of that maximum: a histogram of ONE value per thread instead of one LDS atomic per element on a
+      // few hot bins (|x0| of one sample sits in a handful of exponents), then the usual compaction.
+      if (has) atomicAdd(&hist[mx >> 20], 1u);
+      __syncthreads();
+      if (k > 1) {
+        uint32_t* gh = ws + THR_WS_MAXH;
+#pragma unroll
+        for (int j = 0; j < BPT; ++j) {
+          const uint32_t v = hist[j * T + tid];
+          if (v) __hip_atomic_fetch_add(&gh[j * T + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        cluster_barrier(ws + THR_WS_CNT + 4, k);
+#pragma unroll
+        for (int j = 0; j < BPT; ++j)
+          hist[j * T + tid] = __hip_atomic_load(&gh[j * T + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+      }
+      locate_bin<T>(hist, misc, (uint32_t)tp.mrank, tid);
+      const uint32_t bin_lo = misc[0];
+      (void)compact_candidates<T, true>(sx0, n, bin_lo, misc, cand, tid);
+      __syncthreads();
+      nc = misc[4];
+      bool ok = nc <= (uint32_t)THR_CAP;
+      if (k > 1) {  // one list for the cluster; every workgroup then finishes on identical data by itself
+        uint32_t* gl = ws + THR_WS_LIST;
+        uint32_t* gcnt = ws + THR_WS_CNT + 10;
+        if (tid == 0) misc[5] = __hip_atomic_fetch_add(gcnt, nc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const uint32_t slot0 = misc[5];
+        if (ok && slot0 <= (uint32_t)THR_GCAP && nc <= (uint32_t)THR_GCAP - slot0)
+          for (uint32_t i = tid; i < nc; i += T)
+            __hip_atomic_store(&gl[slot0 + i], cand[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cluster_barrier(ws + THR_WS_CNT + 5, k);
+        const uint32_t total = __hip_atomic_load(gcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = total <= (uint32_t)THR_GCAP;
+        if (ok) {
+          nc = total;
+          for (uint32_t i = tid; i < nc; i += T)
+            cand[i] = __hip_atomic_load(&gl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+      }
+      if (ok && nc >= (uint32_t)tp.topk) {
+        use_cand = true;
+        local_only = true;
+        rank = nc - (uint32_t)tp.topk;  // ascending rank of the wanted element inside the list
+        fast = nc <= (uint32_t)T;
+      } else {  // plateaus: too many elements share the digit -- start over with the full histograms
+        nc = 0u;
+        if (tid == 0) misc[4] = 0u;
+      }
+      hist_ready = false;
+    }
+
+    // 11 + 11 + 9-bit radix select over the candidates, or over the whole chunk.  In the latter case the elements
+    // that share the selected top digit -- the only ones levels 1, 2 and the min-above search can still care about --
+    // are compacted into `cand` after level 0 (wave-aggregated append); everything above that digit only matters
+    // through its minimum, kept per lane in `hi`.
 #pragma unroll 1
-    for (int pass = 0; pass < 3; ++pass) {
+    for (int pass = 0; pass < 3 && !fast; ++pass) {
       const int shift = pass == 0 ? 20 : pass == 1 ? 9 : 0;
       const uint32_t dmask = pass == 2 ? 0x1ffu : 0x7ffu;
-      if (pass > 0) {
-#pragma unroll
-        for (int j = 0; j < BPT; ++j) hist[j * T + tid] = 0u;
-        __syncthreads();
+      if (pass > 0 || !hist_ready) {  // the histogram is all zero here (sample start / locate_bin)
         if (use_cand) {
           for (uint32_t i = tid; i < nc; i += T) {
             const uint32_t u = cand[i];
             if ((u & known) == prefix) atomicAdd(&hist[(u >> shift) & dmask], 1u);
           }
         } else {
-#pragma unroll 4
-          for (int i = tid; i < n; i += T) {
-            const uint32_t u = __float_as_uint(sx0[i]) & 0x7fffffffu;
-            if ((u & known) == prefix) atomicAdd(&hist[(u >> shift) & dmask], 1u);
+          for (int i = tid * 4; i < n; i += T * 4) {
+            const u32x4 q = *reinterpret_cast<const u32x4*>(sx0 + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const uint32_t u = q[j] & ABS;
+              if (i + j < n && (u & known) == prefix) atomicAdd(&hist[(u >> shift) & dmask], 1u);
+            }
           }
         }
         __syncthreads();
@@ -738,54 +961,20 @@ __global__ __launch_bounds__(T) void stage_thresh_kernel(
           const uint32_t v = hist[j * T + tid];
           if (v) __hip_atomic_fetch_add(&gh[j * T + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        cluster_barrier(ws + 3 * THR_NB + pass, k);
+        cluster_barrier(ws + THR_WS_CNT + pass, k);
 #pragma unroll
         for (int j = 0; j < BPT; ++j)
           hist[j * T + tid] = __hip_atomic_load(&gh[j * T + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
       }
-      // wavefront 0 locates the bin holding `rank`: two levels of wavefront prefix sums (64 x 32 bins)
-      if (tid < 64) {
-        const u32x4* h4 = reinterpret_cast<const u32x4*>(hist) + lane * 8;
-        uint32_t tot = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const u32x4 v = h4[j];
-          tot += (v[0] + v[1]) + (v[2] + v[3]);
-        }
-        const uint32_t incl = wave_incl_scan(tot, lane);
-        const int owner = __ffsll((long long)__ballot(incl > rank)) - 1;  // first 32-bin group reaching the rank
-        const uint32_t before_grp = __shfl(incl - tot, owner, 64);
-        const uint32_t cbin = lane < 32 ? hist[owner * 32 + lane] : 0u;
-        const uint32_t incl2 = wave_incl_scan(cbin, lane) + before_grp;
-        const int ob = __ffsll((long long)__ballot(lane < 32 && incl2 > rank)) - 1;
-        if (lane == ob) {
-          misc[0] = (uint32_t)(owner * 32 + ob);
-          misc[1] = rank - (incl2 - cbin);
-          misc[2] = cbin;
-        }
-      }
-      __syncthreads();
+      locate_bin<T>(hist, misc, rank, tid);
       prefix |= misc[0] << shift;
       known |= dmask << shift;
       rank = misc[1];
       cnt_sel = misc[2];
-      if (pass == 0) {  // compact this chunk's candidates, remember the smallest value of the higher digits
+      if (pass == 0 && !use_cand) {  // compact this chunk's candidates, remember the smallest value of the higher digits
         const uint32_t bin0 = prefix >> 20;
-        for (int i = tid; i < n; i += T) {
-          const uint32_t u = __float_as_uint(sx0[i]) & 0x7fffffffu;
-          const uint32_t d = u >> 20;
-          const bool is_c = d == bin0;
-          const uint64_t bal = __ballot(is_c);
-          if (bal) {  // one LDS atomic per wavefront: the first candidate lane reserves slots for all of them
-            const int leader = __ffsll((long long)bal) - 1;
-            uint32_t slot = 0;
-            if (lane == leader) slot = atomicAdd(&misc[4], (uint32_t)__popcll(bal));
-            slot = __shfl(slot, leader, 64) + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-            if (is_c && slot < (uint32_t)THR_CAP) cand[slot] = u;
-          }
-          if (d > bin0 && u < hi) hi = u;
-        }
+        hi = compact_candidates<T, false>(sx0, n, bin0, misc, cand, tid);
         __syncthreads();
         nc = misc[4];
         use_cand = nc <= (uint32_t)THR_CAP;
@@ -793,9 +982,9 @@ __global__ __launch_bounds__(T) void stage_thresh_kernel(
           // The whole cluster's candidates fit one list: exchange them (and the minimum of the higher digits) once.
           // Every workgroup then finishes levels 1, 2 and the min-above search on identical data by itself -- two
           // cluster barriers per sample instead of four.
-          uint32_t* gl = ws + THR_NB;              // the level-1 histogram's words double as the list
-          uint32_t* ghi = ws + 3 * THR_NB + 8;     // complement of the smallest value above the selected digit
-          uint32_t* gcnt = ws + 3 * THR_NB + 9;    // list slots handed out so far
+          uint32_t* gl = ws + THR_NB;               // the level-1 histogram's words double as the list
+          uint32_t* ghi = ws + THR_WS_CNT + 8;      // complement of the smallest value above the selected digit
+          uint32_t* gcnt = ws + THR_WS_CNT + 9;     // list slots handed out so far
 #pragma unroll
           for (int d = 32; d >= 1; d >>= 1) {
             const uint32_t o = __shfl_xor(hi, d, 64);
@@ -805,56 +994,88 @@ __global__ __launch_bounds__(T) void stage_thresh_kernel(
           __syncthreads();
           if (tid == 0) {
             misc[5] = __hip_atomic_fetch_add(gcnt, nc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_max(ghi, 0x7fffffffu - misc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(ghi, ABS - misc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
           __syncthreads();
           const uint32_t slot0 = misc[5];
           for (uint32_t i = tid; i < nc; i += T)
             __hip_atomic_store(&gl[slot0 + i], cand[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          cluster_barrier(ws + 3 * THR_NB + 1, k);
+          cluster_barrier(ws + THR_WS_CNT + 1, k);
           nc = cnt_sel;
           for (uint32_t i = tid; i < nc; i += T)
             cand[i] = __hip_atomic_load(&gl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          hi = 0x7fffffffu - __hip_atomic_load(ghi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          hi = ABS - __hip_atomic_load(ghi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           use_cand = true;
           local_only = true;
           __syncthreads();
         }
+        fast = use_cand && local_only && nc <= (uint32_t)T;
       }
     }
-    const uint32_t a_bits = prefix;
-    float a = __uint_as_float(a_bits), b = a;
-    if (tp.hi != tp.lo && rank + 1u >= cnt_sel) {
-      // the next order statistic is the smallest value above a: wavefront min, one atomic per wave
-      if (tid == 0) misc[3] = 0x7fffffffu;
-      __syncthreads();
-      uint32_t m = hi;
-      if (use_cand) {
-        for (uint32_t i = tid; i < nc; i += T) {
-          const uint32_t u = cand[i];
-          if (u > a_bits && u < m) m = u;
-        }
-      } else {
-#pragma unroll 4
-        for (int i = tid; i < n; i += T) {
-          const uint32_t u = __float_as_uint(sx0[i]) & 0x7fffffffu;
-          if (u > a_bits && u < m) m = u;
-        }
-      }
+    uint32_t a_bits = prefix;
+    float a, b;
+    if (fast) {
+      // the candidates hold the wanted element at ascending position `rank`, and -- unless it is their largest -- the next
+      // order statistic too; otherwise that one is the smallest value of the higher digits
+      rank_select<T>(cand, nc, rank, misc, tid);
+      a_bits = misc[6];
+      a = __uint_as_float(a_bits);
+      b = a;
+      if (tp.hi != tp.lo) {
+        if (rank + 1u < nc) {
+          b = __uint_as_float(misc[7]);
+        } else {
+          if (k == 1) {  // `hi` is still per lane
 #pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t o = __shfl_xor(m, d, 64);
-        m = o < m ? o : m;
+            for (int d = 32; d >= 1; d >>= 1) {
+              const uint32_t o = __shfl_xor(hi, d, 64);
+              hi = o < hi ? o : hi;
+            }
+            if (lane == 0) atomicMin(&misc[3], hi);
+            __syncthreads();
+            hi = misc[3];
+          }
+          b = __uint_as_float(hi);
+        }
       }
-      if (lane == 0) atomicMin(&misc[3], m);
-      __syncthreads();
-      if (!local_only) {  // workspace words start at zero: keep the minimum as a maximum of the complement
-        uint32_t* gm = ws + 3 * THR_NB + 8;
-        if (tid == 0) __hip_atomic_fetch_max(gm, 0x7fffffffu - misc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cluster_barrier(ws + 3 * THR_NB + 3, k);
-        b = __uint_as_float(0x7fffffffu - __hip_atomic_load(gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      } else {
-        b = __uint_as_float(misc[3]);
+    } else {
+      a = __uint_as_float(a_bits);
+      b = a;
+      if (tp.hi != tp.lo && rank + 1u >= cnt_sel) {
+        // the next order statistic is the smallest value above a: wavefront min, one atomic per wave
+        if (tid == 0) misc[3] = ABS;
+        __syncthreads();
+        uint32_t m = hi;
+        if (use_cand) {
+          for (uint32_t i = tid; i < nc; i += T) {
+            const uint32_t u = cand[i];
+            if (u > a_bits && u < m) m = u;
+          }
+        } else {
+          for (int i = tid * 4; i < n; i += T * 4) {
+            const u32x4 q = *reinterpret_cast<const u32x4*>(sx0 + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const uint32_t u = q[j] & ABS;
+              if (i + j < n && u > a_bits && u < m) m = u;
+            }
+          }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+          const uint32_t o = __shfl_xor(m, d, 64);
+          m = o < m ? o : m;
+        }
+        if (lane == 0) atomicMin(&misc[3], m);
+        __syncthreads();
+        if (!local_only) {  // workspace words start at zero: keep the minimum as a maximum of the complement
+          uint32_t* gm = ws + THR_WS_CNT + 8;
+          if (tid == 0) __hip_atomic_fetch_max(gm, ABS - misc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          cluster_barrier(ws + THR_WS_CNT + 3, k);
+          b = __uint_as_float(ABS - __hip_atomic_load(gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        } else {
+          b = __uint_as_float(misc[3]);
+        }
       }
     }
     // torch.quantile 'linear' = ATen lerp(a, b, w)
@@ -1135,7 +1356,22 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
              aligned(xe, a4s) && aligned(h1, a4s) && aligned(h2, a4s) && aligned(xo, a4s) && aligned(mo, a4s) &&
              aligned(ext.xo2, a4s) && aligned(ext.mask, a4s) && aligned(ext.ba, a4s) && aligned(ext.bb, a4s) &&
              aligned(e0, a4e) && aligned(e1, a4e) && aligned(g, a4e);
-    const size_t lds_bytes = (size_t)pl.chunk * 4 + THR_NB * 4 + 32 * 4 + THR_CAP * 4;
+    {
+      // top-K front end: a = the K-th largest element.  It needs at most one wanted element per contributing thread and
+      // pays when the K-th largest per-thread maximum sits in the sparse upper tail (K a small part of the threads) and
+      // the candidates (a small multiple of K) fit the rank-counting finish (<= THR_THREADS of them).
+      const int64_t K = per_sample - (int64_t)tp.lo;
+      int64_t P = 0;
+      for (int64_t c = 0; c < pl.k; ++c) {
+        const int64_t n_c = std::max<int64_t>(0, std::min<int64_t>(pl.chunk, per_sample - c * pl.chunk));
+        P += std::min<int64_t>(THR_THREADS, tp.vec ? (n_c + 3) / 4 : n_c);
+      }
+      if (K >= 1 && K <= P / 4 && K <= THR_THREADS / 4) {  // beyond: the candidates outgrow the rank-counting finish
+        tp.topk = (int32_t)K;
+        tp.mrank = (int32_t)(P - K);
+      }
+    }
+    const size_t lds_bytes = (size_t)pl.chunk * 4 + THR_NB * 4 + 32 * 4 + (THR_CAP + 32) * 4;
     auto kern = stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS>;
     int64_t grid = b->batch;
     tp.groups = (int32_t)b->batch;

@@ -144,6 +144,28 @@ def test_dynamic_thresholding_large_samples(golden):
         np.testing.assert_array_equal(y.cpu().numpy(), O.dynamic_threshold(x0, p, 1.0))
 
 
+def test_dynamic_thresholding_topk_front_end():
+    """Ratios close to 1 take the top-K front end of the select (per-thread maxima -> digit bound -> candidates);
+    plateaus at the top overflow its candidate list and must fall back to the full histograms.  One workgroup per
+    sample, clusters (small batches, large samples), ragged chunks, scalar (unaligned) rows: all exact."""
+    ns = make_schedule("ddpm")
+    rng = np.random.default_rng(11)
+    cases = [((1024, 3, 64, 64), 0.995, None), ((40, 3, 64, 64), 0.995, 0.30), ((40, 3, 64, 64), 0.995, 0.55),
+             ((3, 3, 64, 64), 0.999, 0.10), ((3, 3, 64, 64), 1.0, None), ((2, 3, 256, 256), 0.995, 0.002),
+             ((2, 3, 256, 256), 0.995, 0.10), ((600, 1, 61, 67), 0.99, 0.05), ((600, 1, 50, 50), 0.98, None),
+             ((2, 1, 333, 1001), 0.9995, 0.001), ((700, 1, 1, 97), 0.97, 0.2), ((5, 3, 64, 64), 0.76, None)]
+    for shape, p, top in cases:
+        x0 = (rng.standard_normal(shape) * 2.0).astype(F32)
+        rows = x0.reshape(shape[0], -1)
+        if top is not None:          # a plateau holding the largest values of every second row
+            n = rows.shape[1]
+            idx = rng.permutation(n)[:max(1, int(top * n))]
+            rows[::2, idx] = np.float32(9.5) * np.where(rng.random(idx.size) < 0.5, -1, 1).astype(F32)
+        dpm = D.DPM_Solver(lambda x, t: x, ns, correcting_x0_fn="dynamic_thresholding", dynamic_thresholding_ratio=p)
+        y = dpm.dynamic_thresholding_fn(torch.from_numpy(x0).to(DEV), None)
+        np.testing.assert_array_equal(y.cpu().numpy(), O.dynamic_threshold(x0, p, 1.0), err_msg=str((shape, p, top)))
+
+
 def test_cfg3_sized_thresholded_sampling():
     """[4,3,256,256] pixel-space 2M++ with dynamic thresholding and CFG: the large-sample path inside sample()."""
     case = dict(C.E2E_BY_NAME["cfg5_thresh"], shape=(4, 3, 256, 256), steps=10, model="cond",
