@@ -649,6 +649,20 @@ __device__ __forceinline__ void cluster_barrier(uint32_t* cnt, uint32_t k) {
   __syncthreads();
 }
 
+// keep m1 >= m2 >= m3 >= m4, the four largest values seen so far (duplicates are separate entries)
+__device__ __forceinline__ void top4_insert(uint32_t u, uint32_t& m1, uint32_t& m2, uint32_t& m3, uint32_t& m4) {
+  uint32_t a = u > m1 ? u : m1;
+  u = u > m1 ? m1 : u;
+  m1 = a;
+  a = u > m2 ? u : m2;
+  u = u > m2 ? m2 : u;
+  m2 = a;
+  a = u > m3 ? u : m3;
+  u = u > m3 ? m3 : u;
+  m3 = a;
+  m4 = u > m4 ? u : m4;
+}
+
 // Every thread owns 4 consecutive bins of the workgroup's LDS histogram (THR_NB = 4 T): one conflict-free 16-byte
 // read, a wavefront scan, the wavefront totals through LDS.  The thread whose bins hold the ascending `rank`
 // publishes misc[0] = bin, misc[1] = rank inside that bin, misc[2] = the bin's count.  The histogram is left ZEROED.
@@ -822,7 +836,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
       misc[3] = ABS;  // smallest value above the selected top digit (cluster exchange)
     }
     __syncthreads();
-    uint32_t mx = 0u;
+    uint32_t m1 = 0u, m2 = 0u, m3 = 0u, m4 = 0u;  // top-K: the four largest |x0| bit patterns this thread produced
     if (vec) {
 #pragma unroll 2
       for (int i = tid * 4; i < n; i += T * 4) {
@@ -838,8 +852,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         if (topk) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const uint32_t u = __float_as_uint(o[j]) & ABS;
-            mx = u > mx ? u : mx;
+            top4_insert(__float_as_uint(o[j]) & ABS, m1, m2, m3, m4);
           }
         } else {
 #pragma unroll
@@ -855,7 +868,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         sx0[i] = o;
         const uint32_t u = __float_as_uint(o) & ABS;
         if (topk)
-          mx = u > mx ? u : mx;
+          top4_insert(u, m1, m2, m3, m4);
         else
           atomicAdd(&hist[u >> 20], 1u);
       }
@@ -876,7 +889,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
       // per-thread maxima (those are K distinct elements), so every element that can still matter has a top digit >=
       // the digit of that maximum: a histogram of ONE value per thread instead of one LDS atomic per element on a
       // few hot bins (|x0| of one sample sits in a handful of exponents), then the usual compaction.
-      if (has) atomicAdd(&hist[mx >> 20], 1u);
+      if (has) atomicAdd(&hist[m1 >> 20], 1u);
       __syncthreads();
       if (k > 1) {
         uint32_t* gh = ws + THR_WS_MAXH;
@@ -893,7 +906,29 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
       }
       locate_bin<T>(hist, misc, (uint32_t)tp.mrank, tid);
       const uint32_t bin_lo = misc[0];
-      (void)compact_candidates<T, true>(sx0, n, bin_lo, misc, cand, tid);
+      {
+        // The candidates of a thread are among its four largest values unless even the fourth reaches the digit (and
+        // the thread has more elements): wavefronts where that happens anywhere sweep their LDS rows instead.
+        const int mine = vec ? (has ? 4 * ((n - tid * 4 + T * 4 - 1) / (T * 4)) : 0) : (has ? (n - tid + T - 1) / T : 0);
+        const bool c1 = mine > 0 && (m1 >> 20) >= bin_lo, c2 = mine > 1 && (m2 >> 20) >= bin_lo;
+        const bool c3 = mine > 2 && (m3 >> 20) >= bin_lo, c4 = mine > 3 && (m4 >> 20) >= bin_lo;
+        if (__ballot(c4 && mine > 4)) {
+          (void)compact_candidates<T, true>(sx0, n, bin_lo, misc, cand, tid);
+        } else {
+          const uint32_t cnt = (c1 ? 1u : 0u) + (c2 ? 1u : 0u) + (c3 ? 1u : 0u) + (c4 ? 1u : 0u);
+          const uint32_t incl = wave_incl_scan(cnt);
+          uint32_t slot = 0u;
+          if (lane == 63 && incl) slot = atomicAdd(&misc[4], incl);
+          uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)slot, 63) + incl - cnt;
+          if (c1 && off < (uint32_t)THR_CAP) cand[off] = m1;
+          off += c1 ? 1u : 0u;
+          if (c2 && off < (uint32_t)THR_CAP) cand[off] = m2;
+          off += c2 ? 1u : 0u;
+          if (c3 && off < (uint32_t)THR_CAP) cand[off] = m3;
+          off += c3 ? 1u : 0u;
+          if (c4 && off < (uint32_t)THR_CAP) cand[off] = m4;
+        }
+      }
       __syncthreads();
       nc = misc[4];
       bool ok = nc <= (uint32_t)THR_CAP;
