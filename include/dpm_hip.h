@@ -215,7 +215,7 @@ int dpm_coef_prologue(const dpm_schedule* s, float t_eval, int model_type, int g
 /* one fused stage kernel, asynchronous on `stream` */
 int dpm_stage_launch(const dpm_stage* st, const dpm_buffers* b, void* stream);
 /* scratch needed by stages with DPM_F_THRESH on the current device: 0 when one workgroup per sample is the plan (the
-   sample lives in that workgroup's LDS), else ~24 KiB per sample of histograms / counters through which the workgroup
+   sample lives in that workgroup's LDS), else ~40 KiB per sample of histograms, lists and counters through which the workgroup
    cluster of a sample synchronises (small batches, samples beyond 12288 elements); the launch zeroes it itself.
    Pass it as dpm_buffers.workspace. */
 size_t dpm_threshold_workspace_bytes(int64_t batch, int64_t per_sample);
