@@ -153,7 +153,11 @@ def test_dynamic_thresholding_topk_front_end():
     cases = [((1024, 3, 64, 64), 0.995, None), ((40, 3, 64, 64), 0.995, 0.30), ((40, 3, 64, 64), 0.995, 0.55),
              ((3, 3, 64, 64), 0.999, 0.10), ((3, 3, 64, 64), 1.0, None), ((2, 3, 256, 256), 0.995, 0.002),
              ((2, 3, 256, 256), 0.995, 0.10), ((600, 1, 61, 67), 0.99, 0.05), ((600, 1, 50, 50), 0.98, None),
-             ((2, 1, 333, 1001), 0.9995, 0.001), ((700, 1, 1, 97), 0.97, 0.2), ((5, 3, 64, 64), 0.76, None)]
+             ((2, 1, 333, 1001), 0.9995, 0.001), ((700, 1, 1, 97), 0.97, 0.2), ((5, 3, 64, 64), 0.76, None),
+             # K = n - floor(p (n - 1)) around the front end's limit of 128, one workgroup per sample and clusters
+             ((520, 3, 64, 64), 0.98967, None), ((520, 3, 64, 64), 0.98962, None), ((520, 3, 64, 64), 0.9895, 0.004),
+             ((4, 3, 64, 64), 0.98967, None), ((4, 3, 64, 64), 0.9895, None), ((520, 1, 32, 64), 0.9380, None),
+             ((520, 1, 32, 64), 0.9370, None)]
     for shape, p, top in cases:
         x0 = (rng.standard_normal(shape) * 2.0).astype(F32)
         rows = x0.reshape(shape[0], -1)
