@@ -558,7 +558,7 @@ struct ThrParams {
   int32_t vec;     // 1: 4-element vector accesses are legal for every tensor of this launch
   int32_t topk;    // > 0: K = per_sample - lo is small enough for the top-K front end of the select
   int32_t mrank;   // top-K: ascending rank of the K-th largest per-thread maximum among the contributing threads
-  int32_t pad;
+  int32_t fastdiv; // 1: noise-prediction network + eps -> x0 with a divisor that passes div_invariant_ok (see div_by_alpha)
   uint32_t* ws;    // k > 1: batch x THR_WS_WORDS zeroed words
 };
 
@@ -845,9 +845,16 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         load4<true>(e0, ebase + i, v0);                       // the network outputs are dead after this kernel
         if (GUIDE == DPM_GUIDE_CFG) load4<true>(e1, ebase + i, v1);
         if (GUIDE == DPM_GUIDE_CLASSIFIER) load4<true>(g, base + i, vg);
+        if (tp.fastdiv) {  // uniform: the common parameterisation, division by the invariant alpha (3 VALU ops for ~12)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          o[j] = prologue<GUIDE>(vx[j], v0[j], GUIDE == DPM_GUIDE_CFG ? v1[j] : 0.f, GUIDE == DPM_GUIDE_CLASSIFIER ? vg[j] : 0.f, p);
+          for (int j = 0; j < 4; ++j)
+            o[j] = prologue<GUIDE, SPEC_NOISE_X0>(vx[j], v0[j], GUIDE == DPM_GUIDE_CFG ? v1[j] : 0.f,
+                                                  GUIDE == DPM_GUIDE_CLASSIFIER ? vg[j] : 0.f, p);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            o[j] = prologue<GUIDE>(vx[j], v0[j], GUIDE == DPM_GUIDE_CFG ? v1[j] : 0.f, GUIDE == DPM_GUIDE_CLASSIFIER ? vg[j] : 0.f, p);
+        }
         store4(sx0, i, o);
         if (topk) {
 #pragma unroll
@@ -1117,6 +1124,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     const float diff = b - a;
     const float q = tp.w < 0.5f ? a + tp.w * diff : b - diff * (1.f - tp.w);
     const float s = fmaxf(q, tp.max_val);  // ref :423
+    // x0 / s for every element of the sample: the same division by an invariant (the guard of div_by_alpha, evaluated
+    // here because s is born on the device); ref :424 divides
+    const uint32_t s_bits = __float_as_uint(s), s_ex = (s_bits >> 23) & 0xffu;
+    const bool s_fast = s_ex > 32u && s_ex < 222u && (s_bits & 0x7fffffu) != 0x7fffffu;
+    const float inv_s = 1.f / s;
 
     // phase 3: clamp, scale, combine, epilogue, store
     if (vec) {
@@ -1133,8 +1145,19 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
           if (bb) load4(bb, gi, vb);
         }
 #pragma unroll
+        for (int j = 0; j < 4; ++j) om[j] = fminf(fmaxf(sx0[i + j], -s), s);  // ref :424
+        if (s_fast) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float qd = om[j] * inv_s;
+            om[j] = __builtin_fmaf(__builtin_fmaf(-qd, s, om[j]), inv_s, qd);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) om[j] = om[j] / s;
+        }
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
-          om[j] = fminf(fmaxf(sx0[i + j], -s), s) / s;  // ref :424
           o[j] = combine<FORM>(FT::needs_x ? vx[j] : 0.f, om[j], FT::needs_h1 ? vh1[j] : 0.f, FT::needs_h2 ? vh2[j] : 0.f, p);
           if (mask) o[j] = blend_ref(to_f32(from_f32<TS>(o[j])), vm[j], va[j], bb ? vb[j] : 0.f, bb != nullptr, ext);
         }
@@ -1386,6 +1409,7 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
     tp.chunk = (int32_t)pl.chunk;
     tp.k = (int32_t)pl.k;
     tp.batch = (int32_t)b->batch;
+    tp.fastdiv = st->model_type == DPM_MODEL_NOISE && (st->flags & DPM_F_TO_X0) && div_invariant_ok(st->alpha_e);
     const size_t a4s = sizeof(TS) * 4, a4e = sizeof(TE) * 4;
     tp.vec = per_sample % 4 == 0 && ext.eps_stride % 4 == 0 && ext.mask_period % 4 == 0 && aligned(x, a4s) &&
              aligned(xe, a4s) && aligned(h1, a4s) && aligned(h2, a4s) && aligned(xo, a4s) && aligned(mo, a4s) &&
