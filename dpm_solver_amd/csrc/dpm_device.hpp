@@ -847,9 +847,14 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         if (GUIDE == DPM_GUIDE_CLASSIFIER) load4<true>(g, base + i, vg);
         if (tp.fastdiv) {  // uniform: the common parameterisation, division by the invariant alpha (3 VALU ops for ~12)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            o[j] = prologue<GUIDE, SPEC_NOISE_X0>(vx[j], v0[j], GUIDE == DPM_GUIDE_CFG ? v1[j] : 0.f,
-                                                  GUIDE == DPM_GUIDE_CLASSIFIER ? vg[j] : 0.f, p);
+          for (int j = 0; j < 4; j += 2) {  // adjacent pairs: packed fp32 instructions
+            const f32x2 z = {0.f, 0.f};
+            const f32x2 r = prologue<GUIDE, SPEC_NOISE_X0, f32x2>(
+                f32x2{vx[j], vx[j + 1]}, f32x2{v0[j], v0[j + 1]}, GUIDE == DPM_GUIDE_CFG ? f32x2{v1[j], v1[j + 1]} : z,
+                GUIDE == DPM_GUIDE_CLASSIFIER ? f32x2{vg[j], vg[j + 1]} : z, p);
+            o[j] = r[0];
+            o[j + 1] = r[1];
+          }
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
@@ -1148,18 +1153,30 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         for (int j = 0; j < 4; ++j) om[j] = fminf(fmaxf(sx0[i + j], -s), s);  // ref :424
         if (s_fast) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float qd = om[j] * inv_s;
-            om[j] = __builtin_fmaf(__builtin_fmaf(-qd, s, om[j]), inv_s, qd);
+          for (int j = 0; j < 4; j += 2) {
+            const f32x2 c2 = {om[j], om[j + 1]};
+            const f32x2 qd = c2 * inv_s;
+            const f32x2 r = vfma(vfma(-qd, (f32x2)(s), c2), (f32x2)(inv_s), qd);
+            om[j] = r[0];
+            om[j + 1] = r[1];
           }
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) om[j] = om[j] / s;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          o[j] = combine<FORM>(FT::needs_x ? vx[j] : 0.f, om[j], FT::needs_h1 ? vh1[j] : 0.f, FT::needs_h2 ? vh2[j] : 0.f, p);
-          if (mask) o[j] = blend_ref(to_f32(from_f32<TS>(o[j])), vm[j], va[j], bb ? vb[j] : 0.f, bb != nullptr, ext);
+        for (int j = 0; j < 4; j += 2) {
+          const f32x2 z = {0.f, 0.f};
+          const f32x2 r = combine<FORM, f32x2>(FT::needs_x ? f32x2{vx[j], vx[j + 1]} : z, f32x2{om[j], om[j + 1]},
+                                               FT::needs_h1 ? f32x2{vh1[j], vh1[j + 1]} : z,
+                                               FT::needs_h2 ? f32x2{vh2[j], vh2[j + 1]} : z, p);
+          o[j] = r[0];
+          o[j + 1] = r[1];
+        }
+        if (mask) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            o[j] = blend_ref(to_f32(from_f32<TS>(o[j])), vm[j], va[j], bb ? vb[j] : 0.f, bb != nullptr, ext);
         }
         store4(xo, gi, o);
         if (xo2) store4(xo2, gi, o);
