@@ -649,18 +649,18 @@ __device__ __forceinline__ void cluster_barrier(uint32_t* cnt, uint32_t k) {
   __syncthreads();
 }
 
-// keep m1 >= m2 >= m3 >= m4, the four largest values seen so far (duplicates are separate entries)
+// keep m1 >= m2 >= m3 >= m4, the four largest values seen so far (duplicates are separate entries): inserting u into a
+// sorted list replaces every entry by the median of itself, its larger neighbour and u -- one v_med3_u32 each
+__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {
+  const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;  // the backend folds this shape into v_med3_u32
+  const uint32_t t = hi < c ? hi : c;
+  return lo > t ? lo : t;
+}
 __device__ __forceinline__ void top4_insert(uint32_t u, uint32_t& m1, uint32_t& m2, uint32_t& m3, uint32_t& m4) {
-  uint32_t a = u > m1 ? u : m1;
-  u = u > m1 ? m1 : u;
-  m1 = a;
-  a = u > m2 ? u : m2;
-  u = u > m2 ? m2 : u;
-  m2 = a;
-  a = u > m3 ? u : m3;
-  u = u > m3 ? m3 : u;
-  m3 = a;
-  m4 = u > m4 ? u : m4;
+  m4 = med3_u32(m3, m4, u);
+  m3 = med3_u32(m2, m3, u);
+  m2 = med3_u32(m1, m2, u);
+  m1 = u > m1 ? u : m1;
 }
 
 // Every thread owns 4 consecutive bins of the workgroup's LDS histogram (THR_NB = 4 T): one conflict-free 16-byte
