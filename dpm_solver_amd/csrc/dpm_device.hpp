@@ -748,6 +748,23 @@ __device__ __forceinline__ uint32_t compact_candidates(const float* sx0, int n, 
   return hi;
 }
 
+// maximum over the 64 lanes of a wavefront, valid in lane 63 (the DPP ladder of wave_incl_scan with max; 0 is the identity)
+__device__ __forceinline__ uint32_t wave_max_to_lane63(uint32_t v) {
+#define DPM_DPP_MAX(ctrl, rmask, bc)                                                              \
+  {                                                                                               \
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, bc);    \
+    v = o > v ? o : v;                                                                            \
+  }
+  DPM_DPP_MAX(0x111, 0xf, true)
+  DPM_DPP_MAX(0x112, 0xf, true)
+  DPM_DPP_MAX(0x114, 0xf, true)
+  DPM_DPP_MAX(0x118, 0xf, true)
+  DPM_DPP_MAX(0x142, 0xa, false)
+  DPM_DPP_MAX(0x143, 0xc, false)
+#undef DPM_DPP_MAX
+  return v;
+}
+
 // nc <= T candidates in cand[]: every thread counts the candidates smaller than its own one; the element of ascending
 // rank r is the largest candidate with at most r smaller ones.  misc[6] <- rank-th, misc[7] <- (rank+1)-th (or the
 // largest candidate when there is none).  One pass, two barriers -- instead of three histogram levels + a min search.
@@ -770,17 +787,11 @@ __device__ __forceinline__ void rank_select(uint32_t* cand, uint32_t nc, uint32_
       for (int e = 0; e < 8; ++e)
         lt += (q[e][0] < my ? 1u : 0u) + (q[e][1] < my ? 1u : 0u) + (q[e][2] < my ? 1u : 0u) + (q[e][3] < my ? 1u : 0u);
     }
-    uint32_t ma = ((uint32_t)tid < nc && lt <= rank) ? my : 0u;
-    uint32_t mb = ((uint32_t)tid < nc && lt <= rank + 1u) ? my : 0u;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      const uint32_t oa = __shfl_xor(ma, d, 64), ob = __shfl_xor(mb, d, 64);
-      ma = oa > ma ? oa : ma;
-      mb = ob > mb ? ob : mb;
-    }
-    if ((tid & 63) == 0) {
-      atomicMax(&misc[6], ma);
-      atomicMax(&misc[7], mb);
+    const uint32_t ma = wave_max_to_lane63(((uint32_t)tid < nc && lt <= rank) ? my : 0u);
+    const uint32_t mb = wave_max_to_lane63(((uint32_t)tid < nc && lt <= rank + 1u) ? my : 0u);
+    if ((tid & 63) == 63) {
+      if (ma) atomicMax(&misc[6], ma);
+      if (mb) atomicMax(&misc[7], mb);
     }
   }
   __syncthreads();
