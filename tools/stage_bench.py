@@ -139,6 +139,12 @@ def main():
     e, = frozen(shape, torch.float16)
     s = D.DPM_Solver(D.model_wrapper(lambda x, t: e, sd), sd)
     rows += run("cfg2-size 2M++ f32 state / f16 eps", s, torch.randn(shape, device=DEV), steps=20, order=2)
+    # other parameterisations of the network (SD 2.x is a v-prediction model; x_start: consistency-style / imagen heads)
+    for mt in ("v", "x_start"):
+        shape = (256, 4, 64, 64)
+        e, = frozen(shape, torch.float16)
+        s = D.DPM_Solver(D.model_wrapper(lambda x, t: e, sd, model_type=mt), sd, state_dtype=torch.float16)
+        rows += run("cfg2-size 2M++ float16 %s-prediction" % mt, s, torch.randn(shape, device=DEV).half(), steps=20, order=2)
     # 3M++
     shape = (256, 4, 64, 64)
     e, = frozen(shape, torch.float16)
