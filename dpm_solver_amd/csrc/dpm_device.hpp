@@ -797,7 +797,12 @@ __device__ __forceinline__ void rank_select(uint32_t* cand, uint32_t nc, uint32_
   __syncthreads();
 }
 
-template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int T>
+// HOT != 0: the usual configuration fixed at compile time -- 16-byte accesses legal, noise-prediction network with the
+// division by the invariant alpha, no mask blend; HOT = 1 with the top-K front end, HOT = 2 with the full level-0
+// histogram -- so that the load and store loops are straight-line code without the wave-uniform branches of the general
+// prologue and their operands (the kernel is as sensitive to its instruction count as to HBM).
+// Everything else runs the same source with HOT = 0.
+template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int T, int HOT>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void stage_thresh_kernel(
     const TS* __restrict__ x, const TS* __restrict__ xe, const TE* __restrict__ e0, const TE* __restrict__ e1,
     const TE* __restrict__ g, const TS* __restrict__ h1, const TS* __restrict__ h2, TS* __restrict__ xo,
@@ -812,14 +817,16 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
                                                                      // count, [5] list cursor, [16..23] wavefront totals
   uint32_t* cand = misc + 32;                                        // [THR_CAP + 32] candidates (+ sentinels)
   const bool store_m = p.flags & DPM_F_STORE_M;
-  const bool vec = tp.vec != 0;
+  const bool vec = HOT != 0 || tp.vec != 0;
   const uint32_t k = (uint32_t)tp.k;
-  const bool topk = tp.topk > 0;
+  const bool topk = HOT == 1 || (HOT == 0 && tp.topk > 0);
+  const bool fastdiv = HOT != 0 || tp.fastdiv != 0;
+  const int64_t eps_stride = ext.eps_stride;
   const int grp = k == 1 ? (int)blockIdx.x : (int)(blockIdx.x / k);
   const int c = k == 1 ? 0 : (int)(blockIdx.x % k);
-  const TS* mask = static_cast<const TS*>(ext.mask);
-  const TS* ba = static_cast<const TS*>(ext.ba);
-  const TS* bb = static_cast<const TS*>(ext.bb);
+  const TS* mask = HOT != 0 ? nullptr : static_cast<const TS*>(ext.mask);
+  const TS* ba = HOT != 0 ? nullptr : static_cast<const TS*>(ext.ba);
+  const TS* bb = HOT != 0 ? nullptr : static_cast<const TS*>(ext.bb);
   TS* xo2 = static_cast<TS*>(ext.xo2);
 
   for (int s_idx = grp; s_idx < tp.batch; s_idx += tp.groups) {
@@ -829,7 +836,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int64_t base = (int64_t)s_idx * tp.per_sample + (int64_t)c * tp.chunk;
-    const int64_t ebase = (int64_t)s_idx * (ext.eps_stride ? ext.eps_stride : tp.per_sample) + (int64_t)c * tp.chunk;
+    const int64_t ebase = (int64_t)s_idx * (eps_stride ? eps_stride : tp.per_sample) + (int64_t)c * tp.chunk;
     const int64_t left = tp.per_sample - (int64_t)c * tp.chunk;
     const int n = left <= 0 ? 0 : (left < tp.chunk ? (int)left : tp.chunk);
     uint32_t* ws = k == 1 ? nullptr : tp.ws + (int64_t)s_idx * THR_WS_WORDS;
@@ -856,7 +863,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         load4<true>(e0, ebase + i, v0);                       // the network outputs are dead after this kernel
         if (GUIDE == DPM_GUIDE_CFG) load4<true>(e1, ebase + i, v1);
         if (GUIDE == DPM_GUIDE_CLASSIFIER) load4<true>(g, base + i, vg);
-        if (tp.fastdiv) {  // uniform: the common parameterisation, division by the invariant alpha (3 VALU ops for ~12)
+        if (fastdiv) {  // uniform: the common parameterisation, division by the invariant alpha (3 VALU ops for ~12)
 #pragma unroll
           for (int j = 0; j < 4; j += 2) {  // adjacent pairs: packed fp32 instructions
             const f32x2 z = {0.f, 0.f};
@@ -1459,7 +1466,13 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
       }
     }
     const size_t lds_bytes = (size_t)pl.chunk * 4 + THR_NB * 4 + 32 * 4 + (THR_CAP + 32) * 4;
-    auto kern = stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS>;
+    // the compile-time specialisation exists for the forms / guidance kinds samplers combine with thresholding
+    constexpr bool HOT_BUILT = (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3) &&
+                               (GUIDE == DPM_GUIDE_NONE || GUIDE == DPM_GUIDE_CFG) && !XE;
+    const bool hot = HOT_BUILT && tp.vec && tp.fastdiv && !ext.mask;
+    auto kern = !hot ? stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 0>
+                     : tp.topk > 0 ? stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, HOT_BUILT ? 1 : 0>
+                                   : stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, HOT_BUILT ? 2 : 0>;
     int64_t grid = b->batch;
     tp.groups = (int32_t)b->batch;
     if (pl.k > 1) {
