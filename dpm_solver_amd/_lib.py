@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401  (import order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdpm_hip.so")
+# DPM_SOLVER_AMD_LIB: an instrumented build of the same library (tools/thr_timeline.py); unset in normal use
+LIB_PATH = os.environ.get("DPM_SOLVER_AMD_LIB") or os.path.join(_HERE, "libdpm_hip.so")
 
 # ---- enumerations (mirror include/dpm_hip.h) --------------------------------------------------
 DPM_OK = 0

@@ -25,6 +25,11 @@
 #include <cstdint>
 #include <algorithm>
 #include <cstring>
+#ifdef DPM_THR_TIMING
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#endif
 #include <mutex>
 #include <type_traits>
 #include <new>
@@ -560,6 +565,9 @@ struct ThrParams {
   int32_t mrank;   // top-K: ascending rank of the K-th largest per-thread maximum among the contributing threads
   int32_t fastdiv; // 1: noise-prediction network + eps -> x0 with a divisor that passes div_invariant_ok (see div_by_alpha)
   uint32_t* ws;    // k > 1: batch x THR_WS_WORDS zeroed words
+#ifdef DPM_THR_TIMING
+  uint64_t* tdbg;  // 16 timestamps per workgroup (tools/thr_timeline.py)
+#endif
 };
 
 // inclusive prefix sum over the 64 lanes of a wavefront: DPP row shifts inside the rows of 16 lanes, then the two row
@@ -844,6 +852,16 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     const bool mfull = ext.mask_period >= ((int64_t)1 << 31);
     const uint32_t mbase = (mask && !mfull) ? (uint32_t)(base % ext.mask_period) : 0u;
     const uint32_t mper = (uint32_t)ext.mask_period;
+    // -DDPM_THR_TIMING (tools/thr_timeline.py): wall-clock stamps of the first sample a workgroup processes -- 0 start,
+    // 1 x0 in LDS, 4 maxima histogram, 5 bin located, 6 candidates compacted / exchanged, 7 rank counting, 2 threshold
+    // known, 3 end.  DESIGN.md section 5 quotes them.
+#ifdef DPM_THR_TIMING
+#define DPM_TSTAMP(j) \
+  if (tid == 0 && s_idx == grp) tp.tdbg[(int64_t)blockIdx.x * 16 + (j)] = wall_clock64();
+#else
+#define DPM_TSTAMP(j)
+#endif
+    DPM_TSTAMP(0)
 
     // phase 1: x0 of this workgroup's chunk -> LDS.  On the way: the largest |x0| of every thread (top-K front end),
     // or the level-0 histogram (top 11 bits of |x0|) -- its LDS atomics overlap the global loads
@@ -905,6 +923,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     }
     const bool has = (vec ? tid * 4 : tid) < n;  // this thread produced at least one element (launch: ThrParams.mrank)
     __syncthreads();
+    DPM_TSTAMP(1)
 
     // phase 2: the lo-th smallest |x0| of the whole sample.
     uint32_t prefix = 0u, known = 0u, rank = (uint32_t)tp.lo, cnt_sel = 0u;
@@ -921,6 +940,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
       // few hot bins (|x0| of one sample sits in a handful of exponents), then the usual compaction.
       if (has) atomicAdd(&hist[m1 >> 20], 1u);
       __syncthreads();
+      DPM_TSTAMP(4)
       if (k > 1) {
         uint32_t* gh = ws + THR_WS_MAXH;
 #pragma unroll
@@ -936,6 +956,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
       }
       locate_bin<T>(hist, misc, (uint32_t)tp.mrank, tid);
       const uint32_t bin_lo = misc[0];
+      DPM_TSTAMP(5)
       {
         // The candidates of a thread are among its four largest values unless even the fourth reaches the digit (and
         // the thread has more elements): wavefronts where that happens anywhere sweep their LDS rows instead.
@@ -981,6 +1002,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         }
         __syncthreads();
       }
+      DPM_TSTAMP(6)
       if (ok && nc >= (uint32_t)tp.topk) {
         use_cand = true;
         local_only = true;
@@ -1083,6 +1105,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
       // the candidates hold the wanted element at ascending position `rank`, and -- unless it is their largest -- the next
       // order statistic too; otherwise that one is the smallest value of the higher digits
       rank_select<T>(cand, nc, rank, misc, tid);
+      DPM_TSTAMP(7)
       a_bits = misc[6];
       a = __uint_as_float(a_bits);
       b = a;
@@ -1143,6 +1166,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         }
       }
     }
+    DPM_TSTAMP(2)
     // torch.quantile 'linear' = ATen lerp(a, b, w)
     const float diff = b - a;
     const float q = tp.w < 0.5f ? a + tp.w * diff : b - diff * (1.f - tp.w);
@@ -1217,6 +1241,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
       }
     }
     __syncthreads();  // the next sample of this cluster reuses the LDS
+#ifdef DPM_THR_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stamp means: stores issued AND drained
+#endif
+    DPM_TSTAMP(3)
   }
 }
 
@@ -1465,6 +1493,31 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
         tp.mrank = (int32_t)(P - K);
       }
     }
+#ifdef DPM_THR_TIMING
+    // debug build only: the DPM_THR_TIMING_LAUNCH-th thresholding launch of the process (default 40) is synchronised
+    // and its stamps are written to $DPM_THR_TIMING_FILE, one line of 16 values per workgroup
+    static uint64_t* t_dev = nullptr;
+    static int t_launches = 0;
+    if (!t_dev) (void)hipMalloc(&t_dev, 4096 * 16 * sizeof(uint64_t));
+    tp.tdbg = t_dev;
+    auto t_dump = [&](int64_t wgs) {
+      const char* path = getenv("DPM_THR_TIMING_FILE");
+      const char* at = getenv("DPM_THR_TIMING_LAUNCH");
+      if (!path || ++t_launches != (at ? atoi(at) : 40) || wgs > 4096) return;
+      (void)hipStreamSynchronize(stream.stream);
+      std::vector<uint64_t> h((size_t)wgs * 16);
+      (void)hipMemcpy(h.data(), t_dev, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
+      if (FILE* f = fopen(path, "w")) {
+        for (int64_t i = 0; i < wgs; ++i) {
+          for (int j = 0; j < 16; ++j) fprintf(f, "%llu ", (unsigned long long)h[(size_t)i * 16 + j]);
+          fprintf(f, "\n");
+        }
+        fclose(f);
+      }
+    };
+#else
+    auto t_dump = [](int64_t) {};
+#endif
     const size_t lds_bytes = (size_t)pl.chunk * 4 + THR_NB * 4 + 32 * 4 + (THR_CAP + 32) * 4;
     // the compile-time specialisation exists for the forms / guidance kinds samplers combine with thresholding
     constexpr bool HOT_BUILT = (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3) &&
@@ -1520,12 +1573,14 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
         if (ch.ev && ch.recorded) (void)hipStreamWaitEvent(stream.stream, ch.ev, 0);
         launch(kern, dim3((unsigned)grid), dim3(THR_THREADS), lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo, p, tp, ext);
         if (ch.ev && hipEventRecord(ch.ev, stream.stream) == hipSuccess) ch.recorded = true;
+        t_dump(grid);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return dpm_set_error((int)e, "stage kernel launch failed: %s", hipGetErrorString(e));
         return DPM_OK;
       }
     }
     launch(kern, dim3((unsigned)grid), dim3(THR_THREADS), lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo, p, tp, ext);
+    t_dump(grid);
   } else {
     const size_t as = sizeof(TS) * EPT, ae = sizeof(TE) * EPT;
     bool vec = aligned(x, as) && aligned(xe, as) && aligned(h1, as) && aligned(h2, as) && aligned(xo, as) &&
