@@ -259,6 +259,7 @@ def main():
         L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, nreq, sptr, msb, resm))
         cold.append(np.frombuffer(msb, dtype=np.float32).reshape(nreq, n_stages)[:, 1:n_stages - 1].copy())
     cold_us = float(np.mean(cold) * 1e3)
+    cold_med_us, cold_max_us = float(np.median(cold) * 1e3), float(np.max(cold) * 1e3)
     # what the memory system sustains for this pattern and size with no arithmetic at all (3 read + 2 write streams)
     cal = {}
     msv = C.c_float()
@@ -290,7 +291,8 @@ def main():
                     trajectory_kernel_sum_us=round(float(ms.sum(axis=1).mean() * 1e3), 2),
                     host_wall=dict(achieved=round(traj_alg_bytes * args.steps / wall / 1e9, 1),
                                    frac=round(traj_alg_bytes * args.steps / wall / 1e9 / HBM_PEAK_GBS, 4)),
-                    hbm_cold=dict(kernel_us=round(cold_us, 3), achieved=round(alg_bytes / cold_us / 1e3, 1),
+                    hbm_cold=dict(kernel_us=round(cold_us, 3), median_us=round(cold_med_us, 3), max_us=round(cold_max_us, 1),
+                                  achieved=round(alg_bytes / cold_us / 1e3, 1),
                                   frac=round(alg_bytes / cold_us / 1e3 / HBM_PEAK_GBS, 4),
                                   how="%d requests advanced stage by stage (dpm_plan_run_multi)" % nreq),
                     no_arithmetic_ceiling=dict(pattern="3 read + 2 write streams, same bytes, 256-thread blocks",

@@ -94,13 +94,39 @@ template <bool NT>
 __device__ __forceinline__ u32x4 ld16(const u32x4* p) {
   return NT ? __builtin_nontemporal_load(p) : *p;
 }
+// Output stores are WRITE-THROUGH (`sc0 sc1`): the line goes to the memory side and is dropped from the XCD's L2 instead
+// of lingering there dirty.  Nothing reads a stage's outputs from this L2 again (the next kernel starts with its L2
+// invalidated, and may run the element on another XCD), so keeping them only pollutes the cache during the kernel and
+// leaves a write-back for the kernel boundary: [256,4,64,64] fp16 2M stage 7.29 -> 6.39 us per launch (70.5 -> 80.4 % of
+// HBM peak), fp32 13.22 -> 13.02 (profiles/r01_store_policy.md).  Written as inline assembly: a `volatile` store
+// compiles to the same instruction but the compiler follows each one with `s_waitcnt vmcnt(0)`, which serialises the
+// stores (fp16 6.65 us, HBM-cold 8.9 instead of 8.4).  The compiler does not know about these stores: the two wait
+// states a 16-byte store needs before its data registers may be rewritten (gfx940+) are in the string, and its own
+// `vmcnt` bookkeeping stays correct because loads return in order among themselves -- an unknown older or younger
+// store can only make one of its waits longer, never shorter.  -DDPM_STORE_WRITE_THROUGH=0 restores plain /
+// non-temporal stores (the NT flag) for comparison.
+#ifndef DPM_STORE_WRITE_THROUGH
+#define DPM_STORE_WRITE_THROUGH 1
+#endif
 template <bool NT>
 __device__ __forceinline__ void st16(u32x4* p, u32x4 v) {
-  if (NT)
+  if (DPM_STORE_WRITE_THROUGH)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else if (NT)
     __builtin_nontemporal_store(v, p);
   else
     *p = v;
 }
+template <bool NT, typename V2>
+__device__ __forceinline__ void st8(V2* p, V2 v) {
+  if (DPM_STORE_WRITE_THROUGH)
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  else if (NT)
+    __builtin_nontemporal_store(v, p);
+  else
+    *p = v;
+}
+
 
 // 8 consecutive elements of group `group` -> fp32.  Always global_load_dwordx4 (x2 for fp32).
 template <bool NT>
@@ -624,20 +650,14 @@ __device__ __forceinline__ void store4(__half* __restrict__ p, int64_t i, const 
 #pragma unroll
   for (int j = 0; j < 2; ++j)
     a[j] = pack_half2(v[2 * j], v[2 * j + 1]);
-  if (NT)
-    __builtin_nontemporal_store(a, reinterpret_cast<u32x2*>(p + i));
-  else
-    *reinterpret_cast<u32x2*>(p + i) = a;
+  st8<NT>(reinterpret_cast<u32x2*>(p + i), a);
 }
 template <bool NT = false>
 __device__ __forceinline__ void store4(bf16_t* __restrict__ p, int64_t i, const float (&v)[4]) {
   u32x2 a;
 #pragma unroll
   for (int j = 0; j < 2; ++j) a[j] = pack_bf162(v[2 * j], v[2 * j + 1]);
-  if (NT)
-    __builtin_nontemporal_store(a, reinterpret_cast<u32x2*>(p + i));
-  else
-    *reinterpret_cast<u32x2*>(p + i) = a;
+  st8<NT>(reinterpret_cast<u32x2*>(p + i), a);
 }
 
 // all workgroups of a cluster meet here; `cnt` is a zero-initialised single-use counter.  Everything the cluster
@@ -896,7 +916,12 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
           for (int j = 0; j < 4; ++j)
             o[j] = prologue<GUIDE>(vx[j], v0[j], GUIDE == DPM_GUIDE_CFG ? v1[j] : 0.f, GUIDE == DPM_GUIDE_CLASSIFIER ? vg[j] : 0.f, p);
         }
-        store4(sx0, i, o);
+        {  // LDS, not global memory: a plain 16-byte store (store4 writes through to global memory)
+          u32x4 a;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[j] = __float_as_uint(o[j]);
+          *reinterpret_cast<u32x4*>(sx0 + i) = a;
+        }
         if (topk) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -1179,53 +1204,65 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
 
     // phase 3: clamp, scale, combine, epilogue, store
     if (vec) {
-#pragma unroll 2
-      for (int i = tid * 4; i < n; i += T * 4) {
-        const int64_t gi = base + i;
-        float vx[4], vh1[4], vh2[4], vm[4], va[4], vb[4], o[4], om[4];
-        if (FT::needs_x) load4<true>(x, gi, vx);                 // last use of x and of the cached model values
-        if (FT::needs_h1) load4<true>(h1, gi, vh1);
-        if (FT::needs_h2) load4<true>(h2, gi, vh2);
-        if (mask) {
-          load4(mask, mfull ? gi : (int64_t)((mbase + (uint32_t)i) % mper), vm);
-          load4(ba, gi, va);
-          if (bb) load4(bb, gi, vb);
+      // two tile rows per iteration, the loads of both issued before the first use (an explicit pair: the write-through
+      // stores are assembly the loop unroller will not duplicate)
+      for (int i0 = tid * 4; i0 < n; i0 += 2 * T * 4) {
+        float vx[2][4], vh1[2][4], vh2[2][4];
+        const bool two = i0 + T * 4 < n;  // per lane: the second row may end before this lane
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int64_t gi = base + (r == 0 || two ? i0 + r * T * 4 : i0);  // clamped: loads are unconditional
+          if (FT::needs_x) load4<true>(x, gi, vx[r]);                 // last use of x and of the cached model values
+          if (FT::needs_h1) load4<true>(h1, gi, vh1[r]);
+          if (FT::needs_h2) load4<true>(h2, gi, vh2[r]);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) om[j] = fminf(fmaxf(sx0[i + j], -s), s);  // ref :424
-        if (s_fast) {
+        for (int r = 0; r < 2; ++r) {
+          const int i = i0 + r * T * 4;
+          if (r == 0 || two) {
+            const int64_t gi = base + i;
+            float vm[4], va[4], vb[4], o[4], om[4];
+            if (mask) {
+              load4(mask, mfull ? gi : (int64_t)((mbase + (uint32_t)i) % mper), vm);
+              load4(ba, gi, va);
+              if (bb) load4(bb, gi, vb);
+            }
 #pragma unroll
-          for (int j = 0; j < 4; j += 2) {
-            const f32x2 c2 = {om[j], om[j + 1]};
-            const f32x2 qd = c2 * inv_s;
-            const f32x2 r = vfma(vfma(-qd, (f32x2)(s), c2), (f32x2)(inv_s), qd);
-            om[j] = r[0];
-            om[j + 1] = r[1];
+            for (int j = 0; j < 4; ++j) om[j] = fminf(fmaxf(sx0[i + j], -s), s);  // ref :424
+            if (s_fast) {
+#pragma unroll
+              for (int j = 0; j < 4; j += 2) {
+                const f32x2 c2 = {om[j], om[j + 1]};
+                const f32x2 qd = c2 * inv_s;
+                const f32x2 q2 = vfma(vfma(-qd, (f32x2)(s), c2), (f32x2)(inv_s), qd);
+                om[j] = q2[0];
+                om[j + 1] = q2[1];
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) om[j] = om[j] / s;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+              const f32x2 z = {0.f, 0.f};
+              const f32x2 c2 = combine<FORM, f32x2>(FT::needs_x ? f32x2{vx[r][j], vx[r][j + 1]} : z, f32x2{om[j], om[j + 1]},
+                                                    FT::needs_h1 ? f32x2{vh1[r][j], vh1[r][j + 1]} : z,
+                                                    FT::needs_h2 ? f32x2{vh2[r][j], vh2[r][j + 1]} : z, p);
+              o[j] = c2[0];
+              o[j + 1] = c2[1];
+            }
+            if (mask) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                o[j] = blend_ref(to_f32(from_f32<TS>(o[j])), vm[j], va[j], bb ? vb[j] : 0.f, bb != nullptr, ext);
+            }
+            store4(xo, gi, o);
+            if (xo2) store4(xo2, gi, o);
+            if (store_m) store4<true>(mo, gi, om);                  // read again only after the next network call
           }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) om[j] = om[j] / s;
         }
-#pragma unroll
-        for (int j = 0; j < 4; j += 2) {
-          const f32x2 z = {0.f, 0.f};
-          const f32x2 r = combine<FORM, f32x2>(FT::needs_x ? f32x2{vx[j], vx[j + 1]} : z, f32x2{om[j], om[j + 1]},
-                                               FT::needs_h1 ? f32x2{vh1[j], vh1[j + 1]} : z,
-                                               FT::needs_h2 ? f32x2{vh2[j], vh2[j + 1]} : z, p);
-          o[j] = r[0];
-          o[j + 1] = r[1];
-        }
-        if (mask) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            o[j] = blend_ref(to_f32(from_f32<TS>(o[j])), vm[j], va[j], bb ? vb[j] : 0.f, bb != nullptr, ext);
-        }
-        store4(xo, gi, o);
-        if (xo2) store4(xo2, gi, o);
-        if (store_m) store4<true>(mo, gi, om);                  // read again only after the next network call
       }
     } else {
-#pragma unroll 2
       for (int i = tid; i < n; i += T) {
         const int64_t gi = base + i;
         const float mn = fminf(fmaxf(sx0[i], -s), s) / s;  // ref :424
