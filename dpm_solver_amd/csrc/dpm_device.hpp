@@ -1435,15 +1435,16 @@ inline int64_t thr_ws_bytes(int64_t batch, int64_t per_sample, int n_cu) {
   return thr_plan(batch, per_sample, n_cu).k > 1 ? batch * (int64_t)THR_WS_WORDS * 4 : 0;
 }
 
-// launch-shape defaults (measured on MI355X, profiles/r01_tuning.md and r01_tuning_v3.md) and the run-time tuning hooks.
-// nt mask: bit 0 = nt loads, bit 1 = nt x_out store, bit 2 = nt m_out store.  Two situations, two optima:
-//   * a network ran since the inputs were written (every real sampling loop): the streams come from HBM and
-//     streaming (nt) loads + an nt store of the model value win -- [256,4,64,64] HBM-cold: fp16 8.0 vs 8.9 us,
-//     fp32 14.1 vs 16.9 us against the default cache policy.  This is the default (DefNT = 5).
+// launch-shape defaults (measured on MI355X: profiles/r01_tuning.md, r01_tuning_v3.txt, and r01_tuning_v4.txt with the
+// write-through stores) and the run-time tuning hooks.  nt mask: bit 0 = nt loads; bits 1, 2 = nt x_out / m_out store,
+// which only matter in a -DDPM_STORE_WRITE_THROUGH=0 build.  Two situations, two optima:
+//   * a network ran since the inputs were written (every real sampling loop): the streams come from HBM and streaming
+//     (nt) loads win -- [256,4,64,64] HBM-cold: fp16 8.4 vs 9.3 us, fp32 15.3 vs 16.3-16.5 us against the default cache
+//     policy.  This is the default (DefNT = 5).
 //   * the previous launch wrote the inputs (dpm_buffers.inputs_resident: frozen-model loops such as dpm_plan_run
-//     without a model callback): they sit in the Infinity Cache and the default policy wins, fp32 with two tiles per
-//     workgroup iteration -- fp16 6.26 vs 6.63 us, fp32 12.15 vs 13.3 us.  Variants exist for the 2M / first-order
-//     kernels (HotCombo).
+//     without a model callback): they sit in the Infinity Cache and the default policy wins, with two tiles per
+//     workgroup iteration when there is work for it -- fp16 5.5 vs 7.4-7.6 us, fp32 12.35 vs 12.9 us.  Variants exist for
+//     the 2M / first-order kernels (HotCombo).
 constexpr int DEF_U = 1;
 template <typename TS>
 struct DefNT {
@@ -1692,9 +1693,9 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
         const bool resident = b->inputs_resident != 0 || tn.assume_resident != 0;
         const bool big = ntiles >= 4 * (int64_t)n_cu;  // two tiles per iteration only when there is work for it
         const int key = (tn.unroll > 0 && tn.nontemporal >= 0) ? tn.unroll * 8 + (tn.nontemporal & 7)
-                        : resident                              ? (sizeof(TS) == 4 && big ? 16 : 8) + 0
+                        : resident                              ? (big ? 16 : 8) + 0
                         : sizeof(TS) == 2                       ? 8 + 1
-                        : sizeof(TE) == 4                       ? 8 + 5
+                        : sizeof(TE) == 4                       ? (big ? 16 : 8) + 5
                                                                 : (big ? 16 : 8) + 1;
         switch (key) {
           case 8 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 1, 0); break;
