@@ -258,8 +258,13 @@ def main():
     for r in range(3):
         L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, nreq, sptr, msb, resm))
         cold.append(np.frombuffer(msb, dtype=np.float32).reshape(nreq, n_stages)[:, 1:n_stages - 1].copy())
-    cold_us = float(np.mean(cold) * 1e3)
-    cold_med_us, cold_max_us = float(np.median(cold) * 1e3), float(np.max(cold) * 1e3)
+    cold = np.asarray(cold, dtype=np.float64) * 1e3
+    cold_med_us, cold_max_us = float(np.median(cold)), float(np.max(cold))
+    # On some boxes one launch in a few thousand of this loop shows a 50-75 ms gap between its start and stop events
+    # (seen with both store policies' kernels present on the box and never in the timed region): such launches are
+    # counted, not averaged
+    stalled = cold > 50.0 * cold_med_us
+    cold_us = float(cold[~stalled].mean())
     # what the memory system sustains for this pattern and size with no arithmetic at all (3 read + 2 write streams)
     cal = {}
     msv = C.c_float()
@@ -292,6 +297,7 @@ def main():
                     host_wall=dict(achieved=round(traj_alg_bytes * args.steps / wall / 1e9, 1),
                                    frac=round(traj_alg_bytes * args.steps / wall / 1e9 / HBM_PEAK_GBS, 4)),
                     hbm_cold=dict(kernel_us=round(cold_us, 3), median_us=round(cold_med_us, 3), max_us=round(cold_max_us, 1),
+                                  stalled_launches=int(stalled.sum()), launches=int(cold.size),
                                   achieved=round(alg_bytes / cold_us / 1e3, 1),
                                   frac=round(alg_bytes / cold_us / 1e3 / HBM_PEAK_GBS, 4),
                                   how="%d requests advanced stage by stage (dpm_plan_run_multi)" % nreq),
