@@ -6,29 +6,36 @@ configs[1]) on N GPUs of one node.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A *step* is one complete 20-stage sampling trajectory of one batch of 256 latents: the 20 launches of the fused
-stage kernel recorded by the C ABI (dpm_graph_create = dpm_plan_run under hipGraph capture) and replayed with one
-dpm_graph_launch per trajectory (--mode eager: 20 individual launches through dpm_plan_run), the network frozen
-(its output pre-staged in a buffer distinct from x), every input resident in HBM before the clock starts.  Steps cycle through
-`--sets` independent buffer sets (default 8 x 64 MiB = 512 MiB) so that consecutive trajectories cannot live in
-the 256 MiB Infinity Cache: in real use a UNet runs between two solver stages and evicts it anyway.
+What is timed is the situation every real sampling loop is in: the inputs of a solver stage come from **HBM**, not
+from the 256 MiB Infinity Cache, because a network ran since they were written (ref :1195-1213).  With a frozen network
+that situation is produced by keeping R = 32 independent sampling requests of [256,4,64,64] in flight and advancing them
+stage by stage (`dpm_plan_run_multi`): between two stages of one request the other 31 stream 1.3 GB through the chip.
+The 32 requests of one stage are ONE fused launch (`dpm_stage_launch_multi` -> stage_kernel_multi, a pointer-table
+kernel over 32 x 4.2 M elements), so a launch's ramp-up and drain are paid once per 1.3 GB.
+
+A *step* is one complete 20-stage trajectory of those R requests: 20 fused launches, R x 256 samples.  Every input
+is resident in HBM before the clock starts; the network outputs are pre-staged in buffers distinct from x.
+A timed region shorter than 50 ms is not reported: the step count is raised until the region is long enough, and
+`steps` in the JSON line is the number of steps actually timed (`steps_requested` is what --steps asked for).
 
 One JSON line on rank 0:
-  value              whole-job Msamples/s = N * K * 256 / wall, wall = barrier/sync-bracketed, max over ranks
-  roofline           HBM roofline of the stage kernel (2M steady state: reads x, eps, m_prev; writes x_next, m =
-                     5 * n * sizeof(dtype) algorithmic bytes; first / last stage 4 * n * sizeof).  `achieved` = algorithmic
-                     bytes of the timed region / its GPU time measured with HIP events on the launch stream, i.e. bytes
-                     per launch / average launch duration with the dispatch gaps of the pipelined trajectory included --
-                     the average rocprofv3 --kernel-trace --stats reports for the kernel (profiles/).  `kernel_only`
-                     = the same for the kernel's own start -> stop time (hipExtLaunchKernelGGL events per launch).
-  cpu_baseline       the numpy oracle (oracle/dpm_oracle.py, a port of the reference algorithm) timed on one host
-                     core, rank 0, N=1 only, on a bounded sample of the same workload.
+  value            whole-job Msamples/s = N * K * R * 256 / wall, wall = barrier/sync-bracketed, max over ranks
+  roofline         HBM roofline of the fused 2M stage kernel.  `achieved` = algorithmic bytes of the timed region
+                   (98*n*s per request trajectory = 18 x 5 n s + 2 x 4 n s) / its GPU time by HIP events on the launch
+                   stream, i.e. bytes per launch / average launch duration, dispatch gaps included -- the average
+                   rocprofv3 --kernel-trace --stats reports for the kernel (profiles/).  Secondary entries:
+                   `cache_resident` (ONE request, stages back to back: inputs in the Infinity Cache -- last round's
+                   headline), `single_request_cold` (requests interleaved but one launch each), the no-arithmetic
+                   ceilings of the same streams.
+  cpu_baseline     the reference itself ($DPM_REFERENCE_DIR or /root/reference: dpm_solver_pytorch.py, unmodified) on
+                   this box's host cores when it is present, else the numpy oracle (a port); rank 0, N=1 only, bounded.
 """
 import argparse
 import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -38,7 +45,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 B, SHAPE, STEPS_SOLVER = 256, (4, 64, 64), 20
-HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured float4-copy ceiling is ~6290
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+MIN_REGION_S = 0.050        # shorter timed regions are not reported
+_DT = {"fp16": torch.float16, "fp32": torch.float32, "bf16": torch.bfloat16}
 
 
 def sd_alphas_cumprod():
@@ -54,14 +63,16 @@ def baseline_metric():
         return "solver-update Msamples/sec + HBM GB/s, DPM-Solver++(2M) 20-step, Bx4x64x64"
 
 
-def make_sets(n_sets, dtype, dev, seed):
-    """n_sets independent buffer sets: x_T, frozen eps, 3 state scratch buffers, 2 history slots."""
+def make_sets(n_sets, dtype, dev, seed, eps_dtype=None):
+    """n_sets independent requests: x_T, frozen eps, 3 state scratch buffers, 2 history slots each."""
     from dpm_solver_amd import _lib as L
+    code = {torch.float16: L.DTYPE_F16, torch.float32: L.DTYPE_F32, torch.bfloat16: L.DTYPE_BF16}
+    eps_dtype = eps_dtype or dtype
     g = torch.Generator(device="cpu").manual_seed(seed)
     sets = []
     for _ in range(n_sets):
         x_T = torch.randn((B,) + SHAPE, generator=g).to(dev, dtype)
-        eps = torch.randn((B,) + SHAPE, generator=g).to(dev, dtype)
+        eps = torch.randn((B,) + SHAPE, generator=g).to(dev, eps_dtype)
         xb = [x_T] + [torch.empty_like(x_T) for _ in range(3)]
         hb = [torch.empty_like(x_T) for _ in range(2)]
         rb = L.RunBuffers()
@@ -71,46 +82,129 @@ def make_sets(n_sets, dtype, dev, seed):
             rb.hist[i] = hb[i].data_ptr()
         rb.e0 = eps.data_ptr()
         rb.n, rb.batch = x_T.numel(), B
-        rb.state_dtype = rb.eps_dtype = {torch.float16: L.DTYPE_F16, torch.float32: L.DTYPE_F32,
-                                         torch.bfloat16: L.DTYPE_BF16}[dtype]
+        rb.state_dtype, rb.eps_dtype = code[dtype], code[eps_dtype]
         sets.append(dict(rb=rb, x=xb, h=hb, eps=eps))
     return sets
 
 
-def cpu_baseline(ac, budget_s=12.0):
-    """numpy oracle (port of the reference's algorithm, one thread) on the same workload, bounded sample."""
-    from oracle import dpm_oracle as O
-    osch = O.Schedule.from_alphas_cumprod(ac)
-    rng = np.random.default_rng(0)
-    bs = B
-    x = rng.standard_normal((bs,) + SHAPE).astype(np.float32)
-    eps = rng.standard_normal((bs,) + SHAPE).astype(np.float32)
-    O.Solver(O.wrap_model(lambda xx, t: eps[:4], osch), osch).sample(x[:4], steps=STEPS_SOLVER, order=2)  # warm-up
-    sol = O.Solver(O.wrap_model(lambda xx, t: eps, osch), osch, algorithm_type="dpmsolver++")
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline: the reference's own DPM_Solver.sample() (ref :1047-1245) when the checkout is present, else the port
+# ---------------------------------------------------------------------------------------------------------------
+def reference_dir():
+    d = os.environ.get("DPM_REFERENCE_DIR", "/root/reference")
+    return d if os.path.exists(os.path.join(d, "dpm_solver_pytorch.py")) else None
+
+
+def _time_loop(fn, budget_s, min_runs=2):
+    fn()                                                   # warm-up
     t0 = time.perf_counter()
     n = 0
     while True:
-        sol.sample(x, steps=STEPS_SOLVER, order=2)
+        fn()
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s:
-            break
-    return dict(value=bs * n / el / 1e6, unit="Msamples/s", cores=1, kind="port",
-                sample="%d trajectories of [%d,4,64,64] fp32 (numpy oracle, frozen eps), %.1f s" % (n, bs, el))
+        if el > budget_s and n >= min_runs:
+            return n, el
+
+
+def cpu_baseline_reference(ref, ac, budget_s=8.0):
+    """/root/reference/dpm_solver_pytorch.py, unmodified, on CPU tensors: 2M++ 20 steps, [256,4,64,64] fp32, frozen eps,
+    at 1 thread and at all host cores."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_dpm_reference", os.path.join(ref, "dpm_solver_pytorch.py"))
+    R = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(R)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((B,) + SHAPE, generator=g)
+    eps = torch.randn((B,) + SHAPE, generator=g)
+    ns = R.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(ac))
+    sol = R.DPM_Solver(R.model_wrapper(lambda xx, t: eps, ns), ns, algorithm_type="dpmsolver++")
+    run = lambda: sol.sample(x, steps=STEPS_SOLVER, order=2, skip_type="time_uniform", method="multistep")
+    cores = os.cpu_count() or 1
+    out = {}
+    before = torch.get_num_threads()
+    try:
+        for th in sorted({1, cores}):
+            torch.set_num_threads(th)
+            n, el = _time_loop(run, budget_s / 2)
+            out[th] = dict(value=round(B * n / el / 1e6, 6), unit="Msamples/s", threads=th, trajectories=n,
+                           seconds=round(el, 2), ms_per_trajectory=round(el / n * 1e3, 2))
+    finally:
+        torch.set_num_threads(before)
+    best = out[cores]
+    return dict(value=best["value"], unit="Msamples/s", cores=cores, threads=cores, kind="reference",
+                sample="%d trajectories of [%d,4,64,64] fp32, DPM_Solver.sample(steps=20, order=2, multistep) of the "
+                       "unmodified reference dpm_solver_pytorch.py on CPU tensors, frozen eps, torch %s, %d threads, %.1f s"
+                       % (best["trajectories"], B, torch.__version__, cores, best["seconds"]),
+                single_thread=out[1], all_cores=best)
+
+
+def cpu_baseline_port(ac, budget_s=8.0):
+    """numpy oracle (a port of the reference's algorithm) on the same workload: one thread, and the batch sharded over
+    all host cores (numpy releases the GIL inside its loops)."""
+    from oracle import dpm_oracle as O
+    osch = O.Schedule.from_alphas_cumprod(ac)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((B,) + SHAPE).astype(np.float32)
+    eps = rng.standard_normal((B,) + SHAPE).astype(np.float32)
+
+    def traj(lo, hi):
+        e = eps[lo:hi]
+        O.Solver(O.wrap_model(lambda xx, t: e, osch), osch, algorithm_type="dpmsolver++").sample(
+            x[lo:hi], steps=STEPS_SOLVER, order=2)
+
+    cores = os.cpu_count() or 1
+    n1, el1 = _time_loop(lambda: traj(0, B), budget_s / 2, min_runs=1)
+
+    def sharded():
+        per = (B + cores - 1) // cores
+        ths = [threading.Thread(target=traj, args=(i * per, min(B, (i + 1) * per))) for i in range(cores) if i * per < B]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+
+    nc, elc = _time_loop(sharded, budget_s / 2, min_runs=1)
+    v1, vc = B * n1 / el1 / 1e6, B * nc / elc / 1e6
+    best_v, best_c = (vc, cores) if vc > v1 else (v1, 1)
+    return dict(value=round(best_v, 6), unit="Msamples/s", cores=best_c, kind="port",
+                sample="numpy oracle (oracle/dpm_oracle.py), [%d,4,64,64] fp32 2M++ 20 steps, frozen eps: %d trajectories "
+                       "in %.1f s on 1 thread, %d in %.1f s with the batch sharded over %d threads"
+                       % (B, n1, el1, nc, elc, cores),
+                single_thread=dict(value=round(v1, 6), threads=1), all_cores=dict(value=round(vc, 6), threads=cores))
+
+
+def cpu_baseline(ac):
+    ref = reference_dir()
+    out = cpu_baseline_reference(ref, ac) if ref else cpu_baseline_port(ac)
+    # the reference cannot travel to the GPU box (it is not part of this repository): its timing in the build container
+    # is committed and attached for the record
+    p = os.path.join(ROOT, "profiles", "cpu_baseline_reference.json")
+    if out["kind"] != "reference" and os.path.exists(p):
+        try:
+            out["reference_in_build_container"] = json.load(open(p))
+        except Exception:
+            pass
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--sets", type=int, default=8, help="independent buffer sets cycled through (cache defeat)")
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--requests", type=int, default=32,
+                    help="independent [256,4,64,64] sampling requests in flight, advanced stage by stage (one fused "
+                         "launch per stage); 32 x 42 MB per stage > the 256 MiB Infinity Cache")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32", "bf16"])
-    ap.add_argument("--mode", default="eager", choices=["graph", "eager"],
-                    help="eager: 20 launches per trajectory through dpm_plan_run (default, measured fastest); graph: one hipGraph replay")
+    ap.add_argument("--eps-dtype", default=None, choices=["fp16", "fp32", "bf16"],
+                    help="dtype of the network output (default: the state dtype); fp16 with --dtype fp32 = SD under autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (profiling runs)")
     args = ap.parse_args()
-    dtype = {"fp16": torch.float16, "fp32": torch.float32, "bf16": torch.bfloat16}[args.dtype]
+    dtype = _DT[args.dtype]
+    eps_dtype = _DT[args.eps_dtype] if args.eps_dtype else dtype
+    R = args.requests
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -149,29 +243,17 @@ def main():
                          solver_type="dpmsolver", lower_order_final=True, denoise_to_zero=False,
                          t_T=1.0, t_0=1.0 / ns.total_N)
     n_stages = len(plan.stages)
-    sets = make_sets(args.sets, dtype, dev, seed=1234 + rank)          # independent samples per rank (seed + rank)
+    sets = make_sets(R, dtype, dev, seed=1234 + rank, eps_dtype=eps_dtype)   # independent samples per rank (seed + rank)
     stream = torch.cuda.Stream(device=dev)              # a real stream: hipGraph capture cannot use the null stream
     stream.wait_stream(torch.cuda.current_stream(dev))
     torch.cuda.set_stream(stream)
     sptr = C.c_void_p(stream.cuda_stream)
-    res = C.c_int(-1)
+    rbs = (L.RunBuffers * R)(*[s_["rb"] for s_ in sets])
+    resm = (C.c_int * R)()
 
-    def eager(i):
-        L.check(L.lib.dpm_plan_run(plan.handle, C.byref(sets[i % len(sets)]["rb"]), None, None, sptr, C.byref(res)))
-
-    graphs = []
-    for s_ in sets:                                     # one captured trajectory per buffer set
-        g = C.c_void_p()
-        L.check(L.lib.dpm_graph_create(plan.handle, C.byref(s_["rb"]), None, None, sptr, C.byref(g)))
-        assert L.lib.dpm_graph_num_nodes(g) == n_stages
-        graphs.append(g)
-
-    def replay(i):
-        g = graphs[i % len(graphs)]
-        L.check(L.lib.dpm_graph_launch(g, sptr))
-        res.value = L.lib.dpm_graph_result(g)
-
-    trajectory = replay if args.mode == "graph" else eager
+    def step():
+        """one 20-stage trajectory of the R requests in flight: 20 fused launches"""
+        L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, R, sptr, None, resm))
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -179,137 +261,170 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # ---- parity spot check outside the timed region: native loop == Python host loop (same kernels) ---------
-    s0 = sets[0]
-    dchk = D.DPM_Solver(D.model_wrapper(lambda x, t: s0["eps"], ns), ns, state_dtype=dtype)
-    want = dchk.sample(s0["x"][0], steps=STEPS_SOLVER, order=2)
-    trajectory(0)
+    # ---- parity spot check outside the timed region: fused launches == the Python host loop (single launches) ---
+    step()
     torch.cuda.synchronize(dev)
-    assert torch.equal(s0["x"][res.value], want), "native loop / graph replay and Python loop disagree"
+    for r in sorted({0, R - 1}):
+        s_ = sets[r]
+        dchk = D.DPM_Solver(D.model_wrapper(lambda x, t, e=s_["eps"]: e, ns), ns, state_dtype=dtype)
+        want = dchk.sample(s_["x"][0], steps=STEPS_SOLVER, order=2)
+        torch.cuda.synchronize(dev)
+        assert torch.equal(s_["x"][resm[r]], want), "fused multi-request launches and the Python loop disagree (request %d)" % r
 
-    for i in range(args.warmup):
-        trajectory(i)
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)                                  # HIP events on the launch stream, around the timed region
-    for i in range(args.steps):
-        trajectory(i)
-    ev1.record(stream)
-    barrier()
-    wall = time.perf_counter() - t0
-    region_us = ev0.elapsed_time(ev1) * 1e3             # GPU time of the K trajectories = K * 20 stage launches
-    if dist is not None:
-        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        wall = float(tw.item())
-    # the other launch mode, outside the contract's timed region (same K), for the record
-    other = eager if args.mode == "graph" else replay
-    for i in range(min(args.warmup, 8)):
-        other(i)
-    torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
-    for i in range(args.steps):
-        other(i)
-    torch.cuda.synchronize(dev)
-    other_ms = (time.perf_counter() - t1) / args.steps * 1e3
+    for _ in range(args.warmup):
+        step()
+    steps = args.steps
+    while True:
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)                              # HIP events on the launch stream, around the timed region
+        for _ in range(steps):
+            step()
+        ev1.record(stream)
+        barrier()
+        wall = time.perf_counter() - t0
+        region_us = ev0.elapsed_time(ev1) * 1e3         # GPU time of the K steps = K * 20 fused launches
+        if dist is not None:
+            tw = torch.tensor([wall], dtype=torch.float64, device=dev)
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            wall = float(tw.item())
+        if wall >= MIN_REGION_S:
+            break
+        steps = int(steps * max(2.0, 1.3 * MIN_REGION_S / max(wall, 1e-6))) + 1   # too short to report: time more steps
 
-    # ---- roofline.  Two durations of the stage kernel are reported:
-    #   launch_us  = GPU time of the timed region (HIP events on the launch stream) / number of launches: the average
-    #                launch duration in the pipelined trajectory, dispatch gap to the next dependent launch included.
-    #                This is what rocprofv3 --kernel-trace --stats reports as the kernel's average (its timestamps of
-    #                consecutive launches abut), and what `roofline.achieved` uses: the region's algorithmic bytes
-    #                (98 N s per trajectory = 18 x 5N + 2 x 4N) / region time.
-    #   kernel_only = start -> stop of each launch by hipExtLaunchKernelGGL events (dpm_plan_run_timed), steady-state
-    #                2M stages only, 5 N s bytes: the kernel without the dispatch gap.
+    # ---- roofline of the timed region ---------------------------------------------------------------------------
     n_el = B * int(np.prod(SHAPE))
-    esz = torch.empty((), dtype=dtype).element_size()
-    reps = max(2 * len(sets), 16)
-    ms = np.zeros((reps, n_stages), dtype=np.float64)
-    buf = (C.c_float * n_stages)()
-    for r in range(reps):
-        L.check(L.lib.dpm_plan_run_timed(plan.handle, C.byref(sets[r % len(sets)]["rb"]), sptr, buf, C.byref(res)))
-        ms[r] = np.frombuffer(buf, dtype=np.float32)
-    steady = ms[:, 1:n_stages - 1]                       # stages 1..18: the 5-stream 2M kernel
-    k_us = float(steady.mean() * 1e3)
-    alg_bytes = 5 * n_el * esz
-    kernel_only = alg_bytes / (k_us * 1e-6) / 1e9
-    traj_alg_bytes = (18 * 5 + 2 * 4) * n_el * esz       # 98 N elements per 20-step trajectory
-    launch_us = region_us / (args.steps * n_stages)
-    achieved = traj_alg_bytes * args.steps / (region_us * 1e-6) / 1e9
+    ssz = torch.empty((), dtype=dtype).element_size()
+    esz = torch.empty((), dtype=eps_dtype).element_size()
+    alg_bytes = n_el * (4 * ssz + esz)                   # steady-state 2M stage of ONE request: reads x, eps, m_prev; writes x', m
+    traj_alg_bytes = n_el * (18 * (4 * ssz + esz) + (3 * ssz + esz) + (3 * ssz + esz))  # + first (no history) and last (no m)
+    launches = steps * n_stages
+    launch_us = region_us / launches
+    achieved = traj_alg_bytes * R * steps / (region_us * 1e-6) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per launch from rocprofv3 --pmc passes
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(args.dtype, {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tpath)).get("fused_" + args.dtype, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    # HBM-cold variant of the same kernel: many requests are advanced stage by stage (dpm_plan_run_multi), so between
-    # two stages of one request the other requests' traffic has flushed the 256 MiB Infinity Cache -- what happens in
-    # real use, where a UNet runs between two solver stages.
-    # 32 requests: > 1 GB of other traffic between two uses of a buffer.  (With 8, part of a request's buffers survives
-    # in the cache and the figure is ~6 % too good.)
-    cold_sets = sets + make_sets(max(0, 32 - len(sets)), dtype, dev, seed=4321 + rank)
-    nreq = len(cold_sets)
-    rbs = (L.RunBuffers * nreq)(*[s_["rb"] for s_ in cold_sets])
-    resm = (C.c_int * nreq)()
-    msb = (C.c_float * (nreq * n_stages))()
-    cold = []
-    for r in range(3):
-        L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, nreq, sptr, msb, resm))
-        cold.append(np.frombuffer(msb, dtype=np.float32).reshape(nreq, n_stages)[:, 1:n_stages - 1].copy())
-    cold = np.asarray(cold, dtype=np.float64) * 1e3
-    cold_med_us, cold_max_us = float(np.median(cold)), float(np.max(cold))
-    # On some boxes one launch in a few thousand of this loop shows a 50-75 ms gap between its start and stop events
-    # (seen with both store policies' kernels present on the box and never in the timed region): such launches are
-    # counted, not averaged
-    stalled = cold > 50.0 * cold_med_us
-    cold_us = float(cold[~stalled].mean())
-    # what the memory system sustains for this pattern and size with no arithmetic at all (3 read + 2 write streams)
-    cal = {}
-    msv = C.c_float()
-    for mode in ("warm", "cold"):
-        ts = []
-        for it in range(24):
-            s_ = sets[0] if mode == "warm" else cold_sets[it % nreq]
-            # same cache policy as the stage kernel in that situation: default when warm, streaming loads when cold
-            L.check(L.lib.dpm_calib_launch(1, 256, 8, L.lib.dpm_tuning_get(L.TUNE_NONTEMPORAL) if L.lib.dpm_tuning_get(L.TUNE_NONTEMPORAL) >= 0
-                                           else (0 if mode == "warm" else 5),
-                                           s_["x"][1].data_ptr(), s_["x"][2].data_ptr(), s_["x"][3].data_ptr(),
-                                           s_["h"][0].data_ptr(), s_["h"][1].data_ptr(), n_el * esz, sptr, C.byref(msv)))
-            if it >= 8:
-                ts.append(msv.value)
-        cal[mode] = float(np.mean(ts) * 1e3)
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                    kernel="stage_kernel<%s,%s,FORM_TWO,GUIDE_NONE> (2M steady state)" % (args.dtype, args.dtype),
-                    launch_us=round(launch_us, 3),
-                    algorithmic_bytes_per_launch=round(traj_alg_bytes / n_stages),
-                    how="algorithmic bytes of the timed region (98*N*s per 20-launch trajectory) / its GPU time by HIP "
-                        "events on the launch stream; launch_us = that time / launches (dispatch gaps included, as in "
-                        "the rocprofv3 kernel-trace average)",
-                    kernel_only=dict(us=round(k_us, 3), us_min=round(float(steady.min() * 1e3), 3),
-                                     achieved=round(kernel_only, 1), frac=round(kernel_only / HBM_PEAK_GBS, 4),
-                                     algorithmic_bytes_per_launch=alg_bytes,
-                                     how="steady-state 2M launches, start->stop events of each launch"),
-                    first_last_stage_us=[round(float(ms[:, 0].mean() * 1e3), 3), round(float(ms[:, -1].mean() * 1e3), 3)],
-                    trajectory_kernel_sum_us=round(float(ms.sum(axis=1).mean() * 1e3), 2),
-                    host_wall=dict(achieved=round(traj_alg_bytes * args.steps / wall / 1e9, 1),
-                                   frac=round(traj_alg_bytes * args.steps / wall / 1e9 / HBM_PEAK_GBS, 4)),
-                    hbm_cold=dict(kernel_us=round(cold_us, 3), median_us=round(cold_med_us, 3), max_us=round(cold_max_us, 1),
-                                  stalled_launches=int(stalled.sum()), launches=int(cold.size),
-                                  achieved=round(alg_bytes / cold_us / 1e3, 1),
-                                  frac=round(alg_bytes / cold_us / 1e3 / HBM_PEAK_GBS, 4),
-                                  how="%d requests advanced stage by stage (dpm_plan_run_multi)" % nreq),
-                    no_arithmetic_ceiling=dict(pattern="3 read + 2 write streams, same bytes, 256-thread blocks",
-                                               warm_us=round(cal["warm"], 3), cold_us=round(cal["cold"], 3),
-                                               frac_of_ceiling_warm=round(cal["warm"] / k_us, 3),
-                                               frac_of_ceiling_cold=round(cal["cold"] / cold_us, 3)))
+                    kernel="stage_kernel_multi<%s,%s,FORM_TWO,GUIDE_NONE,SPEC_NOISE_X0> (2M steady state, %d requests per launch)"
+                           % (args.dtype, args.eps_dtype or args.dtype, min(R, L.MULTI_MAX)),
+                    mode="hbm_cold: %d requests of [%d,4,64,64] in flight, advanced stage by stage, one fused launch per "
+                         "stage (%.0f MB per launch)" % (R, B, traj_alg_bytes * R / n_stages / 1e6),
+                    launch_us=round(launch_us, 3), per_request_stage_us=round(launch_us / R, 4),
+                    algorithmic_bytes_per_launch=round(traj_alg_bytes * R / n_stages),
+                    how="algorithmic bytes of the timed region (98*n*s per request trajectory) / its GPU time by HIP events "
+                        "on the launch stream; launch_us = that time / fused launches (dispatch gaps included, as in the "
+                        "rocprofv3 kernel-trace average)",
+                    host_wall=dict(achieved=round(traj_alg_bytes * R * steps / wall / 1e9, 1),
+                                   frac=round(traj_alg_bytes * R * steps / wall / 1e9 / HBM_PEAK_GBS, 4)))
+
+    if not args.no_secondary:
+        # (1) kernel-only durations of the fused launches (start -> stop events of each launch)
+        msb = (C.c_float * (R * n_stages))()
+        ko = []
+        for _ in range(3):
+            L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, R, sptr, msb, resm))
+            ko.append(np.frombuffer(msb, dtype=np.float32).reshape(R, n_stages)[:, 1:n_stages - 1].astype(np.float64).sum(axis=0))
+        ko_us = float(np.mean(ko) * 1e3)                 # per fused steady-state launch
+        roofline["kernel_only"] = dict(us=round(ko_us, 3), achieved=round(alg_bytes * R / ko_us / 1e3, 1),
+                                       frac=round(alg_bytes * R / ko_us / 1e3 / HBM_PEAK_GBS, 4),
+                                       how="steady-state fused launches, start->stop events of each launch")
+        # (2) the same requests, one launch each (interleaved): what a single request's stage costs from HBM
+        L.lib.dpm_tuning_set(L.TUNE_MULTI_FUSE, 0)
+        cold = []
+        for _ in range(3):
+            L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, R, sptr, msb, resm))
+            cold.append(np.frombuffer(msb, dtype=np.float32).reshape(R, n_stages)[:, 1:n_stages - 1].copy())
+        L.lib.dpm_tuning_set(L.TUNE_MULTI_FUSE, 1)
+        cold = np.asarray(cold, dtype=np.float64) * 1e3
+        cold_med = float(np.median(cold))
+        stalled = cold > 50.0 * cold_med                 # see profiles/r02_stall.md
+        cold_us = float(cold[~stalled].mean())
+        roofline["single_request_cold"] = dict(
+            kernel_us=round(cold_us, 3), median_us=round(cold_med, 3), max_us=round(float(cold.max()), 1),
+            stalled_launches=int(stalled.sum()), launches=int(cold.size),
+            achieved=round(alg_bytes / cold_us / 1e3, 1), frac=round(alg_bytes / cold_us / 1e3 / HBM_PEAK_GBS, 4),
+            how="the %d requests advanced stage by stage with ONE launch per request (42 MB launches), kernel-only" % R)
+        # (3) one request, stages back to back: its inputs sit in the Infinity Cache (last round's headline mode)
+        res1 = C.c_int(-1)
+        k2 = max(20, min(200, steps * R // 8))
+        for i in range(8):
+            L.check(L.lib.dpm_plan_run(plan.handle, C.byref(sets[i % min(8, R)]["rb"]), None, None, sptr, C.byref(res1)))
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for i in range(k2):
+            L.check(L.lib.dpm_plan_run(plan.handle, C.byref(sets[i % min(8, R)]["rb"]), None, None, sptr, C.byref(res1)))
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        warm_us = e0.elapsed_time(e1) * 1e3
+        buf = (C.c_float * n_stages)()
+        ms1 = []
+        for r in range(16):
+            L.check(L.lib.dpm_plan_run_timed(plan.handle, C.byref(sets[r % min(8, R)]["rb"]), sptr, buf, C.byref(res1)))
+            ms1.append(np.frombuffer(buf, dtype=np.float32)[1:n_stages - 1].astype(np.float64).mean() * 1e3)
+        k1_us = float(np.mean(ms1))
+        roofline["cache_resident"] = dict(
+            achieved=round(traj_alg_bytes * k2 / warm_us / 1e3, 1),
+            frac=round(traj_alg_bytes * k2 / warm_us / 1e3 / HBM_PEAK_GBS, 4),
+            launch_us=round(warm_us / (k2 * n_stages), 3), msamples_per_s=round(B * k2 / warm_us, 4),
+            kernel_only_us=round(k1_us, 3), kernel_only_frac=round(alg_bytes / k1_us / 1e3 / HBM_PEAK_GBS, 4),
+            how="ONE request, 20 launches back to back (dpm_plan_run, frozen outputs): x and m are re-read from the "
+                "256 MiB Infinity Cache -- not the situation of a real sampling loop")
+        # (4) what the memory system sustains for these streams with no arithmetic at all (3 read + 2 write streams)
+        if ssz == esz:
+            cal = {}
+            msv = C.c_float()
+            for mode in ("warm", "cold"):
+                ts = []
+                for it in range(24):
+                    s_ = sets[0] if mode == "warm" else sets[it % R]
+                    L.check(L.lib.dpm_calib_launch(1, 256, 8, 0 if mode == "warm" else 5,
+                                                   s_["x"][1].data_ptr(), s_["x"][2].data_ptr(), s_["x"][3].data_ptr(),
+                                                   s_["h"][0].data_ptr(), s_["h"][1].data_ptr(), n_el * ssz, sptr, C.byref(msv)))
+                    if it >= 8:
+                        ts.append(msv.value)
+                cal[mode] = float(np.mean(ts) * 1e3)
+            big = [torch.empty(R * n_el * ssz, dtype=torch.uint8, device=dev) for _ in range(5)]
+            ts = []
+            for it in range(6):
+                L.check(L.lib.dpm_calib_launch(1, 256, 8, 1, big[0].data_ptr(), big[1].data_ptr(), big[2].data_ptr(),
+                                               big[3].data_ptr(), big[4].data_ptr(), R * n_el * ssz, sptr, C.byref(msv)))
+                if it >= 2:
+                    ts.append(msv.value)
+            del big
+            cal["fused"] = float(np.mean(ts) * 1e3)
+            roofline["no_arithmetic_ceiling"] = dict(
+                pattern="3 read + 2 write streams, same bytes, 256-thread workgroups",
+                one_request_warm_us=round(cal["warm"], 3), one_request_cold_us=round(cal["cold"], 3),
+                fused_size_us=round(cal["fused"], 3),
+                fused_size_frac_of_peak=round(alg_bytes * R / cal["fused"] / 1e3 / HBM_PEAK_GBS, 4),
+                stage_kernel_vs_ceiling=round(cal["fused"] / roofline["kernel_only"]["us"], 3))
+
+    # ---- the drop-in Python API on the same workload: DPM_Solver.sample() per request, frozen network ------------
+    py_ms = None
+    if not args.no_secondary:
+        s_ = sets[0]
+        dpy = D.DPM_Solver(D.model_wrapper(lambda x, t, e=s_["eps"]: e, ns), ns, state_dtype=dtype)
+        for _ in range(5):
+            dpy.sample(s_["x"][0], steps=STEPS_SOLVER, order=2)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        kk = 50
+        for i in range(kk):
+            dpy.sample(sets[i % min(8, R)]["x"][0], steps=STEPS_SOLVER, order=2)
+        torch.cuda.synchronize(dev)
+        py_ms = (time.perf_counter() - t1) / kk * 1e3
 
     # ---- the single end-of-sampling collective of the sharded path: all-gather of the final x (timed apart) ---
     gather_ms = None
     if dist is not None:
-        final = sets[(args.steps - 1) % len(sets)]["x"][res.value]
+        final = sets[0]["x"][resm[0]]
         out = torch.empty((world,) + tuple(final.shape), dtype=final.dtype, device=dev)
         dist.all_gather_into_tensor(out, final)                          # warm-up (communicator setup)
         barrier()
@@ -320,31 +435,31 @@ def main():
         assert torch.equal(out[rank], final)
 
     if rank == 0:
-        samples = world * args.steps * B
+        samples = world * steps * R * B
         line = {
             "metric": baseline_metric(),
             "value": round(samples / wall / 1e6, 4), "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(wall / args.steps * 1e3, 5),
+            "n_gpus": world, "steps": steps, "steps_requested": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall / steps * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32",          # the arithmetic type of the path: fp32 whatever the storage type of the state is
             "storage_dtype": {"fp16": "f16", "fp32": "f32", "bf16": "bf16"}[args.dtype], "data": "synthetic",
-            "config": {"workload": "DPM-Solver++ 2M, 20 steps, [256,4,64,64] %s state and network output per GPU (fp32 "
-                                   "arithmetic), frozen model_fn (eps pre-staged), SD-v1 scaled-linear schedule, "
-                                   "time_uniform" % args.dtype,
-                       "batch_per_gpu": B, "solver_stages_per_step": n_stages, "buffer_sets": len(sets),
-                       "launch": "hipGraph replay (dpm_graph_launch)" if args.mode == "graph" else "eager (dpm_plan_run)",
+            "config": {"workload": "DPM-Solver++ 2M, 20 steps, [256,4,64,64] %s state / %s network output per request (fp32 "
+                                   "arithmetic), %d requests in flight per GPU advanced stage by stage (inputs of every "
+                                   "stage come from HBM), frozen model_fn (eps pre-staged), SD-v1 scaled-linear schedule, "
+                                   "time_uniform" % (args.dtype, args.eps_dtype or args.dtype, R),
+                       "batch_per_request": B, "requests_in_flight_per_gpu": R, "samples_per_step_per_gpu": R * B,
+                       "solver_stages_per_step": n_stages,
+                       "launch": "one fused launch per stage (dpm_plan_run_multi -> dpm_stage_launch_multi)",
                        "parallelism": "batch-sharded x%d, no data-path collective" % world},
             "msample_steps_per_s": round(samples * n_stages / wall / 1e6, 3),
-            ("eager_ms_per_step" if args.mode == "graph" else "graph_ms_per_step"): round(other_ms, 5),
+            "python_api_ms_per_trajectory": None if py_ms is None else round(py_ms, 4),
             "roofline": roofline,
             "gather_ms": None if gather_ms is None else round(gather_ms, 4),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ac)
         print(json.dumps(line), flush=True)
-    for g in graphs:
-        L.lib.dpm_graph_destroy(g)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

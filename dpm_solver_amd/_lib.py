@@ -31,6 +31,8 @@ FORM_LIN1, FORM_TWO, FORM_MS3, FORM_SS3T, FORM_DENOISE = 0, 1, 2, 3, 4
 F_TO_X0, F_STORE_M, F_BASE_HIST, F_THRESH, F_USER_X0, F_BLEND = 1, 2, 4, 8, 16, 32
 SRC_STATE, SRC_TMP = 0, 1
 TUNE_UNROLL, TUNE_NONTEMPORAL, TUNE_BLOCKS_PER_CU, TUNE_ASSUME_RESIDENT = 0, 1, 2, 3
+TUNE_MULTI_FUSE, TUNE_MULTI_BLOCKS_PER_CU = 4, 5
+MULTI_MAX = 32
 
 
 class Stage(C.Structure):
@@ -117,6 +119,7 @@ _SIGNATURES = [
                                       C.c_double, C.c_int, _P(Stage)]),
     ("dpm_coef_prologue", C.c_int, [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_double, _P(Stage)]),
     ("dpm_stage_launch", C.c_int, [_P(Stage), _P(Buffers), C.c_void_p]),
+    ("dpm_stage_launch_multi", C.c_int, [_P(Stage), _P(Buffers), C.c_int, C.c_void_p]),
     ("dpm_threshold_workspace_bytes", C.c_size_t, [C.c_int64, C.c_int64]),
     ("dpm_add_noise_launch", C.c_int, [C.c_void_p, _P(C.c_float), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int64, C.c_int, C.c_void_p]),

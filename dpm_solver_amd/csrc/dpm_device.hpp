@@ -44,6 +44,8 @@ struct Tuning {
   int nontemporal = -1;     // nt mask; -1 = per-dtype default
   int blocks_per_cu = 8;    // grid cap = CUs x this (8 x 256 threads = every SIMD holds 8 waves)
   int assume_resident = 0;  // treat every launch as dpm_buffers.inputs_resident (benchmarking a frozen loop from Python)
+  int multi_fuse = 1;       // dpm_stage_launch_multi: 1 = one fused launch per group of requests, 0 = one launch per request
+  int multi_blocks_per_cu = 0;  // grid cap of the fused launch in workgroups per CU; 0 = one super-tile per workgroup
 };
 extern Tuning g_tuning;     // defined in dpm_kernels.hip
 // device-wide chain of clustered thresholding launches (see launch_typed): one instance per device for the library
@@ -406,17 +408,18 @@ __device__ __forceinline__ float blend_ref(float v, float m, float a, float b, b
 // EXT = the launch uses one of the KExt extensions (duplicate store, strided network output, mask blend): the same
 // tiling, with the extra index arithmetic and streams compiled in.  EXT launches have no ragged tail (the scalar kernel
 // takes those) and use the split layout only when no per-sample / per-period index is involved.
+// One workgroup iteration: the U tiles that start at tile t0 of ONE tensor set (shared by the single-request kernel and
+// the fused multi-request kernel below).  Everything outside the two unrolled loops is wave-uniform scalar work.
 template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int SPEC, int U, int NT, bool EXT>
-__global__ __launch_bounds__(256) void stage_kernel(const TS* __restrict__ x, const TS* __restrict__ xe,
-                                                    const TE* __restrict__ e0, const TE* __restrict__ e1,
-                                                    const TE* __restrict__ g, const TS* __restrict__ h1,
-                                                    const TS* __restrict__ h2, TS* __restrict__ xo,
-                                                    TS* __restrict__ mo, int64_t n, KParams p, KExt ext) {
+__device__ __forceinline__ void stage_tiles(const TS* __restrict__ x, const TS* __restrict__ xe,
+                                            const TE* __restrict__ e0, const TE* __restrict__ e1,
+                                            const TE* __restrict__ g, const TS* __restrict__ h1,
+                                            const TS* __restrict__ h2, TS* __restrict__ xo, TS* __restrict__ mo,
+                                            const int64_t ngroups, const int64_t t0, const KParams& p, const KExt& ext) {
   using FT = FormTraits<FORM>;
   constexpr bool SPLIT = sizeof(TS) == 4;  // see load_tile
   const bool need_xe = spec_need_xe<SPEC>(p);
   const bool store_m = p.flags & DPM_F_STORE_M;
-  const int64_t ngroups = n / EPT;
   const TS* mask = EXT ? static_cast<const TS*>(ext.mask) : nullptr;
   const TS* ba = EXT ? static_cast<const TS*>(ext.ba) : nullptr;
   const TS* bb = EXT ? static_cast<const TS*>(ext.bb) : nullptr;
@@ -425,77 +428,89 @@ __global__ __launch_bounds__(256) void stage_kernel(const TS* __restrict__ x, co
   const int64_t mgroups = EXT ? ext.mask_period / EPT : 1;
   const bool small = ngroups < (int64_t)0x7fffffff;  // 32-bit index arithmetic is enough (n < 2^34 elements)
   const bool can_split = SPLIT && (!EXT || (!ext.eps_stride && !mask));
+  float vx[U][EPT], vxe[U][EPT], v0[U][EPT], v1[U][EPT], vg[U][EPT], vh1[U][EPT], vh2[U][EPT];
+  float vm[EXT ? U : 1][EPT], va[EXT ? U : 1][EPT], vb[EXT ? U : 1][EPT];
+  // Lanes past the end of the last tile load a clamped (valid) group and only skip the store: loads and arithmetic
+  // stay in straight-line code, so the loaded registers are consumed where they land (no copies at a join).
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t gr = (t0 + u) * 256 + threadIdx.x;
+    const int64_t gi = gr < ngroups ? gr : ngroups - 1;
+    const bool split = can_split && (t0 + u) * 256 + 256 <= ngroups;
+    int64_t ge = gi;  // group index into the network outputs
+    if (EXT && ext.eps_stride) {
+      if (small) {
+        const uint32_t q = (uint32_t)gi / (uint32_t)gps;
+        ge = (int64_t)q * sgroups + ((uint32_t)gi - q * (uint32_t)gps);
+      } else {
+        ge = (gi / gps) * sgroups + gi % gps;
+      }
+    }
+    if (FT::needs_x || (!XE && need_xe)) load_tile<(NT & 1) != 0>(x, gi, split, vx[u]);
+    if (XE && need_xe) load_tile<(NT & 1) != 0>(xe, gi, split, vxe[u]);
+    load_tile<(NT & 1) != 0>(e0, ge, split, v0[u]);
+    if (GUIDE == DPM_GUIDE_CFG) load_tile<(NT & 1) != 0>(e1, ge, split, v1[u]);
+    if (GUIDE == DPM_GUIDE_CLASSIFIER) load_tile<(NT & 1) != 0>(g, gi, split, vg[u]);
+    if (FT::needs_h1) load_tile<(NT & 1) != 0>(h1, gi, split, vh1[u]);
+    if (FT::needs_h2) load_tile<(NT & 1) != 0>(h2, gi, split, vh2[u]);
+    if (EXT && mask) {
+      const int64_t gm = small ? (int64_t)((uint32_t)gi % (uint32_t)mgroups) : gi % mgroups;
+      load_pack<false>(mask, gm, vm[u]);
+      load_pack<false>(ba, gi, va[u]);
+      if (bb) load_pack<(NT & 1) != 0>(bb, gi, vb[u]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t gi = (t0 + u) * 256 + threadIdx.x;
+    const bool split = can_split && (t0 + u) * 256 + 256 <= ngroups;
+    float ox[EPT], om[EPT];
+#pragma unroll
+    for (int q = 0; q < EPT; q += 2) {  // adjacent pairs: see f32x2
+      const f32x2 z = {0.f, 0.f};
+      const f32x2 x2 = FT::needs_x || (!XE && need_xe) ? f32x2{vx[u][q], vx[u][q + 1]} : z;
+      const f32x2 xe2 = XE ? f32x2{vxe[u][q], vxe[u][q + 1]} : x2;
+      const f32x2 mn = prologue<GUIDE, SPEC>(xe2, f32x2{v0[u][q], v0[u][q + 1]},
+                                             GUIDE == DPM_GUIDE_CFG ? f32x2{v1[u][q], v1[u][q + 1]} : z,
+                                             GUIDE == DPM_GUIDE_CLASSIFIER ? f32x2{vg[u][q], vg[u][q + 1]} : z, p);
+      const f32x2 o = combine<FORM>(FT::needs_x ? x2 : z, mn, FT::needs_h1 ? f32x2{vh1[u][q], vh1[u][q + 1]} : z,
+                                    FT::needs_h2 ? f32x2{vh2[u][q], vh2[u][q + 1]} : z, p);
+      om[q] = mn.x;
+      om[q + 1] = mn.y;
+      ox[q] = o.x;
+      ox[q + 1] = o.y;
+    }
+    if (EXT && mask) {
+#pragma unroll
+      for (int j = 0; j < EPT; ++j)
+        ox[j] = blend_ref(to_f32(from_f32<TS>(ox[j])), vm[EXT ? u : 0][j], va[EXT ? u : 0][j],
+                          bb ? vb[EXT ? u : 0][j] : 0.f, bb != nullptr, ext);
+    }
+    if (gi < ngroups) {
+      store_tile<(NT & 2) != 0>(xo, gi, split, ox);
+      if (EXT && xo2) store_tile<(NT & 2) != 0>(xo2, gi, split, ox);
+      if (store_m) store_tile<(NT & 4) != 0>(mo, gi, split, om);
+    }
+  }
+}
+
+template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int SPEC, int U, int NT, bool EXT>
+__global__ __launch_bounds__(256) void stage_kernel(const TS* __restrict__ x, const TS* __restrict__ xe,
+                                                    const TE* __restrict__ e0, const TE* __restrict__ e1,
+                                                    const TE* __restrict__ g, const TS* __restrict__ h1,
+                                                    const TS* __restrict__ h2, TS* __restrict__ xo,
+                                                    TS* __restrict__ mo, int64_t n, KParams p, KExt ext) {
+  using FT = FormTraits<FORM>;
+  const int64_t ngroups = n / EPT;
   // a tile = 256 consecutive groups (one per lane of the workgroup); a workgroup iteration covers U tiles and
   // issues the loads of all of them before the first use
   const int64_t ntiles = (ngroups + 255) / 256;
-  for (int64_t t0 = (int64_t)blockIdx.x * U; t0 < ntiles; t0 += (int64_t)gridDim.x * U) {
-    float vx[U][EPT], vxe[U][EPT], v0[U][EPT], v1[U][EPT], vg[U][EPT], vh1[U][EPT], vh2[U][EPT];
-    float vm[EXT ? U : 1][EPT], va[EXT ? U : 1][EPT], vb[EXT ? U : 1][EPT];
-    // Lanes past the end of the last tile load a clamped (valid) group and only skip the store: loads and arithmetic
-    // stay in straight-line code, so the loaded registers are consumed where they land (no copies at a join).
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t gr = (t0 + u) * 256 + threadIdx.x;
-      const int64_t gi = gr < ngroups ? gr : ngroups - 1;
-      const bool split = can_split && (t0 + u) * 256 + 256 <= ngroups;
-      int64_t ge = gi;  // group index into the network outputs
-      if (EXT && ext.eps_stride) {
-        if (small) {
-          const uint32_t q = (uint32_t)gi / (uint32_t)gps;
-          ge = (int64_t)q * sgroups + ((uint32_t)gi - q * (uint32_t)gps);
-        } else {
-          ge = (gi / gps) * sgroups + gi % gps;
-        }
-      }
-      if (FT::needs_x || (!XE && need_xe)) load_tile<(NT & 1) != 0>(x, gi, split, vx[u]);
-      if (XE && need_xe) load_tile<(NT & 1) != 0>(xe, gi, split, vxe[u]);
-      load_tile<(NT & 1) != 0>(e0, ge, split, v0[u]);
-      if (GUIDE == DPM_GUIDE_CFG) load_tile<(NT & 1) != 0>(e1, ge, split, v1[u]);
-      if (GUIDE == DPM_GUIDE_CLASSIFIER) load_tile<(NT & 1) != 0>(g, gi, split, vg[u]);
-      if (FT::needs_h1) load_tile<(NT & 1) != 0>(h1, gi, split, vh1[u]);
-      if (FT::needs_h2) load_tile<(NT & 1) != 0>(h2, gi, split, vh2[u]);
-      if (EXT && mask) {
-        const int64_t gm = small ? (int64_t)((uint32_t)gi % (uint32_t)mgroups) : gi % mgroups;
-        load_pack<false>(mask, gm, vm[u]);
-        load_pack<false>(ba, gi, va[u]);
-        if (bb) load_pack<(NT & 1) != 0>(bb, gi, vb[u]);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t gi = (t0 + u) * 256 + threadIdx.x;
-      const bool split = can_split && (t0 + u) * 256 + 256 <= ngroups;
-      float ox[EPT], om[EPT];
-#pragma unroll
-      for (int q = 0; q < EPT; q += 2) {  // adjacent pairs: see f32x2
-        const f32x2 z = {0.f, 0.f};
-        const f32x2 x2 = FT::needs_x || (!XE && need_xe) ? f32x2{vx[u][q], vx[u][q + 1]} : z;
-        const f32x2 xe2 = XE ? f32x2{vxe[u][q], vxe[u][q + 1]} : x2;
-        const f32x2 mn = prologue<GUIDE, SPEC>(xe2, f32x2{v0[u][q], v0[u][q + 1]},
-                                               GUIDE == DPM_GUIDE_CFG ? f32x2{v1[u][q], v1[u][q + 1]} : z,
-                                               GUIDE == DPM_GUIDE_CLASSIFIER ? f32x2{vg[u][q], vg[u][q + 1]} : z, p);
-        const f32x2 o = combine<FORM>(FT::needs_x ? x2 : z, mn, FT::needs_h1 ? f32x2{vh1[u][q], vh1[u][q + 1]} : z,
-                                      FT::needs_h2 ? f32x2{vh2[u][q], vh2[u][q + 1]} : z, p);
-        om[q] = mn.x;
-        om[q + 1] = mn.y;
-        ox[q] = o.x;
-        ox[q + 1] = o.y;
-      }
-      if (EXT && mask) {
-#pragma unroll
-        for (int j = 0; j < EPT; ++j)
-          ox[j] = blend_ref(to_f32(from_f32<TS>(ox[j])), vm[EXT ? u : 0][j], va[EXT ? u : 0][j],
-                            bb ? vb[EXT ? u : 0][j] : 0.f, bb != nullptr, ext);
-      }
-      if (gi < ngroups) {
-        store_tile<(NT & 2) != 0>(xo, gi, split, ox);
-        if (EXT && xo2) store_tile<(NT & 2) != 0>(xo2, gi, split, ox);
-        if (store_m) store_tile<(NT & 4) != 0>(mo, gi, split, om);
-      }
-    }
-  }
+  for (int64_t t0 = (int64_t)blockIdx.x * U; t0 < ntiles; t0 += (int64_t)gridDim.x * U)
+    stage_tiles<TS, TE, FORM, GUIDE, XE, SPEC, U, NT, EXT>(x, xe, e0, e1, g, h1, h2, xo, mo, ngroups, t0, p, ext);
   if constexpr (!EXT) {
     // ragged tail (n % 8 elements): first lanes of block 0, scalar
+    const bool need_xe = spec_need_xe<SPEC>(p);
+    const bool store_m = p.flags & DPM_F_STORE_M;
     const int64_t tail0 = ngroups * EPT;
     if (blockIdx.x == 0 && tail0 + threadIdx.x < n) {
       const int64_t i = tail0 + threadIdx.x;
@@ -506,6 +521,41 @@ __global__ __launch_bounds__(256) void stage_kernel(const TS* __restrict__ x, co
       xo[i] = from_f32<TS>(combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[i]) : 0.f, FT::needs_h2 ? to_f32(h2[i]) : 0.f, p));
       if (store_m) mo[i] = from_f32<TS>(mn);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused multi-request stage: ONE launch advances up to DPM_MULTI_MAX independent sampling requests that are at the
+// same stage of the same plan (same scalars, element count and dtypes; their own buffers).  A server holding R requests
+// in flight -- or one caller sampling R batches side by side -- pays the launch's ramp-up and drain (2-3 us of a
+// 42 MB launch's 8.5 us when its inputs come from HBM) once per R x 42 MB instead of once per 42 MB.  The pointer table
+// is a kernel argument (kernarg segment -> scalar loads with a wave-uniform index); the virtual tile index runs over
+// request-major super-tiles (U tiles of one request), so consecutive workgroups stream consecutive addresses.
+// ------------------------------------------------------------------------------------------------
+constexpr int MULTI_MAX = DPM_MULTI_MAX;
+struct MultiTab {
+  const void* x[MULTI_MAX];
+  const void* e0[MULTI_MAX];
+  const void* e1[MULTI_MAX];
+  const void* h1[MULTI_MAX];
+  const void* h2[MULTI_MAX];
+  void* xo[MULTI_MAX];
+  void* mo[MULTI_MAX];
+};
+
+template <typename TS, typename TE, int FORM, int GUIDE, int SPEC, int U, int NT>
+__global__ __launch_bounds__(256) void stage_kernel_multi(const MultiTab tab, int64_t n, uint32_t nreq, uint32_t spr,
+                                                          KParams p) {
+  const int64_t ngroups = n / EPT;
+  KExt ext = {};
+  const uint32_t total = nreq * spr;  // spr = super-tiles (U tiles) per request
+  for (uint32_t v = blockIdx.x; v < total; v += gridDim.x) {
+    const uint32_t r = v / spr;
+    const int64_t t0 = (int64_t)(v - r * spr) * U;
+    stage_tiles<TS, TE, FORM, GUIDE, false, SPEC, U, NT, false>(
+        static_cast<const TS*>(tab.x[r]), nullptr, static_cast<const TE*>(tab.e0[r]), static_cast<const TE*>(tab.e1[r]),
+        nullptr, static_cast<const TS*>(tab.h1[r]), static_cast<const TS*>(tab.h2[r]), static_cast<TS*>(tab.xo[r]),
+        static_cast<TS*>(tab.mo[r]), ngroups, t0, p, ext);
   }
 }
 
@@ -1719,6 +1769,107 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return dpm_set_error((int)e, "stage kernel launch failed: %s", hipGetErrorString(e));
   return DPM_OK;
+}
+
+// ---- fused multi-request launch (stage_kernel_multi).  Returns DPM_ERR_UNSUPPORTED *without* setting an error text
+// when this (form, guidance, prologue) has no fused variant: the caller then launches the requests one by one.
+constexpr int MULTI_NOT_BUILT = -1000;
+// Launch shape of the fused kernel (profiles/r02_tune_multi.txt, 32 x [256,4,64,64], kernel-only per request-stage):
+// the inputs of a fused launch always come from HBM (R x 42 MB of other requests' traffic passed since they were
+// written) -> streaming loads; one super-tile per workgroup -- a grid of all R x tiles workgroups, no grid-stride loop:
+// fp16 7.95 us with the grid capped at 8 workgroups per CU, 7.7 / 7.5 at 16 / 32 per CU, 6.93 uncapped (0.757 of the
+// HBM peak; fp32 15.4 -> 13.9, fp32 state + fp16 output 13.3 -> 12.6); two tiles per workgroup for 4-byte states.
+template <typename TS, typename TE>
+struct MultiShape {
+  static constexpr int U = (sizeof(TS) == 4) ? 2 : 1;
+  static constexpr int NT = 1;
+};
+
+template <typename TS, typename TE, int FORM, int GUIDE, int SPEC>
+int launch_multi_spec(const dpm_stage* st, const dpm_buffers* bs, int n_req, const LaunchCtx& c) {
+  const DeviceInfo& di = device_info();
+  const int n_cu = di.n_cu > 0 ? di.n_cu : 256;
+  const Tuning tn = g_tuning;
+  MultiTab tab;
+  std::memset(&tab, 0, sizeof tab);
+  for (int r = 0; r < n_req; ++r) {
+    tab.x[r] = bs[r].x ? bs[r].x : bs[r].xe;
+    tab.e0[r] = bs[r].e0;
+    tab.e1[r] = bs[r].e1;
+    tab.h1[r] = bs[r].h1;
+    tab.h2[r] = bs[r].h2;
+    tab.xo[r] = bs[r].x_out;
+    tab.mo[r] = bs[r].m_out;
+  }
+  const KParams p = make_params(st);
+  const int64_t n = bs[0].n;
+  const int64_t ntiles = ((n / EPT) + 255) / 256;
+  auto go = [&](auto kern, int u) {
+    const int64_t spr = (ntiles + u - 1) / u;
+    int64_t blocks = spr * n_req;
+    if (tn.multi_blocks_per_cu > 0) {  // tuning hook: cap the grid, workgroups loop over the super-tiles
+      const int64_t cap = (int64_t)n_cu * tn.multi_blocks_per_cu;
+      if (blocks > cap) blocks = cap;
+    }
+    launch(kern, dim3((unsigned)blocks), dim3(256), 0, c, tab, n, (uint32_t)n_req, (uint32_t)spr, p);
+  };
+  constexpr int DU = MultiShape<TS, TE>::U, DN = MultiShape<TS, TE>::NT;
+#ifdef DPM_MULTI_TUNING_VARIANTS  // tools/tune_multi.py: every (tiles per iteration, nt mask) of the 2M kernel
+  if constexpr (FORM == DPM_FORM_TWO && GUIDE == DPM_GUIDE_NONE && SPEC == SPEC_NOISE_X0) {
+    if (tn.unroll > 0 && tn.nontemporal >= 0) {
+      switch (tn.unroll * 8 + (tn.nontemporal & 7)) {
+        case 8 + 0: go(stage_kernel_multi<TS, TE, FORM, GUIDE, SPEC, 1, 0>, 1); break;
+        case 8 + 1: go(stage_kernel_multi<TS, TE, FORM, GUIDE, SPEC, 1, 1>, 1); break;
+        case 8 + 5: go(stage_kernel_multi<TS, TE, FORM, GUIDE, SPEC, 1, 5>, 1); break;
+        case 16 + 0: go(stage_kernel_multi<TS, TE, FORM, GUIDE, SPEC, 2, 0>, 2); break;
+        case 16 + 1: go(stage_kernel_multi<TS, TE, FORM, GUIDE, SPEC, 2, 1>, 2); break;
+        case 16 + 5: go(stage_kernel_multi<TS, TE, FORM, GUIDE, SPEC, 2, 5>, 2); break;
+        default: go(stage_kernel_multi<TS, TE, FORM, GUIDE, SPEC, DU, DN>, DU); break;
+      }
+      hipError_t e2 = hipGetLastError();
+      if (e2 != hipSuccess) return dpm_set_error((int)e2, "fused stage kernel launch failed: %s", hipGetErrorString(e2));
+      return DPM_OK;
+    }
+  }
+#endif
+  go(stage_kernel_multi<TS, TE, FORM, GUIDE, SPEC, DU, DN>, DU);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return dpm_set_error((int)e, "fused stage kernel launch failed: %s", hipGetErrorString(e));
+  return DPM_OK;
+}
+
+// every request of the group: same stage, n, batch, dtypes (checked by the caller); here: is there a fused variant, and
+// do all buffers allow 16-byte accesses?
+template <typename TS, typename TE>
+int launch_multi_typed(const dpm_stage* st, const dpm_buffers* bs, int n_req, const LaunchCtx& c) {
+  if (st->flags & (DPM_F_THRESH | DPM_F_BLEND)) return MULTI_NOT_BUILT;
+  if (st->guidance == DPM_GUIDE_CLASSIFIER) return MULTI_NOT_BUILT;
+  if (st->model_type != DPM_MODEL_NOISE) return MULTI_NOT_BUILT;
+  if ((st->flags & DPM_F_TO_X0) && !div_invariant_ok(st->alpha_e)) return MULTI_NOT_BUILT;
+  if (st->form != DPM_FORM_LIN1 && st->form != DPM_FORM_TWO && st->form != DPM_FORM_MS3) return MULTI_NOT_BUILT;
+  const size_t as = sizeof(TS) * EPT, ae = sizeof(TE) * EPT;
+  if (bs[0].n % EPT != 0) return MULTI_NOT_BUILT;
+  for (int r = 0; r < n_req; ++r) {
+    const dpm_buffers& b = bs[r];
+    if (b.x_out2 || (b.eps_stride && b.eps_stride != b.n / b.batch)) return MULTI_NOT_BUILT;
+    if (b.xe && b.x && b.xe != b.x) return MULTI_NOT_BUILT;
+    if (!(aligned(b.x, as) && aligned(b.xe, as) && aligned(b.h1, as) && aligned(b.h2, as) && aligned(b.x_out, as) &&
+          aligned(b.m_out, as) && aligned(b.e0, ae) && aligned(b.e1, ae)))
+      return MULTI_NOT_BUILT;
+  }
+  const bool x0 = (st->flags & DPM_F_TO_X0) != 0;
+  const bool cfg = st->guidance == DPM_GUIDE_CFG;
+#define DPM_MULTI(FORM_)                                                                                        \
+  (cfg ? (x0 ? launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_CFG, SPEC_NOISE_X0>(st, bs, n_req, c)                 \
+             : launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_CFG, SPEC_NOISE_EPS>(st, bs, n_req, c))               \
+       : (x0 ? launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_NONE, SPEC_NOISE_X0>(st, bs, n_req, c)                \
+             : launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_NONE, SPEC_NOISE_EPS>(st, bs, n_req, c)))
+  switch (st->form) {
+    case DPM_FORM_LIN1: return DPM_MULTI(DPM_FORM_LIN1);
+    case DPM_FORM_TWO: return DPM_MULTI(DPM_FORM_TWO);
+    default: return DPM_MULTI(DPM_FORM_MS3);
+  }
+#undef DPM_MULTI
 }
 
 template <typename TS, typename TE, int FORM, int GUIDE>

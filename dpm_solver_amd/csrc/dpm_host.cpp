@@ -856,7 +856,7 @@ extern "C" int dpm_plan_timesteps(const dpm_plan* p, float* out, int cap, int* n
 // launch hooks implemented in dpm_kernels.hip
 int dpm_stage_launch_ev(const dpm_stage* st, const dpm_buffers* b, void* stream, void* ev_start, void* ev_stop);
 int dpm_timing_begin(int n, void*** starts, void*** stops);
-int dpm_timing_end(int n, void** starts, void** stops, void* stream, float* ms);
+int dpm_timing_end(int n, void** starts, void** stops, void* stream, float* ms, const unsigned char* recorded);
 
 static int plan_run_impl(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model_cb model, void* user, void* stream,
                          int* result, void** ev_start, void** ev_stop) {
@@ -922,9 +922,12 @@ extern "C" int dpm_plan_run_timed(const dpm_plan* p, const dpm_run_buffers* rb, 
   int rc = dpm_timing_begin(n, &starts, &stops);
   if (rc) return rc;
   rc = plan_run_impl(p, rb, nullptr, nullptr, stream, result, starts, stops);
-  int rc2 = dpm_timing_end(n, starts, stops, stream, rc ? nullptr : ms_per_stage);
+  int rc2 = dpm_timing_end(n, starts, stops, stream, rc ? nullptr : ms_per_stage, nullptr);
   return rc ? rc : rc2;
 }
+
+int dpm_stage_launch_multi_ev(const dpm_stage* st, const dpm_buffers* bs, int n_req, void* stream, void** ev_start,
+                              void** ev_stop, int* fused_first);
 
 extern "C" int dpm_plan_run_multi(const dpm_plan* p, const dpm_run_buffers* rbs, int n_req, void* stream, float* ms,
                                   int* results) {
@@ -941,15 +944,16 @@ extern "C" int dpm_plan_run_multi(const dpm_plan* p, const dpm_run_buffers* rbs,
     int rc = dpm_timing_begin(n_req * ns, &starts, &stops);
     if (rc) return rc;
   }
-  std::vector<int> state(n_req, 0), tmp(n_req, -1);
+  std::vector<int> state(n_req, 0), tmp(n_req, -1), first((size_t)n_req * ns, 0);
+  std::vector<dpm_buffers> bs(n_req);
   int rc = DPM_OK;
   for (const dpm_stage& st : p->stages) {
-    for (int r = 0; r < n_req && !rc; ++r) {
+    for (int r = 0; r < n_req; ++r) {
       const dpm_run_buffers& rb = rbs[r];
       const int xe = st.xe_src == DPM_SRC_TMP ? tmp[r] : state[r];
       int out = 1;
       while (out == state[r] || out == xe) ++out;
-      dpm_buffers b;
+      dpm_buffers& b = bs[r];
       std::memset(&b, 0, sizeof b);
       b.x = rb.xbuf[state[r]];
       b.xe = xe == state[r] ? nullptr : rb.xbuf[xe];
@@ -964,9 +968,8 @@ extern "C" int dpm_plan_run_multi(const dpm_plan* p, const dpm_run_buffers* rbs,
       b.batch = rb.batch;
       b.state_dtype = rb.state_dtype;
       b.eps_dtype = rb.eps_dtype;
+      b.eps_stride = rb.eps_stride;
       b.inputs_resident = n_req == 1;  // interleaved requests evict each other's buffers, like a network would
-      const int k = r * ns + st.index;
-      rc = dpm_stage_launch_ev(&st, &b, stream, starts ? starts[k] : nullptr, stops ? stops[k] : nullptr);
       if (st.emits_state) {
         state[r] = out;
         tmp[r] = -1;
@@ -974,11 +977,28 @@ extern "C" int dpm_plan_run_multi(const dpm_plan* p, const dpm_run_buffers* rbs,
         tmp[r] = out;
       }
     }
+    // event k = st.index * n_req + r (stage-major, so a stage's events are one contiguous array)
+    const size_t k0 = (size_t)st.index * n_req;
+    rc = dpm_stage_launch_multi_ev(&st, bs.data(), n_req, stream, starts ? starts + k0 : nullptr,
+                                   stops ? stops + k0 : nullptr, first.data() + k0);
     if (rc) break;
   }
   if (ms) {
-    int rc2 = dpm_timing_end(n_req * ns, starts, stops, stream, rc ? nullptr : ms);
+    std::vector<float> raw((size_t)n_req * ns, 0.f);
+    std::vector<unsigned char> recorded((size_t)n_req * ns, 0);
+    for (int s = 0; s < ns; ++s)
+      for (int r = 0; r < n_req; ++r) recorded[(size_t)s * n_req + r] = first[(size_t)s * n_req + r] == r;
+    int rc2 = dpm_timing_end(n_req * ns, starts, stops, stream, rc ? nullptr : raw.data(), recorded.data());
     if (!rc) rc = rc2;
+    if (!rc)
+      for (int s = 0; s < ns; ++s)
+        for (int r = 0; r < n_req;) {  // a fused group [r, e): its one measured duration, spread evenly
+          int e = r + 1;
+          while (e < n_req && first[(size_t)s * n_req + e] == first[(size_t)s * n_req + r]) ++e;
+          const float each = raw[(size_t)s * n_req + r] / (float)(e - r);
+          for (int q = r; q < e; ++q) ms[(size_t)q * ns + s] = each;
+          r = e;
+        }
   }
   if (!rc && results)
     for (int r = 0; r < n_req; ++r) results[r] = state[r];

@@ -18,7 +18,11 @@ int dpm_launch_f32_f16(const dpm_stage*, const dpm_buffers*, void*, void*, void*
 int dpm_launch_f32_bf16(const dpm_stage*, const dpm_buffers*, void*, void*, void*);
 int dpm_launch_f16_f16(const dpm_stage*, const dpm_buffers*, void*, void*, void*);
 int dpm_launch_bf16_bf16(const dpm_stage*, const dpm_buffers*, void*, void*, void*);
-
+int dpm_launch_multi_f32_f32(const dpm_stage*, const dpm_buffers*, int, void*, void*, void*);
+int dpm_launch_multi_f32_f16(const dpm_stage*, const dpm_buffers*, int, void*, void*, void*);
+int dpm_launch_multi_f32_bf16(const dpm_stage*, const dpm_buffers*, int, void*, void*, void*);
+int dpm_launch_multi_f16_f16(const dpm_stage*, const dpm_buffers*, int, void*, void*, void*);
+int dpm_launch_multi_bf16_bf16(const dpm_stage*, const dpm_buffers*, int, void*, void*, void*);
 
 // ------------------------------------------------------------------------------------------------
 // C ABI
@@ -67,6 +71,58 @@ extern "C" int dpm_stage_launch(const dpm_stage* st, const dpm_buffers* b, void*
   return dpm_stage_launch_ev(st, b, stream, nullptr, nullptr);
 }
 
+// One stage of n_req requests.  ev_start / ev_stop (optional) are arrays of n_req events: a fused launch of the
+// requests [r0, r1) is bracketed by ev_start[r0] / ev_stop[r0] and fused_first[r] = r0 for its members (a request
+// launched on its own has fused_first[r] = r), so the caller can spread the duration.
+int dpm_stage_launch_multi_ev(const dpm_stage* st, const dpm_buffers* bs, int n_req, void* stream, void** ev_start,
+                              void** ev_stop, int* fused_first) {
+  if (!st || !bs || n_req < 1) return dpm_set_error(DPM_ERR_ARG, "stage_launch_multi: bad arguments");
+  int done = 0;  // requests already advanced by fused launches
+  bool same = g_tuning.multi_fuse != 0 && n_req > 1;
+  for (int r = 1; r < n_req && same; ++r)
+    same = bs[r].n == bs[0].n && bs[r].batch == bs[0].batch && bs[r].state_dtype == bs[0].state_dtype &&
+           bs[r].eps_dtype == bs[0].eps_dtype;
+  if (same && bs[0].n > 0 && bs[0].batch > 0 && bs[0].n % bs[0].batch == 0) {
+    // the argument checks of the single launch, once per request
+    const bool needs_h1 = st->form == DPM_FORM_TWO || st->form == DPM_FORM_MS3;
+    const bool needs_h2 = st->form == DPM_FORM_MS3;
+    for (int r = 0; r < n_req && same; ++r) {
+      const dpm_buffers& b = bs[r];
+      same = b.e0 && b.x_out && (b.x || b.xe) && (!needs_h1 || b.h1) && (!needs_h2 || b.h2) &&
+             (!(st->flags & DPM_F_STORE_M) || b.m_out) && (st->guidance != DPM_GUIDE_CFG || b.e1);
+    }
+    const int sd = bs[0].state_dtype, ed = bs[0].eps_dtype;
+    int (*fn)(const dpm_stage*, const dpm_buffers*, int, void*, void*, void*) = nullptr;
+    if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_F32) fn = dpm_launch_multi_f32_f32;
+    else if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_F16) fn = dpm_launch_multi_f32_f16;
+    else if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_BF16) fn = dpm_launch_multi_f32_bf16;
+    else if (sd == DPM_DTYPE_F16 && ed == DPM_DTYPE_F16) fn = dpm_launch_multi_f16_f16;
+    else if (sd == DPM_DTYPE_BF16 && ed == DPM_DTYPE_BF16) fn = dpm_launch_multi_bf16_bf16;
+    if (same && fn) {
+      int r0 = 0;
+      for (; r0 < n_req; r0 += MULTI_MAX) {
+        const int cnt = std::min(MULTI_MAX, n_req - r0);
+        const int rc = fn(st, bs + r0, cnt, stream, ev_start ? ev_start[r0] : nullptr, ev_stop ? ev_stop[r0] : nullptr);
+        if (rc == MULTI_NOT_BUILT) break;  // no fused variant for this stage, or a buffer of this group is unaligned
+        if (rc) return rc;
+        if (fused_first)
+          for (int r = r0; r < r0 + cnt; ++r) fused_first[r] = r0;
+        done = r0 + cnt;
+      }
+    }
+  }
+  for (int r = done; r < n_req; ++r) {
+    const int rc = dpm_stage_launch_ev(st, &bs[r], stream, ev_start ? ev_start[r] : nullptr, ev_stop ? ev_stop[r] : nullptr);
+    if (rc) return rc;
+    if (fused_first) fused_first[r] = r;
+  }
+  return DPM_OK;
+}
+
+extern "C" int dpm_stage_launch_multi(const dpm_stage* st, const dpm_buffers* bs, int n_req, void* stream) {
+  return dpm_stage_launch_multi_ev(st, bs, n_req, stream, nullptr, nullptr, nullptr);
+}
+
 int dpm_timing_begin(int n, void*** starts, void*** stops) {
   void** a = new (std::nothrow) void*[2 * (size_t)n]();
   if (!a) return dpm_set_error(DPM_ERR_NOMEM, "out of memory");
@@ -85,12 +141,14 @@ int dpm_timing_begin(int n, void*** starts, void*** stops) {
   return DPM_OK;
 }
 
-int dpm_timing_end(int n, void** starts, void** stops, void* stream, float* ms) {
+// `recorded` (optional, n flags): event pairs that were never handed to a launch (members of a fused group other than its
+// first) are skipped, their ms stays untouched
+int dpm_timing_end(int n, void** starts, void** stops, void* stream, float* ms, const unsigned char* recorded) {
   int ret = DPM_OK;
   hipError_t rc = hipStreamSynchronize(static_cast<hipStream_t>(stream));
   if (rc != hipSuccess) ret = dpm_set_error((int)rc, "hipStreamSynchronize: %s", hipGetErrorString(rc));
   for (int i = 0; i < n; ++i) {
-    if (ms && ret == DPM_OK) {
+    if (ms && ret == DPM_OK && (!recorded || recorded[i])) {
       rc = hipEventElapsedTime(&ms[i], static_cast<hipEvent_t>(starts[i]), static_cast<hipEvent_t>(stops[i]));
       if (rc != hipSuccess) ret = dpm_set_error((int)rc, "hipEventElapsedTime(stage %d): %s", i, hipGetErrorString(rc));
     }
@@ -106,7 +164,7 @@ extern "C" int dpm_stage_launch_timed(const dpm_stage* st, const dpm_buffers* b,
   int rc = dpm_timing_begin(1, &starts, &stops);
   if (rc) return rc;
   rc = dpm_stage_launch_ev(st, b, stream, starts[0], stops[0]);
-  int rc2 = dpm_timing_end(1, starts, stops, stream, rc ? nullptr : ms);
+  int rc2 = dpm_timing_end(1, starts, stops, stream, rc ? nullptr : ms, nullptr);
   return rc ? rc : rc2;
 }
 
@@ -341,7 +399,7 @@ extern "C" int dpm_calib_launch(int kind, int block, int blocks_per_cu, int nt, 
   else if (kind == 1 && block == 1024) calib_nt<1024, 1>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
   else rc = dpm_set_error(DPM_ERR_ARG, "calib: kind %d / block %d not built", kind, block);
   if (ms) {
-    int rc2 = dpm_timing_end(1, starts, stops, stream, rc ? nullptr : ms);
+    int rc2 = dpm_timing_end(1, starts, stops, stream, rc ? nullptr : ms, nullptr);
     if (!rc) rc = rc2;
   }
   return rc;
@@ -359,6 +417,11 @@ extern "C" int dpm_tuning_set(int knob, int value) {
       g_tuning.blocks_per_cu = value;
       return DPM_OK;
     case DPM_TUNE_ASSUME_RESIDENT: g_tuning.assume_resident = value != 0; return DPM_OK;
+    case DPM_TUNE_MULTI_FUSE: g_tuning.multi_fuse = value != 0; return DPM_OK;
+    case DPM_TUNE_MULTI_BLOCKS_PER_CU:
+      if (value < 0 || value > 4096) return dpm_set_error(DPM_ERR_ARG, "multi_blocks_per_cu must be in 0..4096");
+      g_tuning.multi_blocks_per_cu = value;
+      return DPM_OK;
   }
   return dpm_set_error(DPM_ERR_ARG, "unknown tuning knob %d", knob);
 }
@@ -369,6 +432,8 @@ extern "C" int dpm_tuning_get(int knob) {
     case DPM_TUNE_NONTEMPORAL: return g_tuning.nontemporal;
     case DPM_TUNE_BLOCKS_PER_CU: return g_tuning.blocks_per_cu;
     case DPM_TUNE_ASSUME_RESIDENT: return g_tuning.assume_resident;
+    case DPM_TUNE_MULTI_FUSE: return g_tuning.multi_fuse;
+    case DPM_TUNE_MULTI_BLOCKS_PER_CU: return g_tuning.multi_blocks_per_cu;
   }
   return -1;
 }

@@ -5,3 +5,8 @@ int dpm_launch_f32_f32(const dpm_stage* st, const dpm_buffers* b, void* stream, 
   const LaunchCtx s{static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop)};
   return launch_form<float, float>(st, b, s);
 }
+
+int dpm_launch_multi_f32_f32(const dpm_stage* st, const dpm_buffers* bs, int n_req, void* stream, void* ev_start, void* ev_stop) {
+  const LaunchCtx s{static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop)};
+  return launch_multi_typed<float, float>(st, bs, n_req, s);
+}

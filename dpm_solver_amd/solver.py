@@ -49,6 +49,17 @@ def _raw_stream(dev):
     return torch._C._cuda_getCurrentRawStream(idx), idx
 
 
+def _launch_ctx(dev):
+    """(hipStream_t, device index, stream is capturing, device is not the current one) for launches on `dev`"""
+    stream, idx = _raw_stream(dev)
+    return stream, idx, torch.cuda.is_current_stream_capturing(), idx != torch.cuda.current_device()
+
+
+# the C entry point the prebuilt launch records of _FastRun go through (a module attribute so that the CPU test suite
+# can put its numpy double of the kernel behind the very same records)
+_stage_launch_raw = L.lib.dpm_stage_launch
+
+
 def _conv(t, dt):
     """`t` as a contiguous tensor of dtype `dt` (no copy when it already is one)"""
     if t is None:
@@ -180,6 +191,20 @@ class _Plan:
             self.stages.append(st)
         self._dev = {}
         self._views = {}
+        # static buffer roles per stage, as plan_run_impl (dpm_host.cpp) rotates them: indices into
+        # [x_T, scratch 1, scratch 2, scratch 3] for the update's x, the state the network saw, and the output
+        self.roles = []
+        state, tmp = 0, -1
+        for st in self.stages:
+            xe = tmp if st.xe_src == L.SRC_TMP else state
+            out = 1
+            while out == state or out == xe:
+                out += 1
+            self.roles.append((state, xe, out))
+            if st.emits_state:
+                state, tmp = out, -1
+            else:
+                tmp = out
 
     def times(self, device):
         """(t_eval, t_input, t_out) as fp32 device vectors, one host-to-device copy per plan and device."""
@@ -198,10 +223,15 @@ class _Plan:
         if hit is None:
             T = self.times(device)
             n = len(self.stages)
+            # contiguous (batch,) vectors like the reference hands to the network (t.expand(B) of a fresh tensor,
+            # torch.cat([t] * 2) under CFG): a model may edit them in place or need contiguous inputs.  Materialised
+            # once per (plan, batch) -- two small kernels here, none per step.
+            te = T[0].reshape(n, 1).expand(n, batch).contiguous()
+            ti = T[1].reshape(n, 1).expand(n, 2 * batch if cfg else batch).contiguous()
             hit = dict(t_eval=[T[0, i] for i in range(n)], t_out=[T[2, i] for i in range(n)],
-                       t_eval_b=[T[0, i].expand(batch) for i in range(n)],
-                       t_input_b=[T[1, i].expand(batch) for i in range(n)],
-                       t_input_2b=[T[1, i].expand(2 * batch) for i in range(n)] if cfg else None)
+                       t_eval_b=[te[i] for i in range(n)],
+                       t_input_b=[ti[i, :batch] for i in range(n)],
+                       t_input_2b=[ti[i] for i in range(n)] if cfg else None)
             self._views[key] = hit
         return hit
 
@@ -212,6 +242,60 @@ class _Plan:
             except Exception:
                 pass
             self.handle = None
+
+
+class _FastRun:
+    """Everything of a `sample()` call that does not change from call to call, built once per (plan, shape, dtypes,
+    device, stream): the scratch states the stages ping-pong through, the cached model values, the thresholding
+    workspace, and one ready `dpm_stage` + `dpm_buffers` pair per stage with every static pointer filled in.  A call then
+    only patches the caller's x_T, the fresh output tensor and the network outputs into those structs and launches.
+    Scratch buffers are internal (never handed out), so reusing them across calls on the same stream is safe; the
+    result of a call is always a fresh tensor."""
+
+    def __init__(self, solver, plan, shape, sd, device, dup):
+        B = int(shape[0])
+        n = 1
+        for d in shape:
+            n *= int(d)
+        self.shape, self.sd, self.dup, self.n = tuple(shape), sd, dup, n
+        full = ((2 * B,) + tuple(shape[1:])) if dup else tuple(shape)
+        self.xfull = [None] + [torch.empty(full, dtype=sd, device=device) for _ in range(3)]   # [2B,...] under CFG
+        self.xbuf = [None] + [t[:B] for t in self.xfull[1:]]
+        self.hist = [torch.empty(shape, dtype=sd, device=device) for _ in range(plan.slots)]
+        self.ws = None
+        nstg = len(plan.stages)
+        self.stages, self.bufs, self.refs = [], [], []
+        esz = torch.empty((), dtype=sd).element_size()
+        self.last = nstg - 1
+        for i, ps in enumerate(plan.stages):
+            st = solver._prep_stage(ps.copy())
+            b = L.Buffers()
+            xi, xei, oi = plan.roles[i]
+            if xi > 0:
+                b.x = self.xbuf[xi].data_ptr()
+            if xei != xi and xei > 0:
+                b.xe = self.xbuf[xei].data_ptr()
+            if i != self.last:
+                b.x_out = self.xbuf[oi].data_ptr()
+                if dup:
+                    b.x_out2 = b.x_out + n * esz
+            if st.h1_slot >= 0:
+                b.h1 = self.hist[st.h1_slot].data_ptr()
+            if st.h2_slot >= 0:
+                b.h2 = self.hist[st.h2_slot].data_ptr()
+            if st.flags & L.F_STORE_M:
+                b.m_out = self.hist[st.m_slot].data_ptr()
+            b.n, b.batch = n, max(B, 1)
+            b.state_dtype = _DT[sd]
+            if st.flags & L.F_THRESH:
+                nb = L.lib.dpm_threshold_workspace_bytes(b.batch, n // b.batch)
+                if nb:
+                    if self.ws is None:
+                        self.ws = torch.empty(nb, dtype=torch.uint8, device=device)
+                    b.workspace = self.ws.data_ptr()
+            self.stages.append(st)
+            self.bufs.append(b)
+            self.refs.append((C.byref(st), C.byref(b)))
 
 
 class DPM_Solver:
@@ -249,6 +333,7 @@ class DPM_Solver:
         self.thresholding_max_val = thresholding_max_val
         self._state_dtype = state_dtype
         self._plans = {}
+        self._fast = {}
         # adaptive solver: optional hook applied to the 0-dim batch-maximum error before the controller reads it
         self.error_reduce = None
 
@@ -698,10 +783,81 @@ class DPM_Solver:
                                       "it cannot be captured into a graph")
         return GraphedSample(self, x, warmup, sample_kwargs)
 
+    def _run_plan_fast(self, plan, x, sd, cfg):
+        """`_run_plan` without correctors / intermediates: prebuilt launch records (see _FastRun), the result in a
+        fresh tensor.  Per stage: the opaque network call, three pointer patches, one dpm_stage_launch."""
+        device = x.device
+        stream, idx, capturing, other = _launch_ctx(device)
+        key = (id(plan), tuple(x.shape), sd, idx, stream, cfg)
+        fr = None if capturing else self._fast.get(key)      # a captured graph bakes its buffers in: give it its own
+        if fr is None:
+            fr = _FastRun(self, plan, x.shape, sd, device, cfg)
+            if not capturing:
+                if len(self._fast) >= 8:
+                    self._fast.pop(next(iter(self._fast)))
+                self._fast[key] = fr
+        x0 = _conv(x, sd)
+        p0 = x0.data_ptr()
+        B = x.shape[0]
+        out = torch.empty(x.shape, dtype=sd, device=device)
+        V = plan.time_views(device, B, cfg)
+        tb, ti, t2 = V["t_eval_b"], V["t_input_b"], V["t_input_2b"]
+        bufs, refs, roles = fr.bufs, fr.refs, plan.roles
+        bufs[fr.last].x_out = out.data_ptr()
+        xbuf, xfull = fr.xbuf, fr.xfull
+        launch = _stage_launch_raw
+        dcode = _DT[sd]
+        wrapped = self._wrapped
+        model_fn = self._model_fn
+        for i, b in enumerate(bufs):
+            xi, xei, _ = roles[i]
+            if xi == 0:
+                b.x = p0
+            if xei == 0:
+                xe_t, x2 = x0, None
+                if xi != 0:
+                    b.xe = p0
+            else:
+                xe_t, x2 = xbuf[xei], (xfull[xei] if cfg else None)
+            if wrapped is not None:
+                e0, e1, g = wrapped.raw_outputs(xe_t, tb[i], ti[i], t2[i] if cfg else None, x_in2=x2)
+            else:
+                e0, e1, g = model_fn(xe_t, tb[i]), None, None
+            ed = e0.dtype
+            if ed is not sd and (sd is not torch.float32 or ed not in _DT):
+                ed = sd              # only (fp32 state, any eps) and equal low-precision pairs have kernels
+            stride = 0
+            if e0.dtype is ed and e0.is_contiguous() and (e1 is None or (e1.dtype is ed and e1.is_contiguous())) \
+                    and (g is None or (g.dtype is ed and g.is_contiguous())):
+                pass
+            elif e0.dtype is ed and not e0.is_contiguous() and _sample_strided(e0) and e0.shape == x.shape and (
+                    e1 is None or (e1.dtype is ed and _sample_strided(e1) and e1.stride(0) == e0.stride(0))):
+                stride = int(e0.stride(0))      # channel slice of a wider output: read in place
+                g = _conv(g, ed)
+            else:
+                e0, e1, g = _conv(e0, ed), _conv(e1, ed), _conv(g, ed)
+            b.e0 = e0.data_ptr()
+            if e1 is not None:
+                b.e1 = e1.data_ptr()
+            if g is not None:
+                b.g = g.data_ptr()
+            b.eps_dtype = dcode if ed is sd else _DT[ed]
+            b.eps_stride = stride
+            if other:
+                with torch.cuda.device(idx):
+                    rc = launch(refs[i][0], refs[i][1], stream)
+            else:
+                rc = launch(refs[i][0], refs[i][1], stream)
+            if rc:
+                L.check(rc)
+        return out
+
     def _run_plan(self, plan, x, method, cxt, keep, intermediates):
         device = x.device
         sd = self._sdtype(x)
         cfg = self._wrapped is not None and self._wrapped.effective_guidance == "classifier-free"
+        if cxt is None and not keep and self._user_x0 is None and x.dim() > 0 and x.numel() > 0:
+            return self._run_plan_fast(plan, x, sd, cfg)
         V = plan.time_views(device, x.shape[0] if x.dim() > 0 else 1, cfg)
         blend = cxt if isinstance(cxt, MaskBlend) else None      # folded into the stage kernels' epilogue
         if blend is not None:

@@ -214,6 +214,14 @@ int dpm_coef_prologue(const dpm_schedule* s, float t_eval, int model_type, int g
 /* ---- device side --------------------------------------------------------------------------- */
 /* one fused stage kernel, asynchronous on `stream` */
 int dpm_stage_launch(const dpm_stage* st, const dpm_buffers* b, void* stream);
+/* The same stage of n_req independent requests (same plan position: one dpm_stage; same n, batch and dtypes; each its
+   own buffers) as ONE fused launch per group of DPM_MULTI_MAX requests: a server that keeps R sampling requests in
+   flight pays a launch's ramp-up and drain once per R x (5 n s) bytes instead of once per 5 n s -- with inputs coming
+   from HBM (a network ran in between) that is 8.5 -> ~6.7 us per [256,4,64,64] fp16 request-stage.  Stages the fused
+   kernel family does not cover (thresholding, mask blend, classifier guidance, x_start / v / score networks, strided
+   or unaligned buffers, the singlestep mid-stages) are launched request by request; results are identical either way. */
+#define DPM_MULTI_MAX 32
+int dpm_stage_launch_multi(const dpm_stage* st, const dpm_buffers* bs, int n_req, void* stream);
 /* scratch needed by stages with DPM_F_THRESH on the current device: 0 when one workgroup per sample is the plan (the
    sample lives in that workgroup's LDS), else ~40 KiB per sample of histograms, lists and counters through which the workgroup
    cluster of a sample synchronises (small batches, samples beyond 12288 elements); the launch zeroes it itself.
@@ -262,10 +270,12 @@ int dpm_plan_run(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model_cb mode
 int dpm_stage_launch_timed(const dpm_stage* st, const dpm_buffers* b, void* stream, float* ms);
 int dpm_plan_run_timed(const dpm_plan* p, const dpm_run_buffers* rb, void* stream, float* ms_per_stage, int* result);
 
-/* several independent sampling requests advanced stage by stage (request 0 stage s, request 1 stage s, ...):
-   what a server holding n requests in flight does, and -- with a frozen model -- the HBM-cold measurement
-   mode of bench.py: between two stages of one request the other n-1 requests stream their buffers through the
-   Infinity Cache.  ms (optional, [n_req * num_stages], request-major) receives kernel-only durations. */
+/* several independent sampling requests advanced stage by stage (all requests stage s, then all stage s+1, ...)
+   through dpm_stage_launch_multi: what a server holding n requests in flight does, and -- with a frozen model -- the
+   HBM-cold measurement mode of bench.py: between two stages of one request the other n-1 requests stream their buffers
+   through the 256 MiB Infinity Cache.  All requests must share n, batch and dtypes.  ms (optional,
+   [n_req * num_stages], request-major) receives kernel-only durations; a fused launch's duration is divided evenly
+   over the requests it advanced.  DPM_TUNE_MULTI_FUSE = 0 launches request by request instead. */
 int dpm_plan_run_multi(const dpm_plan* p, const dpm_run_buffers* rbs, int n_req, void* stream, float* ms, int* results);
 
 /* ---- hipGraph capture of a whole trajectory ------------------------------------------------------------
@@ -282,7 +292,11 @@ int dpm_graph_num_nodes(const dpm_graph* g); /* kernel / memset nodes captured  
 void dpm_graph_destroy(dpm_graph* g);
 
 /* ---- launch-shape tuning hooks (autotuning / benchmarking; defaults are the measured best) --------- */
-enum { DPM_TUNE_UNROLL = 0, DPM_TUNE_NONTEMPORAL = 1, DPM_TUNE_BLOCKS_PER_CU = 2, DPM_TUNE_ASSUME_RESIDENT = 3 };
+enum {
+  DPM_TUNE_UNROLL = 0, DPM_TUNE_NONTEMPORAL = 1, DPM_TUNE_BLOCKS_PER_CU = 2, DPM_TUNE_ASSUME_RESIDENT = 3,
+  DPM_TUNE_MULTI_FUSE = 4,          /* 1 (default): dpm_stage_launch_multi fuses; 0: one launch per request          */
+  DPM_TUNE_MULTI_BLOCKS_PER_CU = 5  /* grid cap of the fused launch, workgroups per CU; 0 (default) = no cap      */
+};
 int dpm_tuning_set(int knob, int value);
 int dpm_tuning_get(int knob);
 /* memory-system calibration with no arithmetic (kind 0: copy; kind 1: 3 read + 2 write streams, the 2M stage's

@@ -136,3 +136,80 @@ def _eval1(h, what, t):
     o = np.empty(1, dtype=F32)
     L.check(L.lib.dpm_schedule_eval(h, what, i.ctypes.data_as(C.POINTER(C.c_float)), 1, o.ctypes.data_as(C.POINTER(C.c_float))))
     return o[0]
+
+
+# ------------------------------------------------------------------------------------------------
+# pointer-level double of the C entry point dpm_stage_launch(dpm_stage*, dpm_buffers*, stream): what the prebuilt
+# launch records of DPM_Solver's fast path call (solver._stage_launch_raw).  Works on the raw addresses of CPU tensors,
+# so the buffer choreography (roles, history slots, duplicate store, strided outputs) is exercised exactly as the
+# library sees it.
+# ------------------------------------------------------------------------------------------------
+import ctypes as _C
+
+_SIZES = {L.DTYPE_F32: 4, L.DTYPE_F16: 2, L.DTYPE_BF16: 2}
+
+
+def _rd(ptr, n, code):
+    if not ptr:
+        return None
+    raw = np.frombuffer((_C.c_char * (n * _SIZES[code])).from_address(ptr), dtype=np.uint8)
+    if code == L.DTYPE_F32:
+        return raw.view(np.float32).copy()
+    if code == L.DTYPE_F16:
+        return raw.view(np.float16).astype(F32)
+    return (raw.view(np.uint16).astype(np.uint32) << 16).view(np.float32).copy()
+
+
+def _wr(ptr, arr, code):
+    a = np.ascontiguousarray(arr, dtype=F32).reshape(-1)
+    n = a.size
+    dst = np.frombuffer((_C.c_char * (n * _SIZES[code])).from_address(ptr), dtype=np.uint8)
+    if code == L.DTYPE_F32:
+        dst.view(np.float32)[:] = a
+    elif code == L.DTYPE_F16:
+        dst.view(np.float16)[:] = a.astype(np.float16)
+    else:
+        dst.view(np.uint16)[:] = torch.from_numpy(a).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+
+
+def launch_raw_double(st_ref, b_ref, stream):
+    st, b = st_ref._obj, b_ref._obj
+    n, B = int(b.n), int(b.batch)
+    sd, ed = b.state_dtype, b.eps_dtype
+    per = n // B
+
+    def eps(ptr):
+        if not ptr:
+            return None
+        if b.eps_stride and b.eps_stride != per:
+            full = _rd(ptr, (B - 1) * int(b.eps_stride) + per, ed)
+            return np.concatenate([full[i * int(b.eps_stride): i * int(b.eps_stride) + per] for i in range(B)])
+        return _rd(ptr, n, ed)
+
+    x, xe = _rd(b.x, n, sd), _rd(b.xe, n, sd)
+    if xe is None:
+        xe = x
+    if x is None:
+        x = xe
+    mn = prologue(st, xe, eps(b.e0), eps(b.e1), _rd(b.g, n, ed))
+    if st.flags & L.F_THRESH:
+        mn = O.dynamic_threshold(mn.reshape(B, per), F32(st.thr_ratio), F32(st.thr_max)).reshape(-1)
+    assert not (st.flags & L.F_BLEND), "the fast path never carries a blend"
+    out = combine(st, x, mn, _rd(b.h1, n, sd), _rd(b.h2, n, sd)).astype(F32)
+    _wr(b.x_out, out, sd)
+    if b.x_out2:
+        _wr(b.x_out2, out, sd)
+    if st.flags & L.F_STORE_M:
+        _wr(b.m_out, mn, sd)
+    return 0
+
+
+def install_cpu_double(monkeypatch, S, D):
+    """route every device entry point of dpm_solver_amd.solver to its numpy double (CPU tensors)"""
+    monkeypatch.setattr(S, "_launch_stage", launch_stage_double)
+    monkeypatch.setattr(S, "_stage_launch_raw", launch_raw_double)
+    monkeypatch.setattr(S, "_launch_ctx", lambda dev: (None, 0, False, False))
+    monkeypatch.setattr(S, "_require_gpu", lambda x: None)
+    monkeypatch.setattr(D.MaskBlend, "apply", maskblend_apply_double)
+    monkeypatch.setattr(S, "_adaptive_error", adaptive_error_double)
+    monkeypatch.setattr(S, "_add_noise", add_noise_double)

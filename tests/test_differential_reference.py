@@ -20,7 +20,8 @@ import dpm_solver_amd as D
 import dpm_solver_amd.solver as S
 from conftest import rel_err
 from engine_cases import make_schedule, tt
-from kernel_double import add_noise_double, adaptive_error_double, launch_stage_double, maskblend_apply_double
+from kernel_double import (add_noise_double, adaptive_error_double, install_cpu_double, launch_stage_double,
+                           maskblend_apply_double)
 
 REF_DIR = os.environ.get("DPM_REFERENCE_DIR", "/root/reference")
 pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REF_DIR, "dpm_solver_pytorch.py")),
@@ -39,11 +40,7 @@ def R():
 
 @pytest.fixture(autouse=True)
 def cpu_double(monkeypatch):
-    monkeypatch.setattr(S, "_launch_stage", launch_stage_double)
-    monkeypatch.setattr(S, "_require_gpu", lambda x: None)
-    monkeypatch.setattr(D.MaskBlend, "apply", maskblend_apply_double)
-    monkeypatch.setattr(S, "_adaptive_error", adaptive_error_double)
-    monkeypatch.setattr(S, "_add_noise", add_noise_double)
+    install_cpu_double(monkeypatch, S, D)
 
 
 def ref_schedule(R, name):

@@ -24,8 +24,10 @@ def _worker(rank, world, port, batch, q):
         import dpm_solver_amd.solver as S
         from dpm_solver_amd import distributed as DD
         from engine_cases import build_solver, sample_kwargs
-        from kernel_double import launch_stage_double
+        from kernel_double import launch_raw_double, launch_stage_double
         S._launch_stage = launch_stage_double
+        S._stage_launch_raw = launch_raw_double
+        S._launch_ctx = lambda dev: (None, 0, False, False)
         S._require_gpu = lambda x: None
         case = dict(C.E2E_BY_NAME["cfg_ms2"], shape=(batch, 4, 8, 8))
         x = torch.from_numpy(C.x_T_for(case))

@@ -1,0 +1,197 @@
+"""GPU tests of the fused multi-request path (dpm_stage_launch_multi / dpm_plan_run_multi): R independent requests
+advanced by ONE launch per stage must end bit-identical to the same requests run one by one (dpm_plan_run), for every
+state / network-output dtype pair, for plans that mix fused and unfused stages (singlestep mid-stages, thresholding),
+ragged request counts (R > DPM_MULTI_MAX, R = 1) and unaligned buffers (fallback).  Run on an MI355X:  pytest -m gpu
+"""
+import ctypes as C_
+
+import numpy as np
+import pytest
+import torch
+
+import dpm_solver_amd as D
+from dpm_solver_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+_CODE = {torch.float16: L.DTYPE_F16, torch.float32: L.DTYPE_F32, torch.bfloat16: L.DTYPE_BF16}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    assert torch.cuda.is_available(), "these tests need a GPU; run with -m 'not gpu' elsewhere"
+    yield
+    torch.cuda.synchronize()
+
+
+def sd_schedule():
+    betas = np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=np.float64) ** 2
+    return D.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(np.cumprod(1.0 - betas).astype(np.float32)))
+
+
+def make_requests(n_req, shape, sd, ed, seed, cfg=False, offset=0):
+    g = torch.Generator().manual_seed(seed)
+    reqs = []
+    for _ in range(n_req):
+        def buf(dt, src=None):
+            t = torch.empty(int(np.prod(shape)) + offset, dtype=dt, device=DEV)
+            v = t[offset:].view(shape)
+            if src is not None:
+                v.copy_(src)
+            return v
+        x_T = buf(sd, torch.randn(shape, generator=g))
+        e0 = buf(ed, torch.randn(shape, generator=g))
+        e1 = buf(ed, torch.randn(shape, generator=g)) if cfg else None
+        xb = [x_T] + [buf(sd) for _ in range(3)]
+        hb = [buf(sd) for _ in range(3)]
+        rb = L.RunBuffers()
+        for i in range(4):
+            rb.xbuf[i] = xb[i].data_ptr()
+        for i in range(3):
+            rb.hist[i] = hb[i].data_ptr()
+        rb.e0 = e0.data_ptr()
+        if cfg:
+            rb.e1 = e1.data_ptr()
+        rb.n, rb.batch = x_T.numel(), shape[0]
+        rb.state_dtype, rb.eps_dtype = _CODE[sd], _CODE[ed]
+        reqs.append(dict(rb=rb, x=xb, h=hb, e0=e0, e1=e1))
+    return reqs
+
+
+def plan_for(ns, sd, **kw):
+    model = D.model_wrapper(lambda x, t: x, ns) if not kw.pop("cfg", False) else D.model_wrapper(
+        lambda x, t, c: x, ns, guidance_type="classifier-free", condition=torch.zeros(1), unconditional_condition=torch.zeros(1),
+        guidance_scale=kw.pop("scale", 3.0))
+    dpm = D.DPM_Solver(model, ns, algorithm_type=kw.pop("algorithm_type", "dpmsolver++"), state_dtype=sd,
+                       correcting_x0_fn=kw.pop("correcting_x0_fn", None))
+    args = dict(method="multistep", order=2, steps=8, skip_type="time_uniform", solver_type="dpmsolver",
+                lower_order_final=True, denoise_to_zero=False, t_T=1.0, t_0=1.0 / ns.total_N)
+    args.update(kw)
+    return dpm, dpm._get_plan(**args)
+
+
+def run_both(plan, reqs):
+    """final states of every request: fused multi-request run vs one dpm_plan_run per request"""
+    stream = C_.c_void_p(torch.cuda.current_stream().cuda_stream)
+    n = len(reqs)
+    rbs = (L.RunBuffers * n)(*[r["rb"] for r in reqs])
+    res = (C_.c_int * n)()
+    ws = None
+    nb = L.lib.dpm_threshold_workspace_bytes(reqs[0]["rb"].batch, reqs[0]["rb"].n // reqs[0]["rb"].batch)
+    if nb:
+        ws = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+        for i in range(n):
+            rbs[i].workspace = ws.data_ptr()
+    L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, n, stream, None, res))
+    torch.cuda.synchronize()
+    fused = [reqs[i]["x"][res[i]].clone() for i in range(n)]
+    single = []
+    r1 = C_.c_int(-1)
+    for i in range(n):
+        for b in reqs[i]["x"][1:] + reqs[i]["h"]:
+            b.fill_(float("nan"))
+        L.check(L.lib.dpm_plan_run(plan.handle, C_.byref(rbs[i]), None, None, stream, C_.byref(r1)))
+        torch.cuda.synchronize()
+        single.append(reqs[i]["x"][r1.value].clone())
+    return fused, single
+
+
+@pytest.mark.parametrize("sd,ed", [(torch.float16, torch.float16), (torch.float32, torch.float32),
+                                   (torch.float32, torch.float16), (torch.float32, torch.bfloat16),
+                                   (torch.bfloat16, torch.bfloat16)])
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_fused_equals_single_multistep(sd, ed, order):
+    ns = sd_schedule()
+    _, plan = plan_for(ns, sd, order=order, steps=7)
+    reqs = make_requests(5, (6, 4, 24, 24), sd, ed, seed=order)   # 13824 elements: partial last tile
+    fused, single = run_both(plan, reqs)
+    for a, b in zip(fused, single):
+        assert torch.isfinite(a.float()).all()
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("algo", ["dpmsolver", "dpmsolver++"])
+def test_fused_equals_single_cfg(algo):
+    ns = sd_schedule()
+    _, plan = plan_for(ns, torch.float32, cfg=True, algorithm_type=algo, order=2, steps=6)
+    reqs = make_requests(4, (3, 4, 32, 32), torch.float32, torch.float16, seed=3, cfg=True)
+    fused, single = run_both(plan, reqs)
+    for a, b in zip(fused, single):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n_req", [1, 2, 33, 70])
+def test_request_counts_beyond_one_launch(n_req):
+    ns = sd_schedule()
+    _, plan = plan_for(ns, torch.float16, order=2, steps=5)
+    reqs = make_requests(n_req, (2, 4, 16, 16), torch.float16, torch.float16, seed=n_req)
+    fused, single = run_both(plan, reqs)
+    for a, b in zip(fused, single):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("kw", [dict(method="singlestep", order=3, steps=9),
+                                dict(method="singlestep", order=2, steps=6, solver_type="taylor"),
+                                dict(correcting_x0_fn="dynamic_thresholding", order=2, steps=5),
+                                dict(denoise_to_zero=True, order=2, steps=5)])
+def test_plans_with_unfused_stages(kw):
+    """stages outside the fused family (xe != x mid-stages, thresholding, the denoise stage) run request by request
+    inside the same dpm_plan_run_multi"""
+    ns = sd_schedule()
+    _, plan = plan_for(ns, torch.float32, **kw)
+    reqs = make_requests(3, (4, 3, 16, 16), torch.float32, torch.float32, seed=11)
+    fused, single = run_both(plan, reqs)
+    for a, b in zip(fused, single):
+        assert torch.equal(a, b)
+
+
+def test_unaligned_and_ragged_fall_back():
+    ns = sd_schedule()
+    _, plan = plan_for(ns, torch.float32, order=2, steps=5)
+    for shape, off in (((2, 3, 5, 7), 0), ((2, 4, 16, 16), 1)):          # n % 8 != 0; pointers off by one element
+        reqs = make_requests(3, shape, torch.float32, torch.float32, seed=5, offset=off)
+        fused, single = run_both(plan, reqs)
+        for a, b in zip(fused, single):
+            assert torch.equal(a, b)
+
+
+def test_stage_launch_multi_direct_and_mismatched_requests():
+    """dpm_stage_launch_multi on hand-built buffers; requests of different sizes are launched one by one"""
+    ns = sd_schedule()
+    _, plan = plan_for(ns, torch.float32, order=2, steps=5)
+    st = plan.stages[2].copy()
+    assert st.form == L.FORM_TWO
+    stream = C_.c_void_p(torch.cuda.current_stream().cuda_stream)
+    sizes = [4096, 4096, 2048]
+    bs = (L.Buffers * 3)()
+    keep = []
+    for i, n in enumerate(sizes):
+        t = [torch.randn(n, device=DEV) for _ in range(3)] + [torch.empty(n, device=DEV) for _ in range(2)]
+        keep.append(t)
+        bs[i].x, bs[i].e0, bs[i].h1, bs[i].x_out, bs[i].m_out = [v.data_ptr() for v in t]
+        bs[i].n, bs[i].batch = n, 1
+    for group in (bs, (L.Buffers * 2)(bs[0], bs[1])):
+        L.check(L.lib.dpm_stage_launch_multi(C_.byref(st), group, len(group), stream))
+        torch.cuda.synchronize()
+        for i in range(len(group)):
+            got = (keep[i][3].clone(), keep[i][4].clone())
+            keep[i][3].zero_()
+            keep[i][4].zero_()
+            L.check(L.lib.dpm_stage_launch(C_.byref(st), C_.byref(bs[i]), stream))
+            torch.cuda.synchronize()
+            assert torch.equal(got[0], keep[i][3]) and torch.equal(got[1], keep[i][4])
+    assert L.lib.dpm_stage_launch_multi(C_.byref(st), bs, 0, stream) == L.ERR_ARG
+
+
+def test_fuse_switch_off_gives_identical_results():
+    ns = sd_schedule()
+    _, plan = plan_for(ns, torch.float16, order=2, steps=6)
+    reqs = make_requests(4, (8, 4, 32, 32), torch.float16, torch.float16, seed=2)
+    fused, _ = run_both(plan, reqs)
+    L.lib.dpm_tuning_set(L.TUNE_MULTI_FUSE, 0)
+    try:
+        unfused, _ = run_both(plan, reqs)
+    finally:
+        L.lib.dpm_tuning_set(L.TUNE_MULTI_FUSE, 1)
+    for a, b in zip(fused, unfused):
+        assert torch.equal(a, b)

@@ -18,7 +18,8 @@ import dpm_solver_amd.wrapper as W
 from conftest import rel_err
 from dpm_solver_amd import _lib as L
 from engine_cases import build_solver, make_schedule, run_case, sample_kwargs, tt
-from kernel_double import add_noise_double, adaptive_error_double, launch_stage_double, maskblend_apply_double
+from kernel_double import (add_noise_double, adaptive_error_double, install_cpu_double, launch_stage_double,
+                           maskblend_apply_double)
 from oracle import dpm_oracle as O
 
 F32 = np.float32
@@ -27,11 +28,7 @@ TOL = 1e-5
 
 @pytest.fixture(autouse=True)
 def cpu_double(monkeypatch):
-    monkeypatch.setattr(S, "_launch_stage", launch_stage_double)
-    monkeypatch.setattr(S, "_require_gpu", lambda x: None)
-    monkeypatch.setattr(D.MaskBlend, "apply", maskblend_apply_double)
-    monkeypatch.setattr(S, "_adaptive_error", adaptive_error_double)
-    monkeypatch.setattr(S, "_add_noise", add_noise_double)
+    install_cpu_double(monkeypatch, S, D)
 
 
 def test_linspace_and_time_grids_bitwise_vs_torch_and_golden(golden):
