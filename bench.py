@@ -393,7 +393,7 @@ def main():
             big = [torch.empty(R * n_el * ssz, dtype=torch.uint8, device=dev) for _ in range(5)]
             ts = []
             for it in range(6):
-                L.check(L.lib.dpm_calib_launch(1, 256, 8, 1, big[0].data_ptr(), big[1].data_ptr(), big[2].data_ptr(),
+                L.check(L.lib.dpm_calib_launch(1, 256, 4096, 1, big[0].data_ptr(), big[1].data_ptr(), big[2].data_ptr(),
                                                big[3].data_ptr(), big[4].data_ptr(), R * n_el * ssz, sptr, C.byref(msv)))
                 if it >= 2:
                     ts.append(msv.value)

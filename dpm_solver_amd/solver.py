@@ -394,6 +394,16 @@ class DPM_Solver:
             return self._wrapped.raw_outputs(x_eval, te, ti, t2, x_in2=x_in2)
         return self._model_fn(x_eval, te), None, None
 
+    def _promoted(self, sd, e0):
+        """State dtype after the first network evaluation.  Without an explicit `state_dtype` the reference's type
+        promotion applies: a half-precision state combined with a network output of another floating dtype (fp32
+        eps next to an fp16 x on a 'linear' schedule, or fp16 next to bf16) continues in fp32 from the first update on
+        (ref :573-576 are plain tensor expressions).  An explicit `state_dtype` keeps the state there and the output
+        is converted to it."""
+        if self._state_dtype is None and sd is not torch.float32 and e0.dtype is not sd and e0.dtype in _DT:
+            return torch.float32
+        return sd
+
     def _prep_stage(self, st):
         """stage flags that depend on this solver's correctors"""
         if st.flags & L.F_TO_X0:
@@ -788,6 +798,18 @@ class DPM_Solver:
         fresh tensor.  Per stage: the opaque network call, three pointer patches, one dpm_stage_launch."""
         device = x.device
         stream, idx, capturing, other = _launch_ctx(device)
+        B = x.shape[0]
+        V = plan.time_views(device, B, cfg)
+        tb, ti, t2 = V["t_eval_b"], V["t_input_b"], V["t_input_2b"]
+        wrapped = self._wrapped
+        model_fn = self._model_fn
+        # the first evaluation is on the caller's x_T whatever the plan (ref :1179, :1222): run it before choosing
+        # the buffers, its output dtype decides the state dtype (see _promoted)
+        if wrapped is not None:
+            first = wrapped.raw_outputs(x, tb[0], ti[0], t2[0] if cfg else None, x_in2=None)
+        else:
+            first = (model_fn(x, tb[0]), None, None)
+        sd = self._promoted(sd, first[0])
         key = (id(plan), tuple(x.shape), sd, idx, stream, cfg)
         fr = None if capturing else self._fast.get(key)      # a captured graph bakes its buffers in: give it its own
         if fr is None:
@@ -798,17 +820,12 @@ class DPM_Solver:
                 self._fast[key] = fr
         x0 = _conv(x, sd)
         p0 = x0.data_ptr()
-        B = x.shape[0]
         out = torch.empty(x.shape, dtype=sd, device=device)
-        V = plan.time_views(device, B, cfg)
-        tb, ti, t2 = V["t_eval_b"], V["t_input_b"], V["t_input_2b"]
         bufs, refs, roles = fr.bufs, fr.refs, plan.roles
         bufs[fr.last].x_out = out.data_ptr()
         xbuf, xfull = fr.xbuf, fr.xfull
         launch = _stage_launch_raw
         dcode = _DT[sd]
-        wrapped = self._wrapped
-        model_fn = self._model_fn
         for i, b in enumerate(bufs):
             xi, xei, _ = roles[i]
             if xi == 0:
@@ -819,7 +836,9 @@ class DPM_Solver:
                     b.xe = p0
             else:
                 xe_t, x2 = xbuf[xei], (xfull[xei] if cfg else None)
-            if wrapped is not None:
+            if i == 0:
+                e0, e1, g = first
+            elif wrapped is not None:
                 e0, e1, g = wrapped.raw_outputs(xe_t, tb[i], ti[i], t2[i] if cfg else None, x_in2=x2)
             else:
                 e0, e1, g = model_fn(xe_t, tb[i]), None, None
@@ -875,6 +894,8 @@ class DPM_Solver:
             xe = tmp if from_tmp else state
             outs = self._network(xe, None, None, x_in2=tmp2 if from_tmp else state2,
                                  pre=(V["t_eval_b"][i], V["t_input_b"][i], V["t_input_2b"][i] if cfg else None))
+            if i == 0:
+                sd = self._promoted(sd, outs[0])
             if i == 0 and method == 'multistep':
                 # ref :1179-1183: the model sees the caller's x_T; the corrector and the list see it afterwards
                 if cxt is not None:

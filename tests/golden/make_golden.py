@@ -394,8 +394,28 @@ def gen_guided(out):
         out["guided/" + tag] = run(**kw).detach().numpy()
 
 
+def gen_utils(out):
+    """the module-level helpers interpolate_fn / expand_dims (ref :1253-1305) on seeded inputs: queries inside the
+    keypoint range, on keypoints, beyond both ends (linear extrapolation), several channels"""
+    rng = np.random.default_rng(21)
+    for tag, (n, c, k) in dict(a=(37, 1, 9), b=(5, 3, 2), c=(64, 2, 1000)).items():
+        xp = np.sort(rng.uniform(-2.0, 3.0, size=(c, k)).astype(np.float32), axis=1)
+        yp = rng.standard_normal((c, k)).astype(np.float32)
+        x = rng.uniform(-3.0, 4.0, size=(n, c)).astype(np.float32)
+        x[0, :] = xp[:, 0]               # exactly on the first / last keypoint, and on an inner one
+        x[1, :] = xp[:, -1]
+        x[2, :] = xp[:, k // 2]
+        out["utils/%s/x" % tag], out["utils/%s/xp" % tag], out["utils/%s/yp" % tag] = x, xp, yp
+        out["utils/%s/y" % tag] = R.interpolate_fn(tt(x), tt(xp), tt(yp)).numpy()
+    v = rng.standard_normal(6).astype(np.float32)
+    out["utils/expand/v"] = v
+    for dims in (1, 2, 4):
+        out["utils/expand/shape%d" % dims] = np.array(R.expand_dims(tt(v), dims).shape, dtype=np.int64)
+        out["utils/expand/val%d" % dims] = R.expand_dims(tt(v), dims).numpy()
+
+
 def main():
-    groups = dict(guided=gen_guided, legacy=gen_legacy, schedules=gen_schedules, timesteps=gen_timesteps, updates=gen_updates,
+    groups = dict(utils=gen_utils, guided=gen_guided, legacy=gen_legacy, schedules=gen_schedules, timesteps=gen_timesteps, updates=gen_updates,
                   quantile=gen_quantile, add_noise=gen_add_noise, e2e=gen_e2e,
                   callbacks=gen_callbacks, adaptive=gen_adaptive, sampler=gen_sampler)
     only = sys.argv[1:]

@@ -191,3 +191,32 @@ def test_adaptive_solver_against_the_reference(R, capsys):
         nfe_got = capsys.readouterr().out.strip()
         assert nfe_got == nfe_ref, (k, sname, order, algo, st, nfe_got, nfe_ref)
         assert rel_err(got.numpy(), want.numpy()) < 5e-5, (k, sname, order, algo, st)
+
+
+@pytest.mark.parametrize("xdt,edt", [(torch.float16, torch.float32), (torch.bfloat16, torch.float32),
+                                     (torch.float16, torch.float16), (torch.float16, torch.bfloat16)])
+def test_dtype_promotion_of_a_half_state_follows_the_reference(R, xdt, edt):
+    """'linear' schedule (0-dim coefficients do not promote): the state stays half only while the network output has
+    the same dtype; a wider / different output promotes it to fp32 from the first update on (plain tensor arithmetic,
+    ref :573-576).  Same dtype and, within the dtype's rounding, same values as the reference."""
+    rng = np.random.default_rng(33)
+    x = torch.from_numpy(rng.standard_normal((2, 4, 8, 8)).astype(F32)).to(xdt)
+    net = lambda xx, t: (xx.float() * 0.5).to(edt)
+    rns = ref_schedule(R, "vp_linear")
+    want = R.DPM_Solver(R.model_wrapper(net, rns), rns, algorithm_type="dpmsolver").sample(x, steps=6, order=2)
+    ns = make_schedule("vp_linear")
+    got = D.DPM_Solver(D.model_wrapper(net, ns), ns, algorithm_type="dpmsolver").sample(x, steps=6, order=2)
+    assert got.dtype == want.dtype, (got.dtype, want.dtype)
+    # values: within the half type's rounding of the reference, not 1e-5 -- in the reference's first update the product
+    # coefficient * x is still a half tensor (a 0-dim fp32 coefficient does not promote it, ref :585) and is rounded to
+    # half before the fp32 noise term promotes the sum; the engine converts x_T to fp32 exactly and rounds nothing.  The
+    # noise-prediction updates of this run then amplify that one rounding (2^-11 fp16, 2^-8 bf16) a few times.
+    tol = 1e-2 if xdt == torch.float16 else 8e-2
+    assert rel_err(got.float().numpy(), want.float().numpy()) < tol
+    # an explicit state_dtype is an explicit request: the state stays there
+    keep = D.DPM_Solver(D.model_wrapper(net, ns), ns, algorithm_type="dpmsolver", state_dtype=xdt).sample(x, steps=6, order=2)
+    assert keep.dtype == xdt
+    # the general loop (return_intermediate) takes the same decision as the prebuilt one
+    got2, inter = D.DPM_Solver(D.model_wrapper(net, ns), ns, algorithm_type="dpmsolver").sample(
+        x, steps=6, order=2, return_intermediate=True)
+    assert got2.dtype == want.dtype and torch.equal(got2, got)

@@ -44,6 +44,7 @@ class LaunchSpy:
             return real(st, b, stream)
 
         monkeypatch.setattr(S.L.lib, "dpm_stage_launch", spy)
+        monkeypatch.setattr(S, "_stage_launch_raw", spy)          # the prebuilt launch records of sample()
 
 
 # ------------------------------------------------------------------------------------------------

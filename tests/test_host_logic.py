@@ -146,7 +146,7 @@ def test_adaptive_control_loop_against_reference_goldens(golden, capsys, name, s
     g = lambda k: golden.get("adaptive", "adaptive/%s/%s" % (name, k))
     xf = dpm.sample(tt(g("x"), "cpu"), method="adaptive", order=order, t_end=1e-3)
     assert capsys.readouterr().out.strip() == "adaptive solver nfe %d" % int(g("nfe"))
-    assert rel_err(xf.numpy(), g("final")) < 5e-5
+    assert rel_err(xf.numpy(), g("final")) < TOL
 
 
 def test_maskblend_against_reference_callback_goldens(golden):

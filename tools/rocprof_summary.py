@@ -36,15 +36,19 @@ def main():
         r = cur.execute("select vgpr_count, accum_vgpr_count, sgpr_count, grid_x, workgroup_x, lds_size, scratch_size from kernels "
                         "where name like ? limit 1", ("%" + kern + "%",)).fetchone()
         out.append("resources: vgpr=%s agpr=%s sgpr=%s grid=%s wg=%s lds=%s scratch=%s\n" % r)
-    for name, ctr in [("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")]:
+    import os
+    passes = [("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")]
+    passes += [(d, d[4:]) for d in sorted(os.listdir(root)) if d.startswith("pmc_")]
+    for name, ctr in passes:
         db = db_of(root + "/" + name)
         if not db:
             continue
         v = np.array([x[0] for x in db.cursor().execute(
             "select value from counters_collection where kernel_name like ? and counter_name=?", ("%" + kern + "%", ctr))])
         if len(v):
-            out.append("\n## rocprofv3 --pmc %s (separate pass)\n%s per launch of `%s`: mean %.1f KiB, median %.1f KiB (n=%d)\n" % (
-                ctr, ctr, kern, v.mean(), np.median(v), len(v)))
+            unit = "KiB" if ctr in ("FETCH_SIZE", "WRITE_SIZE") else "events"
+            out.append("\n## rocprofv3 --pmc %s (separate pass)\n%s per launch of `%s`: mean %.1f %s, median %.1f, max %.1f (n=%d)\n" % (
+                ctr, ctr, kern, v.mean(), unit, np.median(v), v.max(), len(v)))
     open(outp, "w").writelines(out)
     print("".join(out))
 
