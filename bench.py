@@ -153,7 +153,7 @@ def cpu_baseline_port(ac, budget_s=8.0):
         O.Solver(O.wrap_model(lambda xx, t: e, osch), osch, algorithm_type="dpmsolver++").sample(
             x[lo:hi], steps=STEPS_SOLVER, order=2)
 
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)                 # >= 8 samples per thread: below that Python overhead dominates
     n1, el1 = _time_loop(lambda: traj(0, B), budget_s / 2, min_runs=1)
 
     def sharded():
