@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("DPM_SOLVER_AMD_LIB") or os.path.join(_HERE, "libdpm_h
 
 # ---- enumerations (mirror include/dpm_hip.h) --------------------------------------------------
 DPM_OK = 0
-ERR_ARG, ERR_UNSUPPORTED, ERR_ALIGN, ERR_NOMEM, ERR_CALLBACK = -1, -2, -3, -4, -5
+ERR_ARG, ERR_UNSUPPORTED, ERR_ALIGN, ERR_NOMEM, ERR_CALLBACK, ERR_FAULT = -1, -2, -3, -4, -5, -6
 ALGO = {"dpmsolver": 0, "dpmsolver++": 1}
 SOLVER = {"dpmsolver": 0, "taylor": 1}
 METHOD = {"multistep": 0, "singlestep": 1, "singlestep_fixed": 2}
@@ -31,7 +31,7 @@ FORM_LIN1, FORM_TWO, FORM_MS3, FORM_SS3T, FORM_DENOISE = 0, 1, 2, 3, 4
 F_TO_X0, F_STORE_M, F_BASE_HIST, F_THRESH, F_USER_X0, F_BLEND = 1, 2, 4, 8, 16, 32
 SRC_STATE, SRC_TMP = 0, 1
 TUNE_UNROLL, TUNE_NONTEMPORAL, TUNE_BLOCKS_PER_CU, TUNE_ASSUME_RESIDENT = 0, 1, 2, 3
-TUNE_MULTI_FUSE, TUNE_MULTI_BLOCKS_PER_CU = 4, 5
+TUNE_MULTI_FUSE, TUNE_MULTI_BLOCKS_PER_CU, TUNE_CLUSTER_IN_GRAPH, TUNE_CLUSTER_ONE_HOP = 4, 5, 6, 7
 MULTI_MAX = 32
 
 

@@ -25,6 +25,7 @@
 #include <cstdint>
 #include <algorithm>
 #include <cstring>
+#include <cmath>
 #ifdef DPM_THR_TIMING
 #include <cstdio>
 #include <cstdlib>
@@ -45,6 +46,8 @@ struct Tuning {
   int blocks_per_cu = 8;    // grid cap = CUs x this (8 x 256 threads = every SIMD holds 8 waves)
   int assume_resident = 0;  // treat every launch as dpm_buffers.inputs_resident (benchmarking a frozen loop from Python)
   int multi_fuse = 1;       // dpm_stage_launch_multi: 1 = one fused launch per group of requests, 0 = one launch per request
+  int cluster_in_graph = 0; // 1: thresholding keeps workgroup clusters under stream capture also for samples that fit one workgroup
+  int cluster_one_hop = 1;  // 0: clusters always take the general route (merged histograms, several barriers)
   int multi_blocks_per_cu = 0;  // grid cap of the fused launch in workgroups per CU; 0 = one super-tile per workgroup
 };
 extern Tuning g_tuning;     // defined in dpm_kernels.hip
@@ -55,11 +58,15 @@ struct ClusterChain {
   bool recorded = false;
 };
 ClusterChain& cluster_chain(int dev);  // defined in dpm_kernels.hip
+// host-mapped word a clustered kernel raises when one of its waits timed out; nullptr until created (create = false
+// never allocates: stream capture)
+uint32_t* cluster_fault_word(bool create);
 }  // namespace dpmk
 using dpmk::Tuning;
 using dpmk::g_tuning;
 using dpmk::ClusterChain;
 using dpmk::cluster_chain;
+using dpmk::cluster_fault_word;
 
 namespace {
 
@@ -630,6 +637,15 @@ constexpr int THR_WS_CNT = 5 * THR_NB;  // [0..3] barriers of the radix levels /
 constexpr int THR_CHUNK_MAX = 12288;         // elements of a sample one workgroup keeps in LDS (48 KiB)
 constexpr int THR_CAP = 4096;                // candidates (elements sharing the selected top digit) kept compacted
 constexpr int THR_GCAP = THR_NB;             // cluster-wide candidates exchanged through the level-1 histogram's words
+// single-exchange route of a cluster (cluster_select_once): every workgroup publishes the elements of its chunk that
+// can still be among the sample's K largest into its own slot of the workspace -- header + values, every word tagged
+constexpr int THR_SLOT_CAP = 256;            // values one workgroup may publish
+constexpr int THR_SLOT_HDR = 8;              // [0] tag | count (or overflow), [1] tag | bound
+constexpr int THR_SLOTW = THR_SLOT_CAP + THR_SLOT_HDR;
+constexpr uint32_t THR_TAG = 0x80000000u;    // |x0| bit patterns have bit 31 clear: a tagged word is never 0
+constexpr uint32_t THR_OVERFLOW = 0x40000000u;
+constexpr int THR_WS_DONE = THR_WS_CNT + 12; // workgroups of the cluster that are through with the workspace
+constexpr uint32_t THR_SPIN_LIMIT = 1u << 22; // polls (about a microsecond each) before a wait gives up: seconds
 
 struct ThrParams {
   int64_t per_sample;
@@ -644,7 +660,14 @@ struct ThrParams {
   int32_t topk;    // > 0: K = per_sample - lo is small enough for the top-K front end of the select
   int32_t mrank;   // top-K: ascending rank of the K-th largest per-thread maximum among the contributing threads
   int32_t fastdiv; // 1: noise-prediction network + eps -> x0 with a divisor that passes div_invariant_ok (see div_by_alpha)
-  uint32_t* ws;    // k > 1: batch x THR_WS_WORDS zeroed words
+  int32_t quota;   // > 0: single-exchange cluster route; values beyond this rank of the per-thread maxima are not published
+  int32_t kbig;    // K = per_sample - lo (the wanted element is the K-th largest of the sample)
+  int32_t slot_cap; // values per workgroup slot: a power of two <= THR_SLOT_CAP with k * slot_cap <= THR_CAP
+  int32_t slot_shift; // log2(slot_cap)
+  int32_t debug_reject; // testing: run the single-exchange select but always take the general route afterwards
+  int64_t ws_stride; // words per sample in ws
+  uint32_t* ws;    // k > 1: batch x ws_stride words, all zero between launches (the kernel cleans up after itself)
+  uint32_t* fault; // host-mapped word: set when a cluster wait timed out (the launch's results are then garbage)
 #ifdef DPM_THR_TIMING
   uint64_t* tdbg;  // 16 timestamps per workgroup (tools/thr_timeline.py)
 #endif
@@ -714,18 +737,31 @@ __device__ __forceinline__ void store4(bf16_t* __restrict__ p, int64_t i, const 
   st8<NT>(reinterpret_cast<u32x2*>(p + i), a);
 }
 
+// A wait on another workgroup gives up after THR_SPIN_LIMIT polls (seconds): the peers of a cluster are co-resident by
+// construction, so this only happens when something else keeps them off the chip that long (two clustered graphs
+// replayed concurrently on different streams) or on a true deadlock.  It never traps: the waiter raises the library's
+// host-mapped fault word, stops waiting for the rest of the launch (its results are garbage) and the kernel terminates;
+// the next clustered launch returns DPM_ERR_FAULT.
+__device__ __forceinline__ void raise_fault(uint32_t* fault) {
+  if (fault) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // all workgroups of a cluster meet here; `cnt` is a zero-initialised single-use counter.  Everything the cluster
 // shares travels as agent-scope atomics and sc1 loads, so no cache write-back / invalidate is needed: drain this
 // wave's atomics, arrive with a relaxed atomic, poll with relaxed sc1 loads (MI355X_MICROARCH.md, barrier-counter).
-__device__ __forceinline__ void cluster_barrier(uint32_t* cnt, uint32_t k) {
+// `dead` (LDS word): a previous wait of this workgroup timed out -- do not wait again.
+__device__ __forceinline__ void cluster_barrier(uint32_t* cnt, uint32_t k, uint32_t* dead, uint32_t* fault) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t spins = 0;
-    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k) {
+    while (!*dead && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 26)) __builtin_trap();  // peers are co-resident by construction: never expected
+      if (++spins > THR_SPIN_LIMIT) {
+        *dead = 1u;
+        raise_fault(fault);
+      }
     }
   }
   __syncthreads();
@@ -785,9 +821,10 @@ __device__ __forceinline__ void locate_bin(uint32_t* hist, uint32_t* misc, uint3
 // Append the elements of sx0[0..n) whose top digit d satisfies (GE ? d >= bin : d == bin) to cand[] (capacity THR_CAP;
 // misc[4] counts all of them): count in registers, wavefront scan, ONE LDS atomic per wavefront for the base slot,
 // write -- not one atomic round trip per 64 elements.  Returns this lane's minimum of the elements above digit `bin`.
+// The digit of a value is (u >> shift) - dbase, clamped at 0 (shift = 20, dbase = 0: the top 11 bits).
 template <int T, bool GE>
 __device__ __forceinline__ uint32_t compact_candidates(const float* sx0, int n, uint32_t bin, uint32_t* misc,
-                                                       uint32_t* cand, int tid) {
+                                                       uint32_t* cand, int tid, int shift = 20, uint32_t dbase = 0u) {
   constexpr int NIT = THR_CHUNK_MAX / (T * 4);
   constexpr uint32_t ABS = 0x7fffffffu;
   u32x4 q[NIT];
@@ -804,7 +841,7 @@ __device__ __forceinline__ uint32_t compact_candidates(const float* sx0, int n, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const uint32_t u = q[it][j] & ABS;
-      const uint32_t d = u >> 20;
+      const uint32_t dr = u >> shift, d = dr > dbase ? dr - dbase : 0u;
       const bool in = i + j < n;
       cnt += (in && (GE ? d >= bin : d == bin)) ? 1u : 0u;
       if (!GE && in && d > bin && u < hi) hi = u;
@@ -820,7 +857,7 @@ __device__ __forceinline__ uint32_t compact_candidates(const float* sx0, int n, 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const uint32_t u = q[it][j] & ABS;
-      const uint32_t d = u >> 20;
+      const uint32_t dr = u >> shift, d = dr > dbase ? dr - dbase : 0u;
       if (i + j < n && (GE ? d >= bin : d == bin)) {
         if (off < (uint32_t)THR_CAP) cand[off] = u;
         ++off;
@@ -879,6 +916,331 @@ __device__ __forceinline__ void rank_select(uint32_t* cand, uint32_t nc, uint32_
   __syncthreads();
 }
 
+// workgroup-wide exclusive prefix sum of one value per thread (wavefront scan + the wavefront totals through misc[16..]);
+// misc[24] <- grand total.  Two barriers.
+template <int T>
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* misc, int tid) {
+  static_assert(T / 64 == 8, "eight wavefronts");
+  const uint32_t incl = wave_incl_scan(v);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __syncthreads();  // misc[16..24] may still be read by a previous user
+  if ((tid & 63) == 63) misc[16 + wave] = incl;
+  __syncthreads();
+  uint32_t before = 0u, total = 0u;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) {
+    const uint32_t t = misc[16 + w];
+    before += w < wave ? t : 0u;
+    total += t;
+  }
+  if (tid == 0) misc[24] = total;
+  return before + incl - v;
+}
+
+// nc candidates in cand[] (any number up to THR_CAP): 11/11/9-bit radix select of the element of ascending rank `rank`
+// and of its successor.  hist must be all zero on entry and is left all zero.  a <- element, b <- next order statistic
+// (or a when there is none).
+template <int T>
+__device__ __forceinline__ void list_select(const uint32_t* cand, uint32_t nc, uint32_t rank, uint32_t* hist, uint32_t* misc,
+                                            int tid, uint32_t& a, uint32_t& b) {
+  uint32_t prefix = 0u, known = 0u, cnt_sel = 0u;
+#pragma unroll 1
+  for (int pass = 0; pass < 3; ++pass) {
+    const int shift = pass == 0 ? 20 : pass == 1 ? 9 : 0;
+    const uint32_t dmask = pass == 2 ? 0x1ffu : 0x7ffu;
+    for (uint32_t i = tid; i < nc; i += T) {
+      const uint32_t u = cand[i];
+      if ((u & known) == prefix) atomicAdd(&hist[(u >> shift) & dmask], 1u);
+    }
+    __syncthreads();
+    locate_bin<T>(hist, misc, rank, tid);
+    prefix |= misc[0] << shift;
+    known |= dmask << shift;
+    rank = misc[1];
+    cnt_sel = misc[2];
+  }
+  a = prefix;
+  b = prefix;
+  if (rank + 1u >= cnt_sel) {  // the successor is the smallest candidate above a (if any)
+    // misc[12], not misc[3]: that one carries the general route's minimum above the selected digit across this call
+    if (tid == 0) misc[12] = 0x7fffffffu;
+    __syncthreads();
+    uint32_t m = 0x7fffffffu;
+    for (uint32_t i = tid; i < nc; i += T) {
+      const uint32_t u = cand[i];
+      if (u > prefix && u < m) m = u;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint32_t o = __shfl_xor(m, d, 64);
+      m = o < m ? o : m;
+    }
+    if ((tid & 63) == 0) atomicMin(&misc[12], m);
+    __syncthreads();
+    if (misc[12] != 0x7fffffffu) b = misc[12];
+  }
+}
+
+// The same for a list whose values spread over many fine digits (the union of a cluster's candidates: the upper tail of
+// the sample): ONE histogram level over 14-bit digits relative to the list's maximum (1.5 % wide bins), then rank
+// counting among the handful of members of the selected bin -- ~1.4 us instead of 3 us of rank counting over the
+// whole list (340 entries) or three histogram levels.  Falls back to list_select when the bin is crowded (plateaus).
+// hist all zero on entry and exit.
+template <int T>
+__device__ __forceinline__ void union_select(uint32_t* cand, uint32_t nc, uint32_t rank, uint32_t* hist, uint32_t* misc,
+                                             int tid, uint32_t& a, uint32_t& b) {
+  constexpr int PER = THR_CAP / T;
+  const int lane = tid & 63;
+  uint32_t v[PER];
+  uint32_t vmax = 0u;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const uint32_t i = (uint32_t)tid + (uint32_t)j * T;
+    v[j] = i < nc ? cand[i] : 0u;
+    vmax = v[j] > vmax ? v[j] : vmax;
+  }
+  if (tid == 0) {
+    misc[12] = 0u;           // list maximum
+    misc[13] = 0x7fffffffu;  // smallest value above the selected bin
+    misc[14] = 0u;           // members of the selected bin appended so far
+  }
+  __syncthreads();
+  {
+    const uint32_t wm = wave_max_to_lane63(vmax);
+    if (lane == 63 && wm) atomicMax(&misc[12], wm);
+  }
+  __syncthreads();
+  const uint32_t top = misc[12] >> 17;
+  const uint32_t dbase = top > (uint32_t)(THR_NB - 1) ? top - (uint32_t)(THR_NB - 1) : 0u;
+  uint32_t d[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const uint32_t dr = v[j] >> 17;
+    d[j] = dr > dbase ? dr - dbase : 0u;
+    if ((uint32_t)tid + (uint32_t)j * T < nc) atomicAdd(&hist[d[j]], 1u);
+  }
+  __syncthreads();
+  locate_bin<T>(hist, misc, rank, tid);
+  const uint32_t bin = misc[0], r_in = misc[1], cnt_bin = misc[2];
+  if (cnt_bin > (uint32_t)T) {  // crowded bin: the general list select (hist is zero again)
+    list_select<T>(cand, nc, rank, hist, misc, tid, a, b);
+    return;
+  }
+  // members of the bin -> hist[0..cnt_bin) (the zeroed histogram doubles as the buffer); minimum of the higher bins
+  uint32_t above = 0x7fffffffu;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    if ((uint32_t)tid + (uint32_t)j * T < nc) {
+      if (d[j] == bin) hist[atomicAdd(&misc[14], 1u)] = v[j];
+      if (d[j] > bin && v[j] < above) above = v[j];
+    }
+  }
+#pragma unroll
+  for (int dd = 32; dd >= 1; dd >>= 1) {
+    const uint32_t o = __shfl_xor(above, dd, 64);
+    above = o < above ? o : above;
+  }
+  if (lane == 0 && above != 0x7fffffffu) atomicMin(&misc[13], above);
+  __syncthreads();
+  rank_select<T>(hist, cnt_bin, r_in, misc, tid);
+  a = misc[6];
+  b = r_in + 1u < cnt_bin ? misc[7] : (misc[13] != 0x7fffffffu ? misc[13] : a);
+  __syncthreads();
+  if ((uint32_t)tid < cnt_bin + 32u) hist[tid] = 0u;  // members + rank_select's sentinels
+  if (T < 544 && (uint32_t)tid + T < cnt_bin + 32u) hist[tid + T] = 0u;
+  __syncthreads();
+}
+
+// Single-exchange select of a cluster (k workgroups own one sample).  The wanted order statistics are the K-th and
+// (K-1)-th largest |x0| of the sample, K = per_sample - lo.  Every workgroup publishes ALL elements of its chunk at or
+// above a bound of its own choosing -- the bound of the `quota`-th largest of its per-thread maxima, so about `quota`
+// values, where quota = the chunk's expected share K/k of the top K plus six standard deviations -- into its slot of the
+// workspace, reads the other slots, and finishes on the union U by itself (rank counting or a radix select in LDS; all
+// workgroups hold identical data).  The result is exact whenever the K-th largest of U is not below any workgroup's
+// bound M_c = the smallest value it would have published: every unpublished element is then smaller than K elements of
+// U, so top-K(U) = top-K(sample).  Otherwise (a slot overflowed, U too small, K-th(U) < max M_c: samples whose large
+// values cluster in one chunk) every workgroup reaches the same verdict from the same data and the cluster takes the
+// general route with merged histograms -- no extra exchange for the decision.
+// One hop: tagged words (bit 31, never set in |x0|) written with sc1 stores into zeroed slots, readers poll the words
+// they need -- no drain -> arrive -> poll -> read-back barrier.  Digits here are 14 bits (8 exponent + 6 mantissa bits)
+// relative to the chunk's maximum: 1.5 % wide bins instead of 12.5 %, so a bound admits ~10 % more than `quota`, not 2x.
+// Returns true with a (K-th largest) and b ((K-1)-th largest, = a when K = 1); false = not solved, LDS state
+// (hist zero, misc[4] = 0) ready for the general route.
+template <int T>
+__device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, bool vec, uint32_t m1, uint32_t m2,
+                                                    uint32_t m3, uint32_t m4, bool has, uint32_t* hist, uint32_t* misc,
+                                                    uint32_t* cand, uint32_t* slots, const ThrParams& tp, uint32_t k, int c,
+                                                    int tid, uint32_t& a_out, uint32_t& b_out, bool stamp) {
+#ifdef DPM_THR_TIMING
+#define DPM_R1STAMP(j) \
+  if (tid == 0 && stamp) tp.tdbg[(int64_t)blockIdx.x * 16 + (j)] = wall_clock64();
+#else
+#define DPM_R1STAMP(j)
+  (void)stamp;
+#endif
+  const int lane = tid & 63;
+  const uint32_t K = (uint32_t)tp.kbig;
+  const uint32_t cap = (uint32_t)tp.slot_cap;
+  // 1. the chunk's maximum -> digit base
+  {
+    const uint32_t wm = wave_max_to_lane63(has ? m1 : 0u);
+    if (lane == 63 && wm) atomicMax(&misc[8], wm);
+  }
+  __syncthreads();
+  const uint32_t top = misc[8] >> 17;
+  const uint32_t dbase = top > (uint32_t)(THR_NB - 1) ? top - (uint32_t)(THR_NB - 1) : 0u;
+  auto digit = [&](uint32_t u) {
+    const uint32_t d = u >> 17;
+    return d > dbase ? d - dbase : 0u;
+  };
+  // 2. histogram of one value per thread, bound = digit of the quota-th largest maximum
+  if (has) atomicAdd(&hist[digit(m1)], 1u);
+  __syncthreads();
+  const int P = vec ? (n + 3) / 4 : n;  // threads that produced at least one element
+  const uint32_t Pl = (uint32_t)(P < T ? P : T);
+  locate_bin<T>(hist, misc, Pl > (uint32_t)tp.quota ? Pl - (uint32_t)tp.quota : 0u, tid);
+  const uint32_t bin_lo = Pl ? misc[0] : 0u;
+  DPM_R1STAMP(8)
+  // 3. this chunk's candidates: a thread's are among its four largest values unless even the fourth qualifies
+  {
+    const int mine = vec ? (has ? 4 * ((n - tid * 4 + T * 4 - 1) / (T * 4)) : 0) : (has ? (n - tid + T - 1) / T : 0);
+    const bool c1 = mine > 0 && digit(m1) >= bin_lo, c2 = mine > 1 && digit(m2) >= bin_lo;
+    const bool c3 = mine > 2 && digit(m3) >= bin_lo, c4 = mine > 3 && digit(m4) >= bin_lo;
+    if (__ballot(c4 && mine > 4)) {
+      (void)compact_candidates<T, true>(sx0, n, bin_lo, misc, cand, tid, 17, dbase);
+    } else {
+      const uint32_t cnt = (c1 ? 1u : 0u) + (c2 ? 1u : 0u) + (c3 ? 1u : 0u) + (c4 ? 1u : 0u);
+      const uint32_t incl = wave_incl_scan(cnt);
+      uint32_t slot = 0u;
+      if (lane == 63 && incl) slot = atomicAdd(&misc[4], incl);
+      uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)slot, 63) + incl - cnt;
+      if (c1 && off < (uint32_t)THR_CAP) cand[off] = m1;
+      off += c1 ? 1u : 0u;
+      if (c2 && off < (uint32_t)THR_CAP) cand[off] = m2;
+      off += c2 ? 1u : 0u;
+      if (c3 && off < (uint32_t)THR_CAP) cand[off] = m3;
+      off += c3 ? 1u : 0u;
+      if (c4 && off < (uint32_t)THR_CAP) cand[off] = m4;
+    }
+  }
+  __syncthreads();
+  // 4. publish: values, then the header (bound, count); every word carries the tag
+  const uint32_t ncl = misc[4];
+  const bool over = ncl > cap;
+  uint32_t* mine_slot = slots + (size_t)c * THR_SLOTW;
+  if (!over)
+    for (uint32_t i = tid; i < ncl; i += T)
+      __hip_atomic_store(&mine_slot[THR_SLOT_HDR + i], cand[i] | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) {
+    const uint32_t bound = bin_lo ? (bin_lo + dbase) << 17 : 0u;  // smallest |x0| with that digit; digit 0 = everything
+    __hip_atomic_store(&mine_slot[1], bound | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&mine_slot[0], (over ? THR_OVERFLOW : ncl) | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  DPM_R1STAMP(9)
+  // 5. the other workgroups' slots.  Word p of the slot area (slot p >> shift, entry p & (W - 1)) belongs to thread
+  // p mod T whatever the counts turn out to be, so the value loads go out together with the header loads -- one round
+  // trip for both; entries beyond a slot's count are ignored, entries that have not landed yet are polled.
+  constexpr int PER = THR_CAP / T;
+  const int shift = tp.slot_shift;
+  const uint32_t W = 1u << shift, words = k << shift;  // <= THR_CAP
+  uint32_t w[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const uint32_t q = (uint32_t)tid + (uint32_t)j * T;
+    w[j] = 0u;
+    if (q < words)
+      w[j] = __hip_atomic_load(slots + (size_t)(q >> shift) * THR_SLOTW + THR_SLOT_HDR + (q & (W - 1u)), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+  }
+  uint32_t h0 = THR_TAG, h1 = THR_TAG;
+  if ((uint32_t)tid < k) {
+    const uint32_t* sl = slots + (size_t)tid * THR_SLOTW;
+    uint32_t spins = 0;
+    h0 = __hip_atomic_load(&sl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    h1 = __hip_atomic_load(&sl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while ((!(h0 & THR_TAG) || !(h1 & THR_TAG)) && !misc[30]) {
+      __builtin_amdgcn_s_sleep(1);
+      if (!(h0 & THR_TAG)) h0 = __hip_atomic_load(&sl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!(h1 & THR_TAG)) h1 = __hip_atomic_load(&sl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (++spins > THR_SPIN_LIMIT) {
+        misc[30] = 1u;
+        raise_fault(tp.fault);
+      }
+    }
+  }
+  DPM_R1STAMP(10)
+  const bool bad = (uint32_t)tid < k && (!(h0 & THR_TAG) || !(h1 & THR_TAG) || (h0 & THR_OVERFLOW));
+  const uint32_t cnt_t = ((uint32_t)tid < k && !bad) ? (h0 & 0xffffu) : 0u;
+  const uint32_t off_t = block_excl_scan<T>(cnt_t, misc, tid);
+  if ((uint32_t)tid < k) {
+    hist[tid] = cnt_t;
+    hist[k + tid] = off_t;
+  }
+  {
+    const uint32_t wb = wave_max_to_lane63((uint32_t)tid < k ? (h1 & ~THR_TAG) : 0u);
+    if (lane == 63 && wb) atomicMax(&misc[9], wb);
+    if (__ballot(bad) && lane == 0) misc[10] = 1u;
+  }
+  __syncthreads();
+  const uint32_t total = misc[24], bound_max = misc[9];
+  bool ok = !misc[10] && total >= K && total <= (uint32_t)THR_CAP;
+  // 6. the union -> cand[]: entry i of slot s goes to off[s] + i
+  if (ok) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const uint32_t q = (uint32_t)tid + (uint32_t)j * T;
+      const uint32_t sl = q >> shift, i = q & (W - 1u);
+      if (q < words && i < hist[sl]) {
+        const uint32_t* src = slots + (size_t)sl * THR_SLOTW + THR_SLOT_HDR + i;
+        uint32_t spins = 0;
+        while (!(w[j] & THR_TAG) && !misc[30]) {
+          __builtin_amdgcn_s_sleep(1);
+          w[j] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (++spins > THR_SPIN_LIMIT) {
+            misc[30] = 1u;
+            raise_fault(tp.fault);
+          }
+        }
+        cand[hist[k + sl] + i] = w[j] & ~THR_TAG;
+      }
+    }
+  }
+  __syncthreads();
+  DPM_R1STAMP(11)
+  // the scratch words of the histogram go back to zero (the general route and the next sample expect that)
+  if ((uint32_t)tid < k) {
+    hist[tid] = 0u;
+    hist[k + tid] = 0u;
+  }
+  if (tid == 0) {
+    misc[4] = 0u;
+    misc[8] = 0u;
+    misc[9] = 0u;
+    misc[10] = 0u;
+  }
+  __syncthreads();
+  if (!ok || misc[30]) return false;
+  // 7. K-th and (K-1)-th largest of the union
+  uint32_t a, b;
+  const uint32_t rank = total - K;  // ascending
+  if (total <= 64u) {
+    rank_select<T>(cand, total, rank, misc, tid);
+    a = misc[6];
+    b = rank + 1u < total ? misc[7] : a;
+    __syncthreads();
+  } else {
+    union_select<T>(cand, total, rank, hist, misc, tid, a, b);
+  }
+  a_out = a;
+  b_out = b;
+  DPM_R1STAMP(12)
+#ifdef DPM_THR_DEBUG
+  if (tid == 0 && c < 2) printf("[r1] c=%d ncl=%u total=%u K=%u rank=%u bound_max=%08x a=%08x b=%08x\n", c, ncl, total, K, rank, bound_max, a, b);
+#endif
+  if (tp.debug_reject) return false;
+  return a >= bound_max;  // else: an unpublished element of some chunk could be among the K largest
+}
+
 // HOT != 0: the usual configuration fixed at compile time -- 16-byte accesses legal, noise-prediction network with the
 // division by the invariant alpha, no mask blend; HOT = 1 with the top-K front end, HOT = 2 with the full level-0
 // histogram -- so that the load and store loops are straight-line code without the wave-uniform branches of the general
@@ -901,7 +1263,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
   const bool store_m = p.flags & DPM_F_STORE_M;
   const bool vec = HOT != 0 || tp.vec != 0;
   const uint32_t k = (uint32_t)tp.k;
-  const bool topk = HOT == 1 || (HOT == 0 && tp.topk > 0);
+  const bool route1 = k > 1 && tp.quota > 0;                              // single-exchange cluster select
+  const bool track = HOT == 1 || (HOT == 0 && (tp.topk > 0 || route1));  // phase 1 keeps every thread's four largest |x0|
+  const bool topk = track && tp.topk > 0;                                 // top-K front end of the general route
   const bool fastdiv = HOT != 0 || tp.fastdiv != 0;
   const int64_t eps_stride = ext.eps_stride;
   const int grp = k == 1 ? (int)blockIdx.x : (int)(blockIdx.x / k);
@@ -910,6 +1274,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
   const TS* ba = HOT != 0 ? nullptr : static_cast<const TS*>(ext.ba);
   const TS* bb = HOT != 0 ? nullptr : static_cast<const TS*>(ext.bb);
   TS* xo2 = static_cast<TS*>(ext.xo2);
+  if (threadIdx.x == 0) misc[30] = 0u;  // set when a wait on a peer workgroup timed out (see raise_fault)
 
   for (int s_idx = grp; s_idx < tp.batch; s_idx += tp.groups) {
     // The thread index is re-materialised per sample: otherwise the compiler hoists every per-thread predicate of the
@@ -921,7 +1286,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     const int64_t ebase = (int64_t)s_idx * (eps_stride ? eps_stride : tp.per_sample) + (int64_t)c * tp.chunk;
     const int64_t left = tp.per_sample - (int64_t)c * tp.chunk;
     const int n = left <= 0 ? 0 : (left < tp.chunk ? (int)left : tp.chunk);
-    uint32_t* ws = k == 1 ? nullptr : tp.ws + (int64_t)s_idx * THR_WS_WORDS;
+    uint32_t* ws = k == 1 ? nullptr : tp.ws + (int64_t)s_idx * tp.ws_stride;
     // mask index of element base + i without a 64-bit division per element (launch: period < 2^31 or period == n)
     const bool mfull = ext.mask_period >= ((int64_t)1 << 31);
     const uint32_t mbase = (mask && !mfull) ? (uint32_t)(base % ext.mask_period) : 0u;
@@ -944,6 +1309,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     if (tid == 0) {
       misc[4] = 0u;   // candidate counter
       misc[3] = ABS;  // smallest value above the selected top digit (cluster exchange)
+      misc[8] = 0u;   // cluster_select_once: chunk maximum, largest bound, bad-slot flag
+      misc[9] = 0u;
+      misc[10] = 0u;
     }
     __syncthreads();
     uint32_t m1 = 0u, m2 = 0u, m3 = 0u, m4 = 0u;  // top-K: the four largest |x0| bit patterns this thread produced
@@ -976,7 +1344,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
           for (int j = 0; j < 4; ++j) a[j] = __float_as_uint(o[j]);
           *reinterpret_cast<u32x4*>(sx0 + i) = a;
         }
-        if (topk) {
+        if (track) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             top4_insert(__float_as_uint(o[j]) & ABS, m1, m2, m3, m4);
@@ -994,7 +1362,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
                                         GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[base + i]) : 0.f, p);
         sx0[i] = o;
         const uint32_t u = __float_as_uint(o) & ABS;
-        if (topk)
+        if (track)
           top4_insert(u, m1, m2, m3, m4);
         else
           atomicAdd(&hist[u >> 20], 1u);
@@ -1008,10 +1376,16 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     uint32_t prefix = 0u, known = 0u, rank = (uint32_t)tp.lo, cnt_sel = 0u;
     uint32_t hi = ABS, nc = 0u;
     bool use_cand = false, local_only = k == 1;  // local_only: no further cluster-wide step is needed
-    bool hist_ready = !topk;                     // the level-0 histogram of the whole chunk exists
+    bool hist_ready = !track;                    // the level-0 histogram of the whole chunk exists
     bool fast = false;                           // the candidates are few: finish by rank counting
+    // clusters first try to settle the sample with ONE exchange (cluster_select_once); the general route below is the
+    // fallback for samples whose large values sit in one chunk, and the only route when the quantile is not near 1
+    uint32_t a1 = 0u, b1 = 0u;
+    const bool solved = route1 && cluster_select_once<T>(sx0, n, vec, m1, m2, m3, m4, has, hist, misc, cand,
+                                                         ws + THR_WS_WORDS, tp, k, c, tid, a1, b1, s_idx == grp);
+    const bool general = !solved;                // the general route runs (for clusters: it dirties the merged histograms)
 
-    if (topk) {
+    if (general && topk) {
       // Top-K front end (the usual case: ratio close to 1, K = n - lo elements at or above the wanted one, K much smaller
       // than the number of threads).  The K-th largest element of the sample is at least the K-th largest of the
       // per-thread maxima (those are K distinct elements), so every element that can still matter has a top digit >=
@@ -1027,7 +1401,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
           const uint32_t v = hist[j * T + tid];
           if (v) __hip_atomic_fetch_add(&gh[j * T + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        cluster_barrier(ws + THR_WS_CNT + 4, k);
+        cluster_barrier(ws + THR_WS_CNT + 4, k, misc + 30, tp.fault);
 #pragma unroll
         for (int j = 0; j < BPT; ++j)
           hist[j * T + tid] = __hip_atomic_load(&gh[j * T + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1071,7 +1445,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         if (ok && slot0 <= (uint32_t)THR_GCAP && nc <= (uint32_t)THR_GCAP - slot0)
           for (uint32_t i = tid; i < nc; i += T)
             __hip_atomic_store(&gl[slot0 + i], cand[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cluster_barrier(ws + THR_WS_CNT + 5, k);
+        cluster_barrier(ws + THR_WS_CNT + 5, k, misc + 30, tp.fault);
         const uint32_t total = __hip_atomic_load(gcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = total <= (uint32_t)THR_GCAP;
         if (ok) {
@@ -1099,7 +1473,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     // are compacted into `cand` after level 0 (wave-aggregated append); everything above that digit only matters
     // through its minimum, kept per lane in `hi`.
 #pragma unroll 1
-    for (int pass = 0; pass < 3 && !fast; ++pass) {
+    for (int pass = 0; pass < 3 && !fast && general; ++pass) {
       const int shift = pass == 0 ? 20 : pass == 1 ? 9 : 0;
       const uint32_t dmask = pass == 2 ? 0x1ffu : 0x7ffu;
       if (pass > 0 || !hist_ready) {  // the histogram is all zero here (sample start / locate_bin)
@@ -1127,7 +1501,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
           const uint32_t v = hist[j * T + tid];
           if (v) __hip_atomic_fetch_add(&gh[j * T + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        cluster_barrier(ws + THR_WS_CNT + pass, k);
+        cluster_barrier(ws + THR_WS_CNT + pass, k, misc + 30, tp.fault);
 #pragma unroll
         for (int j = 0; j < BPT; ++j)
           hist[j * T + tid] = __hip_atomic_load(&gh[j * T + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1138,6 +1512,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
       known |= dmask << shift;
       rank = misc[1];
       cnt_sel = misc[2];
+#ifdef DPM_THR_DEBUG
+      if (tid == 0 && c < 2) printf("[gen] c=%d pass=%d prefix=%08x rank=%u cnt_sel=%u nc=%u use_cand=%d local_only=%d\n", c, pass, prefix, rank, cnt_sel, nc, (int)use_cand, (int)local_only);
+#endif
       if (pass == 0 && !use_cand) {  // compact this chunk's candidates, remember the smallest value of the higher digits
         const uint32_t bin0 = prefix >> 20;
         hi = compact_candidates<T, false>(sx0, n, bin0, misc, cand, tid);
@@ -1166,7 +1543,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
           const uint32_t slot0 = misc[5];
           for (uint32_t i = tid; i < nc; i += T)
             __hip_atomic_store(&gl[slot0 + i], cand[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          cluster_barrier(ws + THR_WS_CNT + 1, k);
+          cluster_barrier(ws + THR_WS_CNT + 1, k, misc + 30, tp.fault);
           nc = cnt_sel;
           for (uint32_t i = tid; i < nc; i += T)
             cand[i] = __hip_atomic_load(&gl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1180,7 +1557,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     }
     uint32_t a_bits = prefix;
     float a, b;
-    if (fast) {
+    if (solved) {
+      a = __uint_as_float(a1);
+      b = tp.hi != tp.lo ? __uint_as_float(b1) : a;
+    } else if (fast) {
       // the candidates hold the wanted element at ascending position `rank`, and -- unless it is their largest -- the next
       // order statistic too; otherwise that one is the smallest value of the higher digits
       rank_select<T>(cand, nc, rank, misc, tid);
@@ -1238,7 +1618,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         if (!local_only) {  // workspace words start at zero: keep the minimum as a maximum of the complement
           uint32_t* gm = ws + THR_WS_CNT + 8;
           if (tid == 0) __hip_atomic_fetch_max(gm, ABS - misc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          cluster_barrier(ws + THR_WS_CNT + 3, k);
+          cluster_barrier(ws + THR_WS_CNT + 3, k, misc + 30, tp.fault);
           b = __uint_as_float(ABS - __hip_atomic_load(gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         } else {
           b = __uint_as_float(misc[3]);
@@ -1246,6 +1626,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
       }
     }
     DPM_TSTAMP(2)
+    // This workgroup is through with the sample's workspace.  The last of the cluster to say so puts every word it and
+    // its peers dirtied back to zero (end of the sample loop): the workspace is all zero between launches, so no launch
+    // has to clear it first.  The returning atomic is in flight during phase 3.
+    uint32_t done_old = 0u;
+    if (k > 1 && tid == 0) done_old = __hip_atomic_fetch_add(ws + THR_WS_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // torch.quantile 'linear' = ATen lerp(a, b, w)
     const float diff = b - a;
     const float q = tp.w < 0.5f ? a + tp.w * diff : b - diff * (1.f - tp.w);
@@ -1329,6 +1714,19 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         xo[gi] = ov;
         if (xo2) xo2[gi] = ov;
         if (store_m) mo[gi] = from_f32<TS>(mn);
+      }
+    }
+    if (k > 1) {
+      if (tid == 0) misc[11] = done_old == k - 1u ? 1u : 0u;
+      __syncthreads();
+      if (misc[11]) {
+        uint32_t* slots = ws + THR_WS_WORDS;
+        for (uint32_t i = tid; i < k * (uint32_t)THR_SLOTW; i += T) slots[i] = 0u;
+        if (general || !route1) {
+          for (uint32_t i = tid; i < (uint32_t)THR_WS_WORDS; i += T) ws[i] = 0u;
+        } else if (tid == 0) {
+          ws[THR_WS_DONE] = 0u;
+        }
       }
     }
     __syncthreads();  // the next sample of this cluster reuses the LDS
@@ -1481,8 +1879,11 @@ inline ThrPlan thr_plan(int64_t batch, int64_t per_sample, int n_cu) {
   chunk = (chunk + 3) / 4 * 4;
   return ThrPlan{k, chunk};
 }
+// words per sample: the merged histograms / lists / counters of the general route + one slot per workgroup of the cluster
+inline int64_t thr_ws_stride(int64_t k) { return (int64_t)THR_WS_WORDS + k * (int64_t)THR_SLOTW; }
 inline int64_t thr_ws_bytes(int64_t batch, int64_t per_sample, int n_cu) {
-  return thr_plan(batch, per_sample, n_cu).k > 1 ? batch * (int64_t)THR_WS_WORDS * 4 : 0;
+  const ThrPlan pl = thr_plan(batch, per_sample, n_cu);
+  return pl.k > 1 ? batch * thr_ws_stride(pl.k) * 4 : 0;
 }
 
 // launch-shape defaults (measured on MI355X: profiles/r01_tuning.md, r01_tuning_v3.txt, and r01_tuning_v4.txt with the
@@ -1551,7 +1952,19 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
     const int64_t per_sample = b->n / b->batch;
     if (b->batch > 0x7fffffff || per_sample > ((int64_t)1 << 40))
       return dpm_set_error(DPM_ERR_UNSUPPORTED, "thresholding: batch / sample size out of range");
-    const ThrPlan pl = thr_plan(b->batch, per_sample, n_cu);
+    ThrPlan pl = thr_plan(b->batch, per_sample, n_cu);
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream.stream, &cap_status);
+    const bool capturing = cap_status != hipStreamCaptureStatusNone;
+    // Clusters wait for each other inside the kernel, which is only safe while no OTHER clustered launch can hold part of
+    // the chip at the same time.  Eager launches of this process are chained device-wide (below); a captured graph is
+    // replayed outside that chain, possibly next to another graph on another stream.  Under capture a sample that fits
+    // one workgroup's LDS therefore takes the cluster-free shape (one workgroup per sample) unless the caller opts in
+    // (DPM_TUNE_CLUSTER_IN_GRAPH); larger samples have no such shape and keep their clusters, with bounded waits.
+    if (capturing && pl.k > 1 && per_sample <= THR_CHUNK_MAX && !g_tuning.cluster_in_graph) {
+      pl.k = 1;
+      pl.chunk = (per_sample + 3) / 4 * 4;
+    }
     ThrParams tp;
     std::memset(&tp, 0, sizeof tp);
     tp.per_sample = per_sample;
@@ -1583,6 +1996,27 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
       if (K >= 1 && K <= P / 4 && K <= THR_THREADS / 4) {  // beyond: the candidates outgrow the rank-counting finish
         tp.topk = (int32_t)K;
         tp.mrank = (int32_t)(P - K);
+      }
+      // single-exchange cluster route (cluster_select_once): a chunk's share of the K largest is ~ K/k; publishing the
+      // ~quota = K/k + 6 sigma + 8 largest values of every chunk makes the one-hop answer exact except for samples whose
+      // large values sit in one chunk (those fall back inside the kernel).  Needs room in the slots for the 14-bit digit's
+      // granularity (x1.5) and a union that fits the LDS list.
+      if (pl.k > 1 && pl.k <= THR_THREADS && K >= 1 && K < ((int64_t)1 << 30)) {
+        const double mu = (double)K / (double)pl.k;
+        const int64_t quota = (int64_t)std::ceil(mu + 6.0 * std::sqrt(mu) + 8.0);
+        // slot size: the smallest power of two >= 64 with room for the quota and the digit granularity (fewer words to
+        // fetch per slot); at most THR_SLOT_CAP and THR_CAP / k
+        int slot_shift = 6;
+        while (((int64_t)1 << slot_shift) < quota * 3 / 2 && slot_shift < 8) ++slot_shift;
+        while (slot_shift > 0 && ((int64_t)1 << slot_shift) > std::min<int64_t>(THR_SLOT_CAP, THR_CAP / pl.k)) --slot_shift;
+        const int64_t slot_cap = (int64_t)1 << slot_shift;
+        if (quota * 3 / 2 <= slot_cap && g_tuning.cluster_one_hop) {
+          tp.quota = (int32_t)quota;
+          tp.kbig = (int32_t)K;
+          tp.slot_cap = (int32_t)slot_cap;
+          tp.slot_shift = slot_shift;
+          tp.debug_reject = g_tuning.cluster_one_hop == 2;
+        }
       }
     }
 #ifdef DPM_THR_TIMING
@@ -1616,7 +2050,7 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
                                (GUIDE == DPM_GUIDE_NONE || GUIDE == DPM_GUIDE_CFG) && !XE;
     const bool hot = HOT_BUILT && tp.vec && tp.fastdiv && !ext.mask;
     auto kern = !hot ? stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 0>
-                     : tp.topk > 0 ? stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, HOT_BUILT ? 1 : 0>
+                     : (tp.topk > 0 || tp.quota > 0) ? stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, HOT_BUILT ? 1 : 0>
                                    : stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, HOT_BUILT ? 2 : 0>;
     int64_t grid = b->batch;
     tp.groups = (int32_t)b->batch;
@@ -1647,16 +2081,23 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
       const int64_t groups = std::min<int64_t>(b->batch, cap / pl.k);
       tp.groups = (int32_t)groups;
       tp.ws = static_cast<uint32_t*>(b->workspace);
+      tp.ws_stride = thr_ws_stride(pl.k);
       grid = groups * pl.k;
-      hipError_t me = hipMemsetAsync(b->workspace, 0, (size_t)thr_ws_bytes(b->batch, per_sample, n_cu), stream.stream);
-      if (me != hipSuccess) return dpm_set_error((int)me, "hipMemsetAsync: %s", hipGetErrorString(me));
+      // No clearing of the workspace here: the caller hands it over zero-filled once, the kernel leaves it zero-filled
+      // (dpm_threshold_workspace_bytes).  A wait that timed out in an earlier clustered launch is reported now.
+      uint32_t* fault = cluster_fault_word(!capturing);
+      if (fault && *fault) {
+        *fault = 0u;
+        return dpm_set_error(DPM_ERR_FAULT, "a clustered dynamic-thresholding launch gave up waiting for a peer workgroup "
+                             "(another clustered launch held the GPU concurrently?); its results are invalid and its "
+                             "workspace must be zero-filled again");
+      }
+      tp.fault = fault;
       // Two clustered launches on different streams could each hold part of the CUs with spinning workgroups and
       // starve the other's missing peers.  Within this process they are therefore chained device-wide: wait for the
       // previous clustered launch (whatever its stream), record after this one.  (Not under stream capture, where an
-      // event recorded outside the capture cannot be waited on; a captured graph is the caller's to serialise.)
-      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-      (void)hipStreamIsCapturing(stream.stream, &cs);
-      if (cs == hipStreamCaptureStatusNone) {
+      // event recorded outside the capture cannot be waited on; see above.)
+      if (!capturing) {
         int dev = 0;
         (void)hipGetDevice(&dev);
         ClusterChain& ch = cluster_chain(dev);

@@ -10,6 +10,19 @@ ClusterChain& cluster_chain(int dev) {
   static ClusterChain chains[64];
   return chains[(dev < 0 ? 0 : dev) % 64];
 }
+uint32_t* cluster_fault_word(bool create) {
+  static std::mutex mu;
+  static uint32_t* word = nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!word && create) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 64, hipHostMallocMapped) == hipSuccess && p) {
+      word = static_cast<uint32_t*>(p);
+      *word = 0u;
+    }
+  }
+  return word;
+}
 }  // namespace dpmk
 
 // one translation unit per (state, eps) dtype pair
@@ -418,6 +431,8 @@ extern "C" int dpm_tuning_set(int knob, int value) {
       return DPM_OK;
     case DPM_TUNE_ASSUME_RESIDENT: g_tuning.assume_resident = value != 0; return DPM_OK;
     case DPM_TUNE_MULTI_FUSE: g_tuning.multi_fuse = value != 0; return DPM_OK;
+    case DPM_TUNE_CLUSTER_IN_GRAPH: g_tuning.cluster_in_graph = value != 0; return DPM_OK;
+    case DPM_TUNE_CLUSTER_ONE_HOP: g_tuning.cluster_one_hop = value < 0 ? 0 : (value > 2 ? 2 : value); return DPM_OK;
     case DPM_TUNE_MULTI_BLOCKS_PER_CU:
       if (value < 0 || value > 4096) return dpm_set_error(DPM_ERR_ARG, "multi_blocks_per_cu must be in 0..4096");
       g_tuning.multi_blocks_per_cu = value;
@@ -433,6 +448,8 @@ extern "C" int dpm_tuning_get(int knob) {
     case DPM_TUNE_BLOCKS_PER_CU: return g_tuning.blocks_per_cu;
     case DPM_TUNE_ASSUME_RESIDENT: return g_tuning.assume_resident;
     case DPM_TUNE_MULTI_FUSE: return g_tuning.multi_fuse;
+    case DPM_TUNE_CLUSTER_IN_GRAPH: return g_tuning.cluster_in_graph;
+    case DPM_TUNE_CLUSTER_ONE_HOP: return g_tuning.cluster_one_hop;
     case DPM_TUNE_MULTI_BLOCKS_PER_CU: return g_tuning.multi_blocks_per_cu;
   }
   return -1;

@@ -128,11 +128,12 @@ def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=No
     b.state_dtype = _DT[sd]
     b.eps_dtype = _DT[ed]
     b.eps_stride = eps_stride
+    stream, idx = _raw_stream(dev)
     ws = None
     if st.flags & L.F_THRESH:
         nb = L.lib.dpm_threshold_workspace_bytes(b.batch, b.n // b.batch)
         if nb:
-            ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+            ws = _cluster_workspace(dev, idx, stream, nb)
             b.workspace = ws.data_ptr()
     if ext is not None and ext.get("blend") is not None:
         mask, period, ba, bb, alpha, sigma = ext["blend"]
@@ -141,13 +142,31 @@ def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=No
         b.mask, b.blend_a, b.mask_period = mask.data_ptr(), ba.data_ptr(), period
         if bb is not None:
             b.blend_b = bb.data_ptr()
-    stream, idx = _raw_stream(dev)
     if idx == torch.cuda.current_device():
         L.check(L.lib.dpm_stage_launch(C.byref(st), C.byref(b), stream))
     else:
         with torch.cuda.device(idx):
             L.check(L.lib.dpm_stage_launch(C.byref(st), C.byref(b), stream))
     return x_out, m_out
+
+
+_WS_CACHE = {}
+
+
+def _cluster_workspace(dev, idx, stream, nbytes):
+    """Workspace of the clustered thresholding kernel (dpm_threshold_workspace_bytes): zero-filled ONCE here -- every
+    launch leaves it zero-filled again -- and kept per (device, stream): launches that share one must be ordered.  Under
+    stream capture the graph gets a workspace of its own (its address is baked in)."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    key = (idx, stream)
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if len(_WS_CACHE) >= 16:
+            _WS_CACHE.pop(next(iter(_WS_CACHE)))
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        _WS_CACHE[key] = ws
+    return ws
 
 
 def _add_noise(sched_handle, x, noise, t_host):
@@ -290,8 +309,8 @@ class _FastRun:
             if st.flags & L.F_THRESH:
                 nb = L.lib.dpm_threshold_workspace_bytes(b.batch, n // b.batch)
                 if nb:
-                    if self.ws is None:
-                        self.ws = torch.empty(nb, dtype=torch.uint8, device=device)
+                    if self.ws is None:      # zero-filled once; every launch leaves it zero-filled
+                        self.ws = torch.zeros(nb, dtype=torch.uint8, device=device)
                     b.workspace = self.ws.data_ptr()
             self.stages.append(st)
             self.bufs.append(b)

@@ -42,7 +42,9 @@ enum {
   DPM_ERR_UNSUPPORTED = -2, /* valid in the reference, not (yet) built here -- never silent   */
   DPM_ERR_ALIGN = -3,       /* reserved                                                      */
   DPM_ERR_NOMEM = -4,
-  DPM_ERR_CALLBACK = -5     /* the model callback of dpm_plan_run returned non-zero           */
+  DPM_ERR_CALLBACK = -5,    /* the model callback of dpm_plan_run returned non-zero           */
+  DPM_ERR_FAULT = -6        /* an earlier clustered thresholding launch gave up waiting for a peer
+                               workgroup (bounded wait, never a trap): its results are invalid    */
 };
 
 /* ---- enumerations (values are ABI) ----------------------------------------------------- */
@@ -223,9 +225,11 @@ int dpm_stage_launch(const dpm_stage* st, const dpm_buffers* b, void* stream);
 #define DPM_MULTI_MAX 32
 int dpm_stage_launch_multi(const dpm_stage* st, const dpm_buffers* bs, int n_req, void* stream);
 /* scratch needed by stages with DPM_F_THRESH on the current device: 0 when one workgroup per sample is the plan (the
-   sample lives in that workgroup's LDS), else ~40 KiB per sample of histograms, lists and counters through which the workgroup
-   cluster of a sample synchronises (small batches, samples beyond 12288 elements); the launch zeroes it itself.
-   Pass it as dpm_buffers.workspace. */
+   sample lives in that workgroup's LDS), else ~40-60 KiB per sample of slots, histograms and counters through which the
+   workgroup cluster of a sample exchanges its candidates (small batches, samples beyond 12288 elements).
+   Pass it as dpm_buffers.workspace.  Contract: the caller ZERO-FILLS the workspace once (hipMemset) before its first use;
+   every launch leaves it zero-filled again (the last workgroup of a cluster cleans up), so no launch pays for a clear.
+   Launches that share a workspace must be ordered (same stream).  After DPM_ERR_FAULT zero-fill it again. */
 size_t dpm_threshold_workspace_bytes(int64_t batch, int64_t per_sample);
 /* x_t = alpha_t*x + sigma_t*noise for nt times (add_noise, ref :1012-1030); out is [nt, n] */
 int dpm_add_noise_launch(const dpm_schedule* s, const float* t_host, int nt, const void* x, const void* noise,
@@ -295,7 +299,10 @@ void dpm_graph_destroy(dpm_graph* g);
 enum {
   DPM_TUNE_UNROLL = 0, DPM_TUNE_NONTEMPORAL = 1, DPM_TUNE_BLOCKS_PER_CU = 2, DPM_TUNE_ASSUME_RESIDENT = 3,
   DPM_TUNE_MULTI_FUSE = 4,          /* 1 (default): dpm_stage_launch_multi fuses; 0: one launch per request          */
-  DPM_TUNE_MULTI_BLOCKS_PER_CU = 5  /* grid cap of the fused launch, workgroups per CU; 0 (default) = no cap      */
+  DPM_TUNE_MULTI_BLOCKS_PER_CU = 5, /* grid cap of the fused launch, workgroups per CU; 0 (default) = no cap      */
+  DPM_TUNE_CLUSTER_IN_GRAPH = 6,    /* 1: thresholding keeps workgroup clusters under stream capture for samples that
+                                       fit one workgroup too (default 0: one workgroup per sample there)           */
+  DPM_TUNE_CLUSTER_ONE_HOP = 7      /* 0: clusters skip the single-exchange select (testing the general route)     */
 };
 int dpm_tuning_set(int knob, int value);
 int dpm_tuning_get(int knob);

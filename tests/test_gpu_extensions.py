@@ -460,15 +460,22 @@ def test_sharded_sampling_over_rccl_single_rank():
         dist.destroy_process_group()
 
 
-def test_captured_sample_with_clustered_thresholding():
-    """hipGraph capture of a trajectory whose thresholding kernel runs as clusters (workspace memset + spin barriers
-    inside the graph): replays must keep matching eager runs"""
-    case = dict(C.E2E_BY_NAME["cfg5_thresh"], shape=(2, 3, 64, 64), steps=8)
+@pytest.mark.parametrize("shape,in_graph", [((2, 3, 64, 64), 0), ((2, 3, 64, 64), 1), ((2, 3, 160, 160), 0)])
+def test_captured_sample_with_clustered_thresholding(shape, in_graph):
+    """hipGraph capture of a trajectory with dynamic thresholding.  Eagerly a small batch runs as workgroup clusters; under
+    capture a sample that fits one workgroup takes the cluster-free shape (a replayed graph is outside the library's
+    device-wide chain of clustered launches) unless DPM_TUNE_CLUSTER_IN_GRAPH opts in; larger samples keep their
+    clusters.  Replays must keep matching eager runs in every case."""
+    case = dict(C.E2E_BY_NAME["cfg5_thresh"], shape=shape, steps=8)
     dpm = build_solver(case, DEV)
     x = tt(C.x_T_for(case), DEV)
     kw = sample_kwargs(case, False)
     want = dpm.sample(x, **kw)
-    g = dpm.capture(x, **kw)
+    L.lib.dpm_tuning_set(L.TUNE_CLUSTER_IN_GRAPH, in_graph)
+    try:
+        g = dpm.capture(x, **kw)
+    finally:
+        L.lib.dpm_tuning_set(L.TUNE_CLUSTER_IN_GRAPH, 0)
     for _ in range(3):
         assert torch.equal(g(x), want)
     x2 = x * 0.75

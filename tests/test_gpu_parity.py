@@ -169,6 +169,45 @@ def test_dynamic_thresholding_topk_front_end():
         np.testing.assert_array_equal(y.cpu().numpy(), O.dynamic_threshold(x0, p, 1.0), err_msg=str((shape, p, top)))
 
 
+def test_cluster_single_exchange_route_and_its_fallback():
+    """Clusters (k workgroups per sample) first try to settle a sample with one exchange of per-chunk candidates
+    (cluster_select_once).  That is exact by construction or declared failed inside the kernel, in which case the
+    cluster takes the general route: (i) samples whose largest values all sit in ONE chunk must still be exact,
+    (ii) switching the one-hop route off gives bit-identical results, (iii) the workspace is all zero after every launch
+    (it is zero-filled once, never per launch)."""
+    ns = make_schedule("ddpm")
+    rng = np.random.default_rng(23)
+    cases = [((32, 3, 64, 64), 0.995), ((6, 3, 64, 64), 0.999), ((4, 3, 256, 256), 0.995), ((3, 3, 200, 160), 0.99),
+             ((2, 3, 256, 256), 0.9995), ((40, 1, 96, 96), 0.995)]
+    for shape, p in cases:
+        for mode in ("random", "one_chunk", "two_chunks", "ties"):
+            x0 = (rng.standard_normal(shape) * 1.5).astype(F32)
+            rows = x0.reshape(shape[0], -1)
+            n = rows.shape[1]
+            K = max(2, int(n - np.floor(np.float32(p) * np.float32(n - 1))))
+            if mode == "one_chunk":          # the K largest values of every sample in its first 2K elements
+                rows[:, :2 * K] = (np.abs(rng.standard_normal((shape[0], 2 * K))) + 8.0).astype(F32)
+            elif mode == "two_chunks":       # half of them at the very end of the sample
+                rows[:, :K] = (np.abs(rng.standard_normal((shape[0], K))) + 8.0).astype(F32)
+                rows[:, -K:] = -(np.abs(rng.standard_normal((shape[0], K))) + 8.0).astype(F32)
+            elif mode == "ties":             # the wanted order statistics are a long run of equal values
+                rows[:, rng.permutation(n)[:3 * K]] = np.float32(7.25)
+            want = O.dynamic_threshold(x0, p, 1.0)
+            dpm = D.DPM_Solver(lambda x, t: x, ns, correcting_x0_fn="dynamic_thresholding", dynamic_thresholding_ratio=p)
+            xg = torch.from_numpy(x0).to(DEV)
+            y = dpm.dynamic_thresholding_fn(xg, None)
+            np.testing.assert_array_equal(y.cpu().numpy(), want, err_msg=str((shape, p, mode)))
+            L.lib.dpm_tuning_set(L.TUNE_CLUSTER_ONE_HOP, 0)
+            try:
+                y2 = dpm.dynamic_thresholding_fn(xg, None)
+            finally:
+                L.lib.dpm_tuning_set(L.TUNE_CLUSTER_ONE_HOP, 1)
+            assert torch.equal(y, y2), (shape, p, mode)
+            torch.cuda.synchronize()
+            for ws in S._WS_CACHE.values():
+                assert not bool(ws.any()), ("workspace not left zero-filled", shape, p, mode)
+
+
 def test_thresholded_sampling_random_sweep():
     """seeded random sweep of sample() with dynamic thresholding -- batch / sample sizes (one workgroup per sample,
     clusters, ragged and unaligned rows), ratio (top-K front end and full histograms), max_val, order, steps --

@@ -53,7 +53,10 @@ def run(batch, chw):
     subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT, env=env)
     a = np.loadtxt(dump, dtype=np.float64) / 100.0          # microseconds
     t0 = a[:, 0].min()
-    names = [(0, "start"), (1, "x0 in LDS (load phase)"), (4, "maxima histogram"), (5, "bin located"),
+    names = [(0, "start"), (1, "x0 in LDS (load phase)"), (8, "one-hop: chunk max, maxima histogram, bound"),
+             (9, "one-hop: candidates compacted and published"), (10, "one-hop: headers of all slots arrived"),
+             (11, "one-hop: union gathered"), (12, "one-hop: select on the union"),
+             (4, "maxima histogram"), (5, "bin located"),
              (6, "candidates compacted / exchanged"), (7, "rank counting"), (2, "threshold known"), (3, "end (store phase)")]
     used = [(j, nm) for j, nm in names if np.all(a[:, j] > 0)]
     print("%d workgroups, first-sample span %.1f us" % (len(a), a[:, 3].max() - t0))
