@@ -282,6 +282,7 @@ struct KParams {
   uint32_t flags;
   int32_t model_type;
   float inv_alpha;  // RN(1 / alpha_e), used by the specialised prologue (see div_by_alpha)
+  int32_t form, guidance;  // DPM_FORM_* / DPM_GUIDE_*: read by the run-time dispatched kernels (FORM_RT / GUIDE_RT)
 };
 
 // x / alpha_e for a wave-uniform divisor whose correctly rounded reciprocal r = RN(1/alpha) is known: q = RN(x*r),
@@ -331,13 +332,22 @@ __device__ __forceinline__ V to_noise(V o, V xe, const KParams& p) {
 }
 
 // everything up to (not including) thresholding: returns eps, or x0 when the stage converts (DPM_F_TO_X0)
+// FORM_RT / GUIDE_RT as template arguments: the form / guidance kind is read from the stage record at run time
+// (wave-uniform branches).  The catch-all kernels -- the one-element-per-lane fallback and the general thresholding
+// kernel -- are instantiated once per dtype pair this way instead of once per (form, guidance, xe) combination.
+constexpr int FORM_RT = -1, GUIDE_RT = -1;
+template <int GUIDE>
+__device__ __forceinline__ bool guide_is(int what, const KParams& p) {
+  return GUIDE == GUIDE_RT ? p.guidance == what : GUIDE == what;
+}
+
 template <int GUIDE, int SPEC = SPEC_GENERIC, typename V = float>
 __device__ __forceinline__ V prologue(V xe, V o0, V o1, V gg, const KParams& p) {
   V eps;
-  if (GUIDE == DPM_GUIDE_CFG) {  // ref :326-330: uncond + scale * (cond - uncond)
+  if (guide_is<GUIDE>(DPM_GUIDE_CFG, p)) {  // ref :326-330: uncond + scale * (cond - uncond)
     V nu = to_noise<SPEC>(o1, xe, p), nc = to_noise<SPEC>(o0, xe, p);
     eps = nu + p.cfg_scale * (nc - nu);
-  } else if (GUIDE == DPM_GUIDE_CLASSIFIER) {  // ref :321
+  } else if (guide_is<GUIDE>(DPM_GUIDE_CLASSIFIER, p)) {  // ref :321
     eps = to_noise<SPEC>(o0, xe, p) - p.cg_scale * gg;
   } else {
     eps = to_noise<SPEC>(o0, xe, p);
@@ -372,6 +382,35 @@ __device__ __forceinline__ V combine(V x, V mn, V h1, V h2, const KParams& p) {
   } else {
     return mn;  // DPM_FORM_DENOISE, ref :541-545
   }
+}
+
+template <int FORM, typename V>
+__device__ __forceinline__ V combine_any(V x, V mn, V h1, V h2, const KParams& p) {
+  if constexpr (FORM != FORM_RT) {
+    return combine<FORM>(x, mn, h1, h2, p);
+  } else {
+    switch (p.form) {
+      case DPM_FORM_LIN1: return combine<DPM_FORM_LIN1>(x, mn, h1, h2, p);
+      case DPM_FORM_TWO: return combine<DPM_FORM_TWO>(x, mn, h1, h2, p);
+      case DPM_FORM_MS3: return combine<DPM_FORM_MS3>(x, mn, h1, h2, p);
+      case DPM_FORM_SS3T: return combine<DPM_FORM_SS3T>(x, mn, h1, h2, p);
+      default: return combine<DPM_FORM_DENOISE>(x, mn, h1, h2, p);
+    }
+  }
+}
+template <int FORM>
+__device__ __forceinline__ bool form_needs_x(const KParams& p) {
+  return FORM == FORM_RT ? p.form != DPM_FORM_DENOISE : FORM != DPM_FORM_DENOISE;
+}
+template <int FORM>
+__device__ __forceinline__ bool form_needs_h1(const KParams& p) {
+  const int f = FORM == FORM_RT ? p.form : FORM;
+  return f == DPM_FORM_TWO || f == DPM_FORM_MS3 || f == DPM_FORM_SS3T;
+}
+template <int FORM>
+__device__ __forceinline__ bool form_needs_h2(const KParams& p) {
+  const int f = FORM == FORM_RT ? p.form : FORM;
+  return f == DPM_FORM_MS3 || f == DPM_FORM_SS3T;
 }
 
 template <int FORM>
@@ -566,16 +605,20 @@ __global__ __launch_bounds__(256) void stage_kernel_multi(const MultiTab tab, in
   }
 }
 
-// same arithmetic, one element per lane: used when a pointer is not 16/32-byte aligned (views with offsets)
-template <typename TS, typename TE, int FORM, int GUIDE, bool XE>
+// same arithmetic, one element per lane: used when a pointer is not 16/32-byte aligned (views with offsets), for ragged
+// extended launches and for (form, xe) combinations the streaming family does not instantiate.  ONE kernel per dtype
+// pair: form and guidance are read from the stage record (wave-uniform branches), xe always points at the state the
+// network saw (= x when there is no separate one).
+template <typename TS, typename TE>
 __global__ __launch_bounds__(256) void stage_kernel_scalar(const TS* __restrict__ x, const TS* __restrict__ xe,
                                                            const TE* __restrict__ e0, const TE* __restrict__ e1,
                                                            const TE* __restrict__ g, const TS* __restrict__ h1,
                                                            const TS* __restrict__ h2, TS* __restrict__ xo,
                                                            TS* __restrict__ mo, int64_t n, KParams p, KExt ext) {
-  using FT = FormTraits<FORM>;
   const bool need_xe = (p.flags & DPM_F_TO_X0) || p.model_type == DPM_MODEL_X_START || p.model_type == DPM_MODEL_V;
   const bool store_m = p.flags & DPM_F_STORE_M;
+  const bool nx = form_needs_x<FORM_RT>(p), nh1 = form_needs_h1<FORM_RT>(p), nh2 = form_needs_h2<FORM_RT>(p);
+  const bool cfg = p.guidance == DPM_GUIDE_CFG, clsg = p.guidance == DPM_GUIDE_CLASSIFIER;
   const TS* mask = static_cast<const TS*>(ext.mask);
   const TS* ba = static_cast<const TS*>(ext.ba);
   const TS* bb = static_cast<const TS*>(ext.bb);
@@ -583,11 +626,10 @@ __global__ __launch_bounds__(256) void stage_kernel_scalar(const TS* __restrict_
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int64_t ie = ext.eps_stride ? (i / ext.per_sample) * ext.eps_stride + i % ext.per_sample : i;
-    const float xv = (FT::needs_x || (!XE && need_xe)) ? to_f32(x[i]) : 0.f;
-    const float xev = XE ? (need_xe ? to_f32(xe[i]) : 0.f) : xv;
-    const float mn = prologue<GUIDE>(xev, to_f32(e0[ie]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[ie]) : 0.f,
-                                     GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[i]) : 0.f, p);
-    float o = combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[i]) : 0.f, FT::needs_h2 ? to_f32(h2[i]) : 0.f, p);
+    const float xv = nx ? to_f32(x[i]) : 0.f;
+    const float xev = need_xe ? to_f32(xe[i]) : 0.f;
+    const float mn = prologue<GUIDE_RT>(xev, to_f32(e0[ie]), cfg ? to_f32(e1[ie]) : 0.f, clsg ? to_f32(g[i]) : 0.f, p);
+    float o = combine_any<FORM_RT>(xv, mn, nh1 ? to_f32(h1[i]) : 0.f, nh2 ? to_f32(h2[i]) : 0.f, p);
     if (mask) {
       o = to_f32(from_f32<TS>(o));  // the reference blends the stored state
       o = blend_ref(o, to_f32(mask[i % ext.mask_period]), to_f32(ba[i]), bb ? to_f32(bb[i]) : 0.f, bb != nullptr, ext);
@@ -1251,7 +1293,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     const TS* __restrict__ x, const TS* __restrict__ xe, const TE* __restrict__ e0, const TE* __restrict__ e1,
     const TE* __restrict__ g, const TS* __restrict__ h1, const TS* __restrict__ h2, TS* __restrict__ xo,
     TS* __restrict__ mo, KParams p, ThrParams tp, KExt ext) {
-  using FT = FormTraits<FORM>;
+  // FORM / GUIDE may be FORM_RT / GUIDE_RT (HOT = 0: the general kernel, one per dtype pair): read from p then
+  const bool nx = form_needs_x<FORM>(p), nh1 = form_needs_h1<FORM>(p), nh2 = form_needs_h2<FORM>(p);
+  const bool g_cfg = guide_is<GUIDE>(DPM_GUIDE_CFG, p), g_cls = guide_is<GUIDE>(DPM_GUIDE_CLASSIFIER, p);
   constexpr int BPT = THR_NB / T;  // histogram bins per thread when all threads touch the histogram
   constexpr uint32_t ABS = 0x7fffffffu;
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -1321,22 +1365,22 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         float vx[4], v0[4], v1[4], vg[4], o[4];
         load4(XE ? xe : x, base + i, vx);
         load4<true>(e0, ebase + i, v0);                       // the network outputs are dead after this kernel
-        if (GUIDE == DPM_GUIDE_CFG) load4<true>(e1, ebase + i, v1);
-        if (GUIDE == DPM_GUIDE_CLASSIFIER) load4<true>(g, base + i, vg);
+        if (g_cfg) load4<true>(e1, ebase + i, v1);
+        if (g_cls) load4<true>(g, base + i, vg);
         if (fastdiv) {  // uniform: the common parameterisation, division by the invariant alpha (3 VALU ops for ~12)
 #pragma unroll
           for (int j = 0; j < 4; j += 2) {  // adjacent pairs: packed fp32 instructions
             const f32x2 z = {0.f, 0.f};
             const f32x2 r = prologue<GUIDE, SPEC_NOISE_X0, f32x2>(
-                f32x2{vx[j], vx[j + 1]}, f32x2{v0[j], v0[j + 1]}, GUIDE == DPM_GUIDE_CFG ? f32x2{v1[j], v1[j + 1]} : z,
-                GUIDE == DPM_GUIDE_CLASSIFIER ? f32x2{vg[j], vg[j + 1]} : z, p);
+                f32x2{vx[j], vx[j + 1]}, f32x2{v0[j], v0[j + 1]}, g_cfg ? f32x2{v1[j], v1[j + 1]} : z,
+                g_cls ? f32x2{vg[j], vg[j + 1]} : z, p);
             o[j] = r[0];
             o[j + 1] = r[1];
           }
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            o[j] = prologue<GUIDE>(vx[j], v0[j], GUIDE == DPM_GUIDE_CFG ? v1[j] : 0.f, GUIDE == DPM_GUIDE_CLASSIFIER ? vg[j] : 0.f, p);
+            o[j] = prologue<GUIDE>(vx[j], v0[j], g_cfg ? v1[j] : 0.f, g_cls ? vg[j] : 0.f, p);
         }
         {  // LDS, not global memory: a plain 16-byte store (store4 writes through to global memory)
           u32x4 a;
@@ -1358,8 +1402,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
 #pragma unroll 4
       for (int i = tid; i < n; i += T) {
         const float xev = to_f32(XE ? xe[base + i] : x[base + i]);
-        const float o = prologue<GUIDE>(xev, to_f32(e0[ebase + i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[ebase + i]) : 0.f,
-                                        GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[base + i]) : 0.f, p);
+        const float o = prologue<GUIDE>(xev, to_f32(e0[ebase + i]), g_cfg ? to_f32(e1[ebase + i]) : 0.f,
+                                        g_cls ? to_f32(g[base + i]) : 0.f, p);
         sx0[i] = o;
         const uint32_t u = __float_as_uint(o) & ABS;
         if (track)
@@ -1651,9 +1695,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           const int64_t gi = base + (r == 0 || two ? i0 + r * T * 4 : i0);  // clamped: loads are unconditional
-          if (FT::needs_x) load4<true>(x, gi, vx[r]);                 // last use of x and of the cached model values
-          if (FT::needs_h1) load4<true>(h1, gi, vh1[r]);
-          if (FT::needs_h2) load4<true>(h2, gi, vh2[r]);
+          if (nx) load4<true>(x, gi, vx[r]);                 // last use of x and of the cached model values
+          if (nh1) load4<true>(h1, gi, vh1[r]);
+          if (nh2) load4<true>(h2, gi, vh2[r]);
         }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -1684,9 +1728,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
 #pragma unroll
             for (int j = 0; j < 4; j += 2) {
               const f32x2 z = {0.f, 0.f};
-              const f32x2 c2 = combine<FORM, f32x2>(FT::needs_x ? f32x2{vx[r][j], vx[r][j + 1]} : z, f32x2{om[j], om[j + 1]},
-                                                    FT::needs_h1 ? f32x2{vh1[r][j], vh1[r][j + 1]} : z,
-                                                    FT::needs_h2 ? f32x2{vh2[r][j], vh2[r][j + 1]} : z, p);
+              const f32x2 c2 = combine_any<FORM, f32x2>(nx ? f32x2{vx[r][j], vx[r][j + 1]} : z, f32x2{om[j], om[j + 1]},
+                                                    nh1 ? f32x2{vh1[r][j], vh1[r][j + 1]} : z,
+                                                    nh2 ? f32x2{vh2[r][j], vh2[r][j + 1]} : z, p);
               o[j] = c2[0];
               o[j + 1] = c2[1];
             }
@@ -1705,8 +1749,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
       for (int i = tid; i < n; i += T) {
         const int64_t gi = base + i;
         const float mn = fminf(fmaxf(sx0[i], -s), s) / s;  // ref :424
-        const float xv = FT::needs_x ? to_f32(x[gi]) : 0.f;
-        float o = combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[gi]) : 0.f, FT::needs_h2 ? to_f32(h2[gi]) : 0.f, p);
+        const float xv = nx ? to_f32(x[gi]) : 0.f;
+        float o = combine_any<FORM>(xv, mn, nh1 ? to_f32(h1[gi]) : 0.f, nh2 ? to_f32(h2[gi]) : 0.f, p);
         if (mask)
           o = blend_ref(to_f32(from_f32<TS>(o)), to_f32(mask[mfull ? gi : (int64_t)((mbase + (uint32_t)i) % mper)]),
                         to_f32(ba[gi]), bb ? to_f32(bb[gi]) : 0.f, bb != nullptr, ext);
@@ -1861,6 +1905,8 @@ inline KParams make_params(const dpm_stage* st) {
   p.k4 = st->k[4];
   p.flags = st->flags;
   p.model_type = st->model_type;
+  p.form = st->form;
+  p.guidance = st->guidance;
   return p;
 }
 
@@ -2049,9 +2095,14 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
     constexpr bool HOT_BUILT = (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3) &&
                                (GUIDE == DPM_GUIDE_NONE || GUIDE == DPM_GUIDE_CFG) && !XE;
     const bool hot = HOT_BUILT && tp.vec && tp.fastdiv && !ext.mask;
-    auto kern = !hot ? stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 0>
-                     : (tp.topk > 0 || tp.quota > 0) ? stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, HOT_BUILT ? 1 : 0>
-                                   : stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, HOT_BUILT ? 2 : 0>;
+    // the general kernel reads form / guidance from the stage record and always takes the evaluation state through xe
+    auto kern = stage_thresh_kernel<TS, TE, FORM_RT, GUIDE_RT, true, THR_THREADS, 0>;
+    if constexpr (HOT_BUILT) {
+      if (hot)
+        kern = (tp.topk > 0 || tp.quota > 0) ? stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 1>
+                                            : stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 2>;
+    }
+    if (!xe) xe = x;
     int64_t grid = b->batch;
     tp.groups = (int32_t)b->batch;
     if (pl.k > 1) {
@@ -2122,87 +2173,86 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
       vec = vec && aligned(ext.xo2, as) && aligned(ext.mask, as) && aligned(ext.ba, as) && aligned(ext.bb, as) &&
             b->n % EPT == 0 && ext.mask_period % EPT == 0 &&
             (!ext.eps_stride || (ext.per_sample % EPT == 0 && ext.eps_stride % EPT == 0));
-    if (!vec) {
+    // what the streaming family instantiates (binary size: one kernel per combination and dtype pair):
+    //   * a separate evaluation state (xe != x) only occurs in the singlestep mid / final stages: forms TWO and SS3T;
+    //   * the compile-time prologues (noise-prediction network) for the forms samplers spend their time in -- LIN1, TWO,
+    //     MS3; SS3T and DENOISE run the general prologue (true division: the same bits);
+    //   everything else goes through the one-element-per-lane kernel.
+    constexpr bool COMBO_BUILT = !XE || FORM == DPM_FORM_TWO || FORM == DPM_FORM_SS3T;
+    constexpr bool SPEC_BUILT = FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3;
+    if (!vec || !COMBO_BUILT) {
       int64_t blocks = (b->n + 255) / 256;
       const int64_t cap = (int64_t)n_cu * 16;
       if (blocks > cap) blocks = cap;
-      launch(stage_kernel_scalar<TS, TE, FORM, GUIDE, XE>, dim3((unsigned)blocks), dim3(256), 0, stream, x, xe, e0, e1, g,
-             h1, h2, xo, mo, b->n, p, ext);
-    } else if (use_ext) {
-      // (tiles per iteration, nt mask) of the inputs-from-HBM table below; x_out stays cacheable (it is the next
-      // network input), so bit 1 is never set
-      constexpr int EU = (sizeof(TS) == 4 && sizeof(TE) == 2) ? 2 : 1;
-      constexpr int ENT = sizeof(TS) == 2 ? 1 : (sizeof(TE) == 4 ? 5 : 1);
-      const bool noise = st->model_type == DPM_MODEL_NOISE && (!(st->flags & DPM_F_TO_X0) || div_invariant_ok(st->alpha_e));
-      const int64_t ntiles = ((b->n / EPT) + 255) / 256;
-      const bool two = EU == 2 && ntiles >= 4 * (int64_t)n_cu;  // two tiles per iteration only when there is work for it
-      int64_t blocks = two ? (ntiles + 1) / 2 : ntiles;
-      const int64_t cap = (int64_t)n_cu * g_tuning.blocks_per_cu;
-      if (blocks > cap) blocks = cap;
-      const dim3 grid((unsigned)(blocks < 1 ? 1 : blocks));
-#define DPM_LAUNCH_EXT(SPEC_)                                                                                           \
-  do {                                                                                                                  \
-    if (two)                                                                                                            \
-      launch(stage_kernel<TS, TE, FORM, GUIDE, XE, SPEC_, EU, ENT, true>, grid, dim3(256), 0, stream, x, xe, e0, e1, g, h1, \
-             h2, xo, mo, b->n, p, ext);                                                                                 \
-    else                                                                                                                \
-      launch(stage_kernel<TS, TE, FORM, GUIDE, XE, SPEC_, 1, ENT, true>, grid, dim3(256), 0, stream, x, xe, e0, e1, g, h1,  \
-             h2, xo, mo, b->n, p, ext);                                                                                 \
-  } while (0)
-      if (!noise)
-        DPM_LAUNCH_EXT(SPEC_GENERIC);
-      else if (st->flags & DPM_F_TO_X0)
-        DPM_LAUNCH_EXT(SPEC_NOISE_X0);
-      else
-        DPM_LAUNCH_EXT(SPEC_NOISE_EPS);
-#undef DPM_LAUNCH_EXT
-    } else {
-      // specialise the prologue when the stage allows it (noise-prediction network: the common case)
-      const bool noise = st->model_type == DPM_MODEL_NOISE && (!(st->flags & DPM_F_TO_X0) || div_invariant_ok(st->alpha_e));
+      launch(stage_kernel_scalar<TS, TE>, dim3((unsigned)blocks), dim3(256), 0, stream, x, xe ? xe : x, e0, e1, g, h1, h2, xo,
+             mo, b->n, p, ext);
+    } else if constexpr (COMBO_BUILT) {
+      const bool noise = SPEC_BUILT && st->model_type == DPM_MODEL_NOISE &&
+                         (!(st->flags & DPM_F_TO_X0) || div_invariant_ok(st->alpha_e));
       const int spec = !noise ? SPEC_GENERIC : ((st->flags & DPM_F_TO_X0) ? SPEC_NOISE_X0 : SPEC_NOISE_EPS);
       const int64_t ntiles = ((b->n / EPT) + 255) / 256;
       const Tuning tn = g_tuning;
+      const bool big = ntiles >= 4 * (int64_t)n_cu;  // two tiles per iteration only when there is work for it
       auto grid_for = [&](int u) {
         int64_t blocks = (ntiles + u - 1) / u;
         const int64_t cap = (int64_t)n_cu * tn.blocks_per_cu;
         if (blocks > cap) blocks = cap;
         return dim3((unsigned)(blocks < 1 ? 1 : blocks));
       };
-#define DPM_LAUNCH(SPEC_, U_, NT_)                                                                                  \
-  launch(stage_kernel<TS, TE, FORM, GUIDE, XE, SPEC_, U_, NT_, false>, grid_for(U_), dim3(256), 0, stream, x, xe, e0, e1, \
+#define DPM_LAUNCH(SPEC_, U_, NT_, EXT_)                                                                             \
+  launch(stage_kernel<TS, TE, FORM, GUIDE, XE, SPEC_, U_, NT_, EXT_>, grid_for(U_), dim3(256), 0, stream, x, xe, e0, e1, \
          g, h1, h2, xo, mo, b->n, p, ext)
-      if (spec == SPEC_GENERIC) {
-        DPM_LAUNCH(SPEC_GENERIC, 1, DefNT<TS>::value);
-      } else if (spec == SPEC_NOISE_EPS) {
-        DPM_LAUNCH(SPEC_NOISE_EPS, DEF_U, DefNT<TS>::value);
-      } else if (HotCombo<FORM, GUIDE, XE>::value) {
-        // tuning variants exist only for the north-star kernels (2M / 1st-order update, no guidance)
-        // (tiles per iteration, nt mask) by situation and dtypes, from profiles/r01_tuning_v3.txt:
-        //   inputs cache-resident: default policy; 4-byte states with two tiles per iteration
-        //   inputs from HBM:       2-byte state (1, nt loads); fp32 + fp32 (1, nt loads + nt m store);
-        //                          fp32 state + 2-byte network output (2, nt loads)  [SD under autocast: 12.3 vs 14.0 us]
-        const bool resident = b->inputs_resident != 0 || tn.assume_resident != 0;
-        const bool big = ntiles >= 4 * (int64_t)n_cu;  // two tiles per iteration only when there is work for it
-        const int key = (tn.unroll > 0 && tn.nontemporal >= 0) ? tn.unroll * 8 + (tn.nontemporal & 7)
-                        : resident                              ? (big ? 16 : 8) + 0
-                        : sizeof(TS) == 2                       ? 8 + 1
-                        : sizeof(TE) == 4                       ? (big ? 16 : 8) + 5
-                                                                : (big ? 16 : 8) + 1;
-        switch (key) {
-          case 8 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 1, 0); break;
-          case 8 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 1, 1); break;
-          case 8 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 1, 5); break;
-          case 8 + 6: DPM_LAUNCH(SPEC_NOISE_X0, 1, 6); break;
-          case 8 + 7: DPM_LAUNCH(SPEC_NOISE_X0, 1, 7); break;
-          case 16 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 2, 0); break;
-          case 16 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 2, 1); break;
-          case 16 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 2, 5); break;
-          case 16 + 6: DPM_LAUNCH(SPEC_NOISE_X0, 2, 6); break;
-          case 16 + 7: DPM_LAUNCH(SPEC_NOISE_X0, 2, 7); break;
-          default: DPM_LAUNCH(SPEC_NOISE_X0, DEF_U, DefNT<TS>::value); break;
+      if (use_ext) {
+        // (tiles per iteration, nt mask) of the inputs-from-HBM table below; x_out stays cacheable (it is the next
+        // network input), so bit 1 is never set
+        constexpr int EU = (sizeof(TS) == 4 && sizeof(TE) == 2) ? 2 : 1;
+        constexpr int ENT = sizeof(TS) == 2 ? 1 : (sizeof(TE) == 4 ? 5 : 1);
+        const bool two = EU == 2 && big && SPEC_BUILT;
+        if (spec == SPEC_GENERIC) {
+          DPM_LAUNCH(SPEC_GENERIC, 1, ENT, true);
+        } else if constexpr (SPEC_BUILT) {
+          if (spec == SPEC_NOISE_X0) {
+            if (two) DPM_LAUNCH(SPEC_NOISE_X0, EU, ENT, true); else DPM_LAUNCH(SPEC_NOISE_X0, 1, ENT, true);
+          } else {
+            if (two) DPM_LAUNCH(SPEC_NOISE_EPS, EU, ENT, true); else DPM_LAUNCH(SPEC_NOISE_EPS, 1, ENT, true);
+          }
         }
-      } else {
-        DPM_LAUNCH(SPEC_NOISE_X0, DEF_U, DefNT<TS>::value);
+      } else if (spec == SPEC_GENERIC) {
+        DPM_LAUNCH(SPEC_GENERIC, 1, DefNT<TS>::value, false);
+      } else if constexpr (SPEC_BUILT) {
+        if (spec == SPEC_NOISE_EPS) {
+          DPM_LAUNCH(SPEC_NOISE_EPS, DEF_U, DefNT<TS>::value, false);
+        } else if constexpr (HotCombo<FORM, GUIDE, XE>::value) {
+          // the north-star kernels (2M / 1st-order update, no guidance): (tiles per iteration, nt mask) by situation and
+          // dtypes, from profiles/r01_tuning_v3.txt / r01_tuning_v4.txt:
+          //   inputs cache-resident: default policy, two tiles per iteration when there is work for it
+          //   inputs from HBM:       2-byte state (1, nt loads); fp32 + fp32 (1 | 2, nt loads + nt m store);
+          //                          fp32 state + 2-byte network output (1 | 2, nt loads)  [SD under autocast]
+          const bool resident = b->inputs_resident != 0 || tn.assume_resident != 0;
+          constexpr int CNT = sizeof(TS) == 2 ? 1 : (sizeof(TE) == 4 ? 5 : 1);  // nt mask of the HBM situation
+#ifdef DPM_TUNING_VARIANTS  // tools/tune.py: every (tiles per iteration, nt mask)
+          if (tn.unroll > 0 && tn.nontemporal >= 0) {
+            switch (tn.unroll * 8 + (tn.nontemporal & 7)) {
+              case 8 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 1, 0, false); break;
+              case 8 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 1, 1, false); break;
+              case 8 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 1, 5, false); break;
+              case 16 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 2, 0, false); break;
+              case 16 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 2, 1, false); break;
+              case 16 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 2, 5, false); break;
+              default: DPM_LAUNCH(SPEC_NOISE_X0, DEF_U, DefNT<TS>::value, false); break;
+            }
+          } else
+#endif
+          if (resident) {
+            if (big) DPM_LAUNCH(SPEC_NOISE_X0, 2, 0, false); else DPM_LAUNCH(SPEC_NOISE_X0, 1, 0, false);
+          } else if (sizeof(TS) == 2 || !big) {
+            DPM_LAUNCH(SPEC_NOISE_X0, 1, CNT, false);
+          } else {
+            DPM_LAUNCH(SPEC_NOISE_X0, 2, CNT, false);
+          }
+        } else {
+          DPM_LAUNCH(SPEC_NOISE_X0, DEF_U, DefNT<TS>::value, false);
+        }
       }
 #undef DPM_LAUNCH
     }
@@ -2255,7 +2305,7 @@ int launch_multi_spec(const dpm_stage* st, const dpm_buffers* bs, int n_req, con
     launch(kern, dim3((unsigned)blocks), dim3(256), 0, c, tab, n, (uint32_t)n_req, (uint32_t)spr, p);
   };
   constexpr int DU = MultiShape<TS, TE>::U, DN = MultiShape<TS, TE>::NT;
-#ifdef DPM_MULTI_TUNING_VARIANTS  // tools/tune_multi.py: every (tiles per iteration, nt mask) of the 2M kernel
+#ifdef DPM_TUNING_VARIANTS  // tools/tune_multi.py: every (tiles per iteration, nt mask) of the 2M kernel
   if constexpr (FORM == DPM_FORM_TWO && GUIDE == DPM_GUIDE_NONE && SPEC == SPEC_NOISE_X0) {
     if (tn.unroll > 0 && tn.nontemporal >= 0) {
       switch (tn.unroll * 8 + (tn.nontemporal & 7)) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Launch-shape sweep of the fused multi-request 2M stage (stage_kernel_multi) on HBM-cold inputs.
 
-    DPM_EXTRA_HIPCC_FLAGS=-DDPM_MULTI_TUNING_VARIANTS python __graft_entry__.py --force   # build with all variants
+    DPM_EXTRA_HIPCC_FLAGS=-DDPM_TUNING_VARIANTS python __graft_entry__.py --force   # build with all variants
     python tools/tune_multi.py [--requests 32] > profiles/r02_tune_multi.txt
 
 For every (state dtype, eps dtype) x (tiles per iteration, nt mask) x grid cap it runs 20-stage trajectories of R
