@@ -283,6 +283,8 @@ struct KParams {
   int32_t model_type;
   float inv_alpha;  // RN(1 / alpha_e), used by the specialised prologue (see div_by_alpha)
   int32_t form, guidance;  // DPM_FORM_* / DPM_GUIDE_*: read by the run-time dispatched kernels (FORM_RT / GUIDE_RT)
+  float inv_sigma;         // RN(1 / sigma_e)
+  uint32_t fastdiv;        // bit 0 / 1: alpha_e / sigma_e pass div_invariant_ok (general prologue)
 };
 
 // x / alpha_e for a wave-uniform divisor whose correctly rounded reciprocal r = RN(1/alpha) is known: q = RN(x*r),
@@ -301,6 +303,17 @@ __device__ __forceinline__ V div_by_alpha(V x, const KParams& p) {
   const V q = x * p.inv_alpha;
   const V e = vfma(-q, (V)(p.alpha_e), x);
   return vfma(e, (V)(p.inv_alpha), q);
+}
+// the same for the general prologue: divisor d with reciprocal r when the host-side guard passed (`fast`, wave-uniform),
+// a true division otherwise -- identical bits either way
+template <typename V>
+__device__ __forceinline__ V div_uniform(V x, float d, float r, bool fast) {
+  if (fast) {
+    const V q = x * r;
+    const V e = vfma(-q, (V)(d), x);
+    return vfma(e, (V)(r), q);
+  }
+  return x / d;
 }
 
 // Compile-time knowledge about the prologue.  SPEC_GENERIC reads model_type / TO_X0 from the stage record at
@@ -324,7 +337,7 @@ template <int SPEC, typename V>
 __device__ __forceinline__ V to_noise(V o, V xe, const KParams& p) {
   if (SPEC != SPEC_GENERIC) return o;
   switch (p.model_type) {
-    case DPM_MODEL_X_START: return (xe - p.alpha_e * o) / p.sigma_e;
+    case DPM_MODEL_X_START: return div_uniform(xe - p.alpha_e * o, p.sigma_e, p.inv_sigma, (p.fastdiv & 2u) != 0u);
     case DPM_MODEL_V: return p.alpha_e * o + p.sigma_e * xe;
     case DPM_MODEL_SCORE: return (-p.sigma_e) * o;
     default: return o;
@@ -353,7 +366,7 @@ __device__ __forceinline__ V prologue(V xe, V o0, V o1, V gg, const KParams& p) 
     eps = to_noise<SPEC>(o0, xe, p);
   }
   if (SPEC == SPEC_NOISE_X0) return div_by_alpha(xe - p.sigma_e * eps, p);  // ref :439, division by invariant
-  if (spec_to_x0<SPEC>(p)) return (xe - p.sigma_e * eps) / p.alpha_e;         // ref :439
+  if (spec_to_x0<SPEC>(p)) return div_uniform(xe - p.sigma_e * eps, p.alpha_e, p.inv_alpha, (p.fastdiv & 1u) != 0u);  // ref :439
   return eps;
 }
 
@@ -1907,6 +1920,8 @@ inline KParams make_params(const dpm_stage* st) {
   p.model_type = st->model_type;
   p.form = st->form;
   p.guidance = st->guidance;
+  p.inv_sigma = 1.0f / st->sigma_e;
+  p.fastdiv = (div_invariant_ok(st->alpha_e) ? 1u : 0u) | (div_invariant_ok(st->sigma_e) ? 2u : 0u);
   return p;
 }
 
@@ -2335,8 +2350,6 @@ template <typename TS, typename TE>
 int launch_multi_typed(const dpm_stage* st, const dpm_buffers* bs, int n_req, const LaunchCtx& c) {
   if (st->flags & (DPM_F_THRESH | DPM_F_BLEND)) return MULTI_NOT_BUILT;
   if (st->guidance == DPM_GUIDE_CLASSIFIER) return MULTI_NOT_BUILT;
-  if (st->model_type != DPM_MODEL_NOISE) return MULTI_NOT_BUILT;
-  if ((st->flags & DPM_F_TO_X0) && !div_invariant_ok(st->alpha_e)) return MULTI_NOT_BUILT;
   if (st->form != DPM_FORM_LIN1 && st->form != DPM_FORM_TWO && st->form != DPM_FORM_MS3) return MULTI_NOT_BUILT;
   const size_t as = sizeof(TS) * EPT, ae = sizeof(TE) * EPT;
   if (bs[0].n % EPT != 0) return MULTI_NOT_BUILT;
@@ -2350,11 +2363,15 @@ int launch_multi_typed(const dpm_stage* st, const dpm_buffers* bs, int n_req, co
   }
   const bool x0 = (st->flags & DPM_F_TO_X0) != 0;
   const bool cfg = st->guidance == DPM_GUIDE_CFG;
+  // x_start / v / score networks (and an alpha the division-by-invariant guard rejects) take the general prologue
+  const bool generic = st->model_type != DPM_MODEL_NOISE || (x0 && !div_invariant_ok(st->alpha_e));
 #define DPM_MULTI(FORM_)                                                                                        \
-  (cfg ? (x0 ? launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_CFG, SPEC_NOISE_X0>(st, bs, n_req, c)                 \
-             : launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_CFG, SPEC_NOISE_EPS>(st, bs, n_req, c))               \
-       : (x0 ? launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_NONE, SPEC_NOISE_X0>(st, bs, n_req, c)                \
-             : launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_NONE, SPEC_NOISE_EPS>(st, bs, n_req, c)))
+  (generic ? (cfg ? launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_CFG, SPEC_GENERIC>(st, bs, n_req, c)             \
+                  : launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_NONE, SPEC_GENERIC>(st, bs, n_req, c))           \
+   : cfg   ? (x0 ? launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_CFG, SPEC_NOISE_X0>(st, bs, n_req, c)             \
+                 : launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_CFG, SPEC_NOISE_EPS>(st, bs, n_req, c))           \
+           : (x0 ? launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_NONE, SPEC_NOISE_X0>(st, bs, n_req, c)            \
+                 : launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_NONE, SPEC_NOISE_EPS>(st, bs, n_req, c)))
   switch (st->form) {
     case DPM_FORM_LIN1: return DPM_MULTI(DPM_FORM_LIN1);
     case DPM_FORM_TWO: return DPM_MULTI(DPM_FORM_TWO);

@@ -184,6 +184,8 @@ def _adaptive_error(x_lower, x_higher, x_prev, atol, rtol):
     """max over the batch of the adaptive solver's per-sample error norm (ref :999-1001) as a 0-dim device tensor:
     one kernel (per-sample RMS + atomic max), no host synchronisation here."""
     B = x_lower.shape[0]
+    if B == 0:          # an empty shard of a batch-sharded run: contributes nothing to the batch maximum
+        return torch.zeros((), dtype=torch.float32, device=x_lower.device)
     per_sample = x_lower.numel() // max(B, 1)
     e_dev = torch.empty((B + 1,), dtype=torch.float32, device=x_lower.device)
     xp = x_prev if x_prev.dtype == x_lower.dtype else x_prev.to(x_lower.dtype)

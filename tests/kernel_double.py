@@ -112,6 +112,8 @@ def maskblend_apply_double(self, x, t_host, step):
 def adaptive_error_double(x_lower, x_higher, x_prev, atol, rtol):
     """numpy double of dpm_adaptive_error_launch: per-sample RMS of (xh - xl)/delta (fp32 terms, double accumulation),
     then the batch maximum, returned as a 0-dim tensor"""
+    if x_lower.shape[0] == 0:
+        return torch.tensor(0.0, dtype=torch.float32)
     l, h, p = _np(x_lower), _np(x_higher), _np(x_prev)
     delta = np.maximum(F32(atol), F32(rtol) * np.maximum(np.abs(l), np.abs(p))).astype(F32)
     v = ((h - l) / delta).astype(F32)

@@ -52,6 +52,21 @@ def _worker(rank, world, port, batch, q):
         fa = mk().sample(xa, method="adaptive", order=2, t_end=1e-3)
         ok = ok and bool(torch.equal(oa, fa))
         assert DD.rank_seed(7) == 7 + rank
+        # gather_samples on its own: ragged shards take the padding path, an EMPTY shard (batch < world) included
+        for nb in (1, 3):
+            lo2, hi2 = DD.shard_bounds(nb, rank, world)
+            loc = torch.arange(nb * 6, dtype=torch.float32).reshape(nb, 2, 3)[lo2:hi2]
+            got = DD.gather_samples(loc, batch=nb)
+            ok = ok and bool(torch.equal(got, torch.arange(nb * 6, dtype=torch.float32).reshape(nb, 2, 3)))
+        # a batch smaller than the world: the rank with the empty shard still joins every collective (adaptive: the
+        # MAX all-reduce of every iteration; then the gather)
+        x1 = xa[:1]
+        o1 = DD.sample_sharded(mk(), x1, method="adaptive", order=2, t_end=1e-3)
+        f1 = mk().sample(x1, method="adaptive", order=2, t_end=1e-3)
+        ok = ok and bool(torch.equal(o1, f1)) and o1.shape[0] == 1
+        o2 = DD.sample_sharded(build_solver(dict(case, shape=(hi - lo if False else (1 if rank == 0 else 0), 4, 8, 8)), "cpu"),
+                               x[:1], **kw)
+        ok = ok and bool(torch.equal(o2, full[:1]))
         q.put((rank, ok, tuple(out.shape)))
     finally:
         dist.destroy_process_group()

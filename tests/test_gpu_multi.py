@@ -59,8 +59,10 @@ def make_requests(n_req, shape, sd, ed, seed, cfg=False, offset=0):
 
 
 def plan_for(ns, sd, **kw):
-    model = D.model_wrapper(lambda x, t: x, ns) if not kw.pop("cfg", False) else D.model_wrapper(
-        lambda x, t, c: x, ns, guidance_type="classifier-free", condition=torch.zeros(1), unconditional_condition=torch.zeros(1),
+    mt = kw.pop("model_type", "noise")
+    model = D.model_wrapper(lambda x, t: x, ns, model_type=mt) if not kw.pop("cfg", False) else D.model_wrapper(
+        lambda x, t, c: x, ns, model_type=mt, guidance_type="classifier-free", condition=torch.zeros(1),
+        unconditional_condition=torch.zeros(1),
         guidance_scale=kw.pop("scale", 3.0))
     dpm = D.DPM_Solver(model, ns, algorithm_type=kw.pop("algorithm_type", "dpmsolver++"), state_dtype=sd,
                        correcting_x0_fn=kw.pop("correcting_x0_fn", None))
@@ -117,6 +119,19 @@ def test_fused_equals_single_cfg(algo):
     reqs = make_requests(4, (3, 4, 32, 32), torch.float32, torch.float16, seed=3, cfg=True)
     fused, single = run_both(plan, reqs)
     for a, b in zip(fused, single):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("mt", ["v", "x_start", "score"])
+@pytest.mark.parametrize("cfg", [False, True])
+def test_fused_equals_single_other_parameterisations(mt, cfg):
+    """x_start / v / score networks run the fused launch with the general prologue"""
+    ns = sd_schedule()
+    _, plan = plan_for(ns, torch.float16, cfg=cfg, model_type=mt, order=2, steps=6)
+    reqs = make_requests(3, (4, 4, 32, 32), torch.float16, torch.float16, seed=8, cfg=cfg)
+    fused, single = run_both(plan, reqs)
+    for a, b in zip(fused, single):
+        assert torch.isfinite(a.float()).all()
         assert torch.equal(a, b)
 
 
