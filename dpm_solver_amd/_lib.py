@@ -86,6 +86,15 @@ class RunBuffers(C.Structure):
     ]
 
 
+class AdaptiveDesc(C.Structure):
+    _fields_ = [
+        ("algorithm_type", C.c_int32), ("solver_type", C.c_int32), ("order", C.c_int32), ("model_type", C.c_int32),
+        ("guidance", C.c_int32), ("reserved", C.c_int32),
+        ("guidance_scale", C.c_double), ("t_start", C.c_double), ("t_end", C.c_double), ("h_init", C.c_double),
+        ("atol", C.c_double), ("rtol", C.c_double), ("theta", C.c_double), ("t_err", C.c_double),
+    ]
+
+
 MODEL_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Stage), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 
 # every symbol include/dpm_hip.h declares: (name, restype, argtypes)
@@ -127,6 +136,17 @@ _SIGNATURES = [
                                    C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     ("dpm_adaptive_error_launch", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p,
                                             C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
+    ("dpm_adaptive_create", C.c_int, [C.c_void_p, _P(AdaptiveDesc), _P(C.c_void_p)]),
+    ("dpm_adaptive_destroy", None, [C.c_void_p]),
+    ("dpm_adaptive_stage_template", C.c_int, [C.c_void_p, C.c_int, _P(Stage)]),
+    ("dpm_adaptive_reset", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("dpm_adaptive_begin", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    ("dpm_adaptive_stage_launch", C.c_int, [C.c_void_p, C.c_int, _P(Stage), _P(Buffers), C.c_void_p]),
+    ("dpm_adaptive_error", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
+                                     C.c_void_p, C.c_void_p]),
+    ("dpm_adaptive_done_at", C.c_int, [C.c_void_p, C.c_int]),
+    ("dpm_adaptive_poll", C.c_int, [C.c_void_p, _P(C.c_int), _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
     ("dpm_plan_run", C.c_int, [C.c_void_p, _P(RunBuffers), C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int)]),
     ("dpm_stage_launch_timed", C.c_int, [_P(Stage), _P(Buffers), C.c_void_p, _P(C.c_float)]),
     ("dpm_plan_run_timed", C.c_int, [C.c_void_p, _P(RunBuffers), C.c_void_p, _P(C.c_float), _P(C.c_int)]),
@@ -162,7 +182,7 @@ def _load():
 
 
 lib = _load()
-for _i, _t in enumerate((Stage, Buffers, PlanDesc, RunBuffers)):  # the ctypes mirrors must match the compiled structs
+for _i, _t in enumerate((Stage, Buffers, PlanDesc, RunBuffers, AdaptiveDesc)):  # the ctypes mirrors must match the compiled structs
     if lib.dpm_sizeof(_i) != C.sizeof(_t):
         raise ImportError("dpm_solver_amd: %s is %d bytes in _lib.py but %d in libdpm_hip.so -- stale library, rebuild"
                           % (_t.__name__, C.sizeof(_t), lib.dpm_sizeof(_i)))

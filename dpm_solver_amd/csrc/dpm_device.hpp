@@ -316,6 +316,31 @@ __device__ __forceinline__ V div_uniform(V x, float d, float r, bool fast) {
   return x / d;
 }
 
+// the guard of div_by_alpha / div_uniform on the device (the host's twin is div_invariant_ok below)
+__device__ __forceinline__ bool div_invariant_ok_dev(float d) {
+  const uint32_t u = __float_as_uint(d), ex = (u >> 23) & 0xffu;
+  return ex > 32u && ex < 222u && (u & 0x7fffffu) != 0x7fffffu;
+}
+// coefficients computed on the device (LaunchCtx::dyn): every float of the stage record replaces the launch argument;
+// flags, form, model type and guidance kind stay the host's
+__device__ __forceinline__ void apply_dyn(KParams& p, const dpm_stage* d) {
+  p.alpha_e = d->alpha_e;
+  p.sigma_e = d->sigma_e;
+  p.cg_scale = d->cg_scale;
+  p.cx = d->cx;
+  p.c0 = d->c0;
+  p.c1 = d->c1;
+  p.c2 = d->c2;
+  p.k0 = d->k[0];
+  p.k1 = d->k[1];
+  p.k2 = d->k[2];
+  p.k3 = d->k[3];
+  p.k4 = d->k[4];
+  p.inv_alpha = 1.0f / p.alpha_e;
+  p.inv_sigma = 1.0f / p.sigma_e;
+  p.fastdiv = (div_invariant_ok_dev(p.alpha_e) ? 1u : 0u) | (div_invariant_ok_dev(p.sigma_e) ? 2u : 0u);
+}
+
 // Compile-time knowledge about the prologue.  SPEC_GENERIC reads model_type / TO_X0 from the stage record at
 // run time (wave-uniform scalar branches); the two hot specialisations fix them so the inner loop is
 // branch-free: SPEC_NOISE_X0 = noise-prediction network + eps -> x0 (dpmsolver++), SPEC_NOISE_EPS = noise
@@ -558,8 +583,13 @@ __global__ __launch_bounds__(256) void stage_kernel(const TS* __restrict__ x, co
                                                     const TE* __restrict__ e0, const TE* __restrict__ e1,
                                                     const TE* __restrict__ g, const TS* __restrict__ h1,
                                                     const TS* __restrict__ h2, TS* __restrict__ xo,
-                                                    TS* __restrict__ mo, int64_t n, KParams p, KExt ext) {
+                                                    TS* __restrict__ mo, int64_t n, KParams p, KExt ext,
+                                                    const dpm_stage* dyn, const int32_t* skip) {
   using FT = FormTraits<FORM>;
+  if constexpr (SPEC == SPEC_GENERIC) {  // device-resident coefficients: see LaunchCtx
+    if (skip && *skip) return;
+    if (dyn) apply_dyn(p, dyn);
+  }
   const int64_t ngroups = n / EPT;
   // a tile = 256 consecutive groups (one per lane of the workgroup); a workgroup iteration covers U tiles and
   // issues the loads of all of them before the first use
@@ -627,7 +657,10 @@ __global__ __launch_bounds__(256) void stage_kernel_scalar(const TS* __restrict_
                                                            const TE* __restrict__ e0, const TE* __restrict__ e1,
                                                            const TE* __restrict__ g, const TS* __restrict__ h1,
                                                            const TS* __restrict__ h2, TS* __restrict__ xo,
-                                                           TS* __restrict__ mo, int64_t n, KParams p, KExt ext) {
+                                                           TS* __restrict__ mo, int64_t n, KParams p, KExt ext,
+                                                           const dpm_stage* dyn, const int32_t* skip) {
+  if (skip && *skip) return;
+  if (dyn) apply_dyn(p, dyn);
   const bool need_xe = (p.flags & DPM_F_TO_X0) || p.model_type == DPM_MODEL_X_START || p.model_type == DPM_MODEL_V;
   const bool store_m = p.flags & DPM_F_STORE_M;
   const bool nx = form_needs_x<FORM_RT>(p), nh1 = form_needs_h1<FORM_RT>(p), nh2 = form_needs_h2<FORM_RT>(p);
@@ -1971,6 +2004,11 @@ struct HotCombo {
 struct LaunchCtx {
   hipStream_t stream;
   hipEvent_t start, stop;  // both null: plain launch; else hipExtLaunchKernelGGL brackets the kernel itself
+  // device-resident coefficients (the adaptive solver's on-device controller, dpm_kernels.hip): the float fields of
+  // the stage record are read from `dyn` (device memory) by the kernel instead of from its arguments, and the launch
+  // is a no-op when *skip != 0.  Honoured by the general-prologue kernels only.
+  const dpm_stage* dyn = nullptr;
+  const int32_t* skip = nullptr;
 };
 
 template <typename K, typename... Args>
@@ -2010,6 +2048,7 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
   const bool use_ext = ext.xo2 || ext.mask || ext.eps_stride;
 
   if (st->flags & DPM_F_THRESH) {
+    if (stream.dyn) return dpm_set_error(DPM_ERR_UNSUPPORTED, "dynamic thresholding with device-resident coefficients");
     const int64_t per_sample = b->n / b->batch;
     if (b->batch > 0x7fffffff || per_sample > ((int64_t)1 << 40))
       return dpm_set_error(DPM_ERR_UNSUPPORTED, "thresholding: batch / sample size out of range");
@@ -2200,9 +2239,9 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
       const int64_t cap = (int64_t)n_cu * 16;
       if (blocks > cap) blocks = cap;
       launch(stage_kernel_scalar<TS, TE>, dim3((unsigned)blocks), dim3(256), 0, stream, x, xe ? xe : x, e0, e1, g, h1, h2, xo,
-             mo, b->n, p, ext);
+             mo, b->n, p, ext, stream.dyn, stream.skip);
     } else if constexpr (COMBO_BUILT) {
-      const bool noise = SPEC_BUILT && st->model_type == DPM_MODEL_NOISE &&
+      const bool noise = SPEC_BUILT && !stream.dyn && st->model_type == DPM_MODEL_NOISE &&
                          (!(st->flags & DPM_F_TO_X0) || div_invariant_ok(st->alpha_e));
       const int spec = !noise ? SPEC_GENERIC : ((st->flags & DPM_F_TO_X0) ? SPEC_NOISE_X0 : SPEC_NOISE_EPS);
       const int64_t ntiles = ((b->n / EPT) + 255) / 256;
@@ -2216,7 +2255,7 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
       };
 #define DPM_LAUNCH(SPEC_, U_, NT_, EXT_)                                                                             \
   launch(stage_kernel<TS, TE, FORM, GUIDE, XE, SPEC_, U_, NT_, EXT_>, grid_for(U_), dim3(256), 0, stream, x, xe, e0, e1, \
-         g, h1, h2, xo, mo, b->n, p, ext)
+         g, h1, h2, xo, mo, b->n, p, ext, stream.dyn, stream.skip)
       if (use_ext) {
         // (tiles per iteration, nt mask) of the inputs-from-HBM table below; x_out stays cacheable (it is the next
         // network input), so bit 1 is never set

@@ -42,6 +42,7 @@ extern "C" size_t dpm_sizeof(int which) {
     case DPM_SIZEOF_BUFFERS: return sizeof(dpm_buffers);
     case DPM_SIZEOF_PLAN_DESC: return sizeof(dpm_plan_desc);
     case DPM_SIZEOF_RUN_BUFFERS: return sizeof(dpm_run_buffers);
+    case DPM_SIZEOF_ADAPTIVE_DESC: return sizeof(dpm_adaptive_desc);
   }
   return 0;
 }
@@ -200,6 +201,8 @@ extern "C" int dpm_schedule_create_cosine(dpm_schedule** out) {
 }
 
 extern "C" void dpm_schedule_destroy(dpm_schedule* s) { delete s; }
+// for dpm_kernels.hip (the device-side adaptive controller uploads the tables)
+dpmc::SchedView dpm_schedule_view(const dpm_schedule* s) { return s->view(); }
 extern "C" int dpm_schedule_is_discrete(const dpm_schedule* s) { return s && s->discrete; }
 extern "C" int dpm_schedule_total_N(const dpm_schedule* s) { return s ? s->total_N : 0; }
 

@@ -3,6 +3,7 @@
 // C ABI entry points of the device side; the stage kernels live in dpm_device.hpp and are instantiated per dtype
 // pair in dpm_stage_*.hip.
 #include "dpm_device.hpp"
+#include "dpm_coef.hpp"
 
 namespace dpmk {
 Tuning g_tuning;
@@ -26,11 +27,11 @@ uint32_t* cluster_fault_word(bool create) {
 }  // namespace dpmk
 
 // one translation unit per (state, eps) dtype pair
-int dpm_launch_f32_f32(const dpm_stage*, const dpm_buffers*, void*, void*, void*);
-int dpm_launch_f32_f16(const dpm_stage*, const dpm_buffers*, void*, void*, void*);
-int dpm_launch_f32_bf16(const dpm_stage*, const dpm_buffers*, void*, void*, void*);
-int dpm_launch_f16_f16(const dpm_stage*, const dpm_buffers*, void*, void*, void*);
-int dpm_launch_bf16_bf16(const dpm_stage*, const dpm_buffers*, void*, void*, void*);
+int dpm_launch_f32_f32(const dpm_stage*, const dpm_buffers*, void*, void*, void*, const dpm_stage*, const int32_t*);
+int dpm_launch_f32_f16(const dpm_stage*, const dpm_buffers*, void*, void*, void*, const dpm_stage*, const int32_t*);
+int dpm_launch_f32_bf16(const dpm_stage*, const dpm_buffers*, void*, void*, void*, const dpm_stage*, const int32_t*);
+int dpm_launch_f16_f16(const dpm_stage*, const dpm_buffers*, void*, void*, void*, const dpm_stage*, const int32_t*);
+int dpm_launch_bf16_bf16(const dpm_stage*, const dpm_buffers*, void*, void*, void*, const dpm_stage*, const int32_t*);
 int dpm_launch_multi_f32_f32(const dpm_stage*, const dpm_buffers*, int, void*, void*, void*);
 int dpm_launch_multi_f32_f16(const dpm_stage*, const dpm_buffers*, int, void*, void*, void*);
 int dpm_launch_multi_f32_bf16(const dpm_stage*, const dpm_buffers*, int, void*, void*, void*);
@@ -40,7 +41,8 @@ int dpm_launch_multi_bf16_bf16(const dpm_stage*, const dpm_buffers*, int, void*,
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
-int dpm_stage_launch_ev(const dpm_stage* st, const dpm_buffers* b, void* stream, void* ev_start, void* ev_stop) {
+int dpm_stage_launch_dyn(const dpm_stage* st, const dpm_buffers* b, void* stream, void* ev_start, void* ev_stop,
+                         const dpm_stage* dyn, const int32_t* skip) {
   if (!st || !b) return dpm_set_error(DPM_ERR_ARG, "stage_launch: null pointer");
   if (b->n < 0 || b->batch < 1 || (b->n % b->batch) != 0)
     return dpm_set_error(DPM_ERR_ARG, "stage_launch: n=%lld is not a multiple of batch=%lld", (long long)b->n, (long long)b->batch);
@@ -72,12 +74,16 @@ int dpm_stage_launch_ev(const dpm_stage* st, const dpm_buffers* b, void* stream,
   dpm_buffers bb = *b;
   if (!bb.x) bb.x = bb.xe;  // DENOISE form: only the evaluation state exists
   const int sd = bb.state_dtype, ed = bb.eps_dtype;
-  if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_F32) return dpm_launch_f32_f32(st, &bb, stream, ev_start, ev_stop);
-  if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_F16) return dpm_launch_f32_f16(st, &bb, stream, ev_start, ev_stop);
-  if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_BF16) return dpm_launch_f32_bf16(st, &bb, stream, ev_start, ev_stop);
-  if (sd == DPM_DTYPE_F16 && ed == DPM_DTYPE_F16) return dpm_launch_f16_f16(st, &bb, stream, ev_start, ev_stop);
-  if (sd == DPM_DTYPE_BF16 && ed == DPM_DTYPE_BF16) return dpm_launch_bf16_bf16(st, &bb, stream, ev_start, ev_stop);
+  if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_F32) return dpm_launch_f32_f32(st, &bb, stream, ev_start, ev_stop, dyn, skip);
+  if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_F16) return dpm_launch_f32_f16(st, &bb, stream, ev_start, ev_stop, dyn, skip);
+  if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_BF16) return dpm_launch_f32_bf16(st, &bb, stream, ev_start, ev_stop, dyn, skip);
+  if (sd == DPM_DTYPE_F16 && ed == DPM_DTYPE_F16) return dpm_launch_f16_f16(st, &bb, stream, ev_start, ev_stop, dyn, skip);
+  if (sd == DPM_DTYPE_BF16 && ed == DPM_DTYPE_BF16) return dpm_launch_bf16_bf16(st, &bb, stream, ev_start, ev_stop, dyn, skip);
   return dpm_set_error(DPM_ERR_UNSUPPORTED, "stage_launch: unsupported dtype pair state=%d eps=%d", sd, ed);
+}
+
+int dpm_stage_launch_ev(const dpm_stage* st, const dpm_buffers* b, void* stream, void* ev_start, void* ev_stop) {
+  return dpm_stage_launch_dyn(st, b, stream, ev_start, ev_stop, nullptr, nullptr);
 }
 
 extern "C" int dpm_stage_launch(const dpm_stage* st, const dpm_buffers* b, void* stream) {
@@ -282,10 +288,392 @@ extern "C" int dpm_adaptive_error_launch(const void* x_lower, const void* x_high
       hipLaunchKernelGGL(adaptive_error_kernel<__half>, dim3((unsigned)batch), dim3(1024), 0, st, (const __half*)x_lower,
                          (const __half*)x_higher, (const __half*)x_prev, atol, rtol, e_out, per_sample);
       break;
+    case DPM_DTYPE_BF16:
+      hipLaunchKernelGGL(adaptive_error_kernel<bf16_t>, dim3((unsigned)batch), dim3(1024), 0, st, (const bf16_t*)x_lower,
+                         (const bf16_t*)x_higher, (const bf16_t*)x_prev, atol, rtol, e_out, per_sample);
+      break;
     default: return dpm_set_error(DPM_ERR_UNSUPPORTED, "adaptive_error: unsupported dtype %d", dtype);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return dpm_set_error((int)e, "adaptive_error launch failed: %s", hipGetErrorString(e));
+  return DPM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// adaptive solver, controller on the device (include/dpm_hip.h: dpm_adaptive_*; ref :956-1010)
+// ------------------------------------------------------------------------------------------------
+dpmc::SchedView dpm_schedule_view(const dpm_schedule* s);  // dpm_host.cpp
+int dpm_stage_launch_dyn(const dpm_stage* st, const dpm_buffers* b, void* stream, void* ev_start, void* ev_stop,
+                         const dpm_stage* dyn, const int32_t* skip);
+
+namespace {
+struct AdaptiveDev {  // device-resident controller state
+  float s, lambda_s, lambda_0, h, t_0, t_err, theta, t;
+  int32_t order, nfe, done, iters, accept, accepted, pad0, pad1;
+  dpm_stage st[5];  // 0, 1: the lower-order update's stages; 2, 3, 4: the higher-order update's
+};
+struct AdaptiveStatic {
+  int32_t algo, solver, model_type, guidance;
+  double scale;
+};
+
+// fill the stage records of one iteration s -> t (order 2: DPM-Solver-12, order 3: DPM-Solver-23, ref :976-993)
+template <class S>
+DPM_HD void adaptive_plan(const S* sv, const AdaptiveStatic& c, int order, float s, float t, dpm_stage* st) {
+  if (order == 2) {
+    dpmc::singlestep_fill(sv, c.algo, c.solver, 1, s, t, 0., 0., 0, &st[0]);
+    st[1] = st[0];
+    dpmc::singlestep_fill(sv, c.algo, c.solver, 2, s, t, 0.5, 0., 0, &st[2]);
+    st[4] = st[3];
+  } else {
+    dpmc::singlestep_fill(sv, c.algo, c.solver, 2, s, t, 1. / 3., 0., 0, &st[0]);
+    dpmc::singlestep_fill(sv, c.algo, c.solver, 3, s, t, 1. / 3., 2. / 3., 0, &st[2]);
+  }
+  for (int i = 0; i < 5; ++i) dpmc::set_prologue(sv, st[i].t_eval, c.model_type, c.guidance, c.scale, &st[i]);
+}
+
+__global__ void adaptive_reset_kernel(AdaptiveDev* S, float s, float lambda_s, float lambda_0, float h, float t_0,
+                                      float t_err, float theta, int order, int32_t* status) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  S->s = s;
+  S->lambda_s = lambda_s;
+  S->lambda_0 = lambda_0;
+  S->h = h;
+  S->t_0 = t_0;
+  S->t_err = t_err;
+  S->theta = theta;
+  S->t = s;
+  S->order = order;
+  S->nfe = 0;
+  S->iters = 0;
+  S->accept = 0;
+  S->accepted = 0;
+  S->done = !(fabsf(s - t_0) > t_err);  // the loop condition of ref :995 before the first iteration
+  for (int i = 0; i < 4; ++i) __hip_atomic_store(&status[i], i == 0 ? S->done : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// decision on the previous iteration + plan of the next one (one thread), then the time vectors of the network calls
+__global__ __launch_bounds__(256) void adaptive_begin_kernel(AdaptiveDev* S, dpmc::SchedView sv, AdaptiveStatic c,
+                                                             float* e_dev, float* tvec, int64_t tv_len, int32_t* status) {
+  __shared__ float te[3], ti[3];
+  __shared__ int live;
+  if (threadIdx.x == 0) {
+    if (S->iters > 0 && !S->done) {
+      const float E = *e_dev;
+      const int acc = E <= 1.f;  // ref :1002
+      if (acc) {
+        S->s = S->t;
+        S->lambda_s = sv.lambda(S->s);
+      }
+      // ref :1007: h = min(theta * h * E^(-1/order), lambda_0 - lambda_s); the power in double like the reference's float()
+      const float pw = (float)pow((double)E, -1.0 / (double)S->order);
+      const float hn = (S->theta * S->h) * pw;
+      const float room = S->lambda_0 - S->lambda_s;
+      S->h = room < hn ? room : hn;
+      S->nfe += S->order;
+      S->accept = acc;
+      S->accepted += acc;
+      if (!(fabsf(S->s - S->t_0) > S->t_err)) S->done = 1;  // ref :995
+    } else {
+      S->accept = 0;
+    }
+    *e_dev = 0.f;
+    live = !S->done;
+    if (live) {
+      const float t = sv.inv_lambda(S->lambda_s + S->h);  // ref :996
+      S->t = t;
+      adaptive_plan(&sv, c, S->order, S->s, t, S->st);
+      for (int j = 0; j < 3; ++j) {
+        te[j] = S->st[2 + j].t_eval;
+        ti[j] = S->st[2 + j].t_input;
+      }
+    }
+    // the verdict as of THIS begin, by its index: a host that looks at begin #j (after waiting for it) reads the same
+    // value on every rank of a sharded run, however far its device has run ahead
+    __hip_atomic_store(&status[8 + (S->iters & 31)], S->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    S->iters += 1;
+    __hip_atomic_store(&status[1], S->nfe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&status[2], S->iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&status[3], S->accepted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&status[0], S->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();
+  if (!live) return;
+  for (int j = 0; j < 3; ++j)
+    for (int64_t i = threadIdx.x; i < tv_len; i += blockDim.x) {
+      tvec[(int64_t)(2 * j) * tv_len + i] = te[j];
+      tvec[(int64_t)(2 * j + 1) * tv_len + i] = ti[j];
+    }
+}
+
+// an accepted step becomes the state: x <- x_higher, x_prev <- x_lower (ref :1003-1005)
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void adaptive_commit_kernel(const AdaptiveDev* S, T* __restrict__ x, T* __restrict__ xp,
+                                                              const T* __restrict__ xl, const T* __restrict__ xh, int64_t n) {
+  if (!S->accept) return;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (VEC) {
+    const int64_t nv = n * (int64_t)sizeof(T) / 16;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+      reinterpret_cast<u32x4*>(x)[i] = ld16<true>(reinterpret_cast<const u32x4*>(xh) + i);
+      reinterpret_cast<u32x4*>(xp)[i] = ld16<true>(reinterpret_cast<const u32x4*>(xl) + i);
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+      x[i] = xh[i];
+      xp[i] = xl[i];
+    }
+  }
+}
+
+// error norm with G workgroups per sample: partial sums of squares in double, the last workgroup of a sample adds
+// them in a fixed order (deterministic), E_b = sqrt(mean) and the batch maximum by atomicMax on the bit pattern
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void adaptive_error_kernel2(const T* __restrict__ xl, const T* __restrict__ xh,
+                                                              const T* __restrict__ xp, float atol, float rtol,
+                                                              int64_t per_sample, int G, double* __restrict__ partial,
+                                                              uint32_t* __restrict__ counters, float* __restrict__ e_max,
+                                                              const int32_t* skip) {
+  if (skip && *skip) return;
+  __shared__ double part[4];
+  __shared__ int last;
+  const int b = blockIdx.x / G, g = blockIdx.x % G;
+  const int64_t chunk = ((per_sample + G - 1) / G + 7) / 8 * 8;
+  const int64_t lo = (int64_t)g * chunk, hi = lo + chunk < per_sample ? lo + chunk : per_sample;
+  const int64_t base = (int64_t)b * per_sample;
+  double acc = 0.;
+  auto term = [&](float l, float h, float pv) {
+    const float delta = fmaxf(atol, rtol * fmaxf(fabsf(l), fabsf(pv)));
+    const float v = (h - l) / delta;
+    acc += (double)(v * v);
+  };
+  if (VEC) {
+    for (int64_t i = lo + (int64_t)threadIdx.x * EPT; i < hi; i += (int64_t)blockDim.x * EPT) {
+      float l[EPT], h[EPT], pv[EPT];
+      load_pack<true>(xl, (base + i) / EPT, l);
+      load_pack<true>(xh, (base + i) / EPT, h);
+      load_pack<true>(xp, (base + i) / EPT, pv);
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) term(l[j], h[j], pv[j]);
+    }
+  } else {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
+      term(to_f32(xl[base + i]), to_f32(xh[base + i]), to_f32(xp[base + i]));
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+    __threadfence();
+    last = atomicAdd(&counters[b], 1u) == (uint32_t)(G - 1);
+    if (last) {
+      __threadfence();
+      double t = 0.;
+      for (int q = 0; q < G; ++q) t += __hip_atomic_load(&partial[(int64_t)b * G + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float e = sqrtf((float)(t / (double)per_sample));
+      atomicMax(reinterpret_cast<unsigned int*>(e_max), __float_as_uint(e));  // E >= 0: bit patterns order like values
+      counters[b] = 0u;  // ready for the next launch
+    }
+  }
+}
+}  // namespace
+
+struct dpm_adaptive {
+  dpm_adaptive_desc d;
+  AdaptiveStatic c;
+  dpmc::SchedView sv;        // table pointers into `tables` (device)
+  float* tables = nullptr;   // 4 x K floats
+  AdaptiveDev* dev = nullptr;
+  int32_t* status = nullptr; // host-mapped: done, nfe, iterations, accepted
+  double* partial = nullptr; // error norm scratch, grown on demand
+  uint32_t* counters = nullptr;
+  int64_t scratch_blocks = 0, scratch_batch = 0;
+  dpm_stage tmpl[5];
+  float s0, lambda_s0, lambda_0;
+};
+
+extern "C" void dpm_adaptive_destroy(dpm_adaptive* a) {
+  if (!a) return;
+  if (a->tables) (void)hipFree(a->tables);
+  if (a->dev) (void)hipFree(a->dev);
+  if (a->status) (void)hipHostFree(a->status);
+  if (a->partial) (void)hipFree(a->partial);
+  if (a->counters) (void)hipFree(a->counters);
+  delete a;
+}
+
+extern "C" int dpm_adaptive_create(const dpm_schedule* s, const dpm_adaptive_desc* d, dpm_adaptive** out) {
+  if (!s || !d || !out) return dpm_set_error(DPM_ERR_ARG, "adaptive_create: null pointer");
+  if (d->order != 2 && d->order != 3)
+    return dpm_set_error(DPM_ERR_ARG, "For adaptive step size solver, order must be 2 or 3, got %d", d->order);
+  if (d->algorithm_type < 0 || d->algorithm_type > 1 || d->solver_type < 0 || d->solver_type > 1 || d->model_type < 0 ||
+      d->model_type > 3 || d->guidance < 0 || d->guidance > 2)
+    return dpm_set_error(DPM_ERR_ARG, "adaptive_create: enumeration out of range");
+  dpm_adaptive* a = new (std::nothrow) dpm_adaptive;
+  if (!a) return dpm_set_error(DPM_ERR_NOMEM, "out of memory");
+  a->d = *d;
+  a->c = AdaptiveStatic{d->algorithm_type, d->solver_type, d->model_type, d->guidance, d->guidance_scale};
+  const dpmc::SchedView hv = dpm_schedule_view(s);
+  a->sv = hv;
+  hipError_t e = hipSuccess;
+  if (hv.discrete) {
+    const size_t K = (size_t)hv.total_N;
+    e = hipMalloc(&a->tables, 4 * K * sizeof(float));
+    const float* src[4] = {hv.la, hv.t, hv.la_rev, hv.t_rev};
+    for (int i = 0; i < 4 && e == hipSuccess; ++i)
+      e = hipMemcpy(a->tables + i * K, src[i], K * sizeof(float), hipMemcpyHostToDevice);
+    a->sv.la = a->tables;
+    a->sv.t = a->tables + K;
+    a->sv.la_rev = a->tables + 2 * K;
+    a->sv.t_rev = a->tables + 3 * K;
+  } else {
+    a->sv.la = a->sv.t = a->sv.la_rev = a->sv.t_rev = nullptr;
+  }
+  if (e == hipSuccess) e = hipMalloc(&a->dev, sizeof(AdaptiveDev));
+  if (e == hipSuccess) e = hipMemset(a->dev, 0, sizeof(AdaptiveDev));
+  void* st = nullptr;
+  if (e == hipSuccess) e = hipHostMalloc(&st, 256, hipHostMallocMapped);
+  if (e != hipSuccess) {
+    dpm_adaptive_destroy(a);
+    return dpm_set_error((int)e, "adaptive_create: %s", hipGetErrorString(e));
+  }
+  a->status = static_cast<int32_t*>(st);
+  std::memset(a->status, 0, 256);
+  // host copy of the plan for the static fields (form, flags, slots) and the initial scalars
+  a->s0 = (float)d->t_start;
+  a->lambda_s0 = hv.lambda(a->s0);
+  a->lambda_0 = hv.lambda((float)d->t_end);
+  const float t1 = hv.inv_lambda(a->lambda_s0 + (float)d->h_init);
+  adaptive_plan(&hv, a->c, d->order, a->s0, t1, a->tmpl);
+  *out = a;
+  return DPM_OK;
+}
+
+extern "C" int dpm_adaptive_stage_template(const dpm_adaptive* a, int which, dpm_stage* out) {
+  if (!a || !out || which < 0 || which > 4) return dpm_set_error(DPM_ERR_ARG, "adaptive_stage_template: bad arguments");
+  *out = a->tmpl[which];
+  return DPM_OK;
+}
+
+extern "C" int dpm_adaptive_reset(dpm_adaptive* a, void* stream) {
+  if (!a) return dpm_set_error(DPM_ERR_ARG, "adaptive_reset: null handle");
+  hipLaunchKernelGGL(adaptive_reset_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), a->dev, a->s0,
+                     a->lambda_s0, a->lambda_0, (float)a->d.h_init, (float)a->d.t_end, (float)a->d.t_err, (float)a->d.theta,
+                     a->d.order, a->status);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return dpm_set_error((int)e, "adaptive_reset: %s", hipGetErrorString(e));
+  return DPM_OK;
+}
+
+extern "C" int dpm_adaptive_begin(dpm_adaptive* a, void* x, void* x_prev, const void* x_lower, const void* x_higher, int64_t n,
+                                  int dtype, float* e_dev, float* t_vectors, int64_t tv_len, void* stream) {
+  if (!a || !x || !x_prev || !x_lower || !x_higher || !e_dev || !t_vectors || n < 0 || tv_len < 1)
+    return dpm_set_error(DPM_ERR_ARG, "adaptive_begin: bad arguments");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(adaptive_begin_kernel, dim3(1), dim3(256), 0, st, a->dev, a->sv, a->c, e_dev, t_vectors, tv_len, a->status);
+  if (n > 0) {
+    const DeviceInfo& di = device_info();
+    const int64_t cap = (int64_t)(di.n_cu > 0 ? di.n_cu : 256) * 8;
+#define DPM_COMMIT(T)                                                                                                     \
+  do {                                                                                                                    \
+    const bool v = (n * (int64_t)sizeof(T)) % 16 == 0 && aligned(x, 16) && aligned(x_prev, 16) && aligned(x_lower, 16) && \
+                   aligned(x_higher, 16);                                                                                 \
+    int64_t bl = ((v ? n * (int64_t)sizeof(T) / 16 : n) + 255) / 256;                                                     \
+    if (bl > cap) bl = cap;                                                                                               \
+    if (v)                                                                                                                \
+      hipLaunchKernelGGL((adaptive_commit_kernel<T, true>), dim3((unsigned)bl), dim3(256), 0, st, a->dev, (T*)x,          \
+                         (T*)x_prev, (const T*)x_lower, (const T*)x_higher, n);                                           \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((adaptive_commit_kernel<T, false>), dim3((unsigned)bl), dim3(256), 0, st, a->dev, (T*)x,         \
+                         (T*)x_prev, (const T*)x_lower, (const T*)x_higher, n);                                           \
+  } while (0)
+    switch (dtype) {
+      case DPM_DTYPE_F32: DPM_COMMIT(float); break;
+      case DPM_DTYPE_F16: DPM_COMMIT(__half); break;
+      case DPM_DTYPE_BF16: DPM_COMMIT(bf16_t); break;
+      default: return dpm_set_error(DPM_ERR_UNSUPPORTED, "adaptive_begin: unsupported dtype %d", dtype);
+    }
+#undef DPM_COMMIT
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return dpm_set_error((int)e, "adaptive_begin: %s", hipGetErrorString(e));
+  return DPM_OK;
+}
+
+extern "C" int dpm_adaptive_stage_launch(dpm_adaptive* a, int which, const dpm_stage* st, const dpm_buffers* b, void* stream) {
+  if (!a || !st || !b || which < 0 || which > 4) return dpm_set_error(DPM_ERR_ARG, "adaptive_stage_launch: bad arguments");
+  return dpm_stage_launch_dyn(st, b, stream, nullptr, nullptr, &a->dev->st[which], &a->dev->done);
+}
+
+extern "C" int dpm_adaptive_error(dpm_adaptive* a, const void* x_lower, const void* x_higher, const void* x_prev,
+                                  int64_t batch, int64_t per_sample, int dtype, float* e_dev, void* stream) {
+  if (!a || !x_lower || !x_higher || !x_prev || !e_dev || batch < 0 || per_sample < 1)
+    return dpm_set_error(DPM_ERR_ARG, "adaptive_error: bad arguments");
+  if (batch == 0) return DPM_OK;  // an empty shard contributes nothing to the maximum
+  const DeviceInfo& di = device_info();
+  const int n_cu = di.n_cu > 0 ? di.n_cu : 256;
+  // enough workgroups to fill the chip twice, at least 8192 elements each
+  int64_t G = std::max<int64_t>(1, std::min<int64_t>((2 * (int64_t)n_cu + batch - 1) / batch, per_sample / 8192));
+  if (G > 64) G = 64;
+  const int64_t blocks = batch * G;
+  if (blocks > a->scratch_blocks || batch > a->scratch_batch) {  // grow the scratch (outside any capture: create-time sizes)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(static_cast<hipStream_t>(stream), &cs);
+    if (cs != hipStreamCaptureStatusNone)
+      return dpm_set_error(DPM_ERR_UNSUPPORTED, "adaptive_error: run one iteration outside the capture first (scratch allocation)");
+    (void)hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    if (a->partial) (void)hipFree(a->partial);
+    if (a->counters) (void)hipFree(a->counters);
+    a->partial = nullptr;
+    a->counters = nullptr;
+    hipError_t e = hipMalloc(&a->partial, (size_t)blocks * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&a->counters, (size_t)batch * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(a->counters, 0, (size_t)batch * sizeof(uint32_t));
+    if (e != hipSuccess) return dpm_set_error((int)e, "adaptive_error: %s", hipGetErrorString(e));
+    a->scratch_blocks = blocks;
+    a->scratch_batch = batch;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define DPM_ERRK(T)                                                                                                     \
+  do {                                                                                                                  \
+    const size_t al = sizeof(T) * EPT;                                                                                  \
+    const bool v = per_sample % EPT == 0 && aligned(x_lower, al) && aligned(x_higher, al) && aligned(x_prev, al);       \
+    if (v)                                                                                                              \
+      hipLaunchKernelGGL((adaptive_error_kernel2<T, true>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x_lower, \
+                         (const T*)x_higher, (const T*)x_prev, (float)a->d.atol, (float)a->d.rtol, per_sample, (int)G,   \
+                         a->partial, a->counters, e_dev, &a->dev->done);                                                \
+    else                                                                                                                \
+      hipLaunchKernelGGL((adaptive_error_kernel2<T, false>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x_lower, \
+                         (const T*)x_higher, (const T*)x_prev, (float)a->d.atol, (float)a->d.rtol, per_sample, (int)G,   \
+                         a->partial, a->counters, e_dev, &a->dev->done);                                                \
+  } while (0)
+  switch (dtype) {
+    case DPM_DTYPE_F32: DPM_ERRK(float); break;
+    case DPM_DTYPE_F16: DPM_ERRK(__half); break;
+    case DPM_DTYPE_BF16: DPM_ERRK(bf16_t); break;
+    default: return dpm_set_error(DPM_ERR_UNSUPPORTED, "adaptive_error: unsupported dtype %d", dtype);
+  }
+#undef DPM_ERRK
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return dpm_set_error((int)e, "adaptive_error: %s", hipGetErrorString(e));
+  return DPM_OK;
+}
+
+extern "C" int dpm_adaptive_done_at(const dpm_adaptive* a, int begin_index) {
+  if (!a || begin_index < 0) return -1;
+  const volatile int32_t* s = a->status;
+  return s[8 + (begin_index & 31)];
+}
+
+extern "C" int dpm_adaptive_poll(const dpm_adaptive* a, int* done, int* nfe, int* iterations, int* accepted) {
+  if (!a) return dpm_set_error(DPM_ERR_ARG, "adaptive_poll: null handle");
+  const volatile int32_t* s = a->status;
+  if (done) *done = s[0];
+  if (nfe) *nfe = s[1];
+  if (iterations) *iterations = s[2];
+  if (accepted) *accepted = s[3];
   return DPM_OK;
 }
 

@@ -1,8 +1,9 @@
 // dpm_stage_f32_f32.hip -- stage kernels for state dtype float, network-output dtype float (see dpm_device.hpp)
 #include "dpm_device.hpp"
 
-int dpm_launch_f32_f32(const dpm_stage* st, const dpm_buffers* b, void* stream, void* ev_start, void* ev_stop) {
-  const LaunchCtx s{static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop)};
+int dpm_launch_f32_f32(const dpm_stage* st, const dpm_buffers* b, void* stream, void* ev_start, void* ev_stop, const dpm_stage* dyn,
+          const int32_t* skip) {
+  const LaunchCtx s{static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop), dyn, skip};
   return launch_form<float, float>(st, b, s);
 }
 

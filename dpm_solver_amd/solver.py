@@ -265,6 +265,112 @@ class _Plan:
             self.handle = None
 
 
+def _bind_outputs(b, e0, e1, g, sd, shape):
+    """Point a launch record at the fresh network outputs (e0 / e1 / g): choose the eps dtype the kernels have
+    ((fp32 state, any eps) and equal low-precision pairs), read channel slices of a wider output in place
+    (eps_stride), convert / copy only when there is no kernel for the layout.  Returns the tensors to keep alive."""
+    ed = e0.dtype
+    if ed is not sd and (sd is not torch.float32 or ed not in _DT):
+        ed = sd
+    stride = 0
+    if e0.dtype is ed and e0.is_contiguous() and (e1 is None or (e1.dtype is ed and e1.is_contiguous())) \
+            and (g is None or (g.dtype is ed and g.is_contiguous())):
+        pass
+    elif e0.dtype is ed and not e0.is_contiguous() and _sample_strided(e0) and e0.shape == shape and (
+            e1 is None or (e1.dtype is ed and _sample_strided(e1) and e1.stride(0) == e0.stride(0))):
+        stride = int(e0.stride(0))      # channel slice of a wider output: read in place
+        g = _conv(g, ed)
+    else:
+        e0, e1, g = _conv(e0, ed), _conv(e1, ed), _conv(g, ed)
+    b.e0 = e0.data_ptr()
+    b.e1 = e1.data_ptr() if e1 is not None else None
+    b.g = g.data_ptr() if g is not None else None
+    b.eps_dtype = _DT[ed]
+    b.eps_stride = stride
+    return e0, e1, g
+
+
+class _AdaptiveHandle:
+    """a dpm_adaptive handle (device-resident controller state + schedule tables); created outside stream capture"""
+
+    def __init__(self, sched_handle, desc):
+        self.handle = C.c_void_p()
+        L.check(L.lib.dpm_adaptive_create(sched_handle, C.byref(desc), C.byref(self.handle)))
+        self.order = int(desc.order)
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            try:
+                L.lib.dpm_adaptive_destroy(self.handle)
+            except Exception:
+                pass
+            self.handle = None
+
+
+class _AdaptiveRun:
+    """Device-side adaptive solver (dpm_adaptive_*): the states one run works on and the launch records of the
+    3 (order 2) / 4 (order 3) stage launches of an iteration, built once per (configuration, shape, dtype, stream)."""
+
+    def __init__(self, owner, shape, sd, device, cfg):
+        self.owner = owner                  # keeps the handle alive
+        self.handle = owner.handle
+        self.order = owner.order
+        B = int(shape[0])
+        n = 1
+        for d in shape:
+            n *= int(d)
+        self.n, self.B, self.cfg = n, B, cfg
+        mk = lambda: torch.empty(shape, dtype=sd, device=device)
+        self.x_prev, self.x_lower, self.x_higher, self.mid1, self.mid2, self.m_s, self.m_s1 = (mk() for _ in range(7))
+        self.tv_len = 2 * B if cfg else B
+        self.tvec = torch.zeros((3, 2, self.tv_len), dtype=torch.float32, device=device)
+        self.E = torch.zeros((1,), dtype=torch.float32, device=device)
+        tm = []
+        for i in range(5):
+            st = L.Stage()
+            L.check(L.lib.dpm_adaptive_stage_template(self.handle, i, C.byref(st)))
+            tm.append(st)
+
+        def given(st):       # the update of `st` with the model value already known (no prologue), cf. _run_given
+            g = st.copy()
+            g.flags = st.flags & L.F_BASE_HIST
+            g.model_type, g.guidance = L.MODEL["noise"], L.GUIDE["uncond"]
+            return g
+
+        def rec(st, x, xe, h1, h2, out, m_out):
+            st = st.copy()
+            b = L.Buffers()
+            b.n, b.batch, b.state_dtype, b.eps_dtype = n, max(B, 1), _DT[sd], _DT[sd]
+            if xe is not None:
+                b.xe = xe.data_ptr()
+            if h1 is not None:
+                b.h1 = h1.data_ptr()
+            if h2 is not None:
+                b.h2 = h2.data_ptr()
+            b.x_out = out.data_ptr()
+            if m_out is not None:
+                st.flags |= L.F_STORE_M
+                b.m_out = m_out.data_ptr()
+            else:
+                st.flags &= ~L.F_STORE_M
+            return st, b
+
+        taylor3 = self.order == 3 and tm[4].form == L.FORM_SS3T
+        if self.order == 2:
+            # eval (x, s) -> x_lower (first update) and m_s; x_s1 from m_s; eval (x_s1, s1) -> x_higher
+            self.seq = [(0, True, None) + rec(tm[0], None, None, None, None, self.x_lower, self.m_s),
+                        (2, False, self.m_s) + rec(given(tm[2]), None, None, None, None, self.mid1, None),
+                        (3, True, self.mid1) + rec(tm[3], None, self.mid1, self.m_s, None, self.x_higher, None)]
+        else:
+            # eval (x, s) -> x_s1, m_s; eval (x_s1, s1) -> x_lower (singlestep-2), m_s1; x_s2 from m_s, m_s1;
+            # eval (x_s2, s2) -> x_higher (singlestep-3)
+            self.seq = [(0, True, None) + rec(tm[0], None, None, None, None, self.mid1, self.m_s),
+                        (1, True, self.mid1) + rec(tm[1], None, self.mid1, self.m_s, None, self.x_lower, self.m_s1),
+                        (3, False, self.m_s1) + rec(given(tm[3]), None, None, self.m_s, None, self.mid2, None),
+                        (4, True, self.mid2) + rec(tm[4], None, self.mid2, self.m_s, self.m_s1 if taylor3 else None,
+                                                   self.x_higher, None)]
+
+
 class _FastRun:
     """Everything of a `sample()` call that does not change from call to call, built once per (plan, shape, dtypes,
     device, stream): the scratch states the stages ping-pong through, the cached model values, the thresholding
@@ -355,8 +461,13 @@ class DPM_Solver:
         self._state_dtype = state_dtype
         self._plans = {}
         self._fast = {}
+        self._adaptive_handles = {}
         # adaptive solver: optional hook applied to the 0-dim batch-maximum error before the controller reads it
         self.error_reduce = None
+        # adaptive solver: controller on the device (no host synchronisation per iteration); False = the host loop
+        self.adaptive_on_device = True
+        self.adaptive_lookahead = 1          # iterations the host enqueues ahead of the device's decisions
+        self.adaptive_max_iterations = None  # bound of the loop (required knowledge under hipGraph capture: default 64)
 
     # ------------------------------------------------------------------------------------------
     # helpers
@@ -662,9 +773,115 @@ class DPM_Solver:
     # ------------------------------------------------------------------------------------------
     # adaptive step size (ref :956-1010): the control loop is host logic, the work is stage kernels
     # ------------------------------------------------------------------------------------------
+    def _adaptive_device(self, x, order, t_T, t_0, h_init, atol, rtol, theta, t_err, solver_type):
+        """dpm_solver_adaptive with the controller on the device (C ABI dpm_adaptive_*): no
+        device -> host synchronisation decides anything.  The host enqueues one iteration ahead of the device
+        (`adaptive_lookahead`): before iteration i it waits -- on an event, not on a tensor -- until the device has taken
+        the decisions up to iteration i - 1 - lookahead and reads the host-mapped `done` word.  Iterations enqueued after
+        the device reached t_0 are no-ops in the solver kernels (the network calls in them are the price of the
+        look-ahead: at most `lookahead` iterations).  Under stream capture exactly `adaptive_max_iterations` are
+        recorded."""
+        device = x.device
+        sd = self._sdtype(x)
+        mt, gd, sc = self._model_codes()
+        cfg = self._wrapped is not None and self._wrapped.effective_guidance == "classifier-free"
+        stream, idx, capturing, other = _launch_ctx(device)
+        key = ("adaptive", order, float(t_T), float(t_0), float(h_init), float(atol), float(rtol), float(theta), float(t_err),
+               solver_type, mt, gd, sc, self.algorithm_type, tuple(x.shape), sd, idx, stream, capturing)
+        ar = self._fast.get(key)
+        if ar is None:
+            hkey = key[:15] + (idx,)
+            owner = self._adaptive_handles.get(hkey)
+            if owner is None:
+                if capturing:
+                    raise RuntimeError("adaptive solver under stream capture: run the same sample() call once eagerly first "
+                                       "(the device-side controller allocates its state then; DPM_Solver.capture does that)")
+                d = L.AdaptiveDesc()
+                d.algorithm_type, d.solver_type, d.order = self._algo, L.SOLVER[solver_type], int(order)
+                d.model_type, d.guidance, d.guidance_scale = mt, gd, sc
+                d.t_start, d.t_end, d.h_init = float(t_T), float(t_0), float(h_init)
+                d.atol, d.rtol, d.theta, d.t_err = float(atol), float(rtol), float(theta), float(t_err)
+                owner = self._adaptive_handles[hkey] = _AdaptiveHandle(self._h, d)
+            ar = _AdaptiveRun(owner, x.shape, sd, device, cfg)
+            if len(self._fast) >= 8:
+                self._fast.pop(next(iter(self._fast)))
+            self._fast[key] = ar
+        B, n, h = ar.B, ar.n, ar.handle
+        xs = torch.empty(x.shape, dtype=sd, device=device)
+        xs.copy_(x)
+        ar.x_prev.copy_(xs)
+        px = xs.data_ptr()
+        for _, _, _, st, b in ar.seq:
+            b.x = px
+        dcode = _DT[sd]
+        tv, tvp, ep = ar.tvec, ar.tvec.data_ptr(), ar.E.data_ptr()
+        begin = lambda: L.check(L.lib.dpm_adaptive_begin(h, px, ar.x_prev.data_ptr(), ar.x_lower.data_ptr(),
+                                                        ar.x_higher.data_ptr(), n, dcode, ep, tvp, ar.tv_len, stream))
+        ctx = torch.cuda.device(idx) if other else None
+        if ctx is not None:
+            ctx.__enter__()
+        try:
+            L.check(L.lib.dpm_adaptive_reset(h, stream))
+            max_it = self.adaptive_max_iterations or (64 if capturing else 100000)
+            look = min(max(int(self.adaptive_lookahead), 0), 24)
+            events = []
+            done = C.c_int(0)
+            it = 0
+            while it < max_it:
+                if not capturing and it > look:
+                    j = it - 1 - look
+                    events[j].synchronize()                      # begin #j has run: its verdict is in the status ring
+                    events[j] = None
+                    if L.lib.dpm_adaptive_done_at(h, j):         # the same answer on every rank of a sharded run
+                        break
+                begin()
+                if not capturing:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    events.append(ev)
+                ev_i = 0
+                for which, evaluate, src, st, b in ar.seq:
+                    if evaluate:
+                        xe_t = xs if src is None else src
+                        te, ti = tv[ev_i, 0, :B], tv[ev_i, 1, :B]
+                        if self._wrapped is not None:
+                            outs = self._wrapped.raw_outputs(xe_t, te, ti, tv[ev_i, 1] if cfg else None, x_in2=None)
+                        else:
+                            outs = (self._model_fn(xe_t, te), None, None)
+                        keep = _bind_outputs(b, outs[0], outs[1], outs[2], sd, x.shape)
+                        ev_i += 1
+                    else:
+                        b.e0 = src.data_ptr()
+                    L.check(L.lib.dpm_adaptive_stage_launch(h, which, C.byref(st), C.byref(b), stream))
+                L.check(L.lib.dpm_adaptive_error(h, ar.x_lower.data_ptr(), ar.x_higher.data_ptr(), ar.x_prev.data_ptr(), B,
+                                                 n // max(B, 1), dcode, ep, stream))
+                if self.error_reduce is not None:               # batch-sharded runs: MAX all-reduce over the ranks
+                    ar.E.copy_(self.error_reduce(ar.E[0]).reshape(1))
+                it += 1
+            begin()                                              # the decision on (and commit of) the last iteration
+            if not capturing:
+                torch.cuda.current_stream(device).synchronize()  # the one wait of the run: its end
+                nfe = C.c_int(0)
+                L.lib.dpm_adaptive_poll(h, C.byref(done), C.byref(nfe), None, None)
+                if not done.value:
+                    raise RuntimeError("adaptive solver: t_end not reached within %d iterations" % max_it)
+                print('adaptive solver nfe', nfe.value)
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+        return xs
+
     def dpm_solver_adaptive(self, x, order, t_T, t_0, h_init=0.05, atol=0.0078, rtol=0.05, theta=0.9, t_err=1e-5,
                             solver_type='dpmsolver'):
         _require_gpu(x)
+        if order not in (2, 3):
+            raise ValueError("For adaptive step size solver, order must be 2 or 3, got {}".format(order))
+        if solver_type not in ['dpmsolver', 'taylor']:
+            raise ValueError("'solver_type' must be either 'dpmsolver' or 'taylor', got {}".format(solver_type))
+        half_unknown = self._state_dtype is None and x.dtype is not torch.float32 and self.noise_schedule.schedule != 'discrete'
+        if (self.adaptive_on_device and x.is_cuda and x.dim() > 0 and x.numel() > 0 and not self._thresholding
+                and self._user_x0 is None and not half_unknown):
+            return self._adaptive_device(x, order, t_T, t_0, h_init, atol, rtol, theta, t_err, solver_type)
         ns = self.noise_schedule
         lam = lambda v: _F32(ns._eval_np(L.EVAL_LAMBDA, [v])[0])
         s = _F32(t_T)
@@ -808,10 +1025,11 @@ class DPM_Solver:
 
         Requirements are those of torch.cuda.graph: the wrapped network must be capturable (no host
         synchronisation, no data-dependent control flow), shapes are frozen, and the returned tensors are static
-        buffers that the next replay overwrites.  Not available for method='adaptive' (host control loop)."""
-        if sample_kwargs.get("method", "multistep") == "adaptive":
-            raise NotImplementedError("the adaptive solver's control loop synchronises with the host every iteration; "
-                                      "it cannot be captured into a graph")
+        buffers that the next replay overwrites.  method='adaptive' is captured with its device-side controller: exactly
+        `adaptive_max_iterations` (default 64) iterations are recorded, those after t_end is reached do nothing."""
+        if sample_kwargs.get("method", "multistep") == "adaptive" and not self.adaptive_on_device:
+            raise NotImplementedError("the host-side adaptive control loop synchronises every iteration; it cannot be "
+                                      "captured into a graph (adaptive_on_device = True can)")
         return GraphedSample(self, x, warmup, sample_kwargs)
 
     def _run_plan_fast(self, plan, x, sd, cfg):
@@ -846,7 +1064,6 @@ class DPM_Solver:
         bufs[fr.last].x_out = out.data_ptr()
         xbuf, xfull = fr.xbuf, fr.xfull
         launch = _stage_launch_raw
-        dcode = _DT[sd]
         for i, b in enumerate(bufs):
             xi, xei, _ = roles[i]
             if xi == 0:
@@ -863,26 +1080,7 @@ class DPM_Solver:
                 e0, e1, g = wrapped.raw_outputs(xe_t, tb[i], ti[i], t2[i] if cfg else None, x_in2=x2)
             else:
                 e0, e1, g = model_fn(xe_t, tb[i]), None, None
-            ed = e0.dtype
-            if ed is not sd and (sd is not torch.float32 or ed not in _DT):
-                ed = sd              # only (fp32 state, any eps) and equal low-precision pairs have kernels
-            stride = 0
-            if e0.dtype is ed and e0.is_contiguous() and (e1 is None or (e1.dtype is ed and e1.is_contiguous())) \
-                    and (g is None or (g.dtype is ed and g.is_contiguous())):
-                pass
-            elif e0.dtype is ed and not e0.is_contiguous() and _sample_strided(e0) and e0.shape == x.shape and (
-                    e1 is None or (e1.dtype is ed and _sample_strided(e1) and e1.stride(0) == e0.stride(0))):
-                stride = int(e0.stride(0))      # channel slice of a wider output: read in place
-                g = _conv(g, ed)
-            else:
-                e0, e1, g = _conv(e0, ed), _conv(e1, ed), _conv(g, ed)
-            b.e0 = e0.data_ptr()
-            if e1 is not None:
-                b.e1 = e1.data_ptr()
-            if g is not None:
-                b.g = g.data_ptr()
-            b.eps_dtype = dcode if ed is sd else _DT[ed]
-            b.eps_stride = stride
+            keep = _bind_outputs(b, e0, e1, g, sd, x.shape)
             if other:
                 with torch.cuda.device(idx):
                     rc = launch(refs[i][0], refs[i][1], stream)

@@ -244,6 +244,54 @@ int dpm_adaptive_error_launch(const void* x_lower, const void* x_higher, const v
                               float* e_out /* [batch + 1] device */, int64_t batch, int64_t per_sample, int dtype,
                               void* stream);
 
+/* ---- adaptive step-size solver with the controller ON THE DEVICE (dpm_solver_adaptive, ref :956-1010) --------------
+   The reference's loop decides accept / reject and the next step size on the host from E = max_b ||(x_hi - x_lo)/delta||,
+   i.e. one device -> host synchronisation per iteration.  Here the controller state (s, lambda_s, h, nfe, done) and the
+   coefficients of the iteration's stages live in device memory: a one-thread kernel takes the decision of the previous
+   iteration, evaluates inverse_lambda and every coefficient of the next one with the planner's own code
+   (csrc/dpm_coef.hpp, compiled for the device) and fills the time vectors the network is called with; the stage kernels
+   read their coefficients from there; accepted states are committed by a device-side copy.  After `done` every kernel
+   of the handle is a no-op, so the host may enqueue a fixed number of iterations (hipGraph capture) or poll the
+   host-mapped status words without synchronising.  One iteration =
+       dpm_adaptive_begin -> [network at t_vectors[0]] -> stages ... -> dpm_adaptive_error
+   with the stages of DPM-Solver-12 (order 2: which = 0 lower, 2..3 higher) or -23 (order 3: 0..1 lower, 3..4 higher;
+   stage 2 equals stage 0).  The caller owns x, x_prev, x_lower, x_higher, the scratch states, the time vectors and the
+   error word; the handle owns ~2 KB of device state and a copy of the schedule tables. */
+typedef struct dpm_adaptive_desc {
+  int32_t algorithm_type; /* DPM_ALGO_*   */
+  int32_t solver_type;    /* DPM_SOLVER_* */
+  int32_t order;          /* 2 or 3       */
+  int32_t model_type;     /* DPM_MODEL_*  */
+  int32_t guidance;       /* DPM_GUIDE_*  */
+  int32_t reserved;
+  double guidance_scale;
+  double t_start, t_end;  /* t_T, t_0 */
+  double h_init, atol, rtol, theta, t_err; /* ref :956 defaults 0.05, 0.0078, 0.05, 0.9, 1e-5 */
+} dpm_adaptive_desc;
+typedef struct dpm_adaptive dpm_adaptive;
+int dpm_adaptive_create(const dpm_schedule* s, const dpm_adaptive_desc* d, dpm_adaptive** out);
+void dpm_adaptive_destroy(dpm_adaptive* a);
+/* static fields (form, flags, slots) of stage `which` (0..4); the float fields are placeholders */
+int dpm_adaptive_stage_template(const dpm_adaptive* a, int which, dpm_stage* out);
+/* start of a run: s = t_T, h = h_init, nfe = 0 */
+int dpm_adaptive_reset(dpm_adaptive* a, void* stream);
+/* decision on the previous iteration (E read from *e_dev, then cleared), commit of an accepted step
+   (x <- x_higher, x_prev <- x_lower), plan of the next iteration, t_vectors[j][0 | 1][0..tv_len) <- t_eval | t_input of
+   network evaluation j */
+int dpm_adaptive_begin(dpm_adaptive* a, void* x, void* x_prev, const void* x_lower, const void* x_higher, int64_t n,
+                       int dtype, float* e_dev, float* t_vectors, int64_t tv_len, void* stream);
+/* stage `which` of the current iteration: `st` = the caller's copy of the template (it may edit flags / model_type /
+   guidance, e.g. to feed a known model value), float coefficients come from the device */
+int dpm_adaptive_stage_launch(dpm_adaptive* a, int which, const dpm_stage* st, const dpm_buffers* b, void* stream);
+/* *e_dev <- max(*e_dev, max_b E_b) (ref :999-1001); several workgroups per sample, fp32 / fp16 / bf16 */
+int dpm_adaptive_error(dpm_adaptive* a, const void* x_lower, const void* x_higher, const void* x_prev, int64_t batch,
+                       int64_t per_sample, int dtype, float* e_dev, void* stream);
+/* host-mapped status as of the last dpm_adaptive_begin the device has executed: no synchronisation */
+int dpm_adaptive_poll(const dpm_adaptive* a, int* done, int* nfe, int* iterations, int* accepted);
+/* `done` as recorded by the begin_index-th dpm_adaptive_begin since the last reset (a ring of the last 32): the value to
+   look at after waiting for THAT launch -- identical on every rank of a batch-sharded run, whatever has run since */
+int dpm_adaptive_done_at(const dpm_adaptive* a, int begin_index);
+
 /* native sample loop for non-Python hosts and for the solver-only benchmark.
    model(user, stage, x, t_input, t_eval, e0_out, e1_out): evaluate the network on x, write the raw output(s);
    NULL means the outputs are already staged in e0/e1 (frozen model).  All buffers are the caller's:
@@ -314,7 +362,8 @@ int dpm_calib_launch(int kind, int block, int blocks_per_cu, int nt, const void*
 /* ---- misc ---------------------------------------------------------------------------------- */
 int dpm_version(void);
 /* sizeof() of the ABI structs as compiled, so a binding can verify its own layout at load time */
-enum { DPM_SIZEOF_STAGE = 0, DPM_SIZEOF_BUFFERS = 1, DPM_SIZEOF_PLAN_DESC = 2, DPM_SIZEOF_RUN_BUFFERS = 3 };
+enum { DPM_SIZEOF_STAGE = 0, DPM_SIZEOF_BUFFERS = 1, DPM_SIZEOF_PLAN_DESC = 2, DPM_SIZEOF_RUN_BUFFERS = 3,
+       DPM_SIZEOF_ADAPTIVE_DESC = 4 };
 size_t dpm_sizeof(int which);
 const char* dpm_last_error(void); /* thread-local text of the last non-zero return */
 int dpm_device_info(int* n_cu, int* lds_bytes, char* arch, int arch_len);

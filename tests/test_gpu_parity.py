@@ -284,6 +284,85 @@ def test_adaptive(golden, capsys, name, sname, order, algo):
     assert rel_err(xf.cpu().numpy(), g("final")) < TOL                  # north-star bound (measured: <= 3.2e-7)
 
 
+@pytest.mark.parametrize("name,sname,order,algo", [("a12", "vp_linear", 2, "dpmsolver"), ("a23", "vp_linear", 3, "dpmsolver"),
+                                                   ("a23pp", "sd", 3, "dpmsolver++")])
+def test_adaptive_controller_on_the_device(golden, capsys, monkeypatch, name, sname, order, algo):
+    """the adaptive solver's accept / reject and step-size controller runs on the device (dpm_adaptive_*).
+    (i) nothing in the run reads a tensor back (`.item()` / `.cpu()` / `.tolist()` raise while it runs); (ii) same NFE and
+    result as the reference goldens; (iii) agrees with the host-side control loop (the reference's structure);
+    (iv) half-precision states work (the host loop had no bf16 error norm)."""
+    ns = make_schedule(sname)
+    g = lambda k: golden.get("adaptive", "adaptive/%s/%s" % (name, k))
+    mk = lambda **kw: D.DPM_Solver(D.model_wrapper(lambda xx, t: C.model_half(xx, t), ns), ns, algorithm_type=algo, **kw)
+    x = tt(g("x"), DEV)
+    dpm = mk()
+    assert dpm.adaptive_on_device
+    dpm.sample(x, method="adaptive", order=order, t_end=1e-3)            # warm-up: handle, buffers
+    capsys.readouterr()
+
+    def forbidden(*a, **k):
+        raise AssertionError("device -> host read inside the adaptive loop")
+    with monkeypatch.context() as m:
+        for meth in ("item", "cpu", "tolist", "numpy"):
+            m.setattr(torch.Tensor, meth, forbidden)
+        xf = dpm.sample(x, method="adaptive", order=order, t_end=1e-3)
+    out = capsys.readouterr().out
+    assert out.strip() == "adaptive solver nfe %d" % int(g("nfe"))
+    assert rel_err(xf.cpu().numpy(), g("final")) < TOL
+    host = mk()
+    host.adaptive_on_device = False
+    xh = host.sample(x, method="adaptive", order=order, t_end=1e-3)
+    assert capsys.readouterr().out.strip() == "adaptive solver nfe %d" % int(g("nfe"))
+    assert rel_err(xf.cpu().numpy(), xh.cpu().numpy()) < 2e-6
+    for sdt in (torch.float16, torch.bfloat16):
+        xs = mk(state_dtype=sdt).sample(x.to(sdt), method="adaptive", order=order, t_end=1e-3)
+        assert xs.dtype == sdt and torch.isfinite(xs.float()).all()
+        assert rel_err(xs.float().cpu().numpy(), g("final")) < (2e-2 if sdt == torch.float16 else 1.5e-1)
+    capsys.readouterr()
+
+
+def test_adaptive_with_guidance_and_other_parameterisations(capsys):
+    """the device-side controller fills the prologue scalars too (alpha, sigma at every evaluation time, the classifier
+    term's scale): classifier-free guidance, v-prediction and x_start-prediction against the host-side loop"""
+    ns = make_schedule("sd")
+    rng = np.random.default_rng(41)
+    x = torch.from_numpy(rng.standard_normal((3, 4, 16, 16)).astype(F32)).to(DEV)
+    c = torch.tensor([0.5, 1.0, 1.5], device=DEV)
+    cases = [dict(model_type="v"), dict(model_type="x_start"),
+             dict(guidance_type="classifier-free", condition=c, unconditional_condition=torch.zeros_like(c), guidance_scale=2.5)]
+    for kw in cases:
+        net = (lambda xx, t, cc: xx * (0.4 + 0.1 * cc.reshape(-1, 1, 1, 1))) if "condition" in kw else (lambda xx, t: xx * 0.5)
+        for algo in ("dpmsolver++", "dpmsolver"):
+            for order in (2, 3):
+                res = []
+                for on_dev in (True, False):
+                    dpm = D.DPM_Solver(D.model_wrapper(net, ns, **kw), ns, algorithm_type=algo)
+                    dpm.adaptive_on_device = on_dev
+                    res.append(dpm.sample(x, method="adaptive", order=order, t_end=5e-3, solver_type="taylor" if order == 3 else "dpmsolver"))
+                o = capsys.readouterr().out.strip().splitlines()
+                assert o[0] == o[1], (kw.keys(), algo, order, o)                # same NFE
+                assert rel_err(res[0].cpu().numpy(), res[1].cpu().numpy()) < 5e-6, (list(kw), algo, order)
+
+
+def test_adaptive_captured_into_a_graph(capsys):
+    """DPM_Solver.capture accepts method='adaptive' now: a fixed number of iterations is recorded, those after the device
+    reached t_end are no-ops"""
+    ns = make_schedule("vp_linear")
+    rng = np.random.default_rng(42)
+    x = torch.from_numpy(rng.standard_normal((2, 3, 16, 16)).astype(F32)).to(DEV)
+    dpm = D.DPM_Solver(D.model_wrapper(lambda xx, t: C.model_half(xx, t), ns), ns, algorithm_type="dpmsolver")
+    want = dpm.sample(x, method="adaptive", order=2, t_end=1e-3)
+    nfe = int(capsys.readouterr().out.strip().split()[-1])
+    dpm.adaptive_max_iterations = nfe // 2 + 6
+    g = dpm.capture(x, method="adaptive", order=2, t_end=1e-3)
+    capsys.readouterr()
+    for _ in range(2):
+        assert torch.equal(g(x), want)
+    x2 = x * 1.5
+    dpm.adaptive_max_iterations = None
+    assert torch.equal(g(x2), dpm.sample(x2, method="adaptive", order=2, t_end=1e-3))
+
+
 def test_callbacks(golden):
     case = C.E2E_BY_NAME["cfg1_small"]
     ns = make_schedule("sd")
