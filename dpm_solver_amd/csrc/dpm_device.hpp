@@ -2284,7 +2284,7 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
           //                          fp32 state + 2-byte network output (1 | 2, nt loads)  [SD under autocast]
           const bool resident = b->inputs_resident != 0 || tn.assume_resident != 0;
           constexpr int CNT = sizeof(TS) == 2 ? 1 : (sizeof(TE) == 4 ? 5 : 1);  // nt mask of the HBM situation
-#ifdef DPM_TUNING_VARIANTS  // tools/tune.py: every (tiles per iteration, nt mask)
+#ifdef DPM_TUNING_VARIANTS  // tools/tune.py single: every (tiles per iteration, nt mask)
           if (tn.unroll > 0 && tn.nontemporal >= 0) {
             switch (tn.unroll * 8 + (tn.nontemporal & 7)) {
               case 8 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 1, 0, false); break;
@@ -2359,7 +2359,7 @@ int launch_multi_spec(const dpm_stage* st, const dpm_buffers* bs, int n_req, con
     launch(kern, dim3((unsigned)blocks), dim3(256), 0, c, tab, n, (uint32_t)n_req, (uint32_t)spr, p);
   };
   constexpr int DU = MultiShape<TS, TE>::U, DN = MultiShape<TS, TE>::NT;
-#ifdef DPM_TUNING_VARIANTS  // tools/tune_multi.py: every (tiles per iteration, nt mask) of the 2M kernel
+#ifdef DPM_TUNING_VARIANTS  // tools/tune.py multi: every (tiles per iteration, nt mask) of the 2M kernel
   if constexpr (FORM == DPM_FORM_TWO && GUIDE == DPM_GUIDE_NONE && SPEC == SPEC_NOISE_X0) {
     if (tn.unroll > 0 && tn.nontemporal >= 0) {
       switch (tn.unroll * 8 + (tn.nontemporal & 7)) {
