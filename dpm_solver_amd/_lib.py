@@ -32,6 +32,7 @@ F_TO_X0, F_STORE_M, F_BASE_HIST, F_THRESH, F_USER_X0, F_BLEND = 1, 2, 4, 8, 16, 
 SRC_STATE, SRC_TMP = 0, 1
 TUNE_UNROLL, TUNE_NONTEMPORAL, TUNE_BLOCKS_PER_CU, TUNE_ASSUME_RESIDENT = 0, 1, 2, 3
 TUNE_MULTI_FUSE, TUNE_MULTI_BLOCKS_PER_CU, TUNE_CLUSTER_IN_GRAPH, TUNE_CLUSTER_ONE_HOP = 4, 5, 6, 7
+TUNE_MULTI_XCD_REMAP = 8
 MULTI_MAX = 32
 
 

@@ -48,6 +48,8 @@ struct Tuning {
   int multi_fuse = 1;       // dpm_stage_launch_multi: 1 = one fused launch per group of requests, 0 = one launch per request
   int cluster_in_graph = 0; // 1: thresholding keeps workgroup clusters under stream capture also for samples that fit one workgroup
   int cluster_one_hop = 1;  // 0: clusters always take the general route (merged histograms, several barriers)
+  int multi_xcd_remap = -1; // fused launch maps workgroup b to tile (b % 8) * span + b / 8 (one contiguous eighth of the
+                            // tile space per XCD): 1 on, 0 off, -1 per dtype (on for 2-byte states: +1.4 %; fp32: -3 %)
   int multi_blocks_per_cu = 0;  // grid cap of the fused launch in workgroups per CU; 0 = one super-tile per workgroup
 };
 extern Tuning g_tuning;     // defined in dpm_kernels.hip
@@ -276,15 +278,23 @@ __device__ __forceinline__ void store_tile(T* __restrict__ p, int64_t gi, bool s
 // per-stage scalars (kernel argument => SGPRs)
 // ------------------------------------------------------------------------------------------------
 struct KParams {
-  float alpha_e, sigma_e, cfg_scale, cg_scale;
+  // Field order matters to the optimiser, not to the hardware: with alpha_e, sigma_e and cfg_scale adjacent the SLP
+  // vectoriser loads them as two OVERLAPPING <2 x float> in the mode-dispatching kernels, SROA then cannot split the
+  // argument copy and the backend parks those 12 bytes in LDS (3 KB per workgroup and an LDS round trip per use).
+  // Integers in between keep every float a scalar kernarg load.
+  float alpha_e;
+  uint32_t flags;
+  float sigma_e;
+  int32_t model_type;
+  float cfg_scale;
+  int32_t form;      // DPM_FORM_* / DPM_GUIDE_*: read by the run-time dispatched kernels (FORM_RT / GUIDE_RT)
+  float cg_scale;
+  int32_t guidance;
   float cx, c0, c1, c2;
   float k0, k1, k2, k3, k4;
-  uint32_t flags;
-  int32_t model_type;
-  float inv_alpha;  // RN(1 / alpha_e), used by the specialised prologue (see div_by_alpha)
-  int32_t form, guidance;  // DPM_FORM_* / DPM_GUIDE_*: read by the run-time dispatched kernels (FORM_RT / GUIDE_RT)
-  float inv_sigma;         // RN(1 / sigma_e)
-  uint32_t fastdiv;        // bit 0 / 1: alpha_e / sigma_e pass div_invariant_ok (general prologue)
+  float inv_alpha;   // RN(1 / alpha_e), used by the specialised prologue (see div_by_alpha)
+  float inv_sigma;   // RN(1 / sigma_e)
+  uint32_t fastdiv;  // bit 0 / 1: alpha_e / sigma_e pass div_invariant_ok (general prologue)
 };
 
 // x / alpha_e for a wave-uniform divisor whose correctly rounded reciprocal r = RN(1/alpha) is known: q = RN(x*r),
@@ -321,48 +331,62 @@ __device__ __forceinline__ bool div_invariant_ok_dev(float d) {
   const uint32_t u = __float_as_uint(d), ex = (u >> 23) & 0xffu;
   return ex > 32u && ex < 222u && (u & 0x7fffffu) != 0x7fffffu;
 }
-// coefficients computed on the device (LaunchCtx::dyn): every float of the stage record replaces the launch argument;
-// flags, form, model type and guidance kind stay the host's
-__device__ __forceinline__ void apply_dyn(KParams& p, const dpm_stage* d) {
-  p.alpha_e = d->alpha_e;
-  p.sigma_e = d->sigma_e;
-  p.cg_scale = d->cg_scale;
-  p.cx = d->cx;
-  p.c0 = d->c0;
-  p.c1 = d->c1;
-  p.c2 = d->c2;
-  p.k0 = d->k[0];
-  p.k1 = d->k[1];
-  p.k2 = d->k[2];
-  p.k3 = d->k[3];
-  p.k4 = d->k[4];
-  p.inv_alpha = 1.0f / p.alpha_e;
-  p.inv_sigma = 1.0f / p.sigma_e;
-  p.fastdiv = (div_invariant_ok_dev(p.alpha_e) ? 1u : 0u) | (div_invariant_ok_dev(p.sigma_e) ? 2u : 0u);
+// coefficients computed on the device (LaunchCtx::dyn, kernels instantiated with DYN = true): every float of the stage
+// record comes from device memory; flags, form, model type and guidance kind stay the host's.  Built unconditionally from
+// loads: a conditional overwrite of the kernel argument keeps part of it addressable and the backend parks it in LDS.
+__device__ __forceinline__ KParams params_from_dyn(const KParams& p, const dpm_stage* d) {
+  KParams q;
+  q.alpha_e = d->alpha_e;
+  q.sigma_e = d->sigma_e;
+  q.cfg_scale = p.cfg_scale;
+  q.cg_scale = d->cg_scale;
+  q.cx = d->cx;
+  q.c0 = d->c0;
+  q.c1 = d->c1;
+  q.c2 = d->c2;
+  q.k0 = d->k[0];
+  q.k1 = d->k[1];
+  q.k2 = d->k[2];
+  q.k3 = d->k[3];
+  q.k4 = d->k[4];
+  q.flags = p.flags;
+  q.model_type = p.model_type;
+  q.inv_alpha = 1.0f / q.alpha_e;
+  q.form = p.form;
+  q.guidance = p.guidance;
+  q.inv_sigma = 1.0f / q.sigma_e;
+  q.fastdiv = (div_invariant_ok_dev(q.alpha_e) ? 1u : 0u) | (div_invariant_ok_dev(q.sigma_e) ? 2u : 0u);
+  return q;
 }
 
-// Compile-time knowledge about the prologue.  SPEC_GENERIC reads model_type / TO_X0 from the stage record at
-// run time (wave-uniform scalar branches); the two hot specialisations fix them so the inner loop is
-// branch-free: SPEC_NOISE_X0 = noise-prediction network + eps -> x0 (dpmsolver++), SPEC_NOISE_EPS = noise
-// prediction kept (dpmsolver).
-enum { SPEC_GENERIC = 0, SPEC_NOISE_X0 = 1, SPEC_NOISE_EPS = 2 };
+// Compile-time knowledge about the prologue: a prologue mode PM = model_type * 2 + (eps -> x0 ? 1 : 0) fixes the network's
+// parameterisation and the conversion at compile time (branch-free inner loop, divisions by the wave-uniform alpha /
+// sigma as multiplications by their reciprocal + one exact-residual correction); PM_RT reads everything from the stage
+// record at run time (true divisions when a divisor fails the guard).  Kernels are instantiated for the two modes of a
+// noise-prediction network (SPEC_NOISE_EPS, SPEC_NOISE_X0: the common case) and as SPEC_GENERIC, which picks the mode
+// once per tile iteration (wave-uniform switch) and runs the same straight-line code for x_start / v / score networks.
+enum { PM_RT = -1, SPEC_NOISE_EPS = DPM_MODEL_NOISE * 2, SPEC_NOISE_X0 = DPM_MODEL_NOISE * 2 + 1, SPEC_GENERIC = 100 };
 
-template <int SPEC>
-__device__ __forceinline__ bool spec_to_x0(const KParams& p) {
-  return SPEC == SPEC_GENERIC ? (p.flags & DPM_F_TO_X0) != 0 : SPEC == SPEC_NOISE_X0;
-}
 template <int SPEC>
 __device__ __forceinline__ bool spec_need_xe(const KParams& p) {
-  if (SPEC != SPEC_GENERIC) return SPEC == SPEC_NOISE_X0;
+  if (SPEC >= 0 && SPEC != SPEC_GENERIC)
+    return (SPEC & 1) || (SPEC >> 1) == DPM_MODEL_X_START || (SPEC >> 1) == DPM_MODEL_V;
   return (p.flags & DPM_F_TO_X0) || p.model_type == DPM_MODEL_X_START || p.model_type == DPM_MODEL_V;
+}
+// the mode SPEC_GENERIC dispatches to: PM_RT when a divisor this stage needs fails the division-by-invariant guard
+__device__ __forceinline__ int generic_mode(const KParams& p) {
+  const bool tox0 = (p.flags & DPM_F_TO_X0) != 0;
+  const bool ok = (!tox0 || (p.fastdiv & 1u)) && (p.model_type != DPM_MODEL_X_START || (p.fastdiv & 2u));
+  return ok ? p.model_type * 2 + (tox0 ? 1 : 0) : PM_RT;
 }
 
 // raw network output -> noise prediction (noise_pred_fn, ref :288-298)
-template <int SPEC, typename V>
+template <int PM, typename V>
 __device__ __forceinline__ V to_noise(V o, V xe, const KParams& p) {
-  if (SPEC != SPEC_GENERIC) return o;
-  switch (p.model_type) {
-    case DPM_MODEL_X_START: return div_uniform(xe - p.alpha_e * o, p.sigma_e, p.inv_sigma, (p.fastdiv & 2u) != 0u);
+  const int model = PM >= 0 ? (PM >> 1) : p.model_type;
+  switch (model) {
+    case DPM_MODEL_X_START:
+      return div_uniform(xe - p.alpha_e * o, p.sigma_e, p.inv_sigma, PM >= 0 || (p.fastdiv & 2u) != 0u);
     case DPM_MODEL_V: return p.alpha_e * o + p.sigma_e * xe;
     case DPM_MODEL_SCORE: return (-p.sigma_e) * o;
     default: return o;
@@ -379,8 +403,9 @@ __device__ __forceinline__ bool guide_is(int what, const KParams& p) {
   return GUIDE == GUIDE_RT ? p.guidance == what : GUIDE == what;
 }
 
-template <int GUIDE, int SPEC = SPEC_GENERIC, typename V = float>
+template <int GUIDE, int SPEC = PM_RT, typename V = float>
 __device__ __forceinline__ V prologue(V xe, V o0, V o1, V gg, const KParams& p) {
+  static_assert(SPEC != SPEC_GENERIC, "SPEC_GENERIC dispatches to a mode (stage_tiles); the prologue takes the mode");
   V eps;
   if (guide_is<GUIDE>(DPM_GUIDE_CFG, p)) {  // ref :326-330: uncond + scale * (cond - uncond)
     V nu = to_noise<SPEC>(o1, xe, p), nc = to_noise<SPEC>(o0, xe, p);
@@ -390,8 +415,8 @@ __device__ __forceinline__ V prologue(V xe, V o0, V o1, V gg, const KParams& p) 
   } else {
     eps = to_noise<SPEC>(o0, xe, p);
   }
-  if (SPEC == SPEC_NOISE_X0) return div_by_alpha(xe - p.sigma_e * eps, p);  // ref :439, division by invariant
-  if (spec_to_x0<SPEC>(p)) return div_uniform(xe - p.sigma_e * eps, p.alpha_e, p.inv_alpha, (p.fastdiv & 1u) != 0u);  // ref :439
+  if (SPEC >= 0) return (SPEC & 1) ? div_by_alpha(xe - p.sigma_e * eps, p) : eps;  // ref :439, division by invariant
+  if (p.flags & DPM_F_TO_X0) return div_uniform(xe - p.sigma_e * eps, p.alpha_e, p.inv_alpha, (p.fastdiv & 1u) != 0u);  // ref :439
   return eps;
 }
 
@@ -489,6 +514,27 @@ __device__ __forceinline__ float blend_ref(float v, float m, float a, float b, b
 // ------------------------------------------------------------------------------------------------
 // the streaming stage kernel
 // ------------------------------------------------------------------------------------------------
+// model values of the U tiles of one workgroup iteration for prologue mode PM (the loaded registers arrive by reference:
+// a plain forced-inline function, so that they stay registers).  The empty asm statement is a side effect: without one a
+// switch over these calls is if-converted into computing every mode and selecting.
+template <int GUIDE, bool XE, int PM, int U, bool NEEDS_X>
+__device__ __forceinline__ void tile_models(const float (&vx)[U][EPT], const float (&vxe)[U][EPT], const float (&v0)[U][EPT],
+                                            const float (&v1)[U][EPT], const float (&vg)[U][EPT], const bool need_xe,
+                                            const KParams& p, f32x2 (&mnv)[U][EPT / 2]) {
+  asm volatile("");  // no clobbers: a "memory" clobber would force the kernel arguments behind `p` into memory
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int q = 0; q < EPT; q += 2) {  // adjacent pairs: see f32x2
+      const f32x2 z = {0.f, 0.f};
+      const f32x2 x2 = NEEDS_X || (!XE && need_xe) ? f32x2{vx[u][q], vx[u][q + 1]} : z;
+      const f32x2 xe2 = XE ? f32x2{vxe[u][q], vxe[u][q + 1]} : x2;
+      mnv[u][q / 2] = prologue<GUIDE, PM>(xe2, f32x2{v0[u][q], v0[u][q + 1]},
+                                          GUIDE == DPM_GUIDE_CFG ? f32x2{v1[u][q], v1[u][q + 1]} : z,
+                                          GUIDE == DPM_GUIDE_CLASSIFIER ? f32x2{vg[u][q], vg[u][q + 1]} : z, p);
+    }
+}
+
 // EXT = the launch uses one of the KExt extensions (duplicate store, strided network output, mask blend): the same
 // tiling, with the extra index arithmetic and streams compiled in.  EXT launches have no ragged tail (the scalar kernel
 // takes those) and use the split layout only when no per-sample / per-period index is involved.
@@ -544,20 +590,36 @@ __device__ __forceinline__ void stage_tiles(const TS* __restrict__ x, const TS* 
       if (bb) load_pack<(NT & 1) != 0>(bb, gi, vb[u]);
     }
   }
+  // the model values of all U tiles; SPEC_GENERIC picks the prologue mode here, once per workgroup iteration
+  f32x2 mnv[U][EPT / 2];
+#define DPM_MODELS(PM_) tile_models<GUIDE, XE, PM_, U, FT::needs_x>(vx, vxe, v0, v1, vg, need_xe, p, mnv)
+  if constexpr (SPEC == SPEC_GENERIC) {
+    switch (generic_mode(p)) {
+      case 0: DPM_MODELS(0); break;
+      case 1: DPM_MODELS(1); break;
+      case 2: DPM_MODELS(2); break;
+      case 3: DPM_MODELS(3); break;
+      case 4: DPM_MODELS(4); break;
+      case 5: DPM_MODELS(5); break;
+      case 6: DPM_MODELS(6); break;
+      case 7: DPM_MODELS(7); break;
+      default: DPM_MODELS(PM_RT); break;
+    }
+  } else {
+    DPM_MODELS(SPEC);
+  }
+#undef DPM_MODELS
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int64_t gi = (t0 + u) * 256 + threadIdx.x;
     const bool split = can_split && (t0 + u) * 256 + 256 <= ngroups;
     float ox[EPT], om[EPT];
 #pragma unroll
-    for (int q = 0; q < EPT; q += 2) {  // adjacent pairs: see f32x2
+    for (int q = 0; q < EPT; q += 2) {
       const f32x2 z = {0.f, 0.f};
-      const f32x2 x2 = FT::needs_x || (!XE && need_xe) ? f32x2{vx[u][q], vx[u][q + 1]} : z;
-      const f32x2 xe2 = XE ? f32x2{vxe[u][q], vxe[u][q + 1]} : x2;
-      const f32x2 mn = prologue<GUIDE, SPEC>(xe2, f32x2{v0[u][q], v0[u][q + 1]},
-                                             GUIDE == DPM_GUIDE_CFG ? f32x2{v1[u][q], v1[u][q + 1]} : z,
-                                             GUIDE == DPM_GUIDE_CLASSIFIER ? f32x2{vg[u][q], vg[u][q + 1]} : z, p);
-      const f32x2 o = combine<FORM>(FT::needs_x ? x2 : z, mn, FT::needs_h1 ? f32x2{vh1[u][q], vh1[u][q + 1]} : z,
+      const f32x2 mn = mnv[u][q / 2];
+      const f32x2 o = combine<FORM>(FT::needs_x ? f32x2{vx[u][q], vx[u][q + 1]} : z, mn,
+                                    FT::needs_h1 ? f32x2{vh1[u][q], vh1[u][q + 1]} : z,
                                     FT::needs_h2 ? f32x2{vh2[u][q], vh2[u][q + 1]} : z, p);
       om[q] = mn.x;
       om[q + 1] = mn.y;
@@ -578,18 +640,20 @@ __device__ __forceinline__ void stage_tiles(const TS* __restrict__ x, const TS* 
   }
 }
 
-template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int SPEC, int U, int NT, bool EXT>
+template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int SPEC, int U, int NT, bool EXT, bool DYN = false>
 __global__ __launch_bounds__(256) void stage_kernel(const TS* __restrict__ x, const TS* __restrict__ xe,
                                                     const TE* __restrict__ e0, const TE* __restrict__ e1,
                                                     const TE* __restrict__ g, const TS* __restrict__ h1,
                                                     const TS* __restrict__ h2, TS* __restrict__ xo,
-                                                    TS* __restrict__ mo, int64_t n, KParams p, KExt ext,
+                                                    TS* __restrict__ mo, int64_t n, const KParams p_arg, KExt ext,
                                                     const dpm_stage* dyn, const int32_t* skip) {
   using FT = FormTraits<FORM>;
-  if constexpr (SPEC == SPEC_GENERIC) {  // device-resident coefficients: see LaunchCtx
-    if (skip && *skip) return;
-    if (dyn) apply_dyn(p, dyn);
+  if constexpr (DYN) {  // device-resident coefficients: see LaunchCtx
+    if (*skip) return;
   }
+  KParams p_dyn;  // (a copy of the argument, even a const one, would leave part of it in memory -> LDS)
+  if constexpr (DYN) p_dyn = params_from_dyn(p_arg, dyn);
+  const KParams& p = DYN ? p_dyn : p_arg;
   const int64_t ngroups = n / EPT;
   // a tile = 256 consecutive groups (one per lane of the workgroup); a workgroup iteration covers U tiles and
   // issues the loads of all of them before the first use
@@ -605,8 +669,8 @@ __global__ __launch_bounds__(256) void stage_kernel(const TS* __restrict__ x, co
       const int64_t i = tail0 + threadIdx.x;
       const float xv = (FT::needs_x || (!XE && need_xe)) ? to_f32(x[i]) : 0.f;
       const float xev = XE ? (need_xe ? to_f32(xe[i]) : 0.f) : xv;
-      const float mn = prologue<GUIDE, SPEC>(xev, to_f32(e0[i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[i]) : 0.f,
-                                             GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[i]) : 0.f, p);
+      const float mn = prologue<GUIDE, SPEC == SPEC_GENERIC ? (int)PM_RT : SPEC>(
+          xev, to_f32(e0[i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[i]) : 0.f, GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[i]) : 0.f, p);
       xo[i] = from_f32<TS>(combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[i]) : 0.f, FT::needs_h2 ? to_f32(h2[i]) : 0.f, p));
       if (store_m) mo[i] = from_f32<TS>(mn);
     }
@@ -634,11 +698,14 @@ struct MultiTab {
 
 template <typename TS, typename TE, int FORM, int GUIDE, int SPEC, int U, int NT>
 __global__ __launch_bounds__(256) void stage_kernel_multi(const MultiTab tab, int64_t n, uint32_t nreq, uint32_t spr,
-                                                          KParams p) {
+                                                          KParams p, uint32_t xcd_span) {
   const int64_t ngroups = n / EPT;
   KExt ext = {};
   const uint32_t total = nreq * spr;  // spr = super-tiles (U tiles) per request
-  for (uint32_t v = blockIdx.x; v < total; v += gridDim.x) {
+  for (uint32_t v0 = blockIdx.x; v0 < (xcd_span ? 8u * xcd_span : total); v0 += gridDim.x) {
+    // xcd_span != 0 (tuning): workgroup b runs on XCD b % 8 -- give every XCD one contiguous eighth of the tile space
+    const uint32_t v = xcd_span ? (v0 & 7u) * xcd_span + (v0 >> 3) : v0;
+    if (v >= total) continue;
     const uint32_t r = v / spr;
     const int64_t t0 = (int64_t)(v - r * spr) * U;
     stage_tiles<TS, TE, FORM, GUIDE, false, SPEC, U, NT, false>(
@@ -652,15 +719,19 @@ __global__ __launch_bounds__(256) void stage_kernel_multi(const MultiTab tab, in
 // extended launches and for (form, xe) combinations the streaming family does not instantiate.  ONE kernel per dtype
 // pair: form and guidance are read from the stage record (wave-uniform branches), xe always points at the state the
 // network saw (= x when there is no separate one).
-template <typename TS, typename TE>
+template <typename TS, typename TE, bool DYN = false>
 __global__ __launch_bounds__(256) void stage_kernel_scalar(const TS* __restrict__ x, const TS* __restrict__ xe,
                                                            const TE* __restrict__ e0, const TE* __restrict__ e1,
                                                            const TE* __restrict__ g, const TS* __restrict__ h1,
                                                            const TS* __restrict__ h2, TS* __restrict__ xo,
-                                                           TS* __restrict__ mo, int64_t n, KParams p, KExt ext,
+                                                           TS* __restrict__ mo, int64_t n, const KParams p_arg, KExt ext,
                                                            const dpm_stage* dyn, const int32_t* skip) {
-  if (skip && *skip) return;
-  if (dyn) apply_dyn(p, dyn);
+  if constexpr (DYN) {
+    if (*skip) return;
+  }
+  KParams p_dyn;  // (a copy of the argument, even a const one, would leave part of it in memory -> LDS)
+  if constexpr (DYN) p_dyn = params_from_dyn(p_arg, dyn);
+  const KParams& p = DYN ? p_dyn : p_arg;
   const bool need_xe = (p.flags & DPM_F_TO_X0) || p.model_type == DPM_MODEL_X_START || p.model_type == DPM_MODEL_V;
   const bool store_m = p.flags & DPM_F_STORE_M;
   const bool nx = form_needs_x<FORM_RT>(p), nh1 = form_needs_h1<FORM_RT>(p), nh2 = form_needs_h2<FORM_RT>(p);
@@ -2234,12 +2305,21 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
     //   everything else goes through the one-element-per-lane kernel.
     constexpr bool COMBO_BUILT = !XE || FORM == DPM_FORM_TWO || FORM == DPM_FORM_SS3T;
     constexpr bool SPEC_BUILT = FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3;
-    if (!vec || !COMBO_BUILT) {
+    // device-resident coefficients (adaptive solver): DYN kernels exist for the forms it launches -- first-order,
+    // second-order and the singlestep-3 'taylor' combination -- without the KExt extensions; anything else takes the
+    // one-element-per-lane kernel
+    constexpr bool DYN_BUILT = COMBO_BUILT && (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_SS3T);
+    const bool dyn_vec = stream.dyn && DYN_BUILT && !use_ext;
+    if (!vec || !COMBO_BUILT || (stream.dyn && !dyn_vec)) {
       int64_t blocks = (b->n + 255) / 256;
       const int64_t cap = (int64_t)n_cu * 16;
       if (blocks > cap) blocks = cap;
-      launch(stage_kernel_scalar<TS, TE>, dim3((unsigned)blocks), dim3(256), 0, stream, x, xe ? xe : x, e0, e1, g, h1, h2, xo,
-             mo, b->n, p, ext, stream.dyn, stream.skip);
+      if (stream.dyn)
+        launch(stage_kernel_scalar<TS, TE, true>, dim3((unsigned)blocks), dim3(256), 0, stream, x, xe ? xe : x, e0, e1, g, h1,
+               h2, xo, mo, b->n, p, ext, stream.dyn, stream.skip);
+      else
+        launch(stage_kernel_scalar<TS, TE>, dim3((unsigned)blocks), dim3(256), 0, stream, x, xe ? xe : x, e0, e1, g, h1, h2, xo,
+               mo, b->n, p, ext, stream.dyn, stream.skip);
     } else if constexpr (COMBO_BUILT) {
       const bool noise = SPEC_BUILT && !stream.dyn && st->model_type == DPM_MODEL_NOISE &&
                          (!(st->flags & DPM_F_TO_X0) || div_invariant_ok(st->alpha_e));
@@ -2256,7 +2336,11 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
 #define DPM_LAUNCH(SPEC_, U_, NT_, EXT_)                                                                             \
   launch(stage_kernel<TS, TE, FORM, GUIDE, XE, SPEC_, U_, NT_, EXT_>, grid_for(U_), dim3(256), 0, stream, x, xe, e0, e1, \
          g, h1, h2, xo, mo, b->n, p, ext, stream.dyn, stream.skip)
-      if (use_ext) {
+      if (dyn_vec) {
+        if constexpr (DYN_BUILT)
+          launch(stage_kernel<TS, TE, FORM, GUIDE, XE, SPEC_GENERIC, 1, DefNT<TS>::value, false, true>, grid_for(1), dim3(256),
+                 0, stream, x, xe, e0, e1, g, h1, h2, xo, mo, b->n, p, ext, stream.dyn, stream.skip);
+      } else if (use_ext) {
         // (tiles per iteration, nt mask) of the inputs-from-HBM table below; x_out stays cacheable (it is the next
         // network input), so bit 1 is never set
         constexpr int EU = (sizeof(TS) == 4 && sizeof(TE) == 2) ? 2 : 1;
@@ -2352,11 +2436,14 @@ int launch_multi_spec(const dpm_stage* st, const dpm_buffers* bs, int n_req, con
   auto go = [&](auto kern, int u) {
     const int64_t spr = (ntiles + u - 1) / u;
     int64_t blocks = spr * n_req;
+    const bool remap = tn.multi_xcd_remap < 0 ? sizeof(TS) == 2 : tn.multi_xcd_remap != 0;
+    const uint32_t span = remap ? (uint32_t)((blocks + 7) / 8) : 0u;
+    if (span) blocks = (int64_t)span * 8;
     if (tn.multi_blocks_per_cu > 0) {  // tuning hook: cap the grid, workgroups loop over the super-tiles
       const int64_t cap = (int64_t)n_cu * tn.multi_blocks_per_cu;
       if (blocks > cap) blocks = cap;
     }
-    launch(kern, dim3((unsigned)blocks), dim3(256), 0, c, tab, n, (uint32_t)n_req, (uint32_t)spr, p);
+    launch(kern, dim3((unsigned)blocks), dim3(256), 0, c, tab, n, (uint32_t)n_req, (uint32_t)spr, p, span);
   };
   constexpr int DU = MultiShape<TS, TE>::U, DN = MultiShape<TS, TE>::NT;
 #ifdef DPM_TUNING_VARIANTS  // tools/tune.py multi: every (tiles per iteration, nt mask) of the 2M kernel

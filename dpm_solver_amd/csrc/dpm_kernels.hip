@@ -317,19 +317,36 @@ struct AdaptiveStatic {
   double scale;
 };
 
-// fill the stage records of one iteration s -> t (order 2: DPM-Solver-12, order 3: DPM-Solver-23, ref :976-993)
+// the stage records of one iteration s -> t (order 2: DPM-Solver-12, order 3: DPM-Solver-23, ref :976-993), in three
+// independent pieces so that the device can run them on different wavefronts: the lower-order update's stages, the
+// higher-order update's, and the prologue scalars (alpha, sigma, model time, guidance) of one stage
 template <class S>
-DPM_HD void adaptive_plan(const S* sv, const AdaptiveStatic& c, int order, float s, float t, dpm_stage* st) {
+DPM_HD void adaptive_plan_lower(const S* sv, const AdaptiveStatic& c, int order, float s, float t, dpm_stage* st) {
   if (order == 2) {
     dpmc::singlestep_fill(sv, c.algo, c.solver, 1, s, t, 0., 0., 0, &st[0]);
     st[1] = st[0];
+  } else {
+    dpmc::singlestep_fill(sv, c.algo, c.solver, 2, s, t, 1. / 3., 0., 0, &st[0]);
+  }
+}
+template <class S>
+DPM_HD void adaptive_plan_higher(const S* sv, const AdaptiveStatic& c, int order, float s, float t, dpm_stage* st) {
+  if (order == 2) {
     dpmc::singlestep_fill(sv, c.algo, c.solver, 2, s, t, 0.5, 0., 0, &st[2]);
     st[4] = st[3];
   } else {
-    dpmc::singlestep_fill(sv, c.algo, c.solver, 2, s, t, 1. / 3., 0., 0, &st[0]);
     dpmc::singlestep_fill(sv, c.algo, c.solver, 3, s, t, 1. / 3., 2. / 3., 0, &st[2]);
   }
-  for (int i = 0; i < 5; ++i) dpmc::set_prologue(sv, st[i].t_eval, c.model_type, c.guidance, c.scale, &st[i]);
+}
+template <class S>
+DPM_HD void adaptive_plan_prologue(const S* sv, const AdaptiveStatic& c, dpm_stage* st) {
+  dpmc::set_prologue(sv, st->t_eval, c.model_type, c.guidance, c.scale, st);
+}
+template <class S>
+DPM_HD void adaptive_plan(const S* sv, const AdaptiveStatic& c, int order, float s, float t, dpm_stage* st) {
+  adaptive_plan_lower(sv, c, order, s, t, st);
+  adaptive_plan_higher(sv, c, order, s, t, st);
+  for (int i = 0; i < 5; ++i) adaptive_plan_prologue(sv, c, &st[i]);
 }
 
 __global__ void adaptive_reset_kernel(AdaptiveDev* S, float s, float lambda_s, float lambda_0, float h, float t_0,
@@ -352,11 +369,14 @@ __global__ void adaptive_reset_kernel(AdaptiveDev* S, float s, float lambda_s, f
   for (int i = 0; i < 4; ++i) __hip_atomic_store(&status[i], i == 0 ? S->done : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// decision on the previous iteration + plan of the next one (one thread), then the time vectors of the network calls
+// decision on the previous iteration (one thread), plan of the next one -- double-precision exp / log / expm1 chains,
+// spread over the block's four wavefronts: lower-order stages on one, higher-order stages on another, then the five
+// prologues round-robin --, then the time vectors of the network calls (all threads)
 __global__ __launch_bounds__(256) void adaptive_begin_kernel(AdaptiveDev* S, dpmc::SchedView sv, AdaptiveStatic c,
                                                              float* e_dev, float* tvec, int64_t tv_len, int32_t* status) {
   __shared__ float te[3], ti[3];
   __shared__ int live;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (threadIdx.x == 0) {
     if (S->iters > 0 && !S->done) {
       const float E = *e_dev;
@@ -379,15 +399,25 @@ __global__ __launch_bounds__(256) void adaptive_begin_kernel(AdaptiveDev* S, dpm
     }
     *e_dev = 0.f;
     live = !S->done;
-    if (live) {
-      const float t = sv.inv_lambda(S->lambda_s + S->h);  // ref :996
-      S->t = t;
-      adaptive_plan(&sv, c, S->order, S->s, t, S->st);
+    if (live) S->t = sv.inv_lambda(S->lambda_s + S->h);  // ref :996
+  }
+  __syncthreads();
+  if (live && lane == 0) {
+    if (wave == 0) adaptive_plan_lower(&sv, c, S->order, S->s, S->t, S->st);
+    if (wave == 1) adaptive_plan_higher(&sv, c, S->order, S->s, S->t, S->st);
+  }
+  __syncthreads();
+  if (live && lane == 0) {
+    adaptive_plan_prologue(&sv, c, &S->st[wave]);
+    if (wave == 0) adaptive_plan_prologue(&sv, c, &S->st[4]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (live)
       for (int j = 0; j < 3; ++j) {
         te[j] = S->st[2 + j].t_eval;
         ti[j] = S->st[2 + j].t_input;
       }
-    }
     // the verdict as of THIS begin, by its index: a host that looks at begin #j (after waiting for it) reads the same
     // value on every rank of a sharded run, however far its device has run ahead
     __hip_atomic_store(&status[8 + (S->iters & 31)], S->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -820,6 +850,7 @@ extern "C" int dpm_tuning_set(int knob, int value) {
     case DPM_TUNE_ASSUME_RESIDENT: g_tuning.assume_resident = value != 0; return DPM_OK;
     case DPM_TUNE_MULTI_FUSE: g_tuning.multi_fuse = value != 0; return DPM_OK;
     case DPM_TUNE_CLUSTER_IN_GRAPH: g_tuning.cluster_in_graph = value != 0; return DPM_OK;
+    case DPM_TUNE_MULTI_XCD_REMAP: g_tuning.multi_xcd_remap = value < 0 ? -1 : (value != 0); return DPM_OK;
     case DPM_TUNE_CLUSTER_ONE_HOP: g_tuning.cluster_one_hop = value < 0 ? 0 : (value > 2 ? 2 : value); return DPM_OK;
     case DPM_TUNE_MULTI_BLOCKS_PER_CU:
       if (value < 0 || value > 4096) return dpm_set_error(DPM_ERR_ARG, "multi_blocks_per_cu must be in 0..4096");
@@ -837,6 +868,7 @@ extern "C" int dpm_tuning_get(int knob) {
     case DPM_TUNE_ASSUME_RESIDENT: return g_tuning.assume_resident;
     case DPM_TUNE_MULTI_FUSE: return g_tuning.multi_fuse;
     case DPM_TUNE_CLUSTER_IN_GRAPH: return g_tuning.cluster_in_graph;
+    case DPM_TUNE_MULTI_XCD_REMAP: return g_tuning.multi_xcd_remap;
     case DPM_TUNE_CLUSTER_ONE_HOP: return g_tuning.cluster_one_hop;
     case DPM_TUNE_MULTI_BLOCKS_PER_CU: return g_tuning.multi_blocks_per_cu;
   }

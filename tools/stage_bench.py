@@ -217,6 +217,32 @@ def main():
             res[mode] = (time.perf_counter() - t0) / 50 * 1e6
         loop.append((label, res["eager"], res["graph"]))
 
+    # adaptive solver (DPM-Solver-12 / -23): host-side control loop (one .item() per iteration) vs the controller on the device
+    adaptive = []
+    if not ONLY:
+        import contextlib
+        import io
+        lin = D.NoiseScheduleVP("linear")
+        for shape in ((8, 4, 64, 64), (256, 4, 64, 64)):
+            xa = torch.randn(shape, device=DEV)
+            for order in (2, 3):
+                row = [str(shape), order]
+                for on_dev in (False, True):
+                    s = D.DPM_Solver(D.model_wrapper(lambda x, t: x * 0.5, lin), lin, algorithm_type="dpmsolver")
+                    s.adaptive_on_device = on_dev
+                    buf = io.StringIO()
+                    with contextlib.redirect_stdout(buf):
+                        for _ in range(3):
+                            s.sample(xa, method="adaptive", order=order, t_end=1e-3)
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(10):
+                            s.sample(xa, method="adaptive", order=order, t_end=1e-3)
+                        torch.cuda.synchronize()
+                    nfe = int(buf.getvalue().strip().splitlines()[-1].split()[-1])
+                    row += [(time.perf_counter() - t0) / 10 * 1e3, nfe]
+                adaptive.append(row)
+
     hdr = ("| scenario | kernel (form guidance flags) | launches | alg. MB | back-to-back us | GB/s | % of 8 TB/s "
            "| caches evicted us | GB/s | % of 8 TB/s |\n|---|---|---|---|---|---|---|---|---|---|")
     lines = [hdr]
@@ -238,8 +264,14 @@ def main():
                     "| workload | eager us / trajectory | captured us / trajectory |\n|---|---|---|\n")
             for label, a, b in loop:
                 f.write("| %s | %.1f | %.1f |\n" % (label, a, b))
+            f.write("\n## Adaptive solver, frozen network x*0.5, 'linear' schedule, t_end = 1e-3: wall per sample() call\n\n"
+                    "| state | order | host control loop ms | NFE | controller on the device ms | NFE |\n|---|---|---|---|---|---|\n")
+            for shp, order, th, nh, td, nd in adaptive:
+                f.write("| %s | %d | %.3f | %d | %.3f | %d |\n" % (shp, order, th, nh, td, nd))
     for label, a, b in loop:
         print("python loop %s: eager %.1f us, captured %.1f us" % (label, a, b))
+    for shp, order, th, nh, td, nd in adaptive:
+        print("adaptive %s order %d: host loop %.3f ms (nfe %d), device controller %.3f ms (nfe %d)" % (shp, order, th, nh, td, nd))
 
 
 if __name__ == "__main__":
