@@ -557,7 +557,9 @@ __device__ __forceinline__ void stage_tiles(const TS* __restrict__ x, const TS* 
   const int64_t gps = EXT ? ext.per_sample / EPT : 1, sgroups = EXT ? ext.eps_stride / EPT : 0;
   const int64_t mgroups = EXT ? ext.mask_period / EPT : 1;
   const bool small = ngroups < (int64_t)0x7fffffff;  // 32-bit index arithmetic is enough (n < 2^34 elements)
-  const bool can_split = SPLIT && (!EXT || (!ext.eps_stride && !mask));
+  // the split layout needs every tensor of the launch indexed by whole tiles: no per-sample stride, and a mask whose
+  // period is a multiple of the 2048-element tile ([64,64] and larger masks)
+  const bool can_split = SPLIT && (!EXT || (!ext.eps_stride && (!mask || ext.mask_period % (256 * EPT) == 0)));
   float vx[U][EPT], vxe[U][EPT], v0[U][EPT], v1[U][EPT], vg[U][EPT], vh1[U][EPT], vh2[U][EPT];
   float vm[EXT ? U : 1][EPT], va[EXT ? U : 1][EPT], vb[EXT ? U : 1][EPT];
   // Lanes past the end of the last tile load a clamped (valid) group and only skip the store: loads and arithmetic
@@ -584,10 +586,18 @@ __device__ __forceinline__ void stage_tiles(const TS* __restrict__ x, const TS* 
     if (FT::needs_h1) load_tile<(NT & 1) != 0>(h1, gi, split, vh1[u]);
     if (FT::needs_h2) load_tile<(NT & 1) != 0>(h2, gi, split, vh2[u]);
     if (EXT && mask) {
-      const int64_t gm = small ? (int64_t)((uint32_t)gi % (uint32_t)mgroups) : gi % mgroups;
-      load_pack<false>(mask, gm, vm[u]);
-      load_pack<false>(ba, gi, va[u]);
-      if (bb) load_pack<(NT & 1) != 0>(bb, gi, vb[u]);
+      if (split) {  // mask, known image and noise in the state's split layout: whole 1 KiB runs per access
+        const int64_t mtiles = mgroups / 256;
+        const int64_t mt = small ? (int64_t)((uint32_t)(t0 + u) % (uint32_t)mtiles) : (t0 + u) % mtiles;
+        load_tile<false>(mask, mt * 256 + threadIdx.x, true, vm[u]);
+        load_tile<(NT & 1) != 0>(ba, gi, true, va[u]);
+        if (bb) load_tile<(NT & 1) != 0>(bb, gi, true, vb[u]);
+      } else {
+        const int64_t gm = small ? (int64_t)((uint32_t)gi % (uint32_t)mgroups) : gi % mgroups;
+        load_pack<false>(mask, gm, vm[u]);
+        load_pack<false>(ba, gi, va[u]);
+        if (bb) load_pack<(NT & 1) != 0>(bb, gi, vb[u]);
+      }
     }
   }
   // the model values of all U tiles; SPEC_GENERIC picks the prologue mode here, once per workgroup iteration

@@ -160,6 +160,18 @@ def main():
     s = D.DPM_Solver(D.model_wrapper(lambda x, t, cc: e2, sd, guidance_type="classifier-free", condition=c,
                                      unconditional_condition=c, guidance_scale=7.5), sd)
     rows += run("SD 2M++ cfg, f32 state / f16 eps", s, torch.randn(shape, device=DEV), steps=20, order=2)
+    # the same two at cfg2 size ([256,4,64,64]): large enough for the two-tile variant / not bounded by launch ramp-up
+    shape = (256, 4, 64, 64)
+    e2, = frozen((512, 4, 64, 64), torch.float16)
+    c = torch.zeros(256, device=DEV)
+    s = D.DPM_Solver(D.model_wrapper(lambda x, t, cc: e2, sd, guidance_type="classifier-free", condition=c,
+                                     unconditional_condition=c, guidance_scale=7.5), sd)
+    rows += run("cfg2-size 2M++ cfg, f32 state / f16 eps", s, torch.randn(shape, device=DEV), steps=20, order=2)
+    del e2
+    e, = frozen(shape, torch.float32)
+    mb = D.MaskBlend(sd, torch.rand(64, 64, device=DEV), x0=torch.randn(shape, device=DEV), noise=torch.randn(shape, device=DEV))
+    s = D.DPM_Solver(D.model_wrapper(lambda x, t: e, sd), sd, correcting_xt_fn=mb)
+    rows += run("cfg2-size inpaint 2M++ MaskBlend f32", s, torch.randn(shape, device=DEV), steps=20, order=2)
     # cfg3: DPM-Solver-3 singlestep, 15 NFE, [64,3,256,256] fp32, CFG 7.5
     shape = (64, 3, 256, 256)
     e2, = frozen((128, 3, 256, 256), torch.float32)
