@@ -50,6 +50,7 @@ struct Tuning {
   int cluster_one_hop = 1;  // 0: clusters always take the general route (merged histograms, several barriers)
   int multi_xcd_remap = -1; // fused launch maps workgroup b to tile (b % 8) * span + b / 8 (one contiguous eighth of the
                             // tile space per XCD): 1 on, 0 off, -1 per dtype (on for 2-byte states: +1.4 %; fp32: -3 %)
+  int thr_stagger_ticks = 0; // thresholding: 100 MHz ticks the second dispatch round is held back (see stage_thresh_kernel)
   int multi_blocks_per_cu = 0;  // grid cap of the fused launch in workgroups per CU; 0 = one super-tile per workgroup
 };
 extern Tuning g_tuning;     // defined in dpm_kernels.hip
@@ -808,8 +809,14 @@ constexpr int THR_CAP = 4096;                // candidates (elements sharing the
 constexpr int THR_GCAP = THR_NB;             // cluster-wide candidates exchanged through the level-1 histogram's words
 // single-exchange route of a cluster (cluster_select_once): every workgroup publishes the elements of its chunk that
 // can still be among the sample's K largest into its own slot of the workspace -- header + values, every word tagged
+#ifndef DPM_THR_ROWS
+#define DPM_THR_ROWS 2
+#endif
+constexpr int THR_ROWS = DPM_THR_ROWS;  // tile rows a thread keeps in flight in the streaming phases of the thresholding kernel
+constexpr int THR_KMAX = 256;                // largest cluster the single-exchange route serves
+constexpr int THR_MISC = 32 + 2 * THR_KMAX;  // scalar LDS words of the thresholding kernel (see stage_thresh_kernel)
 constexpr int THR_SLOT_CAP = 256;            // values one workgroup may publish
-constexpr int THR_SLOT_HDR = 8;              // [0] tag | count (or overflow), [1] tag | bound
+constexpr int THR_SLOT_HDR = 8;              // [0] tag | count (or overflow), [1] tag | bound, [2] tag | chunk maximum
 constexpr int THR_SLOTW = THR_SLOT_CAP + THR_SLOT_HDR;
 constexpr uint32_t THR_TAG = 0x80000000u;    // |x0| bit patterns have bit 31 clear: a tagged word is never 0
 constexpr uint32_t THR_OVERFLOW = 0x40000000u;
@@ -831,6 +838,8 @@ struct ThrParams {
   int32_t fastdiv; // 1: noise-prediction network + eps -> x0 with a divisor that passes div_invariant_ok (see div_by_alpha)
   int32_t quota;   // > 0: single-exchange cluster route; values beyond this rank of the per-thread maxima are not published
   int32_t kbig;    // K = per_sample - lo (the wanted element is the K-th largest of the sample)
+  int32_t stagger_ticks; // > 0: 100 MHz ticks the second dispatch round waits before its first sample
+  int32_t stagger_span;  // workgroups per dispatch round (the CU count)
   int32_t slot_cap; // values per workgroup slot: a power of two <= THR_SLOT_CAP with k * slot_cap <= THR_CAP
   int32_t slot_shift; // log2(slot_cap)
   int32_t debug_reject; // testing: run the single-exchange select but always take the general route afterwards
@@ -1055,15 +1064,11 @@ __device__ __forceinline__ uint32_t wave_max_to_lane63(uint32_t v) {
 
 // nc <= T candidates in cand[]: every thread counts the candidates smaller than its own one; the element of ascending
 // rank r is the largest candidate with at most r smaller ones.  misc[6] <- rank-th, misc[7] <- (rank+1)-th (or the
-// largest candidate when there is none).  One pass, two barriers -- instead of three histogram levels + a min search.
+// largest candidate when there is none).  One pass -- instead of three histogram levels + a min search.
+// rank_count expects misc[6] = misc[7] = 0 and 32 sentinels (0xffffffff: never smaller than anything, the list becomes a
+// multiple of 32) behind the list, both visible to the workgroup (a barrier behind the writes); one barrier at its end.
 template <int T>
-__device__ __forceinline__ void rank_select(uint32_t* cand, uint32_t nc, uint32_t rank, uint32_t* misc, int tid) {
-  if (tid == 0) {
-    misc[6] = 0u;
-    misc[7] = 0u;
-  }
-  if (tid < 32) cand[nc + tid] = 0xffffffffu;  // sentinels (never smaller than anything): the list becomes a multiple of 32
-  __syncthreads();
+__device__ __forceinline__ void rank_count(const uint32_t* cand, uint32_t nc, uint32_t rank, uint32_t* misc, int tid) {
   if ((uint32_t)(tid & ~63) < nc) {  // wavefronts beyond the list have nothing to do
     const uint32_t my = (uint32_t)tid < nc ? cand[tid] : 0xffffffffu;
     uint32_t lt = 0u;
@@ -1083,6 +1088,17 @@ __device__ __forceinline__ void rank_select(uint32_t* cand, uint32_t nc, uint32_
     }
   }
   __syncthreads();
+}
+
+template <int T>
+__device__ __forceinline__ void rank_select(uint32_t* cand, uint32_t nc, uint32_t rank, uint32_t* misc, int tid) {
+  if (tid == 0) {
+    misc[6] = 0u;
+    misc[7] = 0u;
+  }
+  if (tid < 32) cand[nc + tid] = 0xffffffffu;
+  __syncthreads();
+  rank_count<T>(cand, nc, rank, misc, tid);
 }
 
 // workgroup-wide exclusive prefix sum of one value per thread (wavefront scan + the wavefront totals through misc[16..]);
@@ -1151,51 +1167,36 @@ __device__ __forceinline__ void list_select(const uint32_t* cand, uint32_t nc, u
 }
 
 // The same for a list whose values spread over many fine digits (the union of a cluster's candidates: the upper tail of
-// the sample): ONE histogram level over 14-bit digits relative to the list's maximum (1.5 % wide bins), then rank
-// counting among the handful of members of the selected bin -- ~1.4 us instead of 3 us of rank counting over the
-// whole list (340 entries) or three histogram levels.  Falls back to list_select when the bin is crowded (plateaus).
-// hist all zero on entry and exit.
+// the sample): ONE histogram level over 14-bit digits relative to `umax` (any value >= the list's maximum; 1.5 % wide
+// bins), then rank counting among the handful of members of the selected bin -- ~1.4 us instead of 3 us of rank counting
+// over the whole list (340 entries) or three histogram levels.  Falls back to list_select when the bin is crowded
+// (plateaus).  Entry: hist all zero, misc[13] = 0x7fffffff, misc[14] = 0, all visible (a barrier behind the writes).
+// Exit: returns true when hist[0 .. T + 32) may hold leftovers (the bin's members), false when hist is all zero.
 template <int T>
-__device__ __forceinline__ void union_select(uint32_t* cand, uint32_t nc, uint32_t rank, uint32_t* hist, uint32_t* misc,
-                                             int tid, uint32_t& a, uint32_t& b) {
+__device__ __forceinline__ bool union_select(const uint32_t* cand, uint32_t nc, uint32_t rank, uint32_t umax, uint32_t* hist,
+                                             uint32_t* misc, int tid, uint32_t& a, uint32_t& b) {
   constexpr int PER = THR_CAP / T;
   const int lane = tid & 63;
-  uint32_t v[PER];
-  uint32_t vmax = 0u;
+  const uint32_t top = umax >> 17;
+  const uint32_t dbase = top > (uint32_t)(THR_NB - 1) ? top - (uint32_t)(THR_NB - 1) : 0u;
+  uint32_t v[PER], d[PER];
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
     const uint32_t i = (uint32_t)tid + (uint32_t)j * T;
     v[j] = i < nc ? cand[i] : 0u;
-    vmax = v[j] > vmax ? v[j] : vmax;
-  }
-  if (tid == 0) {
-    misc[12] = 0u;           // list maximum
-    misc[13] = 0x7fffffffu;  // smallest value above the selected bin
-    misc[14] = 0u;           // members of the selected bin appended so far
-  }
-  __syncthreads();
-  {
-    const uint32_t wm = wave_max_to_lane63(vmax);
-    if (lane == 63 && wm) atomicMax(&misc[12], wm);
-  }
-  __syncthreads();
-  const uint32_t top = misc[12] >> 17;
-  const uint32_t dbase = top > (uint32_t)(THR_NB - 1) ? top - (uint32_t)(THR_NB - 1) : 0u;
-  uint32_t d[PER];
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
     const uint32_t dr = v[j] >> 17;
     d[j] = dr > dbase ? dr - dbase : 0u;
-    if ((uint32_t)tid + (uint32_t)j * T < nc) atomicAdd(&hist[d[j]], 1u);
+    if (i < nc) atomicAdd(&hist[d[j]], 1u);
   }
   __syncthreads();
   locate_bin<T>(hist, misc, rank, tid);
   const uint32_t bin = misc[0], r_in = misc[1], cnt_bin = misc[2];
   if (cnt_bin > (uint32_t)T) {  // crowded bin: the general list select (hist is zero again)
     list_select<T>(cand, nc, rank, hist, misc, tid, a, b);
-    return;
+    return false;
   }
-  // members of the bin -> hist[0..cnt_bin) (the zeroed histogram doubles as the buffer); minimum of the higher bins
+  // members of the bin -> hist[0..cnt_bin) (the zeroed histogram doubles as the buffer) + rank_count's sentinels and
+  // zeroed result words; minimum of the higher bins
   uint32_t above = 0x7fffffffu;
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
@@ -1204,6 +1205,11 @@ __device__ __forceinline__ void union_select(uint32_t* cand, uint32_t nc, uint32
       if (d[j] > bin && v[j] < above) above = v[j];
     }
   }
+  if (tid < 32) hist[cnt_bin + tid] = 0xffffffffu;
+  if (tid == 32) {
+    misc[6] = 0u;
+    misc[7] = 0u;
+  }
 #pragma unroll
   for (int dd = 32; dd >= 1; dd >>= 1) {
     const uint32_t o = __shfl_xor(above, dd, 64);
@@ -1211,13 +1217,10 @@ __device__ __forceinline__ void union_select(uint32_t* cand, uint32_t nc, uint32
   }
   if (lane == 0 && above != 0x7fffffffu) atomicMin(&misc[13], above);
   __syncthreads();
-  rank_select<T>(hist, cnt_bin, r_in, misc, tid);
+  rank_count<T>(hist, cnt_bin, r_in, misc, tid);
   a = misc[6];
   b = r_in + 1u < cnt_bin ? misc[7] : (misc[13] != 0x7fffffffu ? misc[13] : a);
-  __syncthreads();
-  if ((uint32_t)tid < cnt_bin + 32u) hist[tid] = 0u;  // members + rank_select's sentinels
-  if (T < 544 && (uint32_t)tid + T < cnt_bin + 32u) hist[tid + T] = 0u;
-  __syncthreads();
+  return true;
 }
 
 // Single-exchange select of a cluster (k workgroups own one sample).  The wanted order statistics are the K-th and
@@ -1250,13 +1253,10 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
   const int lane = tid & 63;
   const uint32_t K = (uint32_t)tp.kbig;
   const uint32_t cap = (uint32_t)tp.slot_cap;
-  // 1. the chunk's maximum -> digit base
-  {
-    const uint32_t wm = wave_max_to_lane63(has ? m1 : 0u);
-    if (lane == 63 && wm) atomicMax(&misc[8], wm);
-  }
-  __syncthreads();
-  const uint32_t top = misc[8] >> 17;
+  uint32_t* sc = misc + 32;  // [2 k], k <= THR_KMAX: counts and list offsets of the k slots
+  // 1. the chunk's maximum (misc[8]: the kernel reduces it on the way out of phase 1) -> digit base
+  const uint32_t cmax = misc[8];
+  const uint32_t top = cmax >> 17;
   const uint32_t dbase = top > (uint32_t)(THR_NB - 1) ? top - (uint32_t)(THR_NB - 1) : 0u;
   auto digit = [&](uint32_t u) {
     const uint32_t d = u >> 17;
@@ -1293,7 +1293,7 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
     }
   }
   __syncthreads();
-  // 4. publish: values, then the header (bound, count); every word carries the tag
+  // 4. publish: values, then the header (count, bound, chunk maximum); every word carries the tag
   const uint32_t ncl = misc[4];
   const bool over = ncl > cap;
   uint32_t* mine_slot = slots + (size_t)c * THR_SLOTW;
@@ -1302,6 +1302,7 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
       __hip_atomic_store(&mine_slot[THR_SLOT_HDR + i], cand[i] | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (tid == 0) {
     const uint32_t bound = bin_lo ? (bin_lo + dbase) << 17 : 0u;  // smallest |x0| with that digit; digit 0 = everything
+    __hip_atomic_store(&mine_slot[2], cmax | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&mine_slot[1], bound | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&mine_slot[0], (over ? THR_OVERFLOW : ncl) | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -1321,45 +1322,72 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
       w[j] = __hip_atomic_load(slots + (size_t)(q >> shift) * THR_SLOTW + THR_SLOT_HDR + (q & (W - 1u)), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
   }
-  uint32_t h0 = THR_TAG, h1 = THR_TAG;
-  if ((uint32_t)tid < k) {
-    const uint32_t* sl = slots + (size_t)tid * THR_SLOTW;
-    uint32_t spins = 0;
-    h0 = __hip_atomic_load(&sl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    h1 = __hip_atomic_load(&sl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while ((!(h0 & THR_TAG) || !(h1 & THR_TAG)) && !misc[30]) {
-      __builtin_amdgcn_s_sleep(1);
-      if (!(h0 & THR_TAG)) h0 = __hip_atomic_load(&sl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (!(h1 & THR_TAG)) h1 = __hip_atomic_load(&sl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (++spins > THR_SPIN_LIMIT) {
-        misc[30] = 1u;
-        raise_fault(tp.fault);
+  {  // the headers: counts, list offsets, total, largest bound, maximum of the sample
+    const bool own = (uint32_t)tid < k;
+    uint32_t h0 = THR_TAG, h1 = THR_TAG, h2 = THR_TAG;
+    if (own) {
+      const uint32_t* sl = slots + (size_t)tid * THR_SLOTW;
+      uint32_t spins = 0;
+      h0 = __hip_atomic_load(&sl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      h1 = __hip_atomic_load(&sl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      h2 = __hip_atomic_load(&sl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while ((!(h0 & THR_TAG) || !(h1 & THR_TAG) || !(h2 & THR_TAG)) && !misc[30]) {
+        __builtin_amdgcn_s_sleep(1);
+        if (!(h0 & THR_TAG)) h0 = __hip_atomic_load(&sl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(h1 & THR_TAG)) h1 = __hip_atomic_load(&sl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(h2 & THR_TAG)) h2 = __hip_atomic_load(&sl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spins > THR_SPIN_LIMIT) {
+          misc[30] = 1u;
+          raise_fault(tp.fault);
+        }
       }
     }
-  }
-  DPM_R1STAMP(10)
-  const bool bad = (uint32_t)tid < k && (!(h0 & THR_TAG) || !(h1 & THR_TAG) || (h0 & THR_OVERFLOW));
-  const uint32_t cnt_t = ((uint32_t)tid < k && !bad) ? (h0 & 0xffffu) : 0u;
-  const uint32_t off_t = block_excl_scan<T>(cnt_t, misc, tid);
-  if ((uint32_t)tid < k) {
-    hist[tid] = cnt_t;
-    hist[k + tid] = off_t;
-  }
-  {
-    const uint32_t wb = wave_max_to_lane63((uint32_t)tid < k ? (h1 & ~THR_TAG) : 0u);
-    if (lane == 63 && wb) atomicMax(&misc[9], wb);
-    if (__ballot(bad) && lane == 0) misc[10] = 1u;
+    DPM_R1STAMP(10)
+    const bool bad = own && (!(h0 & THR_TAG) || !(h1 & THR_TAG) || !(h2 & THR_TAG) || (h0 & THR_OVERFLOW));
+    const uint32_t cnt_t = (own && !bad) ? (h0 & 0xffffu) : 0u;
+    const uint32_t bnd_t = own ? (h1 & ~THR_TAG) : 0u, max_t = own ? (h2 & ~THR_TAG) : 0u;
+    if (k <= 64u) {  // the usual cluster sizes: wavefront 0 holds every header -- no barrier until the results are out
+      if (tid < 64) {
+        const uint32_t incl = wave_incl_scan(cnt_t);
+        if (own) {
+          sc[tid] = cnt_t;
+          sc[k + tid] = incl - cnt_t;
+        }
+        const uint32_t wb = wave_max_to_lane63(bnd_t), wx = wave_max_to_lane63(max_t);
+        const bool anybad = __ballot(bad) != 0;
+        if (lane == 63) {
+          misc[24] = incl;  // entries of the union
+          misc[9] = wb;     // largest bound
+          misc[12] = wx;    // maximum of the sample (digit base of union_select)
+          misc[10] = anybad ? 1u : 0u;
+        }
+      }
+    } else {  // misc[9], [10], [12] start at zero (sample start)
+      const uint32_t off_t = block_excl_scan<T>(cnt_t, misc, tid);  // misc[24] <- total
+      if (own) {
+        sc[tid] = cnt_t;
+        sc[k + tid] = off_t;
+      }
+      const uint32_t wb = wave_max_to_lane63(bnd_t), wx = wave_max_to_lane63(max_t);
+      if (lane == 63 && wb) atomicMax(&misc[9], wb);
+      if (lane == 63 && wx) atomicMax(&misc[12], wx);
+      if (__ballot(bad) && lane == 0) misc[10] = 1u;
+    }
+    if (tid == 0) {
+      misc[13] = 0x7fffffffu;  // union_select: smallest value above the selected bin
+      misc[14] = 0u;           //               members of the selected bin appended so far
+    }
   }
   __syncthreads();
-  const uint32_t total = misc[24], bound_max = misc[9];
-  bool ok = !misc[10] && total >= K && total <= (uint32_t)THR_CAP;
+  const uint32_t total = misc[24], bound_max = misc[9], umax = misc[12];
+  const bool ok = !misc[10] && total >= K && total <= (uint32_t)THR_CAP;
   // 6. the union -> cand[]: entry i of slot s goes to off[s] + i
   if (ok) {
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
       const uint32_t q = (uint32_t)tid + (uint32_t)j * T;
       const uint32_t sl = q >> shift, i = q & (W - 1u);
-      if (q < words && i < hist[sl]) {
+      if (q < words && i < sc[sl]) {
         const uint32_t* src = slots + (size_t)sl * THR_SLOTW + THR_SLOT_HDR + i;
         uint32_t spins = 0;
         while (!(w[j] & THR_TAG) && !misc[30]) {
@@ -1370,44 +1398,43 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
             raise_fault(tp.fault);
           }
         }
-        cand[hist[k + sl] + i] = w[j] & ~THR_TAG;
+        cand[sc[k + sl] + i] = w[j] & ~THR_TAG;
       }
     }
   }
   __syncthreads();
   DPM_R1STAMP(11)
-  // the scratch words of the histogram go back to zero (the general route and the next sample expect that)
-  if ((uint32_t)tid < k) {
-    hist[tid] = 0u;
-    hist[k + tid] = 0u;
-  }
-  if (tid == 0) {
-    misc[4] = 0u;
-    misc[8] = 0u;
-    misc[9] = 0u;
-    misc[10] = 0u;
-  }
-  __syncthreads();
-  if (!ok || misc[30]) return false;
   // 7. K-th and (K-1)-th largest of the union
-  uint32_t a, b;
-  const uint32_t rank = total - K;  // ascending
-  if (total <= 64u) {
-    rank_select<T>(cand, total, rank, misc, tid);
-    a = misc[6];
-    b = rank + 1u < total ? misc[7] : a;
-    __syncthreads();
-  } else {
-    union_select<T>(cand, total, rank, hist, misc, tid, a, b);
-  }
-  a_out = a;
-  b_out = b;
-  DPM_R1STAMP(12)
+  bool valid = ok && !misc[30];
+  bool leftovers = false;  // hist[0 .. T + 32) holds the selected bin's members
+  if (valid) {
+    uint32_t a, b;
+    const uint32_t rank = total - K;  // ascending
+    if (total <= 64u) {
+      rank_select<T>(cand, total, rank, misc, tid);
+      a = misc[6];
+      b = rank + 1u < total ? misc[7] : a;
+    } else {
+      leftovers = union_select<T>(cand, total, rank, umax, hist, misc, tid, a, b);
+    }
+    a_out = a;
+    b_out = b;
+    DPM_R1STAMP(12)
 #ifdef DPM_THR_DEBUG
-  if (tid == 0 && c < 2) printf("[r1] c=%d ncl=%u total=%u K=%u rank=%u bound_max=%08x a=%08x b=%08x\n", c, ncl, total, K, rank, bound_max, a, b);
+    if (tid == 0 && c < 2) printf("[r1] c=%d ncl=%u total=%u K=%u rank=%u bound_max=%08x a=%08x b=%08x\n", c, ncl, total, K, rank, bound_max, a, b);
 #endif
-  if (tp.debug_reject) return false;
-  return a >= bound_max;  // else: an unpublished element of some chunk could be among the K largest
+    // an unpublished element of some chunk could be among the K largest when the K-th of the union is below a bound
+    valid = a >= bound_max && !tp.debug_reject;
+  }
+  if (!valid) {  // the general route expects its LDS state: hist all zero, no candidates
+    if (leftovers) {
+      hist[tid] = 0u;
+      hist[tid + T] = 0u;
+    }
+    if (tid == 0) misc[4] = 0u;
+    __syncthreads();
+  }
+  return valid;
 }
 
 // HOT != 0: the usual configuration fixed at compile time -- 16-byte accesses legal, noise-prediction network with the
@@ -1428,9 +1455,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
   extern __shared__ __align__(16) unsigned char lds_raw[];
   float* sx0 = reinterpret_cast<float*>(lds_raw);                    // [chunk]
   uint32_t* hist = reinterpret_cast<uint32_t*>(sx0 + tp.chunk);      // [THR_NB]
-  uint32_t* misc = hist + THR_NB;                                    // [32]: [0..2] locate_bin result, [3] min-above, [4] candidate
+  uint32_t* misc = hist + THR_NB;                                    // [THR_MISC]: [0..2] locate_bin result, [3] min-above, [4] candidate
                                                                      // count, [5] list cursor, [16..23] wavefront totals
-  uint32_t* cand = misc + 32;                                        // [THR_CAP + 32] candidates (+ sentinels)
+                                                                     // [32..] cluster_select_once: slot counts, offsets
+  uint32_t* cand = misc + THR_MISC;                                  // [THR_CAP + 32] candidates (+ sentinels)
   const bool store_m = p.flags & DPM_F_STORE_M;
   const bool vec = HOT != 0 || tp.vec != 0;
   const uint32_t k = (uint32_t)tp.k;
@@ -1446,6 +1474,14 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
   const TS* bb = HOT != 0 ? nullptr : static_cast<const TS*>(ext.bb);
   TS* xo2 = static_cast<TS*>(ext.xo2);
   if (threadIdx.x == 0) misc[30] = 0u;  // set when a wait on a peer workgroup timed out (see raise_fault)
+  // Two workgroups share a CU (LDS) and its ~10 B/clk memory pipe.  Left alone they run in lock-step -- both in the
+  // load phase, both in the select, both in the store phase -- and the pipe idles during every select.  Holding back the
+  // second dispatch round (workgroups n_cu .. 2 n_cu - 1 land on the CUs of 0 .. n_cu - 1) by about half a sample period
+  // puts the pair in opposite phases: each streams at the whole pipe's rate while the other selects.
+  if (tp.stagger_ticks > 0 && ((blockIdx.x / (uint32_t)tp.stagger_span) & 1u)) {
+    const uint64_t t_end = wall_clock64() + (uint64_t)tp.stagger_ticks;
+    while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8);
+  }
 
   for (int s_idx = grp; s_idx < tp.batch; s_idx += tp.groups) {
     // The thread index is re-materialised per sample: otherwise the compiler hoists every per-thread predicate of the
@@ -1480,49 +1516,62 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     if (tid == 0) {
       misc[4] = 0u;   // candidate counter
       misc[3] = ABS;  // smallest value above the selected top digit (cluster exchange)
-      misc[8] = 0u;   // cluster_select_once: chunk maximum, largest bound, bad-slot flag
+      misc[8] = 0u;   // cluster_select_once: chunk maximum, largest bound, bad-slot flag, maximum of the sample
       misc[9] = 0u;
       misc[10] = 0u;
+      misc[12] = 0u;
     }
     __syncthreads();
     uint32_t m1 = 0u, m2 = 0u, m3 = 0u, m4 = 0u;  // top-K: the four largest |x0| bit patterns this thread produced
     if (vec) {
-#pragma unroll 2
-      for (int i = tid * 4; i < n; i += T * 4) {
-        float vx[4], v0[4], v1[4], vg[4], o[4];
-        load4(XE ? xe : x, base + i, vx);
-        load4<true>(e0, ebase + i, v0);                       // the network outputs are dead after this kernel
-        if (g_cfg) load4<true>(e1, ebase + i, v1);
-        if (g_cls) load4<true>(g, base + i, vg);
-        if (fastdiv) {  // uniform: the common parameterisation, division by the invariant alpha (3 VALU ops for ~12)
+      // THR_ROWS tile rows per iteration, the loads of all of them issued before the first use: the phase is bound by
+      // the bytes one workgroup keeps in flight (two workgroups per CU, and while one of them selects only one streams)
+      for (int i0 = tid * 4; i0 < n; i0 += THR_ROWS * T * 4) {
+        float vx[THR_ROWS][4], v0[THR_ROWS][4], v1[THR_ROWS][4], vg[THR_ROWS][4];
 #pragma unroll
-          for (int j = 0; j < 4; j += 2) {  // adjacent pairs: packed fp32 instructions
-            const f32x2 z = {0.f, 0.f};
-            const f32x2 r = prologue<GUIDE, SPEC_NOISE_X0, f32x2>(
-                f32x2{vx[j], vx[j + 1]}, f32x2{v0[j], v0[j + 1]}, g_cfg ? f32x2{v1[j], v1[j + 1]} : z,
-                g_cls ? f32x2{vg[j], vg[j + 1]} : z, p);
-            o[j] = r[0];
-            o[j + 1] = r[1];
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            o[j] = prologue<GUIDE>(vx[j], v0[j], g_cfg ? v1[j] : 0.f, g_cls ? vg[j] : 0.f, p);
+        for (int r = 0; r < THR_ROWS; ++r) {
+          const int ir = i0 + r * T * 4 < n ? i0 + r * T * 4 : i0;  // clamped: loads are unconditional
+          load4(XE ? xe : x, base + ir, vx[r]);
+          load4<true>(e0, ebase + ir, v0[r]);                     // the network outputs are dead after this kernel
+          if (g_cfg) load4<true>(e1, ebase + ir, v1[r]);
+          if (g_cls) load4<true>(g, base + ir, vg[r]);
         }
-        {  // LDS, not global memory: a plain 16-byte store (store4 writes through to global memory)
-          u32x4 a;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) a[j] = __float_as_uint(o[j]);
-          *reinterpret_cast<u32x4*>(sx0 + i) = a;
-        }
-        if (track) {
+        for (int r = 0; r < THR_ROWS; ++r) {
+          const int i = i0 + r * T * 4;
+          if (r == 0 || i < n) {
+            float o[4];
+            if (fastdiv) {  // uniform: the common parameterisation, division by the invariant alpha (3 VALU ops for ~12)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            top4_insert(__float_as_uint(o[j]) & ABS, m1, m2, m3, m4);
+              for (int j = 0; j < 4; j += 2) {  // adjacent pairs: packed fp32 instructions
+                const f32x2 z = {0.f, 0.f};
+                const f32x2 rr = prologue<GUIDE, SPEC_NOISE_X0, f32x2>(
+                    f32x2{vx[r][j], vx[r][j + 1]}, f32x2{v0[r][j], v0[r][j + 1]},
+                    g_cfg ? f32x2{v1[r][j], v1[r][j + 1]} : z, g_cls ? f32x2{vg[r][j], vg[r][j + 1]} : z, p);
+                o[j] = rr[0];
+                o[j + 1] = rr[1];
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                o[j] = prologue<GUIDE>(vx[r][j], v0[r][j], g_cfg ? v1[r][j] : 0.f, g_cls ? vg[r][j] : 0.f, p);
+            }
+            {  // LDS, not global memory: a plain 16-byte store (store4 writes through to global memory)
+              u32x4 a;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) a[j] = __float_as_uint(o[j]);
+              *reinterpret_cast<u32x4*>(sx0 + i) = a;
+            }
+            if (track) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                top4_insert(__float_as_uint(o[j]) & ABS, m1, m2, m3, m4);
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) atomicAdd(&hist[(__float_as_uint(o[j]) & ABS) >> 20], 1u);
+            }
           }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) atomicAdd(&hist[(__float_as_uint(o[j]) & ABS) >> 20], 1u);
         }
       }
     } else {
@@ -1540,6 +1589,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
       }
     }
     const bool has = (vec ? tid * 4 : tid) < n;  // this thread produced at least one element (launch: ThrParams.mrank)
+    if (route1) {  // cluster_select_once starts from the chunk's maximum: reduced here, behind the barrier phase 1 ends with
+      const uint32_t wm = wave_max_to_lane63(has ? m1 : 0u);
+      if (lane == 63 && wm) atomicMax(&misc[8], wm);
+    }
     __syncthreads();
     DPM_TSTAMP(1)
 
@@ -1814,22 +1867,21 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
 
     // phase 3: clamp, scale, combine, epilogue, store
     if (vec) {
-      // two tile rows per iteration, the loads of both issued before the first use (an explicit pair: the write-through
+      // THR_ROWS tile rows per iteration, the loads of all issued before the first use (explicit: the write-through
       // stores are assembly the loop unroller will not duplicate)
-      for (int i0 = tid * 4; i0 < n; i0 += 2 * T * 4) {
-        float vx[2][4], vh1[2][4], vh2[2][4];
-        const bool two = i0 + T * 4 < n;  // per lane: the second row may end before this lane
+      for (int i0 = tid * 4; i0 < n; i0 += THR_ROWS * T * 4) {
+        float vx[THR_ROWS][4], vh1[THR_ROWS][4], vh2[THR_ROWS][4];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const int64_t gi = base + (r == 0 || two ? i0 + r * T * 4 : i0);  // clamped: loads are unconditional
+        for (int r = 0; r < THR_ROWS; ++r) {
+          const int64_t gi = base + (i0 + r * T * 4 < n ? i0 + r * T * 4 : i0);  // clamped: loads are unconditional
           if (nx) load4<true>(x, gi, vx[r]);                 // last use of x and of the cached model values
           if (nh1) load4<true>(h1, gi, vh1[r]);
           if (nh2) load4<true>(h2, gi, vh2[r]);
         }
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < THR_ROWS; ++r) {
           const int i = i0 + r * T * 4;
-          if (r == 0 || two) {
+          if (r == 0 || i < n) {  // per lane: a later row may end before this lane
             const int64_t gi = base + i;
             float vm[4], va[4], vb[4], o[4], om[4];
             if (mask) {
@@ -2158,6 +2210,8 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
     tp.chunk = (int32_t)pl.chunk;
     tp.k = (int32_t)pl.k;
     tp.batch = (int32_t)b->batch;
+    tp.stagger_span = n_cu;
+    tp.stagger_ticks = g_tuning.thr_stagger_ticks;
     tp.fastdiv = st->model_type == DPM_MODEL_NOISE && (st->flags & DPM_F_TO_X0) && div_invariant_ok(st->alpha_e);
     const size_t a4s = sizeof(TS) * 4, a4e = sizeof(TE) * 4;
     tp.vec = per_sample % 4 == 0 && ext.eps_stride % 4 == 0 && ext.mask_period % 4 == 0 && aligned(x, a4s) &&
@@ -2182,7 +2236,7 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
       // ~quota = K/k + 6 sigma + 8 largest values of every chunk makes the one-hop answer exact except for samples whose
       // large values sit in one chunk (those fall back inside the kernel).  Needs room in the slots for the 14-bit digit's
       // granularity (x1.5) and a union that fits the LDS list.
-      if (pl.k > 1 && pl.k <= THR_THREADS && K >= 1 && K < ((int64_t)1 << 30)) {
+      if (pl.k > 1 && pl.k <= THR_KMAX && K >= 1 && K < ((int64_t)1 << 30)) {
         const double mu = (double)K / (double)pl.k;
         const int64_t quota = (int64_t)std::ceil(mu + 6.0 * std::sqrt(mu) + 8.0);
         // slot size: the smallest power of two >= 64 with room for the quota and the digit granularity (fewer words to
@@ -2225,7 +2279,7 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
 #else
     auto t_dump = [](int64_t) {};
 #endif
-    const size_t lds_bytes = (size_t)pl.chunk * 4 + THR_NB * 4 + 32 * 4 + (THR_CAP + 32) * 4;
+    const size_t lds_bytes = (size_t)pl.chunk * 4 + THR_NB * 4 + THR_MISC * 4 + (THR_CAP + 32) * 4;
     // the compile-time specialisation exists for the forms / guidance kinds samplers combine with thresholding
     constexpr bool HOT_BUILT = (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3) &&
                                (GUIDE == DPM_GUIDE_NONE || GUIDE == DPM_GUIDE_CFG) && !XE;
