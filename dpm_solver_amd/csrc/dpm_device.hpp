@@ -840,6 +840,7 @@ struct ThrParams {
   int32_t kbig;    // K = per_sample - lo (the wanted element is the K-th largest of the sample)
   int32_t stagger_ticks; // > 0: 100 MHz ticks the second dispatch round waits before its first sample
   int32_t stagger_span;  // workgroups per dispatch round (the CU count)
+  int32_t slot_pub; // entries of a slot that are always written (values, then the bare tag)
   int32_t slot_cap; // values per workgroup slot: a power of two <= THR_SLOT_CAP with k * slot_cap <= THR_CAP
   int32_t slot_shift; // log2(slot_cap)
   int32_t debug_reject; // testing: run the single-exchange select but always take the general route afterwards
@@ -1297,9 +1298,15 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
   const uint32_t ncl = misc[4];
   const bool over = ncl > cap;
   uint32_t* mine_slot = slots + (size_t)c * THR_SLOTW;
-  if (!over)
-    for (uint32_t i = tid; i < ncl; i += T)
-      __hip_atomic_store(&mine_slot[THR_SLOT_HDR + i], cand[i] | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // the first `pub` entries of a slot are always written -- the tag alone beyond the count -- so that readers can wait
+  // for them without knowing the count (step 5)
+  const uint32_t pub = (uint32_t)tp.slot_pub;
+  {
+    const uint32_t nv = over ? 0u : ncl, nw = nv > pub ? nv : pub;
+    for (uint32_t i = tid; i < nw; i += T)
+      __hip_atomic_store(&mine_slot[THR_SLOT_HDR + i], (i < nv ? cand[i] : 0u) | THR_TAG, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (tid == 0) {
     const uint32_t bound = bin_lo ? (bin_lo + dbase) << 17 : 0u;  // smallest |x0| with that digit; digit 0 = everything
     __hip_atomic_store(&mine_slot[2], cmax | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1308,40 +1315,51 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
   }
   DPM_R1STAMP(9)
   // 5. the other workgroups' slots.  Word p of the slot area (slot p >> shift, entry p & (W - 1)) belongs to thread
-  // p mod T whatever the counts turn out to be, so the value loads go out together with the header loads -- one round
-  // trip for both; entries beyond a slot's count are ignored, entries that have not landed yet are polled.
+  // p mod T whatever the counts turn out to be, and the first `pub` entries of every slot get written whatever the count:
+  // headers and values are polled TOGETHER, every round's loads issued back to back -- one round trip after the last
+  // peer has published, not one for the headers and another for the values.  Entries beyond `pub` (a chunk with more
+  // candidates than expected) are fetched in step 6.
   constexpr int PER = THR_CAP / T;
   const int shift = tp.slot_shift;
   const uint32_t W = 1u << shift, words = k << shift;  // <= THR_CAP
   uint32_t w[PER];
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    const uint32_t q = (uint32_t)tid + (uint32_t)j * T;
-    w[j] = 0u;
-    if (q < words)
-      w[j] = __hip_atomic_load(slots + (size_t)(q >> shift) * THR_SLOTW + THR_SLOT_HDR + (q & (W - 1u)), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-  }
-  {  // the headers: counts, list offsets, total, largest bound, maximum of the sample
+  {
     const bool own = (uint32_t)tid < k;
+    const uint32_t* sl = slots + (size_t)(own ? tid : 0) * THR_SLOTW;
     uint32_t h0 = THR_TAG, h1 = THR_TAG, h2 = THR_TAG;
-    if (own) {
-      const uint32_t* sl = slots + (size_t)tid * THR_SLOTW;
-      uint32_t spins = 0;
-      h0 = __hip_atomic_load(&sl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      h1 = __hip_atomic_load(&sl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      h2 = __hip_atomic_load(&sl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      while ((!(h0 & THR_TAG) || !(h1 & THR_TAG) || !(h2 & THR_TAG)) && !misc[30]) {
-        __builtin_amdgcn_s_sleep(1);
-        if (!(h0 & THR_TAG)) h0 = __hip_atomic_load(&sl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!(h1 & THR_TAG)) h1 = __hip_atomic_load(&sl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!(h2 & THR_TAG)) h2 = __hip_atomic_load(&sl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (++spins > THR_SPIN_LIMIT) {
-          misc[30] = 1u;
-          raise_fault(tp.fault);
-        }
+    bool act[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const uint32_t q = (uint32_t)tid + (uint32_t)j * T;
+      act[j] = q < words && (q & (W - 1u)) < pub;
+      w[j] = act[j] ? 0u : THR_TAG;
+    }
+    if (own) h0 = h1 = h2 = 0u;
+    uint32_t spins = 0;
+    for (;;) {
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const uint32_t q = (uint32_t)tid + (uint32_t)j * T;
+        if (!(w[j] & THR_TAG))
+          w[j] = __hip_atomic_load(slots + (size_t)(q >> shift) * THR_SLOTW + THR_SLOT_HDR + (q & (W - 1u)), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (!(h0 & THR_TAG)) h0 = __hip_atomic_load(&sl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!(h1 & THR_TAG)) h1 = __hip_atomic_load(&sl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!(h2 & THR_TAG)) h2 = __hip_atomic_load(&sl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t all = h0 & h1 & h2;
+#pragma unroll
+      for (int j = 0; j < PER; ++j) all &= w[j];
+      if ((all & THR_TAG) || misc[30]) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > THR_SPIN_LIMIT) {
+        misc[30] = 1u;
+        raise_fault(tp.fault);
       }
     }
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+      if (!act[j]) w[j] = 0u;  // not fetched yet (step 6 does if the slot's count reaches that far)
     DPM_R1STAMP(10)
     const bool bad = own && (!(h0 & THR_TAG) || !(h1 & THR_TAG) || !(h2 & THR_TAG) || (h0 & THR_OVERFLOW));
     const uint32_t cnt_t = (own && !bad) ? (h0 & 0xffffu) : 0u;
@@ -2249,6 +2267,7 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
           tp.quota = (int32_t)quota;
           tp.kbig = (int32_t)K;
           tp.slot_cap = (int32_t)slot_cap;
+          tp.slot_pub = (int32_t)std::min<int64_t>(slot_cap, quota + quota / 4 + 4);
           tp.slot_shift = slot_shift;
           tp.debug_reject = g_tuning.cluster_one_hop == 2;
         }
