@@ -50,7 +50,6 @@ struct Tuning {
   int cluster_one_hop = 1;  // 0: clusters always take the general route (merged histograms, several barriers)
   int multi_xcd_remap = -1; // fused launch maps workgroup b to tile (b % 8) * span + b / 8 (one contiguous eighth of the
                             // tile space per XCD): 1 on, 0 off, -1 per dtype (on for 2-byte states: +1.4 %; fp32: -3 %)
-  int thr_stagger_ticks = 0; // thresholding: 100 MHz ticks the second dispatch round is held back (see stage_thresh_kernel)
   int multi_blocks_per_cu = 0;  // grid cap of the fused launch in workgroups per CU; 0 = one super-tile per workgroup
 };
 extern Tuning g_tuning;     // defined in dpm_kernels.hip
@@ -809,10 +808,11 @@ constexpr int THR_CAP = 4096;                // candidates (elements sharing the
 constexpr int THR_GCAP = THR_NB;             // cluster-wide candidates exchanged through the level-1 histogram's words
 // single-exchange route of a cluster (cluster_select_once): every workgroup publishes the elements of its chunk that
 // can still be among the sample's K largest into its own slot of the workspace -- header + values, every word tagged
-#ifndef DPM_THR_ROWS
-#define DPM_THR_ROWS 2
-#endif
-constexpr int THR_ROWS = DPM_THR_ROWS;  // tile rows a thread keeps in flight in the streaming phases of the thresholding kernel
+constexpr int THR_ROWS = 2;  // tile rows a thread keeps in flight in the streaming phases (3 and 6 measured: no faster)
+// fine digits of the single-exchange route: |x0| bits >> THR_FSHIFT (8 exponent + 9 mantissa bits: 0.2 % wide bins),
+// THR_NB of them below a maximum (a factor 54).  Measured against 1.5 % bins (shift 17) on [64,3,256,256]: 55.7 -> 53.1 us
+// per stage -- the union's values crowd into ~40 of the coarse bins and their LDS atomics serialise.
+constexpr int THR_FSHIFT = 14;
 constexpr int THR_KMAX = 256;                // largest cluster the single-exchange route serves
 constexpr int THR_MISC = 32 + 2 * THR_KMAX;  // scalar LDS words of the thresholding kernel (see stage_thresh_kernel)
 constexpr int THR_SLOT_CAP = 256;            // values one workgroup may publish
@@ -838,8 +838,6 @@ struct ThrParams {
   int32_t fastdiv; // 1: noise-prediction network + eps -> x0 with a divisor that passes div_invariant_ok (see div_by_alpha)
   int32_t quota;   // > 0: single-exchange cluster route; values beyond this rank of the per-thread maxima are not published
   int32_t kbig;    // K = per_sample - lo (the wanted element is the K-th largest of the sample)
-  int32_t stagger_ticks; // > 0: 100 MHz ticks the second dispatch round waits before its first sample
-  int32_t stagger_span;  // workgroups per dispatch round (the CU count)
   int32_t slot_pub; // entries of a slot that are always written (values, then the bare tag)
   int32_t slot_cap; // values per workgroup slot: a power of two <= THR_SLOT_CAP with k * slot_cap <= THR_CAP
   int32_t slot_shift; // log2(slot_cap)
@@ -1178,14 +1176,14 @@ __device__ __forceinline__ bool union_select(const uint32_t* cand, uint32_t nc, 
                                              uint32_t* misc, int tid, uint32_t& a, uint32_t& b) {
   constexpr int PER = THR_CAP / T;
   const int lane = tid & 63;
-  const uint32_t top = umax >> 17;
+  const uint32_t top = umax >> THR_FSHIFT;
   const uint32_t dbase = top > (uint32_t)(THR_NB - 1) ? top - (uint32_t)(THR_NB - 1) : 0u;
   uint32_t v[PER], d[PER];
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
     const uint32_t i = (uint32_t)tid + (uint32_t)j * T;
     v[j] = i < nc ? cand[i] : 0u;
-    const uint32_t dr = v[j] >> 17;
+    const uint32_t dr = v[j] >> THR_FSHIFT;
     d[j] = dr > dbase ? dr - dbase : 0u;
     if (i < nc) atomicAdd(&hist[d[j]], 1u);
   }
@@ -1257,10 +1255,10 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
   uint32_t* sc = misc + 32;  // [2 k], k <= THR_KMAX: counts and list offsets of the k slots
   // 1. the chunk's maximum (misc[8]: the kernel reduces it on the way out of phase 1) -> digit base
   const uint32_t cmax = misc[8];
-  const uint32_t top = cmax >> 17;
+  const uint32_t top = cmax >> THR_FSHIFT;
   const uint32_t dbase = top > (uint32_t)(THR_NB - 1) ? top - (uint32_t)(THR_NB - 1) : 0u;
   auto digit = [&](uint32_t u) {
-    const uint32_t d = u >> 17;
+    const uint32_t d = u >> THR_FSHIFT;
     return d > dbase ? d - dbase : 0u;
   };
   // 2. histogram of one value per thread, bound = digit of the quota-th largest maximum
@@ -1277,7 +1275,7 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
     const bool c1 = mine > 0 && digit(m1) >= bin_lo, c2 = mine > 1 && digit(m2) >= bin_lo;
     const bool c3 = mine > 2 && digit(m3) >= bin_lo, c4 = mine > 3 && digit(m4) >= bin_lo;
     if (__ballot(c4 && mine > 4)) {
-      (void)compact_candidates<T, true>(sx0, n, bin_lo, misc, cand, tid, 17, dbase);
+      (void)compact_candidates<T, true>(sx0, n, bin_lo, misc, cand, tid, THR_FSHIFT, dbase);
     } else {
       const uint32_t cnt = (c1 ? 1u : 0u) + (c2 ? 1u : 0u) + (c3 ? 1u : 0u) + (c4 ? 1u : 0u);
       const uint32_t incl = wave_incl_scan(cnt);
@@ -1308,7 +1306,7 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
                          __HIP_MEMORY_SCOPE_AGENT);
   }
   if (tid == 0) {
-    const uint32_t bound = bin_lo ? (bin_lo + dbase) << 17 : 0u;  // smallest |x0| with that digit; digit 0 = everything
+    const uint32_t bound = bin_lo ? (bin_lo + dbase) << THR_FSHIFT : 0u;  // smallest |x0| with that digit; digit 0 = everything
     __hip_atomic_store(&mine_slot[2], cmax | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&mine_slot[1], bound | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&mine_slot[0], (over ? THR_OVERFLOW : ncl) | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1492,15 +1490,6 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
   const TS* bb = HOT != 0 ? nullptr : static_cast<const TS*>(ext.bb);
   TS* xo2 = static_cast<TS*>(ext.xo2);
   if (threadIdx.x == 0) misc[30] = 0u;  // set when a wait on a peer workgroup timed out (see raise_fault)
-  // Two workgroups share a CU (LDS) and its ~10 B/clk memory pipe.  Left alone they run in lock-step -- both in the
-  // load phase, both in the select, both in the store phase -- and the pipe idles during every select.  Holding back the
-  // second dispatch round (workgroups n_cu .. 2 n_cu - 1 land on the CUs of 0 .. n_cu - 1) by about half a sample period
-  // puts the pair in opposite phases: each streams at the whole pipe's rate while the other selects.
-  if (tp.stagger_ticks > 0 && ((blockIdx.x / (uint32_t)tp.stagger_span) & 1u)) {
-    const uint64_t t_end = wall_clock64() + (uint64_t)tp.stagger_ticks;
-    while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(8);
-  }
-
   for (int s_idx = grp; s_idx < tp.batch; s_idx += tp.groups) {
     // The thread index is re-materialised per sample: otherwise the compiler hoists every per-thread predicate of the
     // body (dozens of 64-bit lane masks) out of this loop, runs out of SGPRs and pays v_readlane pairs all over the select.
@@ -2228,8 +2217,6 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
     tp.chunk = (int32_t)pl.chunk;
     tp.k = (int32_t)pl.k;
     tp.batch = (int32_t)b->batch;
-    tp.stagger_span = n_cu;
-    tp.stagger_ticks = g_tuning.thr_stagger_ticks;
     tp.fastdiv = st->model_type == DPM_MODEL_NOISE && (st->flags & DPM_F_TO_X0) && div_invariant_ok(st->alpha_e);
     const size_t a4s = sizeof(TS) * 4, a4e = sizeof(TE) * 4;
     tp.vec = per_sample % 4 == 0 && ext.eps_stride % 4 == 0 && ext.mask_period % 4 == 0 && aligned(x, a4s) &&

@@ -351,7 +351,6 @@ enum {
   DPM_TUNE_CLUSTER_IN_GRAPH = 6,    /* 1: thresholding keeps workgroup clusters under stream capture for samples that
                                        fit one workgroup too (default 0: one workgroup per sample there)           */
   DPM_TUNE_CLUSTER_ONE_HOP = 7,     /* 0: clusters skip the single-exchange select (testing the general route)     */
-  DPM_TUNE_THR_STAGGER = 9,         /* thresholding: hold the second dispatch round back by this many 10 ns ticks          */
   DPM_TUNE_MULTI_XCD_REMAP = 8      /* fused launch gives every XCD one contiguous eighth of the tiles: 1 on, 0 off,
                                        -1 (default) on for 2-byte states only (measured +1.4 % fp16, -3 % fp32)    */
 };

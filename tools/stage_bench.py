@@ -120,10 +120,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--md", default=None)
     ap.add_argument("--only", default=None, help="substring filter on scenario names (skips the others and the loop timing)")
-    ap.add_argument("--stagger", type=int, default=None, help="DPM_TUNE_THR_STAGGER value (10 ns ticks) for this run")
     args = ap.parse_args()
-    if args.stagger is not None:
-        L.lib.dpm_tuning_set(L.TUNE_THR_STAGGER, args.stagger)
     torch.manual_seed(0)
     global ONLY
     ONLY = args.only

@@ -35,7 +35,7 @@ def build():
     print("built", LIB)
 
 
-def run(batch, chw, stagger=0):
+def run(batch, chw):
     import numpy as np
     dump = os.path.join(OUT, "stamps.txt")
     if os.path.exists(dump):
@@ -43,15 +43,13 @@ def run(batch, chw, stagger=0):
     env = dict(os.environ, DPM_SOLVER_AMD_LIB=LIB, DPM_THR_TIMING_FILE=dump)
     code = (
         "import numpy as np, torch, dpm_solver_amd as D\n"
-        "from dpm_solver_amd import _lib as L\n"
-        "L.lib.dpm_tuning_set(L.TUNE_THR_STAGGER, %d)\n"
         "ns = D.NoiseScheduleVP('discrete', betas=torch.from_numpy(np.linspace(1e-4, 0.02, 1000).astype(np.float32)))\n"
         "shape = (%d, %d, %d, %d)\n"
         "e = torch.randn(shape, device='cuda')\n"
         "s = D.DPM_Solver(D.model_wrapper(lambda x, t: e, ns), ns, correcting_x0_fn='dynamic_thresholding')\n"
         "x = torch.randn(shape, device='cuda')\n"
         "for _ in range(3): s.sample(x, steps=25, order=2)\n"
-        "torch.cuda.synchronize()\n" % ((stagger, batch) + tuple(chw)))
+        "torch.cuda.synchronize()\n" % ((batch,) + tuple(chw)))
     subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT, env=env)
     a = np.loadtxt(dump, dtype=np.float64) / 100.0          # microseconds
     t0 = a[:, 0].min()
@@ -65,13 +63,6 @@ def run(batch, chw, stagger=0):
     for (j0, n0), (j1, n1) in zip(used[:-1], used[1:]):
         d = a[:, j1] - a[:, j0]
         print("  %-36s %6.2f us  (p10 %.2f, p90 %.2f)" % (n1, np.median(d), np.percentile(d, 10), np.percentile(d, 90)))
-    if stagger:
-        for half in (0, 1):
-            sel = (np.arange(len(a)) // 256) % 2 == half
-            h = a[sel]
-            print("  dispatch round %d (%d workgroups): start %.1f us, load %.2f, select %.2f, store %.2f, end %.1f us" % (
-                half, sel.sum(), np.median(h[:, 0]) - t0, np.median(h[:, 1] - h[:, 0]), np.median(h[:, 2] - h[:, 1]),
-                np.median(h[:, 3] - h[:, 2]), np.median(h[:, 3]) - t0))
     print("workgroups per phase over time:")
     for ts in np.arange(0.0, a[:, 3].max() - t0, 4.0):
         x = ts + t0
@@ -85,9 +76,8 @@ if __name__ == "__main__":
     ap.add_argument("--run", action="store_true")
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--chw", type=int, nargs=3, default=[3, 64, 64])
-    ap.add_argument("--stagger", type=int, default=0, help="DPM_TUNE_THR_STAGGER ticks (experiment; see profiles/r02_thr_overlap.md)")
     args = ap.parse_args()
     if args.build or not os.path.exists(LIB):
         build()
     if args.run:
-        run(args.batch, args.chw, args.stagger)
+        run(args.batch, args.chw)
