@@ -63,6 +63,11 @@ ClusterChain& cluster_chain(int dev);  // defined in dpm_kernels.hip
 // host-mapped word a clustered kernel raises when one of its waits timed out; nullptr until created (create = false
 // never allocates: stream capture)
 uint32_t* cluster_fault_word(bool create);
+// bfloat16 storage (a named type with external linkage: it is a template argument of functions shared between
+// translation units, dpm_catchall_* below)
+struct bf16_t {
+  uint16_t v;
+};
 }  // namespace dpmk
 using dpmk::Tuning;
 using dpmk::g_tuning;
@@ -70,14 +75,20 @@ using dpmk::ClusterChain;
 using dpmk::cluster_chain;
 using dpmk::cluster_fault_word;
 
+// The catch-all kernels of a dtype pair (run-time form / guidance: the one-element-per-lane stage kernel and the general
+// thresholding kernel) are compiled in ONE of the pair's two translation units (dpm_stage_<pair>.hip defines
+// DPM_CATCHALL_HOME); the sibling unit launches them through their host-side handles.
+template <typename TS, typename TE>
+const void* dpm_catchall_thresh();
+template <typename TS, typename TE, bool DYN>
+const void* dpm_catchall_scalar();
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
 // element types
 // ------------------------------------------------------------------------------------------------
-struct bf16_t {
-  uint16_t v;
-};
+using dpmk::bf16_t;
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(__half v) { return __half2float(v); }
@@ -2291,7 +2302,8 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
                                (GUIDE == DPM_GUIDE_NONE || GUIDE == DPM_GUIDE_CFG) && !XE;
     const bool hot = HOT_BUILT && tp.vec && tp.fastdiv && !ext.mask;
     // the general kernel reads form / guidance from the stage record and always takes the evaluation state through xe
-    auto kern = stage_thresh_kernel<TS, TE, FORM_RT, GUIDE_RT, true, THR_THREADS, 0>;
+    using ThrKernel = decltype(&stage_thresh_kernel<TS, TE, FORM_RT, GUIDE_RT, true, THR_THREADS, 0>);
+    auto kern = reinterpret_cast<ThrKernel>(const_cast<void*>(dpm_catchall_thresh<TS, TE>()));
     if constexpr (HOT_BUILT) {
       if (hot)
         kern = (tp.topk > 0 || tp.quota > 0) ? stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 1>
@@ -2384,12 +2396,10 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
       int64_t blocks = (b->n + 255) / 256;
       const int64_t cap = (int64_t)n_cu * 16;
       if (blocks > cap) blocks = cap;
-      if (stream.dyn)
-        launch(stage_kernel_scalar<TS, TE, true>, dim3((unsigned)blocks), dim3(256), 0, stream, x, xe ? xe : x, e0, e1, g, h1,
-               h2, xo, mo, b->n, p, ext, stream.dyn, stream.skip);
-      else
-        launch(stage_kernel_scalar<TS, TE>, dim3((unsigned)blocks), dim3(256), 0, stream, x, xe ? xe : x, e0, e1, g, h1, h2, xo,
-               mo, b->n, p, ext, stream.dyn, stream.skip);
+      using ScalarKernel = decltype(&stage_kernel_scalar<TS, TE, false>);  // the DYN = true variant has the same signature
+      const void* k = stream.dyn ? dpm_catchall_scalar<TS, TE, true>() : dpm_catchall_scalar<TS, TE, false>();
+      launch(reinterpret_cast<ScalarKernel>(const_cast<void*>(k)), dim3((unsigned)blocks), dim3(256), 0, stream, x, xe ? xe : x,
+             e0, e1, g, h1, h2, xo, mo, b->n, p, ext, stream.dyn, stream.skip);
     } else if constexpr (COMBO_BUILT) {
       const bool noise = SPEC_BUILT && !stream.dyn && st->model_type == DPM_MODEL_NOISE &&
                          (!(st->flags & DPM_F_TO_X0) || div_invariant_ok(st->alpha_e));
@@ -2592,16 +2602,38 @@ int launch_guide(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& s) 
   return dpm_set_error(DPM_ERR_ARG, "unknown guidance %d", st->guidance);
 }
 
-template <typename TS, typename TE>
+// The single-request launchers of one dtype pair are spread over two translation units (compile time: the build is the
+// slowest unit).  FORMS = the update forms this unit instantiates (bit f = form f); a stage of another form returns
+// FORM_ELSEWHERE and the caller (dpm_stage_<pair>.hip) passes it on to the sibling unit.
+constexpr int FORM_ELSEWHERE = -1001;
+constexpr unsigned FORMS_A = (1u << DPM_FORM_TWO) | (1u << DPM_FORM_SS3T);  // + the fused multi-request launchers
+constexpr unsigned FORMS_B = (1u << DPM_FORM_LIN1) | (1u << DPM_FORM_MS3) | (1u << DPM_FORM_DENOISE);
+template <typename TS, typename TE, unsigned FORMS>
 int launch_form(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& s) {
   switch (st->form) {
-    case DPM_FORM_LIN1: return launch_guide<TS, TE, DPM_FORM_LIN1>(st, b, s);
-    case DPM_FORM_TWO: return launch_guide<TS, TE, DPM_FORM_TWO>(st, b, s);
-    case DPM_FORM_MS3: return launch_guide<TS, TE, DPM_FORM_MS3>(st, b, s);
-    case DPM_FORM_SS3T: return launch_guide<TS, TE, DPM_FORM_SS3T>(st, b, s);
-    case DPM_FORM_DENOISE: return launch_guide<TS, TE, DPM_FORM_DENOISE>(st, b, s);
+#define DPM_FORM_CASE(F)                                            \
+  case F:                                                           \
+    if constexpr ((FORMS >> F) & 1u) return launch_guide<TS, TE, F>(st, b, s); \
+    return FORM_ELSEWHERE;
+    DPM_FORM_CASE(DPM_FORM_LIN1)
+    DPM_FORM_CASE(DPM_FORM_TWO)
+    DPM_FORM_CASE(DPM_FORM_MS3)
+    DPM_FORM_CASE(DPM_FORM_SS3T)
+    DPM_FORM_CASE(DPM_FORM_DENOISE)
+#undef DPM_FORM_CASE
   }
   return dpm_set_error(DPM_ERR_ARG, "unknown update form %d", st->form);
 }
 
 }  // namespace
+
+#ifdef DPM_CATCHALL_HOME
+template <typename TS, typename TE>
+const void* dpm_catchall_thresh() {
+  return reinterpret_cast<const void*>(&stage_thresh_kernel<TS, TE, FORM_RT, GUIDE_RT, true, THR_THREADS, 0>);
+}
+template <typename TS, typename TE, bool DYN>
+const void* dpm_catchall_scalar() {
+  return reinterpret_cast<const void*>(&stage_kernel_scalar<TS, TE, DYN>);
+}
+#endif

@@ -1,10 +1,20 @@
-// dpm_stage_bf16_bf16.hip -- stage kernels for state dtype bf16_t, network-output dtype bf16_t (see dpm_device.hpp)
+// dpm_stage_bf16_bf16.hip -- stage kernels for state dtype bf16_t, network-output dtype bf16_t (see dpm_device.hpp):
+// the TWO and SS3T update forms, the fused multi-request launchers and the pair's catch-all kernels; dpm_stage_bf16_bf16_b.hip holds the other forms
+#define DPM_CATCHALL_HOME
 #include "dpm_device.hpp"
+
+template const void* dpm_catchall_thresh<bf16_t, bf16_t>();
+template const void* dpm_catchall_scalar<bf16_t, bf16_t, false>();
+template const void* dpm_catchall_scalar<bf16_t, bf16_t, true>();
+
+int dpm_launch_bf16_bf16_b(const dpm_stage* st, const dpm_buffers* b, void* stream, void* ev_start, void* ev_stop, const dpm_stage* dyn,
+          const int32_t* skip);
 
 int dpm_launch_bf16_bf16(const dpm_stage* st, const dpm_buffers* b, void* stream, void* ev_start, void* ev_stop, const dpm_stage* dyn,
           const int32_t* skip) {
   const LaunchCtx s{static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop), dyn, skip};
-  return launch_form<bf16_t, bf16_t>(st, b, s);
+  const int rc = launch_form<bf16_t, bf16_t, FORMS_A>(st, b, s);
+  return rc == FORM_ELSEWHERE ? dpm_launch_bf16_bf16_b(st, b, stream, ev_start, ev_stop, dyn, skip) : rc;
 }
 
 int dpm_launch_multi_bf16_bf16(const dpm_stage* st, const dpm_buffers* bs, int n_req, void* stream, void* ev_start, void* ev_stop) {
