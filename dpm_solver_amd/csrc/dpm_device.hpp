@@ -230,12 +230,13 @@ __device__ __forceinline__ void store_pack(bf16_t* __restrict__ p, int64_t group
 // `split` (4-byte state, tile complete): lane t takes elements [4t, 4t+4) and [1024+4t, 1024+4t+4) of the tile, so
 // each of the two global_load_dwordx4 of a wavefront covers 1 KiB of consecutive addresses; otherwise lane t takes the
 // 8 consecutive elements [8t, 8t+8) (one 16-byte access for 2-byte types, two adjacent ones for fp32).  The op is
-// elementwise, so any mapping that is the same for every tensor of the launch is correct.
+// elementwise, so any mapping that is the same for every tensor of the launch is correct.  In the split case gi is
+// (first group of the tile) + lane; the tile may start at any group of the tensor (strided network outputs).
 template <bool NT, typename T>
 __device__ __forceinline__ void load_tile(const T* __restrict__ p, int64_t gi, bool split, float (&out)[EPT]) {
   if constexpr (sizeof(T) == 4) {
     if (split) {
-      const u32x4* q = reinterpret_cast<const u32x4*>(p) + (gi + (gi & ~(int64_t)255));
+      const u32x4* q = reinterpret_cast<const u32x4*>(p) + (2 * gi - (int64_t)threadIdx.x);
       const u32x4 a = ld16<NT>(q), b = ld16<NT>(q + 256);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -247,7 +248,7 @@ __device__ __forceinline__ void load_tile(const T* __restrict__ p, int64_t gi, b
   } else {
     if (split) {  // 2-byte network output next to a 4-byte state: the same elements as two 8-byte accesses
       typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-      const u32x2_t* q = reinterpret_cast<const u32x2_t*>(p) + (gi + (gi & ~(int64_t)255));
+      const u32x2_t* q = reinterpret_cast<const u32x2_t*>(p) + (2 * gi - (int64_t)threadIdx.x);
       const u32x2_t a = NT ? __builtin_nontemporal_load(q) : *q;
       const u32x2_t b = NT ? __builtin_nontemporal_load(q + 256) : *(q + 256);
       const uint32_t w[4] = {a[0], a[1], b[0], b[1]};
@@ -276,7 +277,7 @@ __device__ __forceinline__ void store_tile(T* __restrict__ p, int64_t gi, bool s
         a[j] = __float_as_uint(in[j]);
         b[j] = __float_as_uint(in[4 + j]);
       }
-      u32x4* q = reinterpret_cast<u32x4*>(p) + (gi + (gi & ~(int64_t)255));
+      u32x4* q = reinterpret_cast<u32x4*>(p) + (2 * gi - (int64_t)threadIdx.x);
       st16<NT>(q, a);
       st16<NT>(q + 256, b);
       return;
@@ -568,9 +569,11 @@ __device__ __forceinline__ void stage_tiles(const TS* __restrict__ x, const TS* 
   const int64_t gps = EXT ? ext.per_sample / EPT : 1, sgroups = EXT ? ext.eps_stride / EPT : 0;
   const int64_t mgroups = EXT ? ext.mask_period / EPT : 1;
   const bool small = ngroups < (int64_t)0x7fffffff;  // 32-bit index arithmetic is enough (n < 2^34 elements)
-  // the split layout needs every tensor of the launch indexed by whole tiles: no per-sample stride, and a mask whose
-  // period is a multiple of the 2048-element tile ([64,64] and larger masks)
-  const bool can_split = SPLIT && (!EXT || (!ext.eps_stride && (!mask || ext.mask_period % (256 * EPT) == 0)));
+  // the split layout needs every tensor of the launch indexed by whole tiles: a mask whose period is a multiple of the
+  // 2048-element tile ([64,64] and larger masks)
+  // (a strided network output: samples made of whole tiles, so that a tile's groups are consecutive in e0 / e1 too)
+  const bool can_split = SPLIT && (!EXT || ((!ext.eps_stride || gps % 256 == 0) &&
+                                            (!mask || ext.mask_period % (256 * EPT) == 0)));
   float vx[U][EPT], vxe[U][EPT], v0[U][EPT], v1[U][EPT], vg[U][EPT], vh1[U][EPT], vh2[U][EPT];
   float vm[EXT ? U : 1][EPT], va[EXT ? U : 1][EPT], vb[EXT ? U : 1][EPT];
   // Lanes past the end of the last tile load a clamped (valid) group and only skip the store: loads and arithmetic
