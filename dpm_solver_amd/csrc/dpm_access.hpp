@@ -1,0 +1,208 @@
+// dpm_access.hpp -- element types and global-memory access of the stage kernels: 16-byte packs, write-through stores,
+// the split-tile layout (part of dpm_device.hpp; include that)
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// element types
+// ------------------------------------------------------------------------------------------------
+using dpmk::bf16_t;
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(__half v) { return __half2float(v); }
+__device__ __forceinline__ float to_f32(bf16_t v) { return __uint_as_float((uint32_t)v.v << 16); }
+
+template <typename T>
+__device__ __forceinline__ T from_f32(float v);
+template <>
+__device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ __half from_f32<__half>(float v) { return __float2half_rn(v); }
+template <>
+__device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) {
+  uint32_t u = __float_as_uint(v);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return bf16_t{(uint16_t)((u >> 16) | 0x40)};  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                                   // round to nearest even
+  return bf16_t{(uint16_t)(u >> 16)};
+}
+
+constexpr int EPT = 8;  // elements per lane per access group: 2 x 16 B (fp32) or 1 x 16 B (fp16/bf16)
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ __forceinline__ u32x4 ld16(const u32x4* p) {
+  return NT ? __builtin_nontemporal_load(p) : *p;
+}
+// Output stores are WRITE-THROUGH (`sc0 sc1`): the line goes to the memory side and is dropped from the XCD's L2 instead
+// of lingering there dirty.  Nothing reads a stage's outputs from this L2 again (the next kernel starts with its L2
+// invalidated, and may run the element on another XCD), so keeping them only pollutes the cache during the kernel and
+// leaves a write-back for the kernel boundary: [256,4,64,64] fp16 2M stage 7.29 -> 6.39 us per launch (70.5 -> 80.4 % of
+// HBM peak), fp32 13.22 -> 13.02 (profiles/r01_store_policy.md).  Written as inline assembly: a `volatile` store
+// compiles to the same instruction but the compiler follows each one with `s_waitcnt vmcnt(0)`, which serialises the
+// stores (fp16 6.65 us, HBM-cold 8.9 instead of 8.4).  The compiler does not know about these stores: the two wait
+// states a 16-byte store needs before its data registers may be rewritten (gfx940+) are in the string, and its own
+// `vmcnt` bookkeeping stays correct because loads return in order among themselves -- an unknown older or younger
+// store can only make one of its waits longer, never shorter.  -DDPM_STORE_WRITE_THROUGH=0 restores plain /
+// non-temporal stores (the NT flag) for comparison.
+#ifndef DPM_STORE_WRITE_THROUGH
+#define DPM_STORE_WRITE_THROUGH 1
+#endif
+// WT = false: a store instruction that leaves gaps (32-byte lane stride): the halves of a line have to meet in L2 first
+template <bool NT, bool WT = true>
+__device__ __forceinline__ void st16(u32x4* p, u32x4 v) {
+  if (DPM_STORE_WRITE_THROUGH && WT)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else if (NT)
+    __builtin_nontemporal_store(v, p);
+  else
+    *p = v;
+}
+template <bool NT, typename V2>
+__device__ __forceinline__ void st8(V2* p, V2 v) {
+  if (DPM_STORE_WRITE_THROUGH)
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  else if (NT)
+    __builtin_nontemporal_store(v, p);
+  else
+    *p = v;
+}
+
+
+// 8 consecutive elements of group `group` -> fp32.  Always global_load_dwordx4 (x2 for fp32).
+template <bool NT>
+__device__ __forceinline__ void load_pack(const float* __restrict__ p, int64_t group, float (&out)[EPT]) {
+  const u32x4* q = reinterpret_cast<const u32x4*>(p) + group * 2;
+  const u32x4 a = ld16<NT>(q), b = ld16<NT>(q + 1);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    out[j] = __uint_as_float(a[j]);
+    out[4 + j] = __uint_as_float(b[j]);
+  }
+}
+template <bool NT>
+__device__ __forceinline__ void load_pack(const __half* __restrict__ p, int64_t group, float (&out)[EPT]) {
+  const u32x4 a = ld16<NT>(reinterpret_cast<const u32x4*>(p) + group);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    out[2 * j] = __half2float(__ushort_as_half((unsigned short)(a[j] & 0xffffu)));
+    out[2 * j + 1] = __half2float(__ushort_as_half((unsigned short)(a[j] >> 16)));
+  }
+}
+template <bool NT>
+__device__ __forceinline__ void load_pack(const bf16_t* __restrict__ p, int64_t group, float (&out)[EPT]) {
+  const u32x4 a = ld16<NT>(reinterpret_cast<const u32x4*>(p) + group);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    out[2 * j] = __uint_as_float(a[j] << 16);
+    out[2 * j + 1] = __uint_as_float(a[j] & 0xffff0000u);
+  }
+}
+
+template <bool NT>
+__device__ __forceinline__ void store_pack(float* __restrict__ p, int64_t group, const float (&in)[EPT]) {
+  u32x4 a, b;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    a[j] = __float_as_uint(in[j]);
+    b[j] = __float_as_uint(in[4 + j]);
+  }
+  u32x4* q = reinterpret_cast<u32x4*>(p) + group * 2;
+  // 32 consecutive bytes per lane, i.e. two instructions that each fill every other 16 bytes (the layout of the
+  // extended kernel when its inputs are strided or masked): written through, every half line would travel on its own --
+  // guided-diffusion's strided 6-channel stage 48.8 -> 77 us.  Cached stores let L2 merge them.
+  st16<NT, false>(q, a);
+  st16<NT, false>(q + 1, b);
+}
+// two fp32 -> one dword of two fp16, round to nearest even (one v_cvt_pk_f16_f32)
+__device__ __forceinline__ uint32_t pack_half2(float lo, float hi) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 v = __builtin_convertvector(f2{lo, hi}, h2);
+  return __builtin_bit_cast(uint32_t, v);
+}
+// two fp32 -> one dword of two bf16, round to nearest even (gfx950: one v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t pack_bf162(float lo, float hi) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  const b2 v = __builtin_convertvector(f2{lo, hi}, b2);
+  return __builtin_bit_cast(uint32_t, v);
+}
+template <bool NT>
+__device__ __forceinline__ void store_pack(__half* __restrict__ p, int64_t group, const float (&in)[EPT]) {
+  u32x4 a;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a[j] = pack_half2(in[2 * j], in[2 * j + 1]);
+  st16<NT>(reinterpret_cast<u32x4*>(p) + group, a);
+}
+template <bool NT>
+__device__ __forceinline__ void store_pack(bf16_t* __restrict__ p, int64_t group, const float (&in)[EPT]) {
+  u32x4 a;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    a[j] = pack_bf162(in[2 * j], in[2 * j + 1]);
+  st16<NT>(reinterpret_cast<u32x4*>(p) + group, a);
+}
+
+// Tile-level access for the streaming kernel.  A tile is the 2048 elements of one workgroup iteration (256 lanes x 8).
+// `split` (4-byte state, tile complete): lane t takes elements [4t, 4t+4) and [1024+4t, 1024+4t+4) of the tile, so
+// each of the two global_load_dwordx4 of a wavefront covers 1 KiB of consecutive addresses; otherwise lane t takes the
+// 8 consecutive elements [8t, 8t+8) (one 16-byte access for 2-byte types, two adjacent ones for fp32).  The op is
+// elementwise, so any mapping that is the same for every tensor of the launch is correct.  In the split case gi is
+// (first group of the tile) + lane; the tile may start at any group of the tensor (strided network outputs).
+template <bool NT, typename T>
+__device__ __forceinline__ void load_tile(const T* __restrict__ p, int64_t gi, bool split, float (&out)[EPT]) {
+  if constexpr (sizeof(T) == 4) {
+    if (split) {
+      const u32x4* q = reinterpret_cast<const u32x4*>(p) + (2 * gi - (int64_t)threadIdx.x);
+      const u32x4 a = ld16<NT>(q), b = ld16<NT>(q + 256);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        out[j] = __uint_as_float(a[j]);
+        out[4 + j] = __uint_as_float(b[j]);
+      }
+      return;
+    }
+  } else {
+    if (split) {  // 2-byte network output next to a 4-byte state: the same elements as two 8-byte accesses
+      typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+      const u32x2_t* q = reinterpret_cast<const u32x2_t*>(p) + (2 * gi - (int64_t)threadIdx.x);
+      const u32x2_t a = NT ? __builtin_nontemporal_load(q) : *q;
+      const u32x2_t b = NT ? __builtin_nontemporal_load(q + 256) : *(q + 256);
+      const uint32_t w[4] = {a[0], a[1], b[0], b[1]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (std::is_same<T, __half>::value) {
+          out[2 * j] = __half2float(__ushort_as_half((unsigned short)(w[j] & 0xffffu)));
+          out[2 * j + 1] = __half2float(__ushort_as_half((unsigned short)(w[j] >> 16)));
+        } else {
+          out[2 * j] = __uint_as_float(w[j] << 16);
+          out[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+        }
+      }
+      return;
+    }
+  }
+  load_pack<NT>(p, gi, out);
+}
+template <bool NT, typename T>
+__device__ __forceinline__ void store_tile(T* __restrict__ p, int64_t gi, bool split, const float (&in)[EPT]) {
+  if constexpr (sizeof(T) == 4) {
+    if (split) {
+      u32x4 a, b;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a[j] = __float_as_uint(in[j]);
+        b[j] = __float_as_uint(in[4 + j]);
+      }
+      u32x4* q = reinterpret_cast<u32x4*>(p) + (2 * gi - (int64_t)threadIdx.x);
+      st16<NT>(q, a);
+      st16<NT>(q + 256, b);
+      return;
+    }
+  }
+  store_pack<NT>(p, gi, in);
+}
+
+}  // namespace

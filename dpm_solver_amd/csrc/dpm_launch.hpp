@@ -1,0 +1,598 @@
+// dpm_launch.hpp -- launch plumbing of the stage kernels: device info, cluster shape, tuning, variant dispatch,
+// the fused multi-request launcher, the catch-all kernel handles (part of dpm_device.hpp; include that)
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// launch plumbing
+// ------------------------------------------------------------------------------------------------
+struct DeviceInfo {
+  int n_cu = 0;
+  int lds = 0;
+  char arch[64] = {0};
+  bool ok = false;
+};
+
+inline const DeviceInfo& device_info() {
+  static thread_local int cached_dev = -1;
+  static thread_local DeviceInfo info;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return info;
+  if (dev != cached_dev || !info.ok) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+      info.n_cu = prop.multiProcessorCount;
+      info.lds = (int)prop.maxSharedMemoryPerMultiProcessor;
+      std::strncpy(info.arch, prop.gcnArchName, sizeof(info.arch) - 1);
+      info.ok = true;
+      cached_dev = dev;
+    }
+  }
+  return info;
+}
+
+inline bool aligned(const void* p, size_t a) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// the division-by-invariant of the specialised prologue is exact unless alpha's significand is all ones (or alpha is
+// not a normal number): then the generic prologue, with a true division, runs instead
+inline bool div_invariant_ok(float alpha) {
+  uint32_t u;
+  std::memcpy(&u, &alpha, 4);
+  const uint32_t ex = (u >> 23) & 0xffu;
+  return ex != 0u && ex != 0xffu && (u & 0x7fffffu) != 0x7fffffu && ex > 32u && ex < 222u;
+}
+
+inline KParams make_params(const dpm_stage* st) {
+  KParams p;
+  p.alpha_e = st->alpha_e;
+  p.inv_alpha = 1.0f / st->alpha_e;
+  p.sigma_e = st->sigma_e;
+  p.cfg_scale = st->cfg_scale;
+  p.cg_scale = st->cg_scale;
+  p.cx = st->cx;
+  p.c0 = st->c0;
+  p.c1 = st->c1;
+  p.c2 = st->c2;
+  p.k0 = st->k[0];
+  p.k1 = st->k[1];
+  p.k2 = st->k[2];
+  p.k3 = st->k[3];
+  p.k4 = st->k[4];
+  p.flags = st->flags;
+  p.model_type = st->model_type;
+  p.form = st->form;
+  p.guidance = st->guidance;
+  p.inv_sigma = 1.0f / st->sigma_e;
+  p.fastdiv = (div_invariant_ok(st->alpha_e) ? 1u : 0u) | (div_invariant_ok(st->sigma_e) ? 2u : 0u);
+  return p;
+}
+
+// cluster shape of the thresholding kernel: k workgroups per sample, `chunk` elements each.  Depends only on the
+// batch, the sample size and the CU count, so dpm_threshold_workspace_bytes() and the launch agree.
+struct ThrPlan {
+  int64_t k, chunk;
+};
+inline ThrPlan thr_plan(int64_t batch, int64_t per_sample, int n_cu) {
+  const int64_t kmin = (per_sample + THR_CHUNK_MAX - 1) / THR_CHUNK_MAX;        // what LDS allows
+  const int64_t kfill = (2 * (int64_t)n_cu) / (batch < 1 ? 1 : batch);          // spread a small batch over the chip
+  const int64_t kmax = std::max<int64_t>(1, per_sample / 2048);                 // but keep >= 2 elements per lane
+  int64_t k = std::max(kmin, std::min(std::min(kfill, kmax), (int64_t)n_cu));
+  if (k < 1) k = 1;
+  int64_t chunk = (per_sample + k - 1) / k;
+  chunk = (chunk + 3) / 4 * 4;
+  return ThrPlan{k, chunk};
+}
+// words per sample: the merged histograms / lists / counters of the general route + one slot per workgroup of the cluster
+inline int64_t thr_ws_stride(int64_t k) { return (int64_t)THR_WS_WORDS + k * (int64_t)THR_SLOTW; }
+inline int64_t thr_ws_bytes(int64_t batch, int64_t per_sample, int n_cu) {
+  const ThrPlan pl = thr_plan(batch, per_sample, n_cu);
+  return pl.k > 1 ? batch * thr_ws_stride(pl.k) * 4 : 0;
+}
+
+// launch-shape defaults (measured on MI355X: profiles/r01_tuning.md, r01_tuning_v3.txt, and r01_tuning_v4.txt with the
+// write-through stores) and the run-time tuning hooks.  nt mask: bit 0 = nt loads; bits 1, 2 = nt x_out / m_out store,
+// which only matter in a -DDPM_STORE_WRITE_THROUGH=0 build.  Two situations, two optima:
+//   * a network ran since the inputs were written (every real sampling loop): the streams come from HBM and streaming
+//     (nt) loads win -- [256,4,64,64] HBM-cold: fp16 8.4 vs 9.3 us, fp32 15.3 vs 16.3-16.5 us against the default cache
+//     policy.  This is the default (DefNT = 5).
+//   * the previous launch wrote the inputs (dpm_buffers.inputs_resident: frozen-model loops such as dpm_plan_run
+//     without a model callback): they sit in the Infinity Cache and the default policy wins, with two tiles per
+//     workgroup iteration when there is work for it -- fp16 5.5 vs 7.4-7.6 us, fp32 12.35 vs 12.9 us.  Variants exist for
+//     the 2M / first-order kernels (HotCombo).
+constexpr int DEF_U = 1;
+template <typename TS>
+struct DefNT {
+  static constexpr int value = 5;
+};
+
+template <int FORM, int GUIDE, bool XE>
+struct HotCombo {
+  static constexpr bool value = (FORM == DPM_FORM_TWO || FORM == DPM_FORM_LIN1) && GUIDE == DPM_GUIDE_NONE && !XE;
+};
+
+struct LaunchCtx {
+  hipStream_t stream;
+  hipEvent_t start, stop;  // both null: plain launch; else hipExtLaunchKernelGGL brackets the kernel itself
+  // device-resident coefficients (the adaptive solver's on-device controller, dpm_kernels.hip): the float fields of
+  // the stage record are read from `dyn` (device memory) by the kernel instead of from its arguments, and the launch
+  // is a no-op when *skip != 0.  Honoured by the general-prologue kernels only.
+  const dpm_stage* dyn = nullptr;
+  const int32_t* skip = nullptr;
+};
+
+template <typename K, typename... Args>
+void launch(K kern, dim3 grid, dim3 block, size_t lds, const LaunchCtx& c, Args... args) {
+  if (c.start || c.stop)
+    hipExtLaunchKernelGGL(kern, grid, block, lds, c.stream, c.start, c.stop, 0, args...);
+  else
+    hipLaunchKernelGGL(kern, grid, block, lds, c.stream, args...);
+}
+
+template <typename TS, typename TE, int FORM, int GUIDE, bool XE>
+int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& stream) {
+  const KParams p = make_params(st);
+  const TS* x = static_cast<const TS*>(b->x);
+  const TS* xe = static_cast<const TS*>(b->xe);
+  const TE* e0 = static_cast<const TE*>(b->e0);
+  const TE* e1 = static_cast<const TE*>(b->e1);
+  const TE* g = static_cast<const TE*>(b->g);
+  const TS* h1 = static_cast<const TS*>(b->h1);
+  const TS* h2 = static_cast<const TS*>(b->h2);
+  TS* xo = static_cast<TS*>(b->x_out);
+  TS* mo = static_cast<TS*>(b->m_out);
+  const DeviceInfo& di = device_info();
+  const int n_cu = di.n_cu > 0 ? di.n_cu : 256;
+  KExt ext;
+  std::memset(&ext, 0, sizeof ext);
+  const bool blend = (st->flags & DPM_F_BLEND) != 0;
+  ext.xo2 = b->x_out2;
+  ext.mask = blend ? b->mask : nullptr;
+  ext.ba = blend ? b->blend_a : nullptr;
+  ext.bb = blend ? b->blend_b : nullptr;
+  ext.mask_period = blend ? b->mask_period : 0;
+  ext.per_sample = b->n / b->batch;
+  ext.eps_stride = (b->eps_stride == ext.per_sample) ? 0 : b->eps_stride;
+  ext.blend_alpha = st->blend_alpha;
+  ext.blend_sigma = st->blend_sigma;
+  const bool use_ext = ext.xo2 || ext.mask || ext.eps_stride;
+
+  if (st->flags & DPM_F_THRESH) {
+    if (stream.dyn) return dpm_set_error(DPM_ERR_UNSUPPORTED, "dynamic thresholding with device-resident coefficients");
+    const int64_t per_sample = b->n / b->batch;
+    if (b->batch > 0x7fffffff || per_sample > ((int64_t)1 << 40))
+      return dpm_set_error(DPM_ERR_UNSUPPORTED, "thresholding: batch / sample size out of range");
+    ThrPlan pl = thr_plan(b->batch, per_sample, n_cu);
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream.stream, &cap_status);
+    const bool capturing = cap_status != hipStreamCaptureStatusNone;
+    // Clusters wait for each other inside the kernel, which is only safe while no OTHER clustered launch can hold part of
+    // the chip at the same time.  Eager launches of this process are chained device-wide (below); a captured graph is
+    // replayed outside that chain, possibly next to another graph on another stream.  Under capture a sample that fits
+    // one workgroup's LDS therefore takes the cluster-free shape (one workgroup per sample) unless the caller opts in
+    // (DPM_TUNE_CLUSTER_IN_GRAPH); larger samples have no such shape and keep their clusters, with bounded waits.
+    if (capturing && pl.k > 1 && per_sample <= THR_CHUNK_MAX && !g_tuning.cluster_in_graph) {
+      pl.k = 1;
+      pl.chunk = (per_sample + 3) / 4 * 4;
+    }
+    ThrParams tp;
+    std::memset(&tp, 0, sizeof tp);
+    tp.per_sample = per_sample;
+    // torch.quantile: rank = q * (n - 1) evaluated in fp32 (q is an fp32 tensor)
+    const float rank = st->thr_ratio * (float)(per_sample - 1);
+    tp.lo = (int32_t)floorf(rank);
+    tp.hi = (int32_t)ceilf(rank);
+    tp.w = rank - (float)tp.lo;
+    tp.max_val = st->thr_max;
+    tp.chunk = (int32_t)pl.chunk;
+    tp.k = (int32_t)pl.k;
+    tp.batch = (int32_t)b->batch;
+    tp.fastdiv = st->model_type == DPM_MODEL_NOISE && (st->flags & DPM_F_TO_X0) && div_invariant_ok(st->alpha_e);
+    const size_t a4s = sizeof(TS) * 4, a4e = sizeof(TE) * 4;
+    tp.vec = per_sample % 4 == 0 && ext.eps_stride % 4 == 0 && ext.mask_period % 4 == 0 && aligned(x, a4s) &&
+             aligned(xe, a4s) && aligned(h1, a4s) && aligned(h2, a4s) && aligned(xo, a4s) && aligned(mo, a4s) &&
+             aligned(ext.xo2, a4s) && aligned(ext.mask, a4s) && aligned(ext.ba, a4s) && aligned(ext.bb, a4s) &&
+             aligned(e0, a4e) && aligned(e1, a4e) && aligned(g, a4e);
+    {
+      // top-K front end: a = the K-th largest element.  It needs at most one wanted element per contributing thread and
+      // pays when the K-th largest per-thread maximum sits in the sparse upper tail (K a small part of the threads) and
+      // the candidates (a small multiple of K) fit the rank-counting finish (<= THR_THREADS of them).
+      const int64_t K = per_sample - (int64_t)tp.lo;
+      int64_t P = 0;
+      for (int64_t c = 0; c < pl.k; ++c) {
+        const int64_t n_c = std::max<int64_t>(0, std::min<int64_t>(pl.chunk, per_sample - c * pl.chunk));
+        P += std::min<int64_t>(THR_THREADS, tp.vec ? (n_c + 3) / 4 : n_c);
+      }
+      if (K >= 1 && K <= P / 4 && K <= THR_THREADS / 4) {  // beyond: the candidates outgrow the rank-counting finish
+        tp.topk = (int32_t)K;
+        tp.mrank = (int32_t)(P - K);
+      }
+      // single-exchange cluster route (cluster_select_once): a chunk's share of the K largest is ~ K/k; publishing the
+      // ~quota = K/k + 6 sigma + 8 largest values of every chunk makes the one-hop answer exact except for samples whose
+      // large values sit in one chunk (those fall back inside the kernel).  Needs room in the slots for the 14-bit digit's
+      // granularity (x1.5) and a union that fits the LDS list.
+      if (pl.k > 1 && pl.k <= THR_KMAX && K >= 1 && K < ((int64_t)1 << 30)) {
+        const double mu = (double)K / (double)pl.k;
+        const int64_t quota = (int64_t)std::ceil(mu + 6.0 * std::sqrt(mu) + 8.0);
+        // slot size: the smallest power of two >= 64 with room for the quota and the digit granularity (fewer words to
+        // fetch per slot); at most THR_SLOT_CAP and THR_CAP / k
+        int slot_shift = 6;
+        while (((int64_t)1 << slot_shift) < quota * 3 / 2 && slot_shift < 8) ++slot_shift;
+        while (slot_shift > 0 && ((int64_t)1 << slot_shift) > std::min<int64_t>(THR_SLOT_CAP, THR_CAP / pl.k)) --slot_shift;
+        const int64_t slot_cap = (int64_t)1 << slot_shift;
+        if (quota * 3 / 2 <= slot_cap && g_tuning.cluster_one_hop) {
+          tp.quota = (int32_t)quota;
+          tp.kbig = (int32_t)K;
+          tp.slot_cap = (int32_t)slot_cap;
+          tp.slot_pub = (int32_t)std::min<int64_t>(slot_cap, quota + quota / 4 + 4);
+          tp.slot_shift = slot_shift;
+          tp.debug_reject = g_tuning.cluster_one_hop == 2;
+        }
+      }
+    }
+#ifdef DPM_THR_TIMING
+    // debug build only: the DPM_THR_TIMING_LAUNCH-th thresholding launch of the process (default 40) is synchronised
+    // and its stamps are written to $DPM_THR_TIMING_FILE, one line of 16 values per workgroup
+    static uint64_t* t_dev = nullptr;
+    static int t_launches = 0;
+    if (!t_dev) (void)hipMalloc(&t_dev, 4096 * 16 * sizeof(uint64_t));
+    tp.tdbg = t_dev;
+    auto t_dump = [&](int64_t wgs) {
+      const char* path = getenv("DPM_THR_TIMING_FILE");
+      const char* at = getenv("DPM_THR_TIMING_LAUNCH");
+      if (!path || ++t_launches != (at ? atoi(at) : 40) || wgs > 4096) return;
+      (void)hipStreamSynchronize(stream.stream);
+      std::vector<uint64_t> h((size_t)wgs * 16);
+      (void)hipMemcpy(h.data(), t_dev, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
+      if (FILE* f = fopen(path, "w")) {
+        for (int64_t i = 0; i < wgs; ++i) {
+          for (int j = 0; j < 16; ++j) fprintf(f, "%llu ", (unsigned long long)h[(size_t)i * 16 + j]);
+          fprintf(f, "\n");
+        }
+        fclose(f);
+      }
+    };
+#else
+    auto t_dump = [](int64_t) {};
+#endif
+    const size_t lds_bytes = (size_t)pl.chunk * 4 + THR_NB * 4 + THR_MISC * 4 + (THR_CAP + 32) * 4;
+    // the compile-time specialisation exists for the forms / guidance kinds samplers combine with thresholding
+    constexpr bool HOT_BUILT = (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3) &&
+                               (GUIDE == DPM_GUIDE_NONE || GUIDE == DPM_GUIDE_CFG) && !XE;
+    const bool hot = HOT_BUILT && tp.vec && tp.fastdiv && !ext.mask;
+    // the general kernel reads form / guidance from the stage record and always takes the evaluation state through xe
+    using ThrKernel = decltype(&stage_thresh_kernel<TS, TE, FORM_RT, GUIDE_RT, true, THR_THREADS, 0>);
+    auto kern = reinterpret_cast<ThrKernel>(const_cast<void*>(dpm_catchall_thresh<TS, TE>()));
+    if constexpr (HOT_BUILT) {
+      if (hot)
+        kern = (tp.topk > 0 || tp.quota > 0) ? stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 1>
+                                            : stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 2>;
+    }
+    if (!xe) xe = x;
+    int64_t grid = b->batch;
+    tp.groups = (int32_t)b->batch;
+    if (pl.k > 1) {
+      // clusters synchronise through spin barriers: every workgroup of the grid must be resident at once
+      static thread_local int occ_dev = -1, occ = 0;
+      static thread_local size_t occ_lds = 0;
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (dev != occ_dev || lds_bytes != occ_lds) {
+        int nb = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), THR_THREADS,
+                                                                    lds_bytes);
+        if (e != hipSuccess) return dpm_set_error((int)e, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s", hipGetErrorString(e));
+        occ_dev = dev;
+        occ_lds = lds_bytes;
+        occ = nb;
+      }
+      const int64_t cap = (int64_t)n_cu * (occ < 1 ? 1 : (occ > 2 ? 2 : occ));
+      if (pl.k > cap)
+        return dpm_set_error(DPM_ERR_UNSUPPORTED, "dynamic thresholding: a sample of %lld elements needs %lld co-resident "
+                             "workgroups, the device holds %lld", (long long)per_sample, (long long)pl.k, (long long)cap);
+      if (!b->workspace)
+        return dpm_set_error(DPM_ERR_ARG,
+                             "dynamic thresholding of %lld samples x %lld elements needs a workspace of "
+                             "dpm_threshold_workspace_bytes() = %lld bytes",
+                             (long long)b->batch, (long long)per_sample, (long long)thr_ws_bytes(b->batch, per_sample, n_cu));
+      const int64_t groups = std::min<int64_t>(b->batch, cap / pl.k);
+      tp.groups = (int32_t)groups;
+      tp.ws = static_cast<uint32_t*>(b->workspace);
+      tp.ws_stride = thr_ws_stride(pl.k);
+      grid = groups * pl.k;
+      // No clearing of the workspace here: the caller hands it over zero-filled once, the kernel leaves it zero-filled
+      // (dpm_threshold_workspace_bytes).  A wait that timed out in an earlier clustered launch is reported now.
+      uint32_t* fault = cluster_fault_word(!capturing);
+      if (fault && *fault) {
+        *fault = 0u;
+        return dpm_set_error(DPM_ERR_FAULT, "a clustered dynamic-thresholding launch gave up waiting for a peer workgroup "
+                             "(another clustered launch held the GPU concurrently?); its results are invalid and its "
+                             "workspace must be zero-filled again");
+      }
+      tp.fault = fault;
+      // Two clustered launches on different streams could each hold part of the CUs with spinning workgroups and
+      // starve the other's missing peers.  Within this process they are therefore chained device-wide: wait for the
+      // previous clustered launch (whatever its stream), record after this one.  (Not under stream capture, where an
+      // event recorded outside the capture cannot be waited on; see above.)
+      if (!capturing) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        ClusterChain& ch = cluster_chain(dev);
+        std::lock_guard<std::mutex> lk(ch.mu);
+        if (!ch.ev && hipEventCreateWithFlags(&ch.ev, hipEventDisableTiming) != hipSuccess) ch.ev = nullptr;
+        if (ch.ev && ch.recorded) (void)hipStreamWaitEvent(stream.stream, ch.ev, 0);
+        launch(kern, dim3((unsigned)grid), dim3(THR_THREADS), lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo, p, tp, ext);
+        if (ch.ev && hipEventRecord(ch.ev, stream.stream) == hipSuccess) ch.recorded = true;
+        t_dump(grid);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return dpm_set_error((int)e, "stage kernel launch failed: %s", hipGetErrorString(e));
+        return DPM_OK;
+      }
+    }
+    launch(kern, dim3((unsigned)grid), dim3(THR_THREADS), lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo, p, tp, ext);
+    t_dump(grid);
+  } else {
+    const size_t as = sizeof(TS) * EPT, ae = sizeof(TE) * EPT;
+    bool vec = aligned(x, as) && aligned(xe, as) && aligned(h1, as) && aligned(h2, as) && aligned(xo, as) &&
+               aligned(mo, as) && aligned(e0, ae) && aligned(e1, ae) && aligned(g, ae);
+    if (use_ext)  // the extended vector kernel has no ragged tail and indexes whole 8-element groups
+      vec = vec && aligned(ext.xo2, as) && aligned(ext.mask, as) && aligned(ext.ba, as) && aligned(ext.bb, as) &&
+            b->n % EPT == 0 && ext.mask_period % EPT == 0 &&
+            (!ext.eps_stride || (ext.per_sample % EPT == 0 && ext.eps_stride % EPT == 0));
+    // what the streaming family instantiates (binary size: one kernel per combination and dtype pair):
+    //   * a separate evaluation state (xe != x) only occurs in the singlestep mid / final stages: forms TWO and SS3T;
+    //   * the compile-time prologues (noise-prediction network) for the forms samplers spend their time in -- LIN1, TWO,
+    //     MS3; SS3T and DENOISE run the general prologue (true division: the same bits);
+    //   everything else goes through the one-element-per-lane kernel.
+    constexpr bool COMBO_BUILT = !XE || FORM == DPM_FORM_TWO || FORM == DPM_FORM_SS3T;
+    constexpr bool SPEC_BUILT = FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3;
+    // device-resident coefficients (adaptive solver): DYN kernels exist for the forms it launches -- first-order,
+    // second-order and the singlestep-3 'taylor' combination -- without the KExt extensions; anything else takes the
+    // one-element-per-lane kernel
+    constexpr bool DYN_BUILT = COMBO_BUILT && (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_SS3T);
+    const bool dyn_vec = stream.dyn && DYN_BUILT && !use_ext;
+    if (!vec || !COMBO_BUILT || (stream.dyn && !dyn_vec)) {
+      int64_t blocks = (b->n + 255) / 256;
+      const int64_t cap = (int64_t)n_cu * 16;
+      if (blocks > cap) blocks = cap;
+      using ScalarKernel = decltype(&stage_kernel_scalar<TS, TE, false>);  // the DYN = true variant has the same signature
+      const void* k = stream.dyn ? dpm_catchall_scalar<TS, TE, true>() : dpm_catchall_scalar<TS, TE, false>();
+      launch(reinterpret_cast<ScalarKernel>(const_cast<void*>(k)), dim3((unsigned)blocks), dim3(256), 0, stream, x, xe ? xe : x,
+             e0, e1, g, h1, h2, xo, mo, b->n, p, ext, stream.dyn, stream.skip);
+    } else if constexpr (COMBO_BUILT) {
+      const bool noise = SPEC_BUILT && !stream.dyn && st->model_type == DPM_MODEL_NOISE &&
+                         (!(st->flags & DPM_F_TO_X0) || div_invariant_ok(st->alpha_e));
+      const int spec = !noise ? SPEC_GENERIC : ((st->flags & DPM_F_TO_X0) ? SPEC_NOISE_X0 : SPEC_NOISE_EPS);
+      const int64_t ntiles = ((b->n / EPT) + 255) / 256;
+      const Tuning tn = g_tuning;
+      const bool big = ntiles >= 4 * (int64_t)n_cu;  // two tiles per iteration only when there is work for it
+      auto grid_for = [&](int u) {
+        int64_t blocks = (ntiles + u - 1) / u;
+        const int64_t cap = (int64_t)n_cu * tn.blocks_per_cu;
+        if (blocks > cap) blocks = cap;
+        return dim3((unsigned)(blocks < 1 ? 1 : blocks));
+      };
+#define DPM_LAUNCH(SPEC_, U_, NT_, EXT_)                                                                             \
+  launch(stage_kernel<TS, TE, FORM, GUIDE, XE, SPEC_, U_, NT_, EXT_>, grid_for(U_), dim3(256), 0, stream, x, xe, e0, e1, \
+         g, h1, h2, xo, mo, b->n, p, ext, stream.dyn, stream.skip)
+      if (dyn_vec) {
+        if constexpr (DYN_BUILT)
+          launch(stage_kernel<TS, TE, FORM, GUIDE, XE, SPEC_GENERIC, 1, DefNT<TS>::value, false, true>, grid_for(1), dim3(256),
+                 0, stream, x, xe, e0, e1, g, h1, h2, xo, mo, b->n, p, ext, stream.dyn, stream.skip);
+      } else if (use_ext) {
+        // (tiles per iteration, nt mask) of the inputs-from-HBM table below; x_out stays cacheable (it is the next
+        // network input), so bit 1 is never set
+        constexpr int EU = (sizeof(TS) == 4 && sizeof(TE) == 2) ? 2 : 1;
+        constexpr int ENT = sizeof(TS) == 2 ? 1 : (sizeof(TE) == 4 ? 5 : 1);
+        const bool two = EU == 2 && big && SPEC_BUILT;
+        if (spec == SPEC_GENERIC) {
+          DPM_LAUNCH(SPEC_GENERIC, 1, ENT, true);
+        } else if constexpr (SPEC_BUILT) {
+          if (spec == SPEC_NOISE_X0) {
+            if (two) DPM_LAUNCH(SPEC_NOISE_X0, EU, ENT, true); else DPM_LAUNCH(SPEC_NOISE_X0, 1, ENT, true);
+          } else {
+            if (two) DPM_LAUNCH(SPEC_NOISE_EPS, EU, ENT, true); else DPM_LAUNCH(SPEC_NOISE_EPS, 1, ENT, true);
+          }
+        }
+      } else if (spec == SPEC_GENERIC) {
+        DPM_LAUNCH(SPEC_GENERIC, 1, DefNT<TS>::value, false);
+      } else if constexpr (SPEC_BUILT) {
+        if (spec == SPEC_NOISE_EPS) {
+          DPM_LAUNCH(SPEC_NOISE_EPS, DEF_U, DefNT<TS>::value, false);
+        } else if constexpr (HotCombo<FORM, GUIDE, XE>::value) {
+          // the north-star kernels (2M / 1st-order update, no guidance): (tiles per iteration, nt mask) by situation and
+          // dtypes, from profiles/r01_tuning_v3.txt / r01_tuning_v4.txt:
+          //   inputs cache-resident: default policy, two tiles per iteration when there is work for it
+          //   inputs from HBM:       2-byte state (1, nt loads); fp32 + fp32 (1 | 2, nt loads + nt m store);
+          //                          fp32 state + 2-byte network output (1 | 2, nt loads)  [SD under autocast]
+          const bool resident = b->inputs_resident != 0 || tn.assume_resident != 0;
+          constexpr int CNT = sizeof(TS) == 2 ? 1 : (sizeof(TE) == 4 ? 5 : 1);  // nt mask of the HBM situation
+#ifdef DPM_TUNING_VARIANTS  // tools/tune.py single: every (tiles per iteration, nt mask)
+          if (tn.unroll > 0 && tn.nontemporal >= 0) {
+            switch (tn.unroll * 8 + (tn.nontemporal & 7)) {
+              case 8 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 1, 0, false); break;
+              case 8 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 1, 1, false); break;
+              case 8 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 1, 5, false); break;
+              case 16 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 2, 0, false); break;
+              case 16 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 2, 1, false); break;
+              case 16 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 2, 5, false); break;
+              default: DPM_LAUNCH(SPEC_NOISE_X0, DEF_U, DefNT<TS>::value, false); break;
+            }
+          } else
+#endif
+          if (resident) {
+            if (big) DPM_LAUNCH(SPEC_NOISE_X0, 2, 0, false); else DPM_LAUNCH(SPEC_NOISE_X0, 1, 0, false);
+          } else if (sizeof(TS) == 2 || !big) {
+            DPM_LAUNCH(SPEC_NOISE_X0, 1, CNT, false);
+          } else {
+            DPM_LAUNCH(SPEC_NOISE_X0, 2, CNT, false);
+          }
+        } else {
+          DPM_LAUNCH(SPEC_NOISE_X0, DEF_U, DefNT<TS>::value, false);
+        }
+      }
+#undef DPM_LAUNCH
+    }
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return dpm_set_error((int)e, "stage kernel launch failed: %s", hipGetErrorString(e));
+  return DPM_OK;
+}
+
+// ---- fused multi-request launch (stage_kernel_multi).  Returns DPM_ERR_UNSUPPORTED *without* setting an error text
+// when this (form, guidance, prologue) has no fused variant: the caller then launches the requests one by one.
+constexpr int MULTI_NOT_BUILT = -1000;
+// Launch shape of the fused kernel (profiles/r02_tune_multi.txt, 32 x [256,4,64,64], kernel-only per request-stage):
+// the inputs of a fused launch always come from HBM (R x 42 MB of other requests' traffic passed since they were
+// written) -> streaming loads; one super-tile per workgroup -- a grid of all R x tiles workgroups, no grid-stride loop:
+// fp16 7.95 us with the grid capped at 8 workgroups per CU, 7.7 / 7.5 at 16 / 32 per CU, 6.93 uncapped (0.757 of the
+// HBM peak; fp32 15.4 -> 13.9, fp32 state + fp16 output 13.3 -> 12.6); two tiles per workgroup for 4-byte states.
+template <typename TS, typename TE>
+struct MultiShape {
+  static constexpr int U = (sizeof(TS) == 4) ? 2 : 1;
+  static constexpr int NT = 1;
+};
+
+template <typename TS, typename TE, int FORM, int GUIDE, int SPEC>
+int launch_multi_spec(const dpm_stage* st, const dpm_buffers* bs, int n_req, const LaunchCtx& c) {
+  const DeviceInfo& di = device_info();
+  const int n_cu = di.n_cu > 0 ? di.n_cu : 256;
+  const Tuning tn = g_tuning;
+  MultiTab tab;
+  std::memset(&tab, 0, sizeof tab);
+  for (int r = 0; r < n_req; ++r) {
+    tab.x[r] = bs[r].x ? bs[r].x : bs[r].xe;
+    tab.e0[r] = bs[r].e0;
+    tab.e1[r] = bs[r].e1;
+    tab.h1[r] = bs[r].h1;
+    tab.h2[r] = bs[r].h2;
+    tab.xo[r] = bs[r].x_out;
+    tab.mo[r] = bs[r].m_out;
+  }
+  const KParams p = make_params(st);
+  const int64_t n = bs[0].n;
+  const int64_t ntiles = ((n / EPT) + 255) / 256;
+  auto go = [&](auto kern, int u) {
+    const int64_t spr = (ntiles + u - 1) / u;
+    int64_t blocks = spr * n_req;
+    const bool remap = tn.multi_xcd_remap < 0 ? sizeof(TS) == 2 : tn.multi_xcd_remap != 0;
+    const uint32_t span = remap ? (uint32_t)((blocks + 7) / 8) : 0u;
+    if (span) blocks = (int64_t)span * 8;
+    if (tn.multi_blocks_per_cu > 0) {  // tuning hook: cap the grid, workgroups loop over the super-tiles
+      const int64_t cap = (int64_t)n_cu * tn.multi_blocks_per_cu;
+      if (blocks > cap) blocks = cap;
+    }
+    launch(kern, dim3((unsigned)blocks), dim3(256), 0, c, tab, n, (uint32_t)n_req, (uint32_t)spr, p, span);
+  };
+  constexpr int DU = MultiShape<TS, TE>::U, DN = MultiShape<TS, TE>::NT;
+#ifdef DPM_TUNING_VARIANTS  // tools/tune.py multi: every (tiles per iteration, nt mask) of the 2M kernel
+  if constexpr (FORM == DPM_FORM_TWO && GUIDE == DPM_GUIDE_NONE && SPEC == SPEC_NOISE_X0) {
+    if (tn.unroll > 0 && tn.nontemporal >= 0) {
+      switch (tn.unroll * 8 + (tn.nontemporal & 7)) {
+        case 8 + 0: go(stage_kernel_multi<TS, TE, FORM, GUIDE, SPEC, 1, 0>, 1); break;
+        case 8 + 1: go(stage_kernel_multi<TS, TE, FORM, GUIDE, SPEC, 1, 1>, 1); break;
+        case 8 + 5: go(stage_kernel_multi<TS, TE, FORM, GUIDE, SPEC, 1, 5>, 1); break;
+        case 16 + 0: go(stage_kernel_multi<TS, TE, FORM, GUIDE, SPEC, 2, 0>, 2); break;
+        case 16 + 1: go(stage_kernel_multi<TS, TE, FORM, GUIDE, SPEC, 2, 1>, 2); break;
+        case 16 + 5: go(stage_kernel_multi<TS, TE, FORM, GUIDE, SPEC, 2, 5>, 2); break;
+        default: go(stage_kernel_multi<TS, TE, FORM, GUIDE, SPEC, DU, DN>, DU); break;
+      }
+      hipError_t e2 = hipGetLastError();
+      if (e2 != hipSuccess) return dpm_set_error((int)e2, "fused stage kernel launch failed: %s", hipGetErrorString(e2));
+      return DPM_OK;
+    }
+  }
+#endif
+  go(stage_kernel_multi<TS, TE, FORM, GUIDE, SPEC, DU, DN>, DU);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return dpm_set_error((int)e, "fused stage kernel launch failed: %s", hipGetErrorString(e));
+  return DPM_OK;
+}
+
+// every request of the group: same stage, n, batch, dtypes (checked by the caller); here: is there a fused variant, and
+// do all buffers allow 16-byte accesses?
+template <typename TS, typename TE>
+int launch_multi_typed(const dpm_stage* st, const dpm_buffers* bs, int n_req, const LaunchCtx& c) {
+  if (st->flags & (DPM_F_THRESH | DPM_F_BLEND)) return MULTI_NOT_BUILT;
+  if (st->guidance == DPM_GUIDE_CLASSIFIER) return MULTI_NOT_BUILT;
+  if (st->form != DPM_FORM_LIN1 && st->form != DPM_FORM_TWO && st->form != DPM_FORM_MS3) return MULTI_NOT_BUILT;
+  const size_t as = sizeof(TS) * EPT, ae = sizeof(TE) * EPT;
+  if (bs[0].n % EPT != 0) return MULTI_NOT_BUILT;
+  for (int r = 0; r < n_req; ++r) {
+    const dpm_buffers& b = bs[r];
+    if (b.x_out2 || (b.eps_stride && b.eps_stride != b.n / b.batch)) return MULTI_NOT_BUILT;
+    if (b.xe && b.x && b.xe != b.x) return MULTI_NOT_BUILT;
+    if (!(aligned(b.x, as) && aligned(b.xe, as) && aligned(b.h1, as) && aligned(b.h2, as) && aligned(b.x_out, as) &&
+          aligned(b.m_out, as) && aligned(b.e0, ae) && aligned(b.e1, ae)))
+      return MULTI_NOT_BUILT;
+  }
+  const bool x0 = (st->flags & DPM_F_TO_X0) != 0;
+  const bool cfg = st->guidance == DPM_GUIDE_CFG;
+  // x_start / v / score networks (and an alpha the division-by-invariant guard rejects) take the general prologue
+  const bool generic = st->model_type != DPM_MODEL_NOISE || (x0 && !div_invariant_ok(st->alpha_e));
+#define DPM_MULTI(FORM_)                                                                                        \
+  (generic ? (cfg ? launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_CFG, SPEC_GENERIC>(st, bs, n_req, c)             \
+                  : launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_NONE, SPEC_GENERIC>(st, bs, n_req, c))           \
+   : cfg   ? (x0 ? launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_CFG, SPEC_NOISE_X0>(st, bs, n_req, c)             \
+                 : launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_CFG, SPEC_NOISE_EPS>(st, bs, n_req, c))           \
+           : (x0 ? launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_NONE, SPEC_NOISE_X0>(st, bs, n_req, c)            \
+                 : launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_NONE, SPEC_NOISE_EPS>(st, bs, n_req, c)))
+  switch (st->form) {
+    case DPM_FORM_LIN1: return DPM_MULTI(DPM_FORM_LIN1);
+    case DPM_FORM_TWO: return DPM_MULTI(DPM_FORM_TWO);
+    default: return DPM_MULTI(DPM_FORM_MS3);
+  }
+#undef DPM_MULTI
+}
+
+template <typename TS, typename TE, int FORM, int GUIDE>
+int launch_xe(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& s) {
+  return (b->xe != nullptr && b->xe != b->x) ? launch_typed<TS, TE, FORM, GUIDE, true>(st, b, s)
+                                            : launch_typed<TS, TE, FORM, GUIDE, false>(st, b, s);
+}
+
+template <typename TS, typename TE, int FORM>
+int launch_guide(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& s) {
+  switch (st->guidance) {
+    case DPM_GUIDE_NONE: return launch_xe<TS, TE, FORM, DPM_GUIDE_NONE>(st, b, s);
+    case DPM_GUIDE_CFG: return launch_xe<TS, TE, FORM, DPM_GUIDE_CFG>(st, b, s);
+    case DPM_GUIDE_CLASSIFIER: return launch_xe<TS, TE, FORM, DPM_GUIDE_CLASSIFIER>(st, b, s);
+  }
+  return dpm_set_error(DPM_ERR_ARG, "unknown guidance %d", st->guidance);
+}
+
+// The single-request launchers of one dtype pair are spread over two translation units (compile time: the build is the
+// slowest unit).  FORMS = the update forms this unit instantiates (bit f = form f); a stage of another form returns
+// FORM_ELSEWHERE and the caller (dpm_stage_<pair>.hip) passes it on to the sibling unit.
+constexpr int FORM_ELSEWHERE = -1001;
+constexpr unsigned FORMS_A = (1u << DPM_FORM_TWO) | (1u << DPM_FORM_SS3T);  // + the fused multi-request launchers
+constexpr unsigned FORMS_B = (1u << DPM_FORM_LIN1) | (1u << DPM_FORM_MS3) | (1u << DPM_FORM_DENOISE);
+template <typename TS, typename TE, unsigned FORMS>
+int launch_form(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& s) {
+  switch (st->form) {
+#define DPM_FORM_CASE(F)                                            \
+  case F:                                                           \
+    if constexpr ((FORMS >> F) & 1u) return launch_guide<TS, TE, F>(st, b, s); \
+    return FORM_ELSEWHERE;
+    DPM_FORM_CASE(DPM_FORM_LIN1)
+    DPM_FORM_CASE(DPM_FORM_TWO)
+    DPM_FORM_CASE(DPM_FORM_MS3)
+    DPM_FORM_CASE(DPM_FORM_SS3T)
+    DPM_FORM_CASE(DPM_FORM_DENOISE)
+#undef DPM_FORM_CASE
+  }
+  return dpm_set_error(DPM_ERR_ARG, "unknown update form %d", st->form);
+}
+
+}  // namespace
+
+#ifdef DPM_CATCHALL_HOME
+template <typename TS, typename TE>
+const void* dpm_catchall_thresh() {
+  return reinterpret_cast<const void*>(&stage_thresh_kernel<TS, TE, FORM_RT, GUIDE_RT, true, THR_THREADS, 0>);
+}
+template <typename TS, typename TE, bool DYN>
+const void* dpm_catchall_scalar() {
+  return reinterpret_cast<const void*>(&stage_kernel_scalar<TS, TE, DYN>);
+}
+#endif
