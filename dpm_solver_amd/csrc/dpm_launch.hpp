@@ -119,6 +119,10 @@ struct LaunchCtx {
   // is a no-op when *skip != 0.  Honoured by the general-prologue kernels only.
   const dpm_stage* dyn = nullptr;
   const int32_t* skip = nullptr;
+  // thresholded stage of n_multi requests fused into ONE launch (dpm_stage_launch_multi): `multi` = their buffer
+  // records, all of the shape and dtypes of multi[0] (which is also the `b` the launcher is called with)
+  const dpm_buffers* multi = nullptr;
+  int n_multi = 0;
 };
 
 template <typename K, typename... Args>
@@ -128,6 +132,10 @@ void launch(K kern, dim3 grid, dim3 block, size_t lds, const LaunchCtx& c, Args.
   else
     hipLaunchKernelGGL(kern, grid, block, lds, c.stream, args...);
 }
+
+// what a fused multi-request launcher returns -- without setting an error text -- when this stage (form, guidance,
+// prologue, buffers) has no fused variant: the caller then launches the requests one by one
+constexpr int MULTI_NOT_BUILT = -1000;
 
 template <typename TS, typename TE, int FORM, int GUIDE, bool XE>
 int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& stream) {
@@ -160,9 +168,13 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
   if (st->flags & DPM_F_THRESH) {
     if (stream.dyn) return dpm_set_error(DPM_ERR_UNSUPPORTED, "dynamic thresholding with device-resident coefficients");
     const int64_t per_sample = b->n / b->batch;
-    if (b->batch > 0x7fffffff || per_sample > ((int64_t)1 << 40))
+    // several requests in one launch: one batch of n_multi * batch samples -- more samples per launch, smaller (or no)
+    // clusters -- whose sample s lives in the tensors of request s / batch (ThrTab)
+    const bool multi = stream.multi != nullptr;
+    const int64_t batch = multi ? (int64_t)stream.n_multi * b->batch : b->batch;
+    if (batch > 0x7fffffff || per_sample > ((int64_t)1 << 40))
       return dpm_set_error(DPM_ERR_UNSUPPORTED, "thresholding: batch / sample size out of range");
-    ThrPlan pl = thr_plan(b->batch, per_sample, n_cu);
+    ThrPlan pl = thr_plan(batch, per_sample, n_cu);
     hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream.stream, &cap_status);
     const bool capturing = cap_status != hipStreamCaptureStatusNone;
@@ -186,13 +198,42 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
     tp.max_val = st->thr_max;
     tp.chunk = (int32_t)pl.chunk;
     tp.k = (int32_t)pl.k;
-    tp.batch = (int32_t)b->batch;
+    tp.batch = (int32_t)batch;
     tp.fastdiv = st->model_type == DPM_MODEL_NOISE && (st->flags & DPM_F_TO_X0) && div_invariant_ok(st->alpha_e);
     const size_t a4s = sizeof(TS) * 4, a4e = sizeof(TE) * 4;
     tp.vec = per_sample % 4 == 0 && ext.eps_stride % 4 == 0 && ext.mask_period % 4 == 0 && aligned(x, a4s) &&
              aligned(xe, a4s) && aligned(h1, a4s) && aligned(h2, a4s) && aligned(xo, a4s) && aligned(mo, a4s) &&
              aligned(ext.xo2, a4s) && aligned(ext.mask, a4s) && aligned(ext.ba, a4s) && aligned(ext.bb, a4s) &&
              aligned(e0, a4e) && aligned(e1, a4e) && aligned(g, a4e);
+    static const ThrTab no_tab = {};
+    ThrTab tab_multi;
+    if (multi) {
+      // the fused launch serves plain requests: no extensions, the evaluation state is the state, distinct workspaces
+      // (clusters of different requests run side by side); anything else is launched request by request
+      if (XE || GUIDE == DPM_GUIDE_CLASSIFIER || stream.n_multi > MULTI_MAX) return MULTI_NOT_BUILT;
+      std::memset(&tab_multi, 0, sizeof tab_multi);
+      tp.bpr = (int32_t)b->batch;
+      for (int r = 0; r < stream.n_multi; ++r) {
+        const dpm_buffers& q = stream.multi[r];
+        if (!q.x || (q.xe && q.xe != q.x) || q.x_out2 || (q.eps_stride && q.eps_stride != per_sample)) return MULTI_NOT_BUILT;
+        if (pl.k > 1) {
+          if (!q.workspace) return MULTI_NOT_BUILT;
+          for (int r2 = 0; r2 < r; ++r2)
+            if (stream.multi[r2].workspace == q.workspace) return MULTI_NOT_BUILT;
+        }
+        tp.vec = tp.vec && aligned(q.x, a4s) && aligned(q.h1, a4s) && aligned(q.h2, a4s) && aligned(q.x_out, a4s) &&
+                 aligned(q.m_out, a4s) && aligned(q.e0, a4e) && aligned(q.e1, a4e);
+        tab_multi.x[r] = q.x;
+        tab_multi.e0[r] = q.e0;
+        tab_multi.e1[r] = q.e1;
+        tab_multi.h1[r] = q.h1;
+        tab_multi.h2[r] = q.h2;
+        tab_multi.xo[r] = q.x_out;
+        tab_multi.mo[r] = q.m_out;
+        tab_multi.ws[r] = static_cast<uint32_t*>(q.workspace);
+      }
+    }
+    const ThrTab& tab = multi ? tab_multi : no_tab;
     {
       // top-K front end: a = the K-th largest element.  It needs at most one wanted element per contributing thread and
       // pays when the K-th largest per-thread maximum sits in the sparse upper tail (K a small part of the threads) and
@@ -269,8 +310,8 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
                                             : stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 2>;
     }
     if (!xe) xe = x;
-    int64_t grid = b->batch;
-    tp.groups = (int32_t)b->batch;
+    int64_t grid = batch;
+    tp.groups = (int32_t)batch;
     if (pl.k > 1) {
       // clusters synchronise through spin barriers: every workgroup of the grid must be resident at once
       static thread_local int occ_dev = -1, occ = 0;
@@ -295,7 +336,7 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
                              "dynamic thresholding of %lld samples x %lld elements needs a workspace of "
                              "dpm_threshold_workspace_bytes() = %lld bytes",
                              (long long)b->batch, (long long)per_sample, (long long)thr_ws_bytes(b->batch, per_sample, n_cu));
-      const int64_t groups = std::min<int64_t>(b->batch, cap / pl.k);
+      const int64_t groups = std::min<int64_t>(batch, cap / pl.k);
       tp.groups = (int32_t)groups;
       tp.ws = static_cast<uint32_t*>(b->workspace);
       tp.ws_stride = thr_ws_stride(pl.k);
@@ -321,7 +362,7 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
         std::lock_guard<std::mutex> lk(ch.mu);
         if (!ch.ev && hipEventCreateWithFlags(&ch.ev, hipEventDisableTiming) != hipSuccess) ch.ev = nullptr;
         if (ch.ev && ch.recorded) (void)hipStreamWaitEvent(stream.stream, ch.ev, 0);
-        launch(kern, dim3((unsigned)grid), dim3(THR_THREADS), lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo, p, tp, ext);
+        launch(kern, dim3((unsigned)grid), dim3(THR_THREADS), lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo, p, tp, ext, tab);
         if (ch.ev && hipEventRecord(ch.ev, stream.stream) == hipSuccess) ch.recorded = true;
         t_dump(grid);
         hipError_t e = hipGetLastError();
@@ -329,7 +370,7 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
         return DPM_OK;
       }
     }
-    launch(kern, dim3((unsigned)grid), dim3(THR_THREADS), lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo, p, tp, ext);
+    launch(kern, dim3((unsigned)grid), dim3(THR_THREADS), lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo, p, tp, ext, tab);
     t_dump(grid);
   } else {
     const size_t as = sizeof(TS) * EPT, ae = sizeof(TE) * EPT;
@@ -439,9 +480,6 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
   return DPM_OK;
 }
 
-// ---- fused multi-request launch (stage_kernel_multi).  Returns DPM_ERR_UNSUPPORTED *without* setting an error text
-// when this (form, guidance, prologue) has no fused variant: the caller then launches the requests one by one.
-constexpr int MULTI_NOT_BUILT = -1000;
 // Launch shape of the fused kernel (profiles/r02_tune_multi.txt, 32 x [256,4,64,64], kernel-only per request-stage):
 // the inputs of a fused launch always come from HBM (R x 42 MB of other requests' traffic passed since they were
 // written) -> streaming loads; one super-tile per workgroup -- a grid of all R x tiles workgroups, no grid-stride loop:
@@ -453,6 +491,8 @@ struct MultiShape {
   static constexpr int NT = 1;
 };
 
+// ---- fused multi-request launch of the streaming family (stage_kernel_multi); thresholded stages fuse inside
+// launch_typed (LaunchCtx::multi)
 template <typename TS, typename TE, int FORM, int GUIDE, int SPEC>
 int launch_multi_spec(const dpm_stage* st, const dpm_buffers* bs, int n_req, const LaunchCtx& c) {
   const DeviceInfo& di = device_info();

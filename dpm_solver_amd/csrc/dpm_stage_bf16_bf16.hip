@@ -8,16 +8,22 @@ template const void* dpm_catchall_scalar<bf16_t, bf16_t, false>();
 template const void* dpm_catchall_scalar<bf16_t, bf16_t, true>();
 
 int dpm_launch_bf16_bf16_b(const dpm_stage* st, const dpm_buffers* b, void* stream, void* ev_start, void* ev_stop, const dpm_stage* dyn,
-          const int32_t* skip);
+          const int32_t* skip, const dpm_buffers* multi, int n_multi);
 
 int dpm_launch_bf16_bf16(const dpm_stage* st, const dpm_buffers* b, void* stream, void* ev_start, void* ev_stop, const dpm_stage* dyn,
           const int32_t* skip) {
   const LaunchCtx s{static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop), dyn, skip};
   const int rc = launch_form<bf16_t, bf16_t, FORMS_A>(st, b, s);
-  return rc == FORM_ELSEWHERE ? dpm_launch_bf16_bf16_b(st, b, stream, ev_start, ev_stop, dyn, skip) : rc;
+  return rc == FORM_ELSEWHERE ? dpm_launch_bf16_bf16_b(st, b, stream, ev_start, ev_stop, dyn, skip, nullptr, 0) : rc;
 }
 
 int dpm_launch_multi_bf16_bf16(const dpm_stage* st, const dpm_buffers* bs, int n_req, void* stream, void* ev_start, void* ev_stop) {
+  if ((st->flags & DPM_F_THRESH) && !(st->flags & DPM_F_BLEND)) {  // one thresholding launch over all requests' samples
+    const LaunchCtx s{static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop),
+                      nullptr, nullptr, bs, n_req};
+    const int rc = launch_form<bf16_t, bf16_t, FORMS_A>(st, bs, s);
+    return rc == FORM_ELSEWHERE ? dpm_launch_bf16_bf16_b(st, bs, stream, ev_start, ev_stop, nullptr, nullptr, bs, n_req) : rc;
+  }
   const LaunchCtx s{static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop)};
   return launch_multi_typed<bf16_t, bf16_t>(st, bs, n_req, s);
 }

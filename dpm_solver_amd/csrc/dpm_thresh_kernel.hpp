@@ -74,6 +74,7 @@ struct ThrParams {
   int32_t fastdiv; // 1: noise-prediction network + eps -> x0 with a divisor that passes div_invariant_ok (see div_by_alpha)
   int32_t quota;   // > 0: single-exchange cluster route; values beyond this rank of the per-thread maxima are not published
   int32_t kbig;    // K = per_sample - lo (the wanted element is the K-th largest of the sample)
+  int32_t bpr;      // > 0: the launch fuses several requests of bpr samples each (ThrTab); sample s belongs to request s / bpr
   int32_t slot_pub; // entries of a slot that are always written (values, then the bare tag)
   int32_t slot_cap; // values per workgroup slot: a power of two <= THR_SLOT_CAP with k * slot_cap <= THR_CAP
   int32_t slot_shift; // log2(slot_cap)
@@ -84,6 +85,19 @@ struct ThrParams {
 #ifdef DPM_THR_TIMING
   uint64_t* tdbg;  // 16 timestamps per workgroup (tools/thr_timeline.py)
 #endif
+};
+
+// pointer table of a fused multi-request thresholding launch (a kernel argument, like MultiTab): request r's tensors
+// and its workspace
+struct ThrTab {
+  const void* x[MULTI_MAX];
+  const void* e0[MULTI_MAX];
+  const void* e1[MULTI_MAX];
+  const void* h1[MULTI_MAX];
+  const void* h2[MULTI_MAX];
+  void* xo[MULTI_MAX];
+  void* mo[MULTI_MAX];
+  uint32_t* ws[MULTI_MAX];
 };
 
 // inclusive prefix sum over the 64 lanes of a wavefront: DPP row shifts inside the rows of 16 lanes, then the two row
@@ -696,9 +710,9 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
 // Everything else runs the same source with HOT = 0.
 template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int T, int HOT>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void stage_thresh_kernel(
-    const TS* __restrict__ x, const TS* __restrict__ xe, const TE* __restrict__ e0, const TE* __restrict__ e1,
-    const TE* __restrict__ g, const TS* __restrict__ h1, const TS* __restrict__ h2, TS* __restrict__ xo,
-    TS* __restrict__ mo, KParams p, ThrParams tp, KExt ext) {
+    const TS* __restrict__ x_1, const TS* __restrict__ xe_1, const TE* __restrict__ e0_1, const TE* __restrict__ e1_1,
+    const TE* __restrict__ g, const TS* __restrict__ h1_1, const TS* __restrict__ h2_1, TS* __restrict__ xo_1,
+    TS* __restrict__ mo_1, KParams p, ThrParams tp, KExt ext, const ThrTab tab) {
   // FORM / GUIDE may be FORM_RT / GUIDE_RT (HOT = 0: the general kernel, one per dtype pair): read from p then
   const bool nx = form_needs_x<FORM>(p), nh1 = form_needs_h1<FORM>(p), nh2 = form_needs_h2<FORM>(p);
   const bool g_cfg = guide_is<GUIDE>(DPM_GUIDE_CFG, p), g_cls = guide_is<GUIDE>(DPM_GUIDE_CLASSIFIER, p);
@@ -732,11 +746,35 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
-    const int64_t base = (int64_t)s_idx * tp.per_sample + (int64_t)c * tp.chunk;
-    const int64_t ebase = (int64_t)s_idx * (eps_stride ? eps_stride : tp.per_sample) + (int64_t)c * tp.chunk;
+    // the sample's tensors: the launch's own, or -- several requests fused into one launch (tp.bpr samples each,
+    // launch_typed) -- those of request s_idx / bpr from the pointer table in the kernel arguments (scalar loads)
+    const TS* __restrict__ x = x_1;
+    const TS* __restrict__ xe = xe_1;
+    const TE* __restrict__ e0 = e0_1;
+    const TE* __restrict__ e1 = e1_1;
+    const TS* __restrict__ h1 = h1_1;
+    const TS* __restrict__ h2 = h2_1;
+    TS* __restrict__ xo = xo_1;
+    TS* __restrict__ mo = mo_1;
+    uint32_t* ws_base = tp.ws;
+    int64_t s_loc = s_idx;
+    if (tp.bpr > 0) {
+      const uint32_t r = (uint32_t)s_idx / (uint32_t)tp.bpr;
+      s_loc = (int64_t)((uint32_t)s_idx - r * (uint32_t)tp.bpr);
+      x = xe = static_cast<const TS*>(tab.x[r]);
+      e0 = static_cast<const TE*>(tab.e0[r]);
+      e1 = static_cast<const TE*>(tab.e1[r]);
+      h1 = static_cast<const TS*>(tab.h1[r]);
+      h2 = static_cast<const TS*>(tab.h2[r]);
+      xo = static_cast<TS*>(tab.xo[r]);
+      mo = static_cast<TS*>(tab.mo[r]);
+      ws_base = tab.ws[r];
+    }
+    const int64_t base = s_loc * tp.per_sample + (int64_t)c * tp.chunk;
+    const int64_t ebase = s_loc * (eps_stride ? eps_stride : tp.per_sample) + (int64_t)c * tp.chunk;
     const int64_t left = tp.per_sample - (int64_t)c * tp.chunk;
     const int n = left <= 0 ? 0 : (left < tp.chunk ? (int)left : tp.chunk);
-    uint32_t* ws = k == 1 ? nullptr : tp.ws + (int64_t)s_idx * tp.ws_stride;
+    uint32_t* ws = k == 1 ? nullptr : ws_base + s_loc * tp.ws_stride;
     // mask index of element base + i without a 64-bit division per element (launch: period < 2^31 or period == n)
     const bool mfull = ext.mask_period >= ((int64_t)1 << 31);
     const uint32_t mbase = (mask && !mfull) ? (uint32_t)(base % ext.mask_period) : 0u;

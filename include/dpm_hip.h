@@ -219,9 +219,12 @@ int dpm_stage_launch(const dpm_stage* st, const dpm_buffers* b, void* stream);
 /* The same stage of n_req independent requests (same plan position: one dpm_stage; same n, batch and dtypes; each its
    own buffers) as ONE fused launch per group of DPM_MULTI_MAX requests: a server that keeps R sampling requests in
    flight pays a launch's ramp-up and drain once per R x (5 n s) bytes instead of once per 5 n s -- with inputs coming
-   from HBM (a network ran in between) that is 8.5 -> ~6.7 us per [256,4,64,64] fp16 request-stage.  Stages the fused
-   kernel family does not cover (thresholding, mask blend, classifier guidance, x_start / v / score networks, strided
-   or unaligned buffers, the singlestep mid-stages) are launched request by request; results are identical either way. */
+   from HBM (a network ran in between) that is 8.5 -> ~6.7 us per [256,4,64,64] fp16 request-stage.  Stages with
+   dynamic thresholding become one thresholding launch over all requests' samples (a batch of n_req * batch: smaller
+   clusters or none -- 32 requests of [32,3,64,64] cost about what one [1024,3,64,64] does), provided clustered shapes
+   find a DIFFERENT workspace in every request.  Stages neither family covers (mask blend, classifier guidance, strided or
+   unaligned buffers, the singlestep mid-stages, thresholding with a shared workspace) are launched request by
+   request; results are identical either way. */
 #define DPM_MULTI_MAX 32
 int dpm_stage_launch_multi(const dpm_stage* st, const dpm_buffers* bs, int n_req, void* stream);
 /* scratch needed by stages with DPM_F_THRESH on the current device: 0 when one workgroup per sample is the plan (the

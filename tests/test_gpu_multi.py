@@ -72,18 +72,19 @@ def plan_for(ns, sd, **kw):
     return dpm, dpm._get_plan(**args)
 
 
-def run_both(plan, reqs):
+def run_both(plan, reqs, own_workspaces=False):
     """final states of every request: fused multi-request run vs one dpm_plan_run per request"""
     stream = C_.c_void_p(torch.cuda.current_stream().cuda_stream)
     n = len(reqs)
     rbs = (L.RunBuffers * n)(*[r["rb"] for r in reqs])
     res = (C_.c_int * n)()
-    ws = None
+    ws = []
     nb = L.lib.dpm_threshold_workspace_bytes(reqs[0]["rb"].batch, reqs[0]["rb"].n // reqs[0]["rb"].batch)
     if nb:
-        ws = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+        # one workspace per request (the thresholded stages of all requests can then share a launch), or one for all
+        ws = [torch.zeros(nb, dtype=torch.uint8, device=DEV) for _ in range(n if own_workspaces else 1)]
         for i in range(n):
-            rbs[i].workspace = ws.data_ptr()
+            rbs[i].workspace = ws[i % len(ws)].data_ptr()
     L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, n, stream, None, res))
     torch.cuda.synchronize()
     fused = [reqs[i]["x"][res[i]].clone() for i in range(n)]
@@ -95,6 +96,8 @@ def run_both(plan, reqs):
         L.check(L.lib.dpm_plan_run(plan.handle, C_.byref(rbs[i]), None, None, stream, C_.byref(r1)))
         torch.cuda.synchronize()
         single.append(reqs[i]["x"][r1.value].clone())
+    for w in ws:
+        assert not bool(w.any()), "a thresholding workspace was not left zero-filled"
     return fused, single
 
 
@@ -158,6 +161,47 @@ def test_plans_with_unfused_stages(kw):
     fused, single = run_both(plan, reqs)
     for a, b in zip(fused, single):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape,n_req", [((2, 3, 64, 64), 3), ((32, 3, 64, 64), 4), ((1, 3, 128, 128), 5), ((4, 3, 16, 16), 7),
+                                         ((8, 3, 64, 64), 40)])
+@pytest.mark.parametrize("sd,ed,cfg", [(torch.float32, torch.float32, False), (torch.float32, torch.float16, True),
+                                       (torch.float16, torch.float16, False)])
+def test_thresholded_stages_share_a_launch(shape, n_req, sd, ed, cfg):
+    """dynamic thresholding over several requests: ONE launch per stage over all requests' samples (smaller or no
+    clusters), bit-identical to the requests run one by one; with a single shared workspace the clustered shapes fall
+    back to one launch per request"""
+    ns = sd_schedule()
+    _, plan = plan_for(ns, sd, correcting_x0_fn="dynamic_thresholding", order=2, steps=5, cfg=cfg)
+    for own in (True, False):
+        reqs = make_requests(n_req, shape, sd, ed, seed=n_req + shape[0], cfg=cfg)
+        fused, single = run_both(plan, reqs, own_workspaces=own)
+        for a, b in zip(fused, single):
+            assert torch.isfinite(a.float()).all()
+            assert torch.equal(a, b)
+
+
+def test_thresholded_fused_launch_count():
+    """the thresholded stages of R requests with their own workspaces really are one launch each"""
+    ns = sd_schedule()
+    _, plan = plan_for(ns, torch.float32, correcting_x0_fn="dynamic_thresholding", order=2, steps=5)
+    reqs = make_requests(6, (8, 3, 64, 64), torch.float32, torch.float32, seed=4)
+    n = len(reqs)
+    rbs = (L.RunBuffers * n)(*[r["rb"] for r in reqs])
+    nb = L.lib.dpm_threshold_workspace_bytes(8, 3 * 64 * 64)
+    assert nb > 0
+    ws = [torch.zeros(nb, dtype=torch.uint8, device=DEV) for _ in range(n)]
+    for i in range(n):
+        rbs[i].workspace = ws[i].data_ptr()
+    res = (C_.c_int * n)()
+    stream = C_.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ms = (C_.c_float * (n * len(plan.stages)))()
+    L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, n, stream, ms, res))
+    torch.cuda.synchronize()
+    per_stage = np.array(list(ms)).reshape(n, len(plan.stages))
+    assert (per_stage > 0).all()
+    # a fused launch's duration is spread evenly over its requests: equal times across requests, stage by stage
+    assert np.allclose(per_stage, per_stage[0:1], rtol=0, atol=0)
 
 
 def test_unaligned_and_ragged_fall_back():

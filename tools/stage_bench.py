@@ -116,6 +116,47 @@ def run(name, solver, x, reps=5, **kw):
     return out
 
 
+def fused_thresholding(ns, shape, n_req, steps=10):
+    """median kernel time per request-stage (steady-state 2M stages) of n_req thresholded requests advanced by
+    dpm_plan_run_multi (a workspace per request): fused launches, and DPM_TUNE_MULTI_FUSE = 0 (a launch per request)"""
+    dpm = D.DPM_Solver(D.model_wrapper(lambda x, t: x, ns), ns, correcting_x0_fn="dynamic_thresholding")
+    plan = dpm._get_plan(method="multistep", order=2, steps=steps, skip_type="time_uniform", solver_type="dpmsolver",
+                         lower_order_final=True, denoise_to_zero=False, t_T=1.0, t_0=1.0 / ns.total_N)
+    n = int(np.prod(shape))
+    keep, rbs = [], (L.RunBuffers * n_req)()
+    for i in range(n_req):
+        t = [torch.randn(shape, device=DEV) for _ in range(2)] + [torch.empty(shape, device=DEV) for _ in range(6)]
+        keep.append(t)
+        rb = rbs[i]
+        rb.xbuf[0], rb.e0 = t[0].data_ptr(), t[1].data_ptr()
+        for j in range(3):
+            rb.xbuf[1 + j] = t[2 + j].data_ptr()
+            rb.hist[j] = t[5 + j].data_ptr()
+        rb.n, rb.batch, rb.state_dtype, rb.eps_dtype = n, shape[0], L.DTYPE_F32, L.DTYPE_F32
+    nb = L.lib.dpm_threshold_workspace_bytes(shape[0], n // shape[0])
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    res = (C.c_int * n_req)()
+    ms = (C.c_float * (n_req * len(plan.stages)))()
+    out = []
+    ws = [torch.zeros(max(nb, 16), dtype=torch.uint8, device=DEV) for _ in range(n_req)]
+    for i in range(n_req):
+        rbs[i].workspace = ws[i].data_ptr() if nb else None
+    for fuse in (1, 0):
+        L.lib.dpm_tuning_set(L.TUNE_MULTI_FUSE, fuse)
+        try:
+            per = []
+            for rep in range(4):
+                L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, n_req, stream, ms, res))
+                torch.cuda.synchronize()
+                a = np.array(list(ms)).reshape(n_req, len(plan.stages))
+                if rep:
+                    per.append(np.median(a[:, 2:-1]))      # the steady-state stages (TWO + m store)
+        finally:
+            L.lib.dpm_tuning_set(L.TUNE_MULTI_FUSE, 1)
+        out.append(float(np.median(per)) * 1e3)
+    return tuple(out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--md", default=None)
@@ -255,6 +296,13 @@ def main():
                     row += [(time.perf_counter() - t0) / 10 * 1e3, nfe]
                 adaptive.append(row)
 
+    # R thresholded requests in flight (a server; dpm_plan_run_multi): one thresholding launch per stage over all
+    # requests' samples vs one launch per request
+    fused_thr = []
+    if not ONLY or "thr" in ONLY:
+        for shape, n_req in (((32, 3, 64, 64), 32), ((32, 3, 64, 64), 8), ((8, 3, 256, 256), 8)):
+            fused_thr.append((shape, n_req) + fused_thresholding(dd, shape, n_req))
+
     hdr = ("| scenario | kernel (form guidance flags) | launches | alg. MB | back-to-back us | GB/s | % of 8 TB/s "
            "| caches evicted us | GB/s | % of 8 TB/s |\n|---|---|---|---|---|---|---|---|---|---|")
     lines = [hdr]
@@ -280,6 +328,14 @@ def main():
                     "| state | order | host control loop ms | NFE | controller on the device ms | NFE |\n|---|---|---|---|---|---|\n")
             for shp, order, th, nh, td, nd in adaptive:
                 f.write("| %s | %d | %.3f | %d | %.3f | %d |\n" % (shp, order, th, nh, td, nd))
+            f.write("\n## Dynamic thresholding with R requests in flight (dpm_plan_run_multi, fp32, 2M++): kernel time per "
+                    "request-stage\n\n| requests x shape | one launch per stage over all requests' samples, us | one launch per "
+                    "request, us |\n|---|---|---|\n")
+            for shape, n_req, t_f, t_s in fused_thr:
+                f.write("| %d x %s | %.2f | %.2f |\n" % (n_req, shape, t_f, t_s))
+    for shape, n_req, t_f, t_s in fused_thr:
+        print("thresholding, %d requests of %s in flight: %.2f us per request-stage in one launch per stage, %.2f us launched "
+              "request by request" % (n_req, shape, t_f, t_s))
     for label, a, b in loop:
         print("python loop %s: eager %.1f us, captured %.1f us" % (label, a, b))
     for shp, order, th, nh, td, nd in adaptive:
