@@ -407,7 +407,7 @@ def main():
                 stage_kernel_vs_ceiling=round(cal["fused"] / roofline["kernel_only"]["us"], 3))
 
     # ---- the drop-in Python API on the same workload: DPM_Solver.sample() per request, frozen network ------------
-    py_ms = None
+    py_ms = py_req_ms = None
     if not args.no_secondary:
         s_ = sets[0]
         dpy = D.DPM_Solver(D.model_wrapper(lambda x, t, e=s_["eps"]: e, ns), ns, state_dtype=dtype)
@@ -420,6 +420,27 @@ def main():
             dpy.sample(sets[i % min(8, R)]["x"][0], steps=STEPS_SOLVER, order=2)
         torch.cuda.synchronize(dev)
         py_ms = (time.perf_counter() - t1) / kk * 1e3
+        # ... and DPM_Solver.sample_requests() on the timed workload itself: the R requests advanced together from
+        # Python, per stage R network calls (each request its own frozen output) and one fused launch
+        calls = [0]
+
+        def frozen(x, t):
+            calls[0] += 1
+            return sets[(calls[0] - 1) % R]["eps"]
+        dpr = D.DPM_Solver(D.model_wrapper(frozen, ns), ns, state_dtype=dtype)
+        xs = [s2["x"][0] for s2 in sets]
+        for _ in range(2):
+            calls[0] = 0
+            dpr.sample_requests(xs, steps=STEPS_SOLVER, order=2)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        kk = 5
+        for i in range(kk):
+            calls[0] = 0
+            dpr.sample_requests(xs, steps=STEPS_SOLVER, order=2)
+        torch.cuda.synchronize(dev)
+        py_req_ms = (time.perf_counter() - t1) / kk * 1e3
+        del dpr
 
     # ---- the single end-of-sampling collective of the sharded path: all-gather of the final x (timed apart) ---
     gather_ms = None
@@ -454,6 +475,8 @@ def main():
                        "parallelism": "batch-sharded x%d, no data-path collective" % world},
             "msample_steps_per_s": round(samples * n_stages / wall / 1e6, 3),
             "python_api_ms_per_trajectory": None if py_ms is None else round(py_ms, 4),
+            # the whole workload through DPM_Solver.sample_requests (compare with ms_per_step, the C loop)
+            "python_api_requests_ms_per_step": None if py_req_ms is None else round(py_req_ms, 4),
             "roofline": roofline,
             "gather_ms": None if gather_ms is None else round(gather_ms, 4),
         }

@@ -206,10 +206,27 @@ def launch_raw_double(st_ref, b_ref, stream):
     return 0
 
 
+class _Ref:
+    """stand-in for ctypes.byref(obj): launch_raw_double only looks at ._obj"""
+
+    def __init__(self, obj):
+        self._obj = obj
+
+
+def launch_multi_double(st_ref, bufs, n_req, stream):
+    """dpm_stage_launch_multi: the same stage of n_req requests, one after the other"""
+    for r in range(int(n_req)):
+        rc = launch_raw_double(st_ref, _Ref(bufs[r]), stream)
+        if rc:
+            return rc
+    return 0
+
+
 def install_cpu_double(monkeypatch, S, D):
     """route every device entry point of dpm_solver_amd.solver to its numpy double (CPU tensors)"""
     monkeypatch.setattr(S, "_launch_stage", launch_stage_double)
     monkeypatch.setattr(S, "_stage_launch_raw", launch_raw_double)
+    monkeypatch.setattr(S, "_stage_launch_multi_raw", launch_multi_double)
     monkeypatch.setattr(S, "_launch_ctx", lambda dev: (None, 0, False, False))
     monkeypatch.setattr(S, "_require_gpu", lambda x: None)
     monkeypatch.setattr(D.MaskBlend, "apply", maskblend_apply_double)

@@ -254,3 +254,46 @@ def test_fuse_switch_off_gives_identical_results():
         L.lib.dpm_tuning_set(L.TUNE_MULTI_FUSE, 1)
     for a, b in zip(fused, unfused):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("kw", [dict(steps=8, order=2), dict(steps=9, order=3, method="singlestep"),
+                                dict(steps=5, order=2, thr=True), dict(steps=6, order=2, cfg=True),
+                                dict(steps=6, order=3, half=True), dict(steps=5, order=2, model_type="v", half=True)])
+def test_sample_requests_python_api(kw, monkeypatch):
+    """DPM_Solver.sample_requests: the requests' results equal sample() of each request bit for bit, and every stage is
+    ONE dpm_stage_launch_multi call"""
+    import dpm_solver_amd.solver as S
+    kw = dict(kw)
+    ns = sd_schedule()
+    thr, cfg, half = kw.pop("thr", False), kw.pop("cfg", False), kw.pop("half", False)
+    mt = kw.pop("model_type", "noise")
+    if cfg:
+        c = torch.ones(8, device=DEV)
+        fn = D.model_wrapper(lambda x, t, cc: torch.tanh(x * 0.7) * (0.5 + 0.1 * cc.reshape(-1, 1, 1, 1)[:x.shape[0]]).to(x.dtype),
+                             ns, model_type=mt, guidance_type="classifier-free", guidance_scale=3.0, condition=c,
+                             unconditional_condition=c * 0)
+    else:
+        fn = D.model_wrapper(lambda x, t: torch.tanh(x * 0.7), ns, model_type=mt)
+    dpm = D.DPM_Solver(fn, ns, correcting_x0_fn="dynamic_thresholding" if thr else None,
+                       state_dtype=torch.float16 if half else None)
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(8, 3, 64, 64, generator=g).to(DEV) for _ in range(6)]
+    if half:
+        xs = [x.half() for x in xs]
+    want = [dpm.sample(x, **kw) for x in xs]
+    calls = []
+    real = S._stage_launch_multi_raw
+
+    def spy(st, bs, n_req, stream):
+        calls.append(int(n_req))
+        return real(st, bs, n_req, stream)
+    monkeypatch.setattr(S, "_stage_launch_multi_raw", spy)
+    got = dpm.sample_requests(xs, **kw)
+    torch.cuda.synchronize()
+    plan_stages = len(calls)
+    assert plan_stages >= kw["steps"] and all(c == len(xs) for c in calls)
+    for a, b in zip(got, want):
+        assert a.dtype == b.dtype and torch.isfinite(a.float()).all() and torch.equal(a, b)
+    again = dpm.sample_requests(xs, **kw)
+    for a, b in zip(again, want):
+        assert torch.equal(a, b)

@@ -216,6 +216,65 @@ def test_cfg_input_buffer_host_logic():
         assert v._base is not None and v._base.shape[0] == 2 * v.shape[0]
 
 
+@pytest.mark.parametrize("kw", [dict(steps=8, order=2), dict(steps=9, order=3, method="singlestep"),
+                                dict(steps=6, order=3, skip_type="logSNR", denoise_to_zero=True),
+                                dict(steps=5, order=2, thr=True), dict(steps=6, order=2, cfg=True),
+                                dict(steps=5, order=2, model_type="v"), dict(steps=4, order=2, half=True)])
+def test_sample_requests_equals_sample_per_request(kw):
+    """DPM_Solver.sample_requests (requests advanced together, one dpm_stage_launch_multi per stage) == sample() of every
+    request; the network is called once per request and stage"""
+    kw = dict(kw)
+    ns = make_schedule("sd")
+    thr, cfg, half = kw.pop("thr", False), kw.pop("cfg", False), kw.pop("half", False)
+    mt = kw.pop("model_type", "noise")
+    calls = []
+    if cfg:
+        def net(x, t, c):
+            calls.append(x.shape[0])
+            return torch.tanh(x * 0.7) * (0.5 + 0.1 * c.reshape(-1, 1, 1, 1)[:x.shape[0]])
+        c = torch.ones(4)
+        fn = D.model_wrapper(net, ns, model_type=mt, guidance_type="classifier-free", guidance_scale=3.0, condition=c,
+                             unconditional_condition=c * 0)
+    else:
+        def net(x, t):
+            calls.append(x.shape[0])
+            return torch.tanh(x * 0.7).to(x.dtype)
+        fn = D.model_wrapper(net, ns, model_type=mt)
+    dpm = D.DPM_Solver(fn, ns, correcting_x0_fn="dynamic_thresholding" if thr else None,
+                       state_dtype=torch.float16 if half else None)
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(4, 3, 8, 8, generator=g) for _ in range(5)]
+    if half:
+        xs = [x.half() for x in xs]
+    want = [dpm.sample(x, **kw) for x in xs]
+    n_single = len(calls)
+    calls.clear()
+    got = dpm.sample_requests(xs, **kw)
+    assert len(calls) == n_single and len(got) == len(xs)
+    for a, b in zip(got, want):
+        assert a.dtype == b.dtype and torch.equal(a, b)
+    # a second call reuses the prebuilt records and must not hand out the same result tensors
+    again = dpm.sample_requests(xs, **kw)
+    for a, b, c in zip(again, want, got):
+        assert torch.equal(a, b) and a.data_ptr() != c.data_ptr()
+
+
+def test_sample_requests_falls_back():
+    """one request, mixed shapes, Python correctors, intermediates or the adaptive method: the requests run one by one"""
+    ns = make_schedule("sd")
+    dpm = D.DPM_Solver(D.model_wrapper(lambda x, t: x * 0.3, ns), ns, correcting_xt_fn=lambda x, t, step: x * 0.99)
+    xs = [torch.randn(2, 3, 4, 4), torch.randn(2, 3, 4, 4)]
+    for a, x in zip(dpm.sample_requests(xs, steps=5), xs):
+        assert torch.equal(a, dpm.sample(x, steps=5))
+    dpm = D.DPM_Solver(D.model_wrapper(lambda x, t: x * 0.3, ns), ns)
+    mixed = [torch.randn(2, 3, 4, 4), torch.randn(1, 3, 4, 4)]
+    for a, x in zip(dpm.sample_requests(mixed, steps=5), mixed):
+        assert torch.equal(a, dpm.sample(x, steps=5))
+    out = dpm.sample_requests(xs, steps=5, return_intermediate=True)
+    assert len(out) == 2 and len(out[0]) == 2 and len(out[0][1]) == 6
+    assert torch.equal(dpm.sample_requests(xs[:1], steps=5)[0], dpm.sample(xs[0], steps=5))
+
+
 @pytest.mark.parametrize("sname", ["sd", "vp_linear", "cosine4000"])
 @pytest.mark.parametrize("algo", ["dpmsolver++", "dpmsolver"])
 def test_public_update_methods(golden, sname, algo):
