@@ -676,6 +676,8 @@ extern "C" int dpm_plan_run_multi(const dpm_plan* p, const dpm_run_buffers* rbs,
       b.eps_dtype = rb.eps_dtype;
       b.eps_stride = rb.eps_stride;
       b.inputs_resident = n_req == 1;  // interleaved requests evict each other's buffers, like a network would
+      if (rb.dup_state && &st != &p->stages.back())  // as in dpm_plan_run: the [2B, ...] network input of CFG
+        b.x_out2 = static_cast<char*>(rb.xbuf[out]) + rb.n * (rb.state_dtype == DPM_DTYPE_F32 ? 4 : 2);
       if (st.emits_state) {
         state[r] = out;
         tmp[r] = -1;

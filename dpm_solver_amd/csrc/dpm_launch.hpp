@@ -508,6 +508,7 @@ int launch_multi_spec(const dpm_stage* st, const dpm_buffers* bs, int n_req, con
     tab.h2[r] = bs[r].h2;
     tab.xo[r] = bs[r].x_out;
     tab.mo[r] = bs[r].m_out;
+    tab.xo2[r] = bs[r].x_out2;
   }
   const KParams p = make_params(st);
   const int64_t n = bs[0].n;
@@ -560,7 +561,8 @@ int launch_multi_typed(const dpm_stage* st, const dpm_buffers* bs, int n_req, co
   if (bs[0].n % EPT != 0) return MULTI_NOT_BUILT;
   for (int r = 0; r < n_req; ++r) {
     const dpm_buffers& b = bs[r];
-    if (b.x_out2 || (b.eps_stride && b.eps_stride != b.n / b.batch)) return MULTI_NOT_BUILT;
+    if (b.eps_stride && b.eps_stride != b.n / b.batch) return MULTI_NOT_BUILT;
+    if (b.x_out2 && (st->guidance != DPM_GUIDE_CFG || !aligned(b.x_out2, as))) return MULTI_NOT_BUILT;
     if (b.xe && b.x && b.xe != b.x) return MULTI_NOT_BUILT;
     if (!(aligned(b.x, as) && aligned(b.xe, as) && aligned(b.h1, as) && aligned(b.h2, as) && aligned(b.x_out, as) &&
           aligned(b.m_out, as) && aligned(b.e0, ae) && aligned(b.e1, ae)))

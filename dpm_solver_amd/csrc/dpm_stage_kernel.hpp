@@ -436,6 +436,7 @@ struct MultiTab {
   const void* h2[MULTI_MAX];
   void* xo[MULTI_MAX];
   void* mo[MULTI_MAX];
+  void* xo2[MULTI_MAX];  // classifier-free guidance: the second half of the [2B, ...] network input (or null)
 };
 
 template <typename TS, typename TE, int FORM, int GUIDE, int SPEC, int U, int NT>
@@ -450,7 +451,10 @@ __global__ __launch_bounds__(256) void stage_kernel_multi(const MultiTab tab, in
     if (v >= total) continue;
     const uint32_t r = v / spr;
     const int64_t t0 = (int64_t)(v - r * spr) * U;
-    stage_tiles<TS, TE, FORM, GUIDE, false, SPEC, U, NT, false>(
+    // the guided variants carry the duplicate store of the CFG network input (KExt::xo2) -- the EXT flavour of the tile body
+    constexpr bool DUP = GUIDE == DPM_GUIDE_CFG;
+    if constexpr (DUP) ext.xo2 = tab.xo2[r];
+    stage_tiles<TS, TE, FORM, GUIDE, false, SPEC, U, NT, DUP>(
         static_cast<const TS*>(tab.x[r]), nullptr, static_cast<const TE*>(tab.e0[r]), static_cast<const TE*>(tab.e1[r]),
         nullptr, static_cast<const TS*>(tab.h1[r]), static_cast<const TS*>(tab.h2[r]), static_cast<TS*>(tab.xo[r]),
         static_cast<TS*>(tab.mo[r]), ngroups, t0, p, ext);

@@ -222,7 +222,8 @@ int dpm_stage_launch(const dpm_stage* st, const dpm_buffers* b, void* stream);
    from HBM (a network ran in between) that is 8.5 -> ~6.7 us per [256,4,64,64] fp16 request-stage.  Stages with
    dynamic thresholding become one thresholding launch over all requests' samples (a batch of n_req * batch: smaller
    clusters or none -- 32 requests of [32,3,64,64] cost about what one [1024,3,64,64] does), provided clustered shapes
-   find a DIFFERENT workspace in every request.  Stages neither family covers (mask blend, classifier guidance, strided or
+   find a DIFFERENT workspace in every request; classifier-free guidance keeps its duplicate store (x_out2).  Stages
+   neither family covers (mask blend, classifier guidance, strided or
    unaligned buffers, the singlestep mid-stages, thresholding with a shared workspace) are launched request by
    request; results are identical either way. */
 #define DPM_MULTI_MAX 32

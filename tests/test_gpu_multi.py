@@ -29,15 +29,19 @@ def sd_schedule():
     return D.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(np.cumprod(1.0 - betas).astype(np.float32)))
 
 
-def make_requests(n_req, shape, sd, ed, seed, cfg=False, offset=0):
+def make_requests(n_req, shape, sd, ed, seed, cfg=False, offset=0, dup=False):
     g = torch.Generator().manual_seed(seed)
     reqs = []
     for _ in range(n_req):
         def buf(dt, src=None):
-            t = torch.empty(int(np.prod(shape)) + offset, dtype=dt, device=DEV)
-            v = t[offset:].view(shape)
+            # a state buffer under `dup` holds the state twice ([2B, ...]: the CFG network input); the view is its first half
+            t = torch.empty(int(np.prod(shape)) * (2 if dup and dt is sd else 1) + offset, dtype=dt, device=DEV)
+            v = t[offset:offset + int(np.prod(shape))].view(shape)
             if src is not None:
                 v.copy_(src)
+                if dup and dt is sd:
+                    t[offset + int(np.prod(shape)):].view(shape).copy_(src)
+            v.full = t
             return v
         x_T = buf(sd, torch.randn(shape, generator=g))
         e0 = buf(ed, torch.randn(shape, generator=g))
@@ -54,6 +58,7 @@ def make_requests(n_req, shape, sd, ed, seed, cfg=False, offset=0):
             rb.e1 = e1.data_ptr()
         rb.n, rb.batch = x_T.numel(), shape[0]
         rb.state_dtype, rb.eps_dtype = _CODE[sd], _CODE[ed]
+        rb.dup_state = 1 if dup else 0
         reqs.append(dict(rb=rb, x=xb, h=hb, e0=e0, e1=e1))
     return reqs
 
@@ -123,6 +128,38 @@ def test_fused_equals_single_cfg(algo):
     fused, single = run_both(plan, reqs)
     for a, b in zip(fused, single):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("sd,ed", [(torch.float32, torch.float16), (torch.float16, torch.float16), (torch.float32, torch.float32)])
+def test_fused_cfg_with_duplicate_state_store(sd, ed):
+    """classifier-free guidance with the [2B, ...] network input written by the stage kernel (dup_state): the fused
+    launch carries the second store too; both halves of every state buffer equal the single-request run's"""
+    ns = sd_schedule()
+    _, plan = plan_for(ns, sd, cfg=True, order=2, steps=6)
+    reqs = make_requests(4, (3, 4, 32, 32), sd, ed, seed=9, cfg=True, dup=True)
+    stream = C_.c_void_p(torch.cuda.current_stream().cuda_stream)
+    n = len(reqs)
+    rbs = (L.RunBuffers * n)(*[r["rb"] for r in reqs])
+    res = (C_.c_int * n)()
+    L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, n, stream, None, res))
+    torch.cuda.synchronize()
+    fused = [[b.full.clone() for b in reqs[i]["x"]] for i in range(n)]
+    r1 = C_.c_int(-1)
+    half = reqs[0]["x"][0].numel()
+    for i in range(n):
+        for b in reqs[i]["x"][1:]:
+            b.full.fill_(float("nan"))
+        L.check(L.lib.dpm_plan_run(plan.handle, C_.byref(rbs[i]), None, None, stream, C_.byref(r1)))
+        torch.cuda.synchronize()
+        assert r1.value == res[i]
+        for j, b in enumerate(reqs[i]["x"]):
+            if j == r1.value:     # the final state feeds no network call: only its first half is written
+                assert torch.isfinite(b.full[:half].float()).all()
+                assert torch.equal(fused[i][j][:half], b.full[:half])
+            elif j > 0 and not bool(torch.isnan(b.full.float()).all()):   # intermediate states (a multistep plan ping-pongs
+                                                                          # between two of the three): both halves written
+                assert torch.isfinite(b.full.float()).all() and torch.equal(b.full[:half], b.full[half:])
+                assert torch.equal(fused[i][j], b.full)
 
 
 @pytest.mark.parametrize("mt", ["v", "x_start", "score"])
