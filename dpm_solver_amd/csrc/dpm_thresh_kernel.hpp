@@ -877,6 +877,21 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     __syncthreads();
     DPM_TSTAMP(1)
 
+    // phase 3's first operand rows do not depend on the threshold: their loads are issued here and land while the
+    // select runs (a sample's select is 4-9 us of barriers and exchanges during which this workgroup moves no data)
+    float vx[THR_ROWS][4], vh1[THR_ROWS][4], vh2[THR_ROWS][4];
+    auto fetch_rows = [&](int i0) {  // rows i0, i0 + 4T, ... of this thread; lanes past the end re-read a valid group
+#pragma unroll
+      for (int r = 0; r < THR_ROWS; ++r) {
+        const int i = i0 + r * T * 4;
+        const int64_t gi = base + (i < n ? i : (i0 < n ? i0 : 0));
+        if (nx) load4<true>(x, gi, vx[r]);                 // last use of x and of the cached model values
+        if (nh1) load4<true>(h1, gi, vh1[r]);
+        if (nh2) load4<true>(h2, gi, vh2[r]);
+      }
+    };
+    if (vec && n > 0) fetch_rows(tid * 4);
+
     // phase 2: the lo-th smallest |x0| of the whole sample.
     uint32_t prefix = 0u, known = 0u, rank = (uint32_t)tp.lo, cnt_sel = 0u;
     uint32_t hi = ABS, nc = 0u;
@@ -1150,15 +1165,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     if (vec) {
       // THR_ROWS tile rows per iteration, the loads of all issued before the first use (explicit: the write-through
       // stores are assembly the loop unroller will not duplicate)
-      for (int i0 = tid * 4; i0 < n; i0 += THR_ROWS * T * 4) {
-        float vx[THR_ROWS][4], vh1[THR_ROWS][4], vh2[THR_ROWS][4];
-#pragma unroll
-        for (int r = 0; r < THR_ROWS; ++r) {
-          const int64_t gi = base + (i0 + r * T * 4 < n ? i0 + r * T * 4 : i0);  // clamped: loads are unconditional
-          if (nx) load4<true>(x, gi, vx[r]);                 // last use of x and of the cached model values
-          if (nh1) load4<true>(h1, gi, vh1[r]);
-          if (nh2) load4<true>(h2, gi, vh2[r]);
-        }
+      for (int i0 = tid * 4; i0 < n; i0 += THR_ROWS * T * 4) {  // (the first rows were fetched before the select)
 #pragma unroll
         for (int r = 0; r < THR_ROWS; ++r) {
           const int i = i0 + r * T * 4;
@@ -1204,6 +1211,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
             if (store_m) store4<true>(mo, gi, om);                  // read again only after the next network call
           }
         }
+        if (i0 + THR_ROWS * T * 4 < n) fetch_rows(i0 + THR_ROWS * T * 4);  // the next iteration's operands
       }
     } else {
       for (int i = tid; i < n; i += T) {
