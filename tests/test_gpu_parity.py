@@ -2,6 +2,7 @@
 size-independent properties at BASELINE.json's full sizes.  Run on an MI355X:  pytest -m gpu
 """
 import ctypes as C_
+import os
 
 import numpy as np
 import pytest
@@ -211,10 +212,12 @@ def test_cluster_single_exchange_route_and_its_fallback():
 def test_thresholded_sampling_random_sweep():
     """seeded random sweep of sample() with dynamic thresholding -- batch / sample sizes (one workgroup per sample,
     clusters, ragged and unaligned rows), ratio (top-K front end and full histograms), max_val, order, steps --
-    against the oracle: bit-identical (a 40 000-configuration run of the same generator found no difference)"""
+    against the oracle: bit-identical.  DPM_THR_SWEEP=<count> extends the run (round 2's kernel: 20 000 configurations,
+    no difference)"""
     rng = np.random.default_rng(7)
     done = 0
-    while done < 250:
+    total = int(os.environ.get("DPM_THR_SWEEP", "250"))
+    while done < total:
         B = int(rng.choice([1, 2, 3, 5, 8, 17, 40, 130, 600]))
         Cc, H, W = int(rng.integers(1, 4)), int(rng.choice([4, 7, 16, 31, 32, 64, 96])), int(rng.choice([4, 9, 16, 32, 64, 128]))
         if B * Cc * H * W > 3e6:
