@@ -60,6 +60,13 @@ def main():
         torch.cuda.synchronize()
         print("%-9s %.0f us per 20-step trajectory" % (name, (time.perf_counter() - t0) / 20 * 1e6))
 
+    # several requests in flight (a server): per stage the network once per request, then one fused solver launch
+    xs = [torch.randn(B, 4, 64, 64, device=dev) for _ in range(8)]
+    with torch.no_grad():
+        ys = solver.sample_requests(xs, steps=20, order=2)
+        assert all(torch.equal(y, solver.sample(x, steps=20, order=2)) for x, y in zip(xs, ys))
+    print("sample_requests: %d requests, identical to sample() of each" % len(ys))
+
     # DiffEdit / inpainting: keep the masked-out region on the known image, noised to the current level
     mask = (torch.rand(64, 64, device=dev) > 0.5).float()
     known = torch.randn(B, 4, 64, 64, device=dev)
