@@ -295,7 +295,9 @@ def test_fuse_switch_off_gives_identical_results():
 
 @pytest.mark.parametrize("kw", [dict(steps=8, order=2), dict(steps=9, order=3, method="singlestep"),
                                 dict(steps=5, order=2, thr=True), dict(steps=6, order=2, cfg=True),
-                                dict(steps=6, order=3, half=True), dict(steps=5, order=2, model_type="v", half=True)])
+                                dict(steps=6, order=3, half=True), dict(steps=5, order=2, model_type="v", half=True),
+                                dict(steps=6, order=3, skip_type="logSNR", denoise_to_zero=True),
+                                dict(steps=7, order=2, method="singlestep", solver_type="taylor", thr=True)])
 def test_sample_requests_python_api(kw, monkeypatch):
     """DPM_Solver.sample_requests: the requests' results equal sample() of each request bit for bit, and every stage is
     ONE dpm_stage_launch_multi call"""
