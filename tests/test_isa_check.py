@@ -1,0 +1,48 @@
+"""build()'s ISA check (__graft_entry__.scan_disassembly) on synthetic disassembly: it must accept the shape the
+library has and reject the two regressions it exists for -- a write-through store separated from its `s_nop`, and a
+compile-time specialised stage kernel that spills to scratch."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as G  # noqa: E402
+
+GOOD = """
+0000000000001000 <_ZN12_GLOBAL__N_112stage_kernelIffLi1ELi0ELb0ELi1ELi1ELi1ELb0ELb0EEEvPKT_>:
+	global_load_dwordx4 v[0:3], v[8:9], off nt                 // 000000001000: DC000000
+	global_store_dwordx4 v[10:11], v[0:3], off sc0 sc1         // 000000001008: DC000000
+	s_nop 1                                                    // 000000001010: BF800001
+--
+	global_store_dwordx4 v[10:11], v[4:7], off sc0 sc1         // 000000001018: DC000000
+	s_nop 1
+0000000000002000 <_ZN12_GLOBAL__N_119stage_thresh_kernelIffLin1ELin1ELb1ELi512ELi0EEEvPKT_>:
+	scratch_store_dword off, v40, s32                          // 000000002000: DC000000
+	global_store_dwordx4 v[10:11], v[0:3], off sc0 sc1
+	s_nop 1
+0000000000003000 <_ZN12_GLOBAL__N_116add_noise_kernelIfLb1EEEvPKT_>:
+	global_store_dwordx4 v[10:11], v[0:3], off
+""".strip("\n").splitlines()
+
+
+def test_accepts_the_expected_shape():
+    n_wt, n_kernels, spilled = G.scan_disassembly(GOOD)
+    assert (n_wt, n_kernels) == (3, 2)
+    assert len(spilled) == 1 and "Lin1ELin1E" in next(iter(spilled))
+
+
+def test_rejects_a_store_without_its_nop():
+    first_nop = next(i for i, ln in enumerate(GOOD) if ln.strip().startswith("s_nop"))
+    bad = GOOD[:first_nop] + ["\tv_mov_b32 v0, v1"] + GOOD[first_nop + 1:]
+    with pytest.raises(AssertionError, match="not by s_nop"):
+        G.scan_disassembly(bad)
+    with pytest.raises(AssertionError, match="without its s_nop"):      # the store is the kernel's last instruction
+        G.scan_disassembly(GOOD[:first_nop] + GOOD[7:])
+
+
+def test_rejects_scratch_in_a_specialised_kernel():
+    bad = GOOD[:2] + ["\tscratch_load_dword v1, off, s32"] + GOOD[2:]
+    with pytest.raises(AssertionError, match="spills to scratch"):
+        G.scan_disassembly(bad)
