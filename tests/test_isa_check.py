@@ -46,3 +46,23 @@ def test_rejects_scratch_in_a_specialised_kernel():
     bad = GOOD[:2] + ["\tscratch_load_dword v1, off, s32"] + GOOD[2:]
     with pytest.raises(AssertionError, match="spills to scratch"):
         G.scan_disassembly(bad)
+
+
+NOTES = """
+    .group_segment_fixed_size: 0
+    .kernarg_segment_size: 240
+    .name:           _ZN12_GLOBAL__N_112stage_kernelIffLi1ELi0ELb0ELi1ELi1ELi1ELb0ELb0EEEvPKT_S3_
+    .private_segment_fixed_size: 0
+    .group_segment_fixed_size: 3072
+    .name:           _ZN12_GLOBAL__N_112stage_kernelIffLi3ELi2ELb1ELi100ELi1ELi5ELb0ELb1EEEvPKT_S3_
+    .group_segment_fixed_size: 32
+    .name:           _ZN12_GLOBAL__N_122adaptive_error_kernel2IfLb1EEEvPKT_
+"""
+
+
+def test_static_lds_rule():
+    assert G.scan_kernel_notes(NOTES) == 2
+    with pytest.raises(AssertionError, match="static LDS"):     # a non-DYN kernel that owns LDS: the KParams trap
+        G.scan_kernel_notes(NOTES.replace("ELb0ELb1EEEv", "ELb0ELb0EEEv"))
+    with pytest.raises(AssertionError, match="static LDS"):     # a DYN kernel of another form
+        G.scan_kernel_notes(NOTES.replace("IffLi3ELi2E", "IffLi1ELi2E"))
