@@ -38,7 +38,6 @@ def main():
         arena = torch.empty(5 * (size + skew) + 4096, dtype=torch.uint8, device=DEV)
         base = (arena.data_ptr() + 4095) // 4096 * 4096
         ptr = [base + k * (size + skew) for k in range(5)]
-        view = [torch.empty(0)] * 5
         arena.zero_()
         b = L.Buffers()
         b.x, b.e0, b.h1, b.x_out, b.m_out = ptr
@@ -54,9 +53,9 @@ def main():
                 v.append(ms.value * 1e3)
             res[evict] = float(np.median(v[5:]))
         by = 5 * size
+        pct = lambda us: by / us / 8e6 * 100          # bytes / us -> % of 8 TB/s
         print("skew %8d B: back to back %6.2f us = %4.1f %%   evicted %6.2f us = %4.1f %%" % (
-            skew, res[False], by / res[False] / 8e3 * 1e-3 * 100 / 1e-3 / 1e3 * 1e3 / 1e3 if False else by / res[False] / 8e6 * 100,
-            res[True], by / res[True] / 8e6 * 100))
+            skew, res[False], pct(res[False]), res[True], pct(res[True])))
         del arena
 
 
