@@ -303,6 +303,44 @@ def main():
         for shape, n_req in (((32, 3, 64, 64), 32), ((32, 3, 64, 64), 8), ((8, 3, 256, 256), 8)):
             fused_thr.append((shape, n_req) + fused_thresholding(dd, shape, n_req))
 
+    # requests in flight through the Python API: DPM_Solver.sample_requests vs sample() per request (wall per step)
+    py_req = []
+    if not ONLY:
+        import time as _t
+        for label, shape, n_req, cfg_on, edt in (
+                ("SD-style CFG 7.5, [64,4,64,64] fp32 state / fp16 outputs", (64, 4, 64, 64), 16, True, torch.float16),
+                ("cfg2 [256,4,64,64] fp16", (256, 4, 64, 64), 16, False, torch.float16)):
+            nb = shape[0] * (2 if cfg_on else 1)
+            outs = [torch.randn((nb,) + shape[1:], device=DEV).to(edt) for _ in range(n_req)]
+            calls = [0]
+
+            def pick():
+                calls[0] += 1
+                return outs[(calls[0] - 1) % n_req]
+            if cfg_on:
+                cnd = torch.zeros(shape[0], device=DEV)
+                fn = D.model_wrapper(lambda x, t, cc: pick(), sd, guidance_type="classifier-free", condition=cnd,
+                                     unconditional_condition=cnd, guidance_scale=7.5)
+                slv = D.DPM_Solver(fn, sd)
+                xs = [torch.randn(shape, device=DEV) for _ in range(n_req)]
+            else:
+                slv = D.DPM_Solver(D.model_wrapper(lambda x, t: pick(), sd), sd, state_dtype=torch.float16)
+                xs = [torch.randn(shape, device=DEV).half() for _ in range(n_req)]
+            row = [label, n_req]
+            for fnc in (lambda: [slv.sample(x, steps=20, order=2) for x in xs], lambda: slv.sample_requests(xs, steps=20, order=2)):
+                for _ in range(2):
+                    calls[0] = 0
+                    fnc()
+                torch.cuda.synchronize()
+                t0 = _t.perf_counter()
+                for _ in range(5):
+                    calls[0] = 0
+                    fnc()
+                torch.cuda.synchronize()
+                row.append((_t.perf_counter() - t0) / 5 * 1e3)
+            py_req.append(row)
+            del outs, xs, slv
+
     hdr = ("| scenario | kernel (form guidance flags) | launches | alg. MB | back-to-back us | GB/s | % of 8 TB/s "
            "| caches evicted us | GB/s | % of 8 TB/s |\n|---|---|---|---|---|---|---|---|---|---|")
     lines = [hdr]
@@ -333,6 +371,12 @@ def main():
                     "request, us |\n|---|---|---|\n")
             for shape, n_req, t_f, t_s in fused_thr:
                 f.write("| %d x %s | %.2f | %.2f |\n" % (n_req, shape, t_f, t_s))
+            f.write("\n## Requests in flight through the Python API (frozen network outputs, one per request): wall per 20-stage "
+                    "step of all requests\n\n| workload | requests | `sample()` per request, ms | `sample_requests()`, ms |\n|---|---|---|---|\n")
+            for label, n_req, t_one, t_grp in py_req:
+                f.write("| %s | %d | %.3f | %.3f |\n" % (label, n_req, t_one, t_grp))
+    for label, n_req, t_one, t_grp in py_req:
+        print("python API, %d requests of %s: sample() per request %.3f ms per step, sample_requests %.3f ms" % (n_req, label, t_one, t_grp))
     for shape, n_req, t_f, t_s in fused_thr:
         print("thresholding, %d requests of %s in flight: %.2f us per request-stage in one launch per stage, %.2f us launched "
               "request by request" % (n_req, shape, t_f, t_s))
