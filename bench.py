@@ -406,6 +406,26 @@ def main():
                 fused_size_frac_of_peak=round(alg_bytes * R / cal["fused"] / 1e3 / HBM_PEAK_GBS, 4),
                 stage_kernel_vs_ceiling=round(cal["fused"] / roofline["kernel_only"]["us"], 3))
 
+        # (5) SURVEY 8(d): what a plain device-to-device copy of the same footprint achieves on this box
+        half = R * n_el * ssz * 5 // 2 // 4096 * 4096          # read + write = the fused launch's bytes
+        src_c = torch.empty(half, dtype=torch.uint8, device=dev)
+        dst_c = torch.empty(half, dtype=torch.uint8, device=dev)
+        for _ in range(2):
+            dst_c.copy_(src_c)
+        ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ce0.record(stream)
+        for _ in range(6):
+            dst_c.copy_(src_c)
+        ce1.record(stream)
+        torch.cuda.synchronize(dev)
+        copy_us = ce0.elapsed_time(ce1) * 1e3 / 6
+        del src_c, dst_c
+        roofline["copy_ceiling"] = dict(
+            pattern="torch copy_ (device to device), %d MB read + %d MB written" % (half // 10**6, half // 10**6),
+            us=round(copy_us, 3), achieved=round(2 * half / copy_us / 1e3, 1),
+            frac=round(2 * half / copy_us / 1e3 / HBM_PEAK_GBS, 4),
+            stage_kernel_vs_copy=round(roofline["achieved"] / (2 * half / copy_us / 1e3), 3))
+
     # ---- the drop-in Python API on the same workload: DPM_Solver.sample() per request, frozen network ------------
     py_ms = py_req_ms = None
     if not args.no_secondary:
