@@ -299,7 +299,7 @@ def main():
     # R thresholded requests in flight (a server; dpm_plan_run_multi): one thresholding launch per stage over all
     # requests' samples vs one launch per request
     fused_thr = []
-    if not ONLY or "thr" in ONLY:
+    if not ONLY or "in flight" in ONLY:
         for shape, n_req in (((32, 3, 64, 64), 32), ((32, 3, 64, 64), 8), ((8, 3, 256, 256), 8)):
             fused_thr.append((shape, n_req) + fused_thresholding(dd, shape, n_req))
 
