@@ -106,6 +106,8 @@ _SIGNATURES = [
     ("dpm_schedule_create_alphas_cumprod_f32", C.c_int, [_P(C.c_float), C.c_int, C.c_int, _P(C.c_void_p)]),
     ("dpm_schedule_create_alphas_cumprod_f64", C.c_int, [_P(C.c_double), C.c_int, C.c_int, _P(C.c_void_p)]),
     ("dpm_schedule_create_log_alpha", C.c_int, [_P(C.c_float), C.c_int, _P(C.c_void_p)]),
+    ("dpm_numerical_clip_len_f32", C.c_int, [_P(C.c_float), C.c_int, C.c_double, _P(C.c_int)]),
+    ("dpm_numerical_clip_len_f64", C.c_int, [_P(C.c_double), C.c_int, C.c_double, _P(C.c_int)]),
     ("dpm_schedule_create_linear", C.c_int, [C.c_double, C.c_double, _P(C.c_void_p)]),
     ("dpm_schedule_create_cosine", C.c_int, [_P(C.c_void_p)]),
     ("dpm_schedule_destroy", None, [C.c_void_p]),

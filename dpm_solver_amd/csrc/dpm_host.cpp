@@ -112,10 +112,10 @@ int finish_discrete(std::vector<float>&& la, dpm_schedule** out) {
 
 // numerical_clip_alpha (ref :114-125), generic over the arithmetic type the caller's array came in
 template <typename T>
-size_t clip_len(const std::vector<T>& la) {
-  const T cl = (T)-5.1;
-  std::vector<T> lam(la.size());
-  for (size_t i = 0; i < la.size(); ++i) {
+size_t clip_len(const T* la, size_t n, double clipped_lambda = -5.1) {
+  const T cl = (T)clipped_lambda;  // searchsorted casts the Python scalar to the tensor's dtype
+  std::vector<T> lam(n);
+  for (size_t i = 0; i < n; ++i) {
     T ls;
     if (sizeof(T) == 4)
       ls = (T)(0.5f * f_log(1.f - f_exp(2.f * (float)la[i])));
@@ -126,9 +126,24 @@ size_t clip_len(const std::vector<T>& la) {
   // searchsorted(flip(lam), cl, right=False) = #{lam_flipped < cl}, lam_flipped ascending
   std::vector<T> fl(lam.rbegin(), lam.rend());
   size_t idx = std::lower_bound(fl.begin(), fl.end(), cl) - fl.begin();
-  return la.size() - idx;
+  return n - idx;
 }
+template <typename T>
+size_t clip_len(const std::vector<T>& la) { return clip_len(la.data(), la.size()); }
 }  // namespace
+
+// NoiseScheduleVP.numerical_clip_alpha as a function of its own (ref :114-125): how many leading entries of a
+// log-alpha table survive the clip of the half-logSNR at `clipped_lambda`
+extern "C" int dpm_numerical_clip_len_f32(const float* log_alphas, int n, double clipped_lambda, int* out_len) {
+  if (!log_alphas || !out_len || n < 0) return dpm_set_error(DPM_ERR_ARG, "numerical_clip_alpha: null pointer or n < 0");
+  *out_len = (int)clip_len(log_alphas, (size_t)n, clipped_lambda);
+  return DPM_OK;
+}
+extern "C" int dpm_numerical_clip_len_f64(const double* log_alphas, int n, double clipped_lambda, int* out_len) {
+  if (!log_alphas || !out_len || n < 0) return dpm_set_error(DPM_ERR_ARG, "numerical_clip_alpha: null pointer or n < 0");
+  *out_len = (int)clip_len(log_alphas, (size_t)n, clipped_lambda);
+  return DPM_OK;
+}
 
 extern "C" int dpm_schedule_create_betas_f32(const float* betas, int n, int clip, dpm_schedule** out) {
   if (!betas || !out || n < 2) return dpm_set_error(DPM_ERR_ARG, "betas: need n >= 2 and non-null pointers");

@@ -65,6 +65,25 @@ class NoiseScheduleVP:
                 pass
             self._h = None
 
+    def numerical_clip_alpha(self, log_alphas, clipped_lambda=-5.1):
+        """Drop the trailing entries of a log-alpha table whose half-logSNR is below `clipped_lambda` (ref :114-125:
+        the cosine schedules of i-DDPM / guided-diffusion / GLIDE are numerically unstable near t = T).  Returns
+        `log_alphas[:K]`, a view like the reference's slice; the count comes from the C planner, in the table's own
+        arithmetic type (the constructor applies the same clip inside `dpm_schedule_create_*`)."""
+        if not torch.is_tensor(log_alphas):
+            log_alphas = torch.as_tensor(log_alphas)
+        arr = log_alphas.detach().cpu().reshape(-1).numpy()
+        f64 = arr.dtype == np.float64
+        arr = np.ascontiguousarray(arr, dtype=np.float64 if f64 else np.float32)
+        keep = C.c_int()
+        fn = L.lib.dpm_numerical_clip_len_f64 if f64 else L.lib.dpm_numerical_clip_len_f32
+        L.check(fn(arr.ctypes.data_as(C.POINTER(C.c_double if f64 else C.c_float)), int(arr.shape[0]),
+                   float(clipped_lambda), C.byref(keep)))
+        idx = int(arr.shape[0]) - keep.value
+        if idx > 0:
+            log_alphas = log_alphas[:-idx]
+        return log_alphas
+
     # ---- host evaluation ------------------------------------------------------------------
     def _eval_np(self, what, v):
         v = np.ascontiguousarray(np.asarray(v, dtype=np.float32).reshape(-1))

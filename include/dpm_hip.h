@@ -152,6 +152,10 @@ int dpm_schedule_create_betas_f64(const double* betas, int n, int clip, dpm_sche
 int dpm_schedule_create_alphas_cumprod_f32(const float* ac, int n, int clip, dpm_schedule** out);      /* ref :103 */
 int dpm_schedule_create_alphas_cumprod_f64(const double* ac, int n, int clip, dpm_schedule** out);
 int dpm_schedule_create_log_alpha(const float* log_alpha, int n, dpm_schedule** out);                  /* ready table */
+/* numerical_clip_alpha on its own (ref :114-125): *out_len = number of leading entries of `log_alphas` whose
+   half-logSNR is >= clipped_lambda (the reference returns log_alphas[:out_len]); arithmetic in the array's type */
+int dpm_numerical_clip_len_f32(const float* log_alphas, int n, double clipped_lambda, int* out_len);
+int dpm_numerical_clip_len_f64(const double* log_alphas, int n, double clipped_lambda, int* out_len);
 int dpm_schedule_create_linear(double beta_0, double beta_1, dpm_schedule** out);                      /* ref :109-112 */
 /* the continuous-time 'cosine' schedule of the older vendored revision (examples/score_sde_pytorch/dpm_solver.py
    :114-124,:134-137,:171-175): s = 0.008, T = 0.9946 (the caller's default end time) */

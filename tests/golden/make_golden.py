@@ -23,6 +23,7 @@ REF_DIR = os.environ.get("DPM_REFERENCE_DIR", "/root/reference")
 sys.path.insert(0, REF_DIR)
 
 import cases as C  # noqa: E402
+from make_golden_api import api_snapshot  # noqa: E402
 import dpm_solver_pytorch as R  # noqa: E402  (the reference)
 
 torch.set_num_threads(1)
@@ -414,8 +415,37 @@ def gen_utils(out):
         out["utils/expand/val%d" % dims] = R.expand_dims(tt(v), dims).numpy()
 
 
+def gen_clip(out):
+    """NoiseScheduleVP.numerical_clip_alpha (ref :114-125) called directly: the raw (unclipped) log-alpha tables of the
+    discrete schedules as ref :100 / :103 compute them, in fp32 and fp64, clipped at several half-logSNR bounds"""
+    any_ns = R.NoiseScheduleVP("linear")
+    for name in ["sd", "ddpm", "cosine4000", "cosine1000"]:
+        si = C.schedule_inputs(name)
+        for prec in ("f32", "f64"):
+            dt = torch.float32 if prec == "f32" else torch.float64
+            if "betas" in si:
+                la = 0.5 * torch.log(1 - tt(si["betas"]).to(dt)).cumsum(dim=0)
+            else:
+                la = 0.5 * torch.log(tt(si["alphas_cumprod"]).to(dt))
+            pre = "clip/%s/%s/" % (name, prec)
+            out[pre + "log_alphas"] = la.numpy()
+            for cl in (-5.1, -3.0, 0.0, -20.0):
+                got = any_ns.numerical_clip_alpha(la, cl) if cl != -5.1 else any_ns.numerical_clip_alpha(la)
+                out[pre + "len/%g" % cl] = np.int64(got.shape[0])
+                assert torch.equal(got, la[:got.shape[0]])
+
+
+def gen_api(out):
+    """signatures of the reference's public API -> tests/golden/api_signatures.json (the engine must keep them)"""
+    import json
+    snap = api_snapshot(R)
+    with open(os.path.join(HERE, "api_signatures.json"), "w") as f:
+        json.dump(snap, f, indent=1, sort_keys=True)
+    out["api/entries"] = np.int64(len(snap))
+
+
 def main():
-    groups = dict(utils=gen_utils, guided=gen_guided, legacy=gen_legacy, schedules=gen_schedules, timesteps=gen_timesteps, updates=gen_updates,
+    groups = dict(api=gen_api, clip=gen_clip, utils=gen_utils, guided=gen_guided, legacy=gen_legacy, schedules=gen_schedules, timesteps=gen_timesteps, updates=gen_updates,
                   quantile=gen_quantile, add_noise=gen_add_noise, e2e=gen_e2e,
                   callbacks=gen_callbacks, adaptive=gen_adaptive, sampler=gen_sampler)
     only = sys.argv[1:]
