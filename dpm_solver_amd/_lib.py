@@ -195,12 +195,18 @@ class DpmError(RuntimeError):
     pass
 
 
+fault_hooks = []          # called on DPM_ERR_FAULT before it is raised (solver.py: re-zero the cluster workspaces)
+
+
 def check(rc):
     """Map a C status to the reference's exception convention: argument errors are
     ValueError, everything else RuntimeError."""
     if rc == DPM_OK:
         return
     msg = lib.dpm_last_error().decode("utf-8", "replace")
+    if rc == ERR_FAULT:
+        for hook in fault_hooks:
+            hook()
     if rc == ERR_ARG:
         raise ValueError(msg)
     if rc == ERR_UNSUPPORTED:

@@ -579,6 +579,19 @@ int dpm_stage_launch_ev(const dpm_stage* st, const dpm_buffers* b, void* stream,
 int dpm_timing_begin(int n, void*** starts, void*** stops);
 int dpm_timing_end(int n, void** starts, void** stops, void* stream, float* ms, const unsigned char* recorded);
 
+// buffer rotation of one stage, shared by the single- and multi-request loops: which xbuf the network saw (xe) and
+// which one the stage writes (out), given where the state and the pending intermediate live.  Negative = plan error.
+static int stage_rotation(const dpm_stage& st, int n_stages, int state, int tmp, int* xe, int* out) {
+  if (st.index < 0 || st.index >= n_stages)
+    return dpm_set_error(DPM_ERR_ARG, "plan_run: stage index %d outside the plan's %d stages", st.index, n_stages);
+  *xe = st.xe_src == DPM_SRC_TMP ? tmp : state;
+  if (*xe < 0) return dpm_set_error(DPM_ERR_ARG, "plan_run: stage %d reads TMP before it exists", st.index);
+  int o = 1;  // xbuf[0] (the caller's x_T) is never written
+  while (o == state || o == *xe) ++o;
+  *out = o;
+  return DPM_OK;
+}
+
 static int plan_run_impl(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model_cb model, void* user, void* stream,
                          int* result, void** ev_start, void** ev_stop) {
   if (!p || !rb) return dpm_set_error(DPM_ERR_ARG, "null pointer");
@@ -588,10 +601,8 @@ static int plan_run_impl(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model
     if (!rb->hist[i]) return dpm_set_error(DPM_ERR_ARG, "plan_run: hist[%d] is null (plan needs %d slots)", i, p->slots);
   int state = 0, tmp = -1;
   for (const dpm_stage& st : p->stages) {
-    const int xe = st.xe_src == DPM_SRC_TMP ? tmp : state;
-    if (xe < 0) return dpm_set_error(DPM_ERR_ARG, "plan_run: stage %d reads TMP before it exists", st.index);
-    int out = 1;  // xbuf[0] (the caller's x_T) is never written
-    while (out == state || out == xe) ++out;
+    int xe = 0, out = 0;
+    if (int rc = stage_rotation(st, (int)p->stages.size(), state, tmp, &xe, &out)) return rc;
     if (model) {
       int rc = model(user, &st, rb->xbuf[xe], rb->e0, rb->e1, stream);
       if (rc) return dpm_set_error(DPM_ERR_CALLBACK, "model callback failed at stage %d (rc=%d)", st.index, rc);
@@ -671,9 +682,8 @@ extern "C" int dpm_plan_run_multi(const dpm_plan* p, const dpm_run_buffers* rbs,
   for (const dpm_stage& st : p->stages) {
     for (int r = 0; r < n_req; ++r) {
       const dpm_run_buffers& rb = rbs[r];
-      const int xe = st.xe_src == DPM_SRC_TMP ? tmp[r] : state[r];
-      int out = 1;
-      while (out == state[r] || out == xe) ++out;
+      int xe = 0, out = 0;
+      if ((rc = stage_rotation(st, ns, state[r], tmp[r], &xe, &out)) != DPM_OK) break;
       dpm_buffers& b = bs[r];
       std::memset(&b, 0, sizeof b);
       b.x = rb.xbuf[state[r]];
@@ -700,6 +710,7 @@ extern "C" int dpm_plan_run_multi(const dpm_plan* p, const dpm_run_buffers* rbs,
         tmp[r] = out;
       }
     }
+    if (rc) break;
     // event k = st.index * n_req + r (stage-major, so a stage's events are one contiguous array)
     const size_t k0 = (size_t)st.index * n_req;
     rc = dpm_stage_launch_multi_ev(&st, bs.data(), n_req, stream, starts ? starts + k0 : nullptr,

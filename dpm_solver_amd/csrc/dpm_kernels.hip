@@ -599,7 +599,9 @@ extern "C" int dpm_adaptive_reset(dpm_adaptive* a, void* stream) {
 
 extern "C" int dpm_adaptive_begin(dpm_adaptive* a, void* x, void* x_prev, const void* x_lower, const void* x_higher, int64_t n,
                                   int dtype, float* e_dev, float* t_vectors, int64_t tv_len, void* stream) {
-  if (!a || !x || !x_prev || !x_lower || !x_higher || !e_dev || !t_vectors || n < 0 || tv_len < 1)
+  // n == 0: an empty shard of a batch-sharded run -- it still runs the controller (every rank must take the same
+  // decisions and issue the same collectives) but has no state to commit, and its tensors have no storage
+  if (!a || !e_dev || !t_vectors || n < 0 || tv_len < 1 || (n > 0 && (!x || !x_prev || !x_lower || !x_higher)))
     return dpm_set_error(DPM_ERR_ARG, "adaptive_begin: bad arguments");
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(adaptive_begin_kernel, dim3(1), dim3(256), 0, st, a->dev, a->sv, a->c, e_dev, t_vectors, tv_len, a->status);
@@ -639,9 +641,9 @@ extern "C" int dpm_adaptive_stage_launch(dpm_adaptive* a, int which, const dpm_s
 
 extern "C" int dpm_adaptive_error(dpm_adaptive* a, const void* x_lower, const void* x_higher, const void* x_prev,
                                   int64_t batch, int64_t per_sample, int dtype, float* e_dev, void* stream) {
-  if (!a || !x_lower || !x_higher || !x_prev || !e_dev || batch < 0 || per_sample < 1)
-    return dpm_set_error(DPM_ERR_ARG, "adaptive_error: bad arguments");
-  if (batch == 0) return DPM_OK;  // an empty shard contributes nothing to the maximum
+  if (!a || !e_dev || batch < 0) return dpm_set_error(DPM_ERR_ARG, "adaptive_error: bad arguments");
+  if (batch == 0) return DPM_OK;  // an empty shard contributes nothing to the maximum (begin left *e_dev = 0)
+  if (!x_lower || !x_higher || !x_prev || per_sample < 1) return dpm_set_error(DPM_ERR_ARG, "adaptive_error: bad arguments");
   const DeviceInfo& di = device_info();
   const int n_cu = di.n_cu > 0 ? di.n_cu : 256;
   // enough workgroups to fill the chip twice, at least 8192 elements each

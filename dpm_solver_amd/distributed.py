@@ -76,6 +76,10 @@ def sample_sharded(solver, x_T, group=None, gather=True, **sample_kwargs):
         # 4-byte MAX all-reduce per iteration makes every rank take the same accept / reject and step-size decisions
         # as the unsharded run (same number of iterations on every rank, so the collectives pair up)
         def reduce_max(e):
+            if e.is_cuda and dist.get_backend(group) == "gloo":      # test rigs: gloo ranks sharing one GPU
+                c = e.detach().cpu()
+                dist.all_reduce(c, op=dist.ReduceOp.MAX, group=group)
+                return c.to(e.device)
             e = e.clone()
             dist.all_reduce(e, op=dist.ReduceOp.MAX, group=group)
             return e

@@ -13,6 +13,7 @@ methods.  What differs is where the work happens:
 """
 import ctypes as C
 import inspect
+import weakref
 
 import numpy as np
 import torch
@@ -152,6 +153,22 @@ def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=No
 
 
 _WS_CACHE = {}
+_WS_LIVE = weakref.WeakSet()          # every thresholding workspace handed to a launch record (_FastRun)
+
+
+def _on_cluster_fault():
+    """DPM_ERR_FAULT: a clustered thresholding launch gave up waiting for a peer; the workspace it used is dirty and the
+    contract (dpm_threshold_workspace_bytes) wants it zero-filled again.  The fault word does not say which one, so
+    every cached workspace is evicted / zeroed before the error reaches the caller."""
+    _WS_CACHE.clear()
+    for ws in list(_WS_LIVE):
+        try:
+            ws.zero_()
+        except Exception:
+            pass
+
+
+L.fault_hooks.append(_on_cluster_fault)
 
 
 def _cluster_workspace(dev, idx, stream, nbytes):
@@ -246,10 +263,13 @@ class _Plan:
             T = self.times(device)
             n = len(self.stages)
             # contiguous (batch,) vectors like the reference hands to the network (t.expand(B) of a fresh tensor,
-            # torch.cat([t] * 2) under CFG): a model may edit them in place or need contiguous inputs.  Materialised
-            # once per (plan, batch) -- two small kernels here, none per step.
+            # torch.cat([t] * 2) under CFG) for models that need contiguous inputs.  Materialised once per (plan, batch)
+            # -- two small kernels here, none per step -- and SHARED by every later call of the plan: a network must not
+            # write into its time argument (DPM_Solver.fresh_time_tensors = True hands out a clone per call instead).
             te = T[0].reshape(n, 1).expand(n, batch).contiguous()
             ti = T[1].reshape(n, 1).expand(n, 2 * batch if cfg else batch).contiguous()
+            if len(self._views) >= 8:                 # bounded: one entry per (device, batch, cfg)
+                self._views.pop(next(iter(self._views)))
             hit = dict(t_eval=[T[0, i] for i in range(n)], t_out=[T[2, i] for i in range(n)],
                        t_eval_b=[te[i] for i in range(n)],
                        t_input_b=[ti[i, :batch] for i in range(n)],
@@ -264,6 +284,16 @@ class _Plan:
             except Exception:
                 pass
             self.handle = None
+
+
+class _Cloning:
+    """list of cached tensors whose items are handed out as clones (DPM_Solver.fresh_time_tensors)"""
+
+    def __init__(self, items):
+        self._items = items
+
+    def __getitem__(self, i):
+        return self._items[i].clone()
 
 
 def _bind_outputs(b, e0, e1, g, sd, shape):
@@ -323,7 +353,7 @@ class _AdaptiveRun:
         self.n, self.B, self.cfg = n, B, cfg
         mk = lambda: torch.empty(shape, dtype=sd, device=device)
         self.x_prev, self.x_lower, self.x_higher, self.mid1, self.mid2, self.m_s, self.m_s1 = (mk() for _ in range(7))
-        self.tv_len = 2 * B if cfg else B
+        self.tv_len = max(2 * B if cfg else B, 1)      # B = 0: an empty shard still runs the controller
         self.tvec = torch.zeros((3, 2, self.tv_len), dtype=torch.float32, device=device)
         self.E = torch.zeros((1,), dtype=torch.float32, device=device)
         tm = []
@@ -420,6 +450,7 @@ class _FastRun:
                 if nb:
                     if self.ws is None:      # zero-filled once; every launch leaves it zero-filled
                         self.ws = torch.zeros(nb, dtype=torch.uint8, device=device)
+                        _WS_LIVE.add(self.ws)
                     b.workspace = self.ws.data_ptr()
             self.stages.append(st)
             self.bufs.append(b)
@@ -460,6 +491,10 @@ class DPM_Solver:
         self.dynamic_thresholding_ratio = dynamic_thresholding_ratio
         self.thresholding_max_val = thresholding_max_val
         self._state_dtype = state_dtype
+        # The (batch,) time vectors handed to the network are built once per (plan, batch) and shared by every call
+        # (the reference makes a fresh tensor per call, ref :404).  A network that writes into its time argument needs
+        # fresh_time_tensors = True: a clone per call.
+        self.fresh_time_tensors = False
         self._plans = {}
         self._fast = {}
         self._fast_groups = {}
@@ -804,6 +839,8 @@ class DPM_Solver:
                 d.model_type, d.guidance, d.guidance_scale = mt, gd, sc
                 d.t_start, d.t_end, d.h_init = float(t_T), float(t_0), float(h_init)
                 d.atol, d.rtol, d.theta, d.t_err = float(atol), float(rtol), float(theta), float(t_err)
+                if len(self._adaptive_handles) >= 8:     # bounded: one handle per (t range, tolerances, ...) combination
+                    self._adaptive_handles.pop(next(iter(self._adaptive_handles)))
                 owner = self._adaptive_handles[hkey] = _AdaptiveHandle(self._h, d)
             ar = _AdaptiveRun(owner, x.shape, sd, device, cfg)
             if len(self._fast) >= 8:
@@ -843,7 +880,7 @@ class DPM_Solver:
                     ev.record()
                     events.append(ev)
                 ev_i = 0
-                for which, evaluate, src, st, b in ar.seq:
+                for which, evaluate, src, st, b in (ar.seq if n else ()):   # an empty shard: controller + collectives only
                     if evaluate:
                         xe_t = xs if src is None else src
                         te, ti = tv[ev_i, 0, :B], tv[ev_i, 1, :B]
@@ -881,8 +918,15 @@ class DPM_Solver:
             raise ValueError("For adaptive step size solver, order must be 2 or 3, got {}".format(order))
         if solver_type not in ['dpmsolver', 'taylor']:
             raise ValueError("'solver_type' must be either 'dpmsolver' or 'taylor', got {}".format(solver_type))
+        # State dtype of the device path = _sdtype(x): fp32 for a 'discrete' schedule whatever x is (the reference's (1,)-
+        # shaped fp32 coefficients promote the first update), the explicit state_dtype when given.  The one case it cannot
+        # know before the first network output is a half-precision x on a 'linear' schedule (see _promoted): host loop.
         half_unknown = self._state_dtype is None and x.dtype is not torch.float32 and self.noise_schedule.schedule != 'discrete'
-        if (self.adaptive_on_device and x.is_cuda and x.dim() > 0 and x.numel() > 0 and not self._thresholding
+        # The choice must be the same on every rank of a batch-sharded run (error_reduce set): the two loops issue
+        # different numbers of all-reduces.  Every condition below is rank-uniform; an EMPTY shard (batch < world) takes
+        # the device path too when sharded -- it runs the controller and the collectives, no stage launches.
+        nonempty = x.numel() > 0 or (self.error_reduce is not None and x.dim() > 0)
+        if (self.adaptive_on_device and x.is_cuda and x.dim() > 0 and nonempty and not self._thresholding
                 and self._user_x0 is None and not half_unknown):
             return self._adaptive_device(x, order, t_T, t_0, h_init, atol, rtol, theta, t_err, solver_type)
         ns = self.noise_schedule
@@ -1051,6 +1095,8 @@ class DPM_Solver:
         R, shape = len(xs), xs[0].shape
         V = plan.time_views(device, shape[0], cfg)
         tb, ti, t2 = V["t_eval_b"], V["t_input_b"], V["t_input_2b"]
+        if self.fresh_time_tensors:
+            tb, ti, t2 = _Cloning(tb), _Cloning(ti), (_Cloning(t2) if cfg else None)
         wrapped, model_fn = self._wrapped, self._model_fn
 
         def net(x_t, i, x2=None):
@@ -1137,6 +1183,8 @@ class DPM_Solver:
         model_fn = self._model_fn
         # the first evaluation is on the caller's x_T whatever the plan (ref :1179, :1222): run it before choosing
         # the buffers, its output dtype decides the state dtype (see _promoted)
+        if self.fresh_time_tensors:
+            tb, ti, t2 = _Cloning(tb), _Cloning(ti), (_Cloning(t2) if cfg else None)
         if wrapped is not None:
             first = wrapped.raw_outputs(x, tb[0], ti[0], t2[0] if cfg else None, x_in2=None)
         else:
@@ -1192,6 +1240,9 @@ class DPM_Solver:
                 return self._run_plan_group(plan, self._group, sd, cfg)
             return self._run_plan_fast(plan, x, sd, cfg)
         V = plan.time_views(device, x.shape[0] if x.dim() > 0 else 1, cfg)
+        if self.fresh_time_tensors:
+            V = dict(V, t_eval_b=_Cloning(V["t_eval_b"]), t_input_b=_Cloning(V["t_input_b"]),
+                     t_input_2b=_Cloning(V["t_input_2b"]) if cfg else None)
         blend = cxt if isinstance(cxt, MaskBlend) else None      # folded into the stage kernels' epilogue
         if blend is not None:
             cxt = None

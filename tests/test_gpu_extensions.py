@@ -492,3 +492,32 @@ def test_guided_diffusion_adapter_against_reference_goldens(golden, monkeypatch)
     spy = LaunchSpy(monkeypatch)
     TH.guided_checks(golden, DEV, 2 * TOL)
     assert all(c["eps_stride"] == 2 * 3 * 8 * 8 for c in spy.calls)       # the mean half is never copied out
+
+
+def test_adaptive_sharded_with_an_empty_shard_on_the_gpu():
+    """batch < world on the GPU: the rank with the empty shard runs the device-side controller too (no stage launches), so
+    every rank issues the same all-reduces; results equal the unsharded run's slices (solver.py adaptive
+    path choice).  Two gloo ranks share cuda:0."""
+    import os
+    import torch.multiprocessing as mp
+    from adaptive_shard_worker import worker
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 90
+    procs = [ctx.Process(target=worker, args=(r, 2, port, 1, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=300) for _ in range(4)]
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    first = sorted(r for r in res if r[4] is None)
+    second = sorted(r for r in res if r[4] is not None)
+    # pass 1: every rank was handed the full 1-sample batch -- both took the device path, same number of all-reduces
+    assert [r[1] for r in first] == [1, 1] and first[0][2] == first[1][2] > 0
+    # pass 2: rank 0 owns the sample, rank 1 an empty shard
+    assert [r[3][0] for r in second] == [1, 0] and all(r[4] for r in second), second

@@ -336,3 +336,118 @@ def test_sample_requests_python_api(kw, monkeypatch):
     again = dpm.sample_requests(xs, **kw)
     for a, b in zip(again, want):
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# the fused kernel at the benchmark's own size (bench.py's timed workload), against the numpy double of the kernel
+# (half states: bit for bit) and against the oracle (fp32: the north-star 1e-5)
+# ------------------------------------------------------------------------------------------------
+def _oracle_2m(ac, x, eps, steps=20):
+    """oracle/dpm_oracle.py on a slice: DPM-Solver++(2M), frozen eps (ref :796-852 through ref :1195-1213)"""
+    from oracle import dpm_oracle as O
+    osch = O.Schedule.from_alphas_cumprod(ac)
+    return O.Solver(O.wrap_model(lambda xx, t: eps, osch), osch, algorithm_type="dpmsolver++").sample(x, steps=steps, order=2)
+
+
+def _sd_ac():
+    betas = np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=np.float64) ** 2
+    return np.cumprod(1.0 - betas).astype(np.float32)
+
+
+@pytest.mark.parametrize("sd", [torch.float16, torch.float32])
+def test_fused_launch_at_bench_size_against_double_and_oracle(sd, monkeypatch):
+    """dpm_plan_run_multi on 32 x [256,4,64,64] (what bench.py times: 20 fused launches of 32 requests, 1.3 GB each in
+    fp16): requests 0, 15 and 31 -- fp16: bit-equal to tests/kernel_double.py driven by the same plan; fp32: <= 1e-5 of
+    the tensor's scale against the oracle on 8-sample slices"""
+    import dpm_solver_amd.solver as S
+    from kernel_double import install_cpu_double
+    shape, R = (256, 4, 64, 64), 32
+    ns = sd_schedule()
+    _, plan = plan_for(ns, sd, steps=20)
+    reqs = make_requests(R, shape, sd, sd, seed=77)
+    stream = C_.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rbs = (L.RunBuffers * R)(*[r["rb"] for r in reqs])
+    res = (C_.c_int * R)()
+    L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, R, stream, None, res))
+    torch.cuda.synchronize()
+    for r in (0, 15, 31):
+        got = reqs[r]["x"][res[r]].cpu()
+        x_T, eps = reqs[r]["x"][0].cpu(), reqs[r]["e0"].cpu()
+        assert torch.isfinite(got.float()).all()
+        if sd is torch.float16:
+            with monkeypatch.context() as m:
+                install_cpu_double(m, S, D)
+                dbl = D.DPM_Solver(D.model_wrapper(lambda x, t: eps, ns), ns, state_dtype=sd)
+                want = dbl.sample(x_T, steps=20, order=2)
+            assert want.dtype == sd and torch.equal(got.view(torch.int16), want.view(torch.int16)), r
+        else:
+            for lo in (0, 124, 248):
+                want = _oracle_2m(_sd_ac(), x_T[lo:lo + 8].numpy(), eps[lo:lo + 8].numpy())
+                g = got[lo:lo + 8].numpy().astype(np.float64)
+                err = float(np.abs(g - want).max() / np.abs(want).max())
+                assert err <= 1e-5, (r, lo, err)
+    # and the Python-loop result of one request (single launches), bit for bit
+    chk = D.DPM_Solver(D.model_wrapper(lambda x, t: reqs[31]["e0"], ns), ns, state_dtype=sd)
+    assert torch.equal(chk.sample(reqs[31]["x"][0], steps=20, order=2), reqs[31]["x"][res[31]])
+
+
+@pytest.mark.parametrize("sd,ed", [(torch.float16, torch.float16), (torch.float32, torch.float16)])
+def test_sample_requests_cfg_duplicate_store_at_sd_size(sd, ed, monkeypatch):
+    """DPM_Solver.sample_requests, classifier-free guidance 7.5, 16 requests of [64,4,64,64] (an SD batch per request): the
+    fused CFG kernel with the duplicate store of the [2B,...] network input.  fp16 state: bit-equal to the kernel double;
+    fp32 state with fp16 network outputs (SD under autocast): <= 1e-5 against the oracle on slices.  Every stage is one
+    fused launch and every launch but the last carries x_out2."""
+    import dpm_solver_amd.solver as S
+    from kernel_double import install_cpu_double
+    from oracle import dpm_oracle as O
+    shape, R, scale = (64, 4, 64, 64), 16, 7.5
+    ns = sd_schedule()
+
+    def net(lib):
+        # a conditional network: output depends on x, t and the condition; returned in the network-output dtype `ed`
+        def f(x, t, c):
+            cc = c.reshape((-1,) + (1,) * (x.ndim - 1))
+            out = x * (0.6 + 0.1 * cc)
+            return out.to(ed) if lib is torch else out
+        return f
+
+    def solver(dev):
+        cond = torch.ones(shape[0], device=dev)
+        fn = D.model_wrapper(net(torch), ns, guidance_type="classifier-free", guidance_scale=scale, condition=cond,
+                             unconditional_condition=cond * 0)
+        return D.DPM_Solver(fn, ns, state_dtype=sd)
+
+    g = torch.Generator().manual_seed(9)
+    xs_cpu = [torch.randn(shape, generator=g).to(sd) for _ in range(R)]
+    xs = [x.to(DEV) for x in xs_cpu]
+    dup = []
+    real = S._stage_launch_multi_raw
+
+    def spy(st, bs, n_req, stream):
+        dup.append((int(n_req), all(bool(bs[r].x_out2) for r in range(n_req))))
+        return real(st, bs, n_req, stream)
+    monkeypatch.setattr(S, "_stage_launch_multi_raw", spy)
+    got = solver(DEV).sample_requests(xs, steps=20, order=2)
+    torch.cuda.synchronize()
+    assert len(dup) == 20 and all(n == R for n, _ in dup)
+    assert all(d for _, d in dup[:-1]) and not dup[-1][1]          # the last stage feeds no network call
+    monkeypatch.setattr(S, "_stage_launch_multi_raw", real)
+    for r in (0, 7, 15):
+        out = got[r].cpu()
+        assert out.dtype == sd and torch.isfinite(out.float()).all()
+        if sd is torch.float16:
+            with monkeypatch.context() as m:
+                install_cpu_double(m, S, D)
+                want = solver("cpu").sample(xs_cpu[r], steps=20, order=2)
+            assert torch.equal(out.view(torch.int16), want.view(torch.int16)), r
+        else:
+            osch = O.Schedule.from_alphas_cumprod(_sd_ac())
+            for lo in (0, 56):
+                c8 = np.ones(8, dtype=np.float32)
+                # the oracle's network rounds its output to fp16 like the torch network does (.to(ed))
+                onet = lambda x, t, c: (x * (np.float32(0.6) + np.float32(0.1) * c.reshape(-1, 1, 1, 1))).astype(np.float16).astype(np.float32)
+                ofn = O.wrap_model(onet, osch, guidance_type="classifier-free", guidance_scale=scale, condition=c8,
+                                   unconditional_condition=c8 * 0)
+                want = O.Solver(ofn, osch, algorithm_type="dpmsolver++").sample(xs_cpu[r][lo:lo + 8].numpy(), steps=20, order=2)
+                err = float(np.abs(out[lo:lo + 8].numpy().astype(np.float64) - want).max() / np.abs(want).max())
+                assert err <= 1e-5, (r, lo, err)
