@@ -13,10 +13,13 @@ stage by stage (`dpm_plan_run_multi`): between two stages of one request the oth
 The 32 requests of one stage are ONE fused launch (`dpm_stage_launch_multi` -> stage_kernel_multi, a pointer-table
 kernel over 32 x 4.2 M elements), so a launch's ramp-up and drain are paid once per 1.3 GB.
 
-A *step* is one complete 20-stage trajectory of those R requests: 20 fused launches, R x 256 samples.  Every input
-is resident in HBM before the clock starts; the network outputs are pre-staged in buffers distinct from x.
-A timed region shorter than 50 ms is not reported: the step count is raised until the region is long enough, and
-`steps` in the JSON line is the number of steps actually timed (`steps_requested` is what --steps asked for).
+A *step* is P = 30 (`--trajectories-per-step`) complete 20-stage trajectories of those R requests: 600 fused launches,
+P x R x 256 = 245 760 samples, about 0.125 s -- so that the driver's `--steps 20` is a SUSTAINED 2.5 s measurement (clocks,
+HBM thermals), not an 80 ms burst.  Every input is resident in HBM before the clock starts; the network outputs are
+pre-staged in buffers distinct from x.  A timed region shorter than 2 s is not reported: the step count is
+raised until the region is long enough, and `steps` in the JSON line is the number of steps actually timed
+(`steps_requested` is what --steps asked for).  `sustained` carries the region's length and the throughput of its second
+half over its first half (a throttling check).
 
 One JSON line on rank 0:
   value            whole-job Msamples/s = N * K * R * 256 / wall, wall = barrier/sync-bracketed, max over ranks
@@ -27,8 +30,14 @@ One JSON line on rank 0:
                    `cache_resident` (ONE request, stages back to back: inputs in the Infinity Cache -- last round's
                    headline), `single_request_cold` (requests interleaved but one launch each), the no-arithmetic
                    ceilings of the same streams.
+                   `in_network_loop`: the stage kernel inside a REAL torch network loop -- DPM_Solver.sample() on ONE
+                   [256,4,64,64] request with a random-init torch network as model_fn (hundreds of MB of activations per
+                   call, its last kernel writes eps microseconds before the stage kernel reads it): kernel-only durations
+                   by events attached to each launch, and the wall time the 20 solver stages add to the 20 network calls.
   cpu_baseline     the reference itself ($DPM_REFERENCE_DIR or /root/reference: dpm_solver_pytorch.py, unmodified) on
                    this box's host cores when it is present, else the numpy oracle (a port); rank 0, N=1 only, bounded.
+                   `reference_on_gpu_box`: the unmodified reference timed on an MI355X box's own host cores
+                   (profiles/cpu_baseline_reference_gpubox.json, tools/cpu_baseline.py through gpurun).
 """
 import argparse
 import ctypes as C
@@ -46,7 +55,7 @@ sys.path.insert(0, ROOT)
 
 B, SHAPE, STEPS_SOLVER = 256, (4, 64, 64), 20
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
-MIN_REGION_S = 0.050        # shorter timed regions are not reported
+MIN_REGION_S = 2.0          # shorter timed regions are not reported (sustained clocks, not a burst)
 _DT = {"fp16": torch.float16, "fp32": torch.float32, "bf16": torch.bfloat16}
 
 
@@ -179,20 +188,168 @@ def cpu_baseline(ac):
     out = cpu_baseline_reference(ref, ac) if ref else cpu_baseline_port(ac)
     # the reference cannot travel to the GPU box (it is not part of this repository): its timing in the build container
     # is committed and attached for the record
-    p = os.path.join(ROOT, "profiles", "cpu_baseline_reference.json")
-    if out["kind"] != "reference" and os.path.exists(p):
-        try:
-            out["reference_in_build_container"] = json.load(open(p))
-        except Exception:
-            pass
+    if out["kind"] != "reference":
+        for key, name in (("reference_on_gpu_box", "cpu_baseline_reference_gpubox.json"),
+                          ("reference_in_build_container", "cpu_baseline_reference.json")):
+            p = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(p):
+                try:
+                    out[key] = json.load(open(p))
+                except Exception:
+                    pass
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the stage kernel inside a real torch network loop (ref :1195-1213): secondary measurement `in_network_loop`
+# ---------------------------------------------------------------------------------------------------------------
+class LoopNet(torch.nn.Module):
+    """Random-init stand-in for a denoising network, sized so that one call moves far more than the 256 MiB Infinity
+    Cache: kind 'gemm' = per-pixel MLP 4 -> W -> W -> 4 with a sinusoidal time embedding (hipBLASLt GEMMs over
+    [B*H*W, W] activations: 0.5 GB per layer at W = 256), kind 'conv' = 3x3 conv stack 4 -> W/2 -> W/2 -> 4 (MIOpen).
+    The last kernel of a call writes eps [B,4,64,64] contiguously, as a UNet's conv_out does."""
+
+    def __init__(self, kind="gemm", width=256, dtype=torch.float16, device="cuda"):
+        super().__init__()
+        g = torch.Generator().manual_seed(0)
+        self.kind, self.width = kind, width
+        mk = lambda *shape, scale: torch.nn.Parameter((torch.randn(*shape, generator=g) * scale).to(device, dtype),
+                                                      requires_grad=False)
+        self.freqs = torch.exp(torch.linspace(0., -6., 32)).to(device)
+        self.wt = mk(64, width if kind == "gemm" else width // 2, scale=0.1)
+        if kind == "gemm":
+            self.w1, self.w2, self.w3 = mk(4, width, scale=0.5), mk(width, width, scale=width ** -0.5), mk(width, 4, scale=width ** -0.5)
+        else:
+            c = width // 2
+            self.c1 = torch.nn.Conv2d(4, c, 3, padding=1).to(device, dtype)
+            self.c2 = torch.nn.Conv2d(c, c, 3, padding=1).to(device, dtype)
+            self.c3 = torch.nn.Conv2d(c, 4, 3, padding=1).to(device, dtype)
+        self.before_last = None        # hook called right before the last layer is enqueued (prefetch experiment)
+
+    def forward(self, x, t):
+        B, C, H, W = x.shape
+        a = t.float()[:, None] * self.freqs[None, :] * 1e-2
+        temb = torch.cat([a.sin(), a.cos()], dim=1).to(x.dtype) @ self.wt             # [B, width]
+        F = torch.nn.functional
+        if self.kind == "gemm":
+            h = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
+            h = F.silu(h @ self.w1 + temb[:, None, :])
+            h = F.silu(h @ self.w2)
+            if self.before_last is not None:
+                self.before_last()
+            return (h @ self.w3).reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+        h = F.silu(self.c1(x) + temb[:, :, None, None])
+        h = F.silu(self.c2(h))
+        if self.before_last is not None:
+            self.before_last()
+        return self.c3(h)
+
+
+def in_network_loop(D, L, ns, dev, dtype, kind="gemm", width=256, trajectories=6, prefetch=None):
+    """DPM_Solver.sample() (2M++, 20 steps) on one [256,4,64,64] request with LoopNet as the network.  Returns the
+    kernel-only duration of the steady-state stage kernel inside the loop (start/stop events attached to each launch,
+    no synchronisation between launches: dpm_stage_launch_traced) and the wall time the solver stages add to the network
+    calls.  prefetch = None | 0 | 1: pull the next stage's x and cached model value towards the memory-side cache from a
+    side stream while the network's last layer runs (dpm_prefetch_launch, default / streaming loads)."""
+    import dpm_solver_amd.solver as S
+    net = LoopNet(kind, width, dtype, dev)
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    x_T = torch.randn((B,) + SHAPE, generator=g).to(dev, dtype)
+    dpm = D.DPM_Solver(D.model_wrapper(net, ns), ns, algorithm_type="dpmsolver++", state_dtype=dtype)
+    with torch.no_grad():
+        out0 = dpm.sample(x_T, steps=STEPS_SOLVER, order=2)              # builds the launch records, warms the allocator
+        torch.cuda.synchronize(dev)
+        n_st = STEPS_SOLVER
+        trace = C.c_void_p()
+        L.check(L.lib.dpm_trace_create(n_st * trajectories, C.byref(trace)))
+        raw = S._stage_launch_raw
+        count = [0]
+        fr = next(iter(dpm._fast.values()))
+        side = torch.cuda.Stream(device=dev)
+        ev = torch.cuda.Event()
+
+        def traced(st, b, stream):
+            k = count[0]
+            count[0] += 1
+            return L.lib.dpm_stage_launch_traced(st, b, stream, trace, k)
+
+        def pull():                                                       # called by the network before its last layer
+            i = count[0] % n_st                                           # the stage this network call feeds
+            b = fr.bufs[i]
+            ptrs = [p for p in (b.x, b.h1, b.h2) if p]
+            if not ptrs:
+                return
+            ev.record()
+            side.wait_event(ev)
+            arr = (C.c_void_p * len(ptrs))(*ptrs)
+            nb = (C.c_int64 * len(ptrs))(*[x_T.numel() * x_T.element_size()] * len(ptrs))
+            L.check(L.lib.dpm_prefetch_launch(arr, nb, len(ptrs), int(prefetch), C.c_void_p(side.cuda_stream)))
+
+        net.before_last = pull if prefetch is not None else None
+        try:
+            S._stage_launch_raw = traced
+            for _ in range(trajectories):
+                out = dpm.sample(x_T, steps=STEPS_SOLVER, order=2)
+            ms = (C.c_float * (n_st * trajectories))()
+            L.check(L.lib.dpm_trace_read(trace, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), ms, n_st * trajectories))
+        finally:
+            S._stage_launch_raw = raw
+            L.lib.dpm_trace_destroy(trace)
+        assert torch.equal(out, out0), "traced / prefetching runs changed the result"
+        us = np.frombuffer(ms, dtype=np.float32).reshape(trajectories, n_st).astype(np.float64) * 1e3
+        steady = us[1:, 1:n_st - 1]                                       # first trajectory: warm-up
+        # wall: K trajectories with the solver vs the same network calls alone
+        tb = dpm._get_plan(method="multistep", order=2, steps=STEPS_SOLVER, skip_type="time_uniform", solver_type="dpmsolver",
+                           lower_order_final=True, denoise_to_zero=False, t_T=1.0, t_0=1.0 / ns.total_N).time_views(dev, B, False)
+        tin = tb["t_input_b"]
+
+        def timed(fn, k):
+            fn()
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(k):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            return e0.elapsed_time(e1) / k * 1e3                          # us per call of fn
+
+        def net_only():
+            for i in range(n_st):
+                net(x_T, tin[i])
+        k = max(3, trajectories)
+        t_solver = timed(lambda: dpm.sample(x_T, steps=STEPS_SOLVER, order=2), k)
+        t_net = timed(net_only, k)
+        net.before_last = None
+    n_el = B * int(np.prod(SHAPE))
+    ssz = x_T.element_size()
+    alg = 5 * n_el * ssz
+    med = float(np.median(steady))
+    added = (t_solver - t_net) / n_st
+    return dict(network="LoopNet(%s, width %d): %.2f ms per call" % (kind, width, t_net / n_st / 1e3),
+                network_ms_per_call=round(t_net / n_st / 1e3, 4),
+                stage_kernel_us=round(med, 3), stage_kernel_mean_us=round(float(steady.mean()), 3),
+                stage_kernel_p10_p90_us=[round(float(np.percentile(steady, 10)), 3), round(float(np.percentile(steady, 90)), 3)],
+                frac=round(alg / med / 1e3 / HBM_PEAK_GBS, 4), achieved=round(alg / med / 1e3, 1),
+                first_stage_us=round(float(np.median(us[1:, 0])), 3), last_stage_us=round(float(np.median(us[1:, -1])), 3),
+                stage_added_wall_us=round(added, 3), frac_wall=round(alg / max(added, 1e-3) / 1e3 / HBM_PEAK_GBS, 4),
+                trajectory_ms=round(t_solver / 1e3, 4), prefetch=prefetch,
+                how="DPM_Solver.sample() on one [%d,4,64,64] %s request, 2M++ 20 steps, torch network as model_fn; "
+                    "stage_kernel_us = median start->stop event interval of the steady-state stage launches inside the "
+                    "loop (dpm_stage_launch_traced); stage_added_wall_us = (trajectory - 20 network calls alone) / 20"
+                    % (B, str(dtype).split(".")[-1]))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--trajectories-per-step", type=int, default=30,
+                    help="a step = this many 20-stage trajectories of the requests in flight (30 x 32 x 256 samples, ~0.125 s): "
+                         "the driver's --steps 20 is then a sustained 2.5 s region")
+    ap.add_argument("--loop-net", default="gemm", choices=["gemm", "conv", "none"],
+                    help="network of the in_network_loop secondary measurement")
     ap.add_argument("--requests", type=int, default=32,
                     help="independent [256,4,64,64] sampling requests in flight, advanced stage by stage (one fused "
                          "launch per stage); 32 x 42 MB per stage > the 256 MiB Infinity Cache")
@@ -251,9 +408,15 @@ def main():
     rbs = (L.RunBuffers * R)(*[s_["rb"] for s_ in sets])
     resm = (C.c_int * R)()
 
-    def step():
+    P = max(1, args.trajectories_per_step)
+
+    def trajectory():
         """one 20-stage trajectory of the R requests in flight: 20 fused launches"""
         L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, R, sptr, None, resm))
+
+    def step():
+        for _ in range(P):
+            trajectory()
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -262,7 +425,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     # ---- parity spot check outside the timed region: fused launches == the Python host loop (single launches) ---
-    step()
+    trajectory()
     torch.cuda.synchronize(dev)
     for r in sorted({0, R - 1}):
         s_ = sets[r]
@@ -276,15 +439,18 @@ def main():
     steps = args.steps
     while True:
         barrier()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0, ev1, evm = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         t0 = time.perf_counter()
         ev0.record(stream)                              # HIP events on the launch stream, around the timed region
-        for _ in range(steps):
+        for k in range(steps):
+            if k == steps // 2:
+                evm.record(stream)                      # midpoint: second half vs first half = throttling check
             step()
         ev1.record(stream)
         barrier()
         wall = time.perf_counter() - t0
-        region_us = ev0.elapsed_time(ev1) * 1e3         # GPU time of the K steps = K * 20 fused launches
+        region_us = ev0.elapsed_time(ev1) * 1e3         # GPU time of the K steps = K * P * 20 fused launches
+        h1_us, h2_us = ev0.elapsed_time(evm) * 1e3, evm.elapsed_time(ev1) * 1e3
         if dist is not None:
             tw = torch.tensor([wall], dtype=torch.float64, device=dev)
             dist.all_reduce(tw, op=dist.ReduceOp.MAX)
@@ -299,9 +465,15 @@ def main():
     esz = torch.empty((), dtype=eps_dtype).element_size()
     alg_bytes = n_el * (4 * ssz + esz)                   # steady-state 2M stage of ONE request: reads x, eps, m_prev; writes x', m
     traj_alg_bytes = n_el * (18 * (4 * ssz + esz) + (3 * ssz + esz) + (3 * ssz + esz))  # + first (no history) and last (no m)
-    launches = steps * n_stages
+    launches = steps * P * n_stages
     launch_us = region_us / launches
-    achieved = traj_alg_bytes * R * steps / (region_us * 1e-6) / 1e9
+    achieved = traj_alg_bytes * R * steps * P / (region_us * 1e-6) / 1e9
+    k1 = steps // 2
+    sustained = dict(region_s=round(wall, 3), gpu_region_s=round(region_us * 1e-6, 3),
+                     second_half_over_first_half=(round((h1_us / max(k1, 1)) / (h2_us / max(steps - k1, 1)), 4)
+                                                  if 0 < k1 < steps else None),
+                     note="throughput of the second half of the timed region / the first half (HIP events at the "
+                          "midpoint); < 1 would mean clocks or HBM throttled while the region ran")
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per launch from rocprofv3 --pmc passes
     if os.path.exists(tpath):
@@ -311,6 +483,9 @@ def main():
             traffic = None
     roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                    traffic_source=("profiles/traffic.json (rocprofv3 --pmc passes of this command, committed: "
+                                    "FETCH_SIZE x 2 + WRITE_SIZE per fused launch; not measured in this run)"
+                                    if traffic is not None else None),
                     kernel="stage_kernel_multi<%s,%s,FORM_TWO,GUIDE_NONE,SPEC_NOISE_X0> (2M steady state, %d requests per launch)"
                            % (args.dtype, args.eps_dtype or args.dtype, min(R, L.MULTI_MAX)),
                     mode="hbm_cold: %d requests of [%d,4,64,64] in flight, advanced stage by stage, one fused launch per "
@@ -320,8 +495,8 @@ def main():
                     how="algorithmic bytes of the timed region (98*n*s per request trajectory) / its GPU time by HIP events "
                         "on the launch stream; launch_us = that time / fused launches (dispatch gaps included, as in the "
                         "rocprofv3 kernel-trace average)",
-                    host_wall=dict(achieved=round(traj_alg_bytes * R * steps / wall / 1e9, 1),
-                                   frac=round(traj_alg_bytes * R * steps / wall / 1e9 / HBM_PEAK_GBS, 4)))
+                    host_wall=dict(achieved=round(traj_alg_bytes * R * steps * P / wall / 1e9, 1),
+                                   frac=round(traj_alg_bytes * R * steps * P / wall / 1e9 / HBM_PEAK_GBS, 4)))
 
     if not args.no_secondary:
         # (1) kernel-only durations of the fused launches (start -> stop events of each launch)
@@ -352,7 +527,7 @@ def main():
             how="the %d requests advanced stage by stage with ONE launch per request (42 MB launches), kernel-only" % R)
         # (3) one request, stages back to back: its inputs sit in the Infinity Cache (last round's headline mode)
         res1 = C.c_int(-1)
-        k2 = max(20, min(200, steps * R // 8))
+        k2 = 200
         for i in range(8):
             L.check(L.lib.dpm_plan_run(plan.handle, C.byref(sets[i % min(8, R)]["rb"]), None, None, sptr, C.byref(res1)))
         torch.cuda.synchronize(dev)
@@ -475,28 +650,38 @@ def main():
         gather_ms = (time.perf_counter() - tg) * 1e3
         assert torch.equal(out[rank], final)
 
+    # ---- the stage kernel inside a real torch network loop (one request, the drop-in sample() call) ------------------
+    if not args.no_secondary and args.loop_net != "none" and world == 1:
+        try:
+            roofline["in_network_loop"] = in_network_loop(D, L, ns, dev, dtype, kind=args.loop_net)
+        except Exception as e:                                          # a secondary must not cost the headline
+            roofline["in_network_loop"] = dict(error="%s: %s" % (type(e).__name__, e))
+
     if rank == 0:
-        samples = world * steps * R * B
+        samples = world * steps * P * R * B
         line = {
             "metric": baseline_metric(),
             "value": round(samples / wall / 1e6, 4), "unit": "Msamples/s",
             "n_gpus": world, "steps": steps, "steps_requested": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / steps * 1e3, 5),
+            "ms_per_trajectory": round(wall / steps / P * 1e3, 5),   # one 20-stage pass over the R requests (C loop)
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32",          # the arithmetic type of the path: fp32 whatever the storage type of the state is
             "storage_dtype": {"fp16": "f16", "fp32": "f32", "bf16": "bf16"}[args.dtype], "data": "synthetic",
             "config": {"workload": "DPM-Solver++ 2M, 20 steps, [256,4,64,64] %s state / %s network output per request (fp32 "
                                    "arithmetic), %d requests in flight per GPU advanced stage by stage (inputs of every "
                                    "stage come from HBM), frozen model_fn (eps pre-staged), SD-v1 scaled-linear schedule, "
-                                   "time_uniform" % (args.dtype, args.eps_dtype or args.dtype, R),
-                       "batch_per_request": B, "requests_in_flight_per_gpu": R, "samples_per_step_per_gpu": R * B,
-                       "solver_stages_per_step": n_stages,
+                                   "time_uniform; a step = %d trajectories of the requests in flight"
+                                   % (args.dtype, args.eps_dtype or args.dtype, R, P),
+                       "batch_per_request": B, "requests_in_flight_per_gpu": R, "trajectories_per_step": P,
+                       "samples_per_step_per_gpu": P * R * B, "solver_stages_per_step": P * n_stages,
                        "launch": "one fused launch per stage (dpm_plan_run_multi -> dpm_stage_launch_multi)",
                        "parallelism": "batch-sharded x%d, no data-path collective" % world},
             "msample_steps_per_s": round(samples * n_stages / wall / 1e6, 3),
+            "sustained": sustained,
             "python_api_ms_per_trajectory": None if py_ms is None else round(py_ms, 4),
-            # the whole workload through DPM_Solver.sample_requests (compare with ms_per_step, the C loop)
-            "python_api_requests_ms_per_step": None if py_req_ms is None else round(py_req_ms, 4),
+            # one trajectory of the R requests through DPM_Solver.sample_requests (compare with ms_per_trajectory, the C loop)
+            "python_api_requests_ms_per_trajectory": None if py_req_ms is None else round(py_req_ms, 4),
             "roofline": roofline,
             "gather_ms": None if gather_ms is None else round(gather_ms, 4),
         }

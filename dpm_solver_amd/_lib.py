@@ -152,6 +152,11 @@ _SIGNATURES = [
     ("dpm_adaptive_poll", C.c_int, [C.c_void_p, _P(C.c_int), _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
     ("dpm_plan_run", C.c_int, [C.c_void_p, _P(RunBuffers), C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int)]),
     ("dpm_stage_launch_timed", C.c_int, [_P(Stage), _P(Buffers), C.c_void_p, _P(C.c_float)]),
+    ("dpm_trace_create", C.c_int, [C.c_int, _P(C.c_void_p)]),
+    ("dpm_stage_launch_traced", C.c_int, [_P(Stage), _P(Buffers), C.c_void_p, C.c_void_p, C.c_int]),
+    ("dpm_trace_read", C.c_int, [C.c_void_p, C.c_void_p, _P(C.c_float), C.c_int]),
+    ("dpm_trace_destroy", None, [C.c_void_p]),
+    ("dpm_prefetch_launch", C.c_int, [_P(C.c_void_p), _P(C.c_int64), C.c_int, C.c_int, C.c_void_p]),
     ("dpm_plan_run_timed", C.c_int, [C.c_void_p, _P(RunBuffers), C.c_void_p, _P(C.c_float), _P(C.c_int)]),
     ("dpm_plan_run_multi", C.c_int, [C.c_void_p, _P(RunBuffers), C.c_int, C.c_void_p, _P(C.c_float), _P(C.c_int)]),
     ("dpm_graph_create", C.c_int, [C.c_void_p, _P(RunBuffers), C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_void_p)]),

@@ -187,6 +187,108 @@ extern "C" int dpm_stage_launch_timed(const dpm_stage* st, const dpm_buffers* b,
   return rc ? rc : rc2;
 }
 
+// ---- event-bracketed launches without a synchronisation per launch (include/dpm_hip.h: dpm_trace_*)
+struct dpm_trace {
+  int cap = 0;
+  void** starts = nullptr;  // 2 * cap events: starts, then stops (dpm_timing_begin's layout)
+  void** stops = nullptr;
+  std::vector<unsigned char> used;
+};
+
+extern "C" int dpm_trace_create(int capacity, dpm_trace** out) {
+  if (!out || capacity < 1 || capacity > (1 << 20)) return dpm_set_error(DPM_ERR_ARG, "trace_create: bad arguments");
+  dpm_trace* t = new (std::nothrow) dpm_trace;
+  if (!t) return dpm_set_error(DPM_ERR_NOMEM, "out of memory");
+  int rc = dpm_timing_begin(capacity, &t->starts, &t->stops);
+  if (rc) {
+    delete t;
+    return rc;
+  }
+  t->cap = capacity;
+  t->used.assign((size_t)capacity, 0);
+  *out = t;
+  return DPM_OK;
+}
+
+extern "C" int dpm_stage_launch_traced(const dpm_stage* st, const dpm_buffers* b, void* stream, dpm_trace* t, int slot) {
+  if (!t || slot < 0 || slot >= t->cap) return dpm_set_error(DPM_ERR_ARG, "stage_launch_traced: slot %d outside the trace", slot);
+  const int rc = dpm_stage_launch_ev(st, b, stream, t->starts[slot], t->stops[slot]);
+  if (!rc) t->used[(size_t)slot] = 1;
+  return rc;
+}
+
+extern "C" int dpm_trace_read(dpm_trace* t, void* stream, float* ms, int n) {
+  if (!t || !ms || n < 0) return dpm_set_error(DPM_ERR_ARG, "trace_read: bad arguments");
+  hipError_t rc = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+  if (rc != hipSuccess) return dpm_set_error((int)rc, "hipStreamSynchronize: %s", hipGetErrorString(rc));
+  for (int i = 0; i < n; ++i) {
+    ms[i] = -1.f;
+    if (i < t->cap && t->used[(size_t)i]) {
+      rc = hipEventElapsedTime(&ms[i], static_cast<hipEvent_t>(t->starts[i]), static_cast<hipEvent_t>(t->stops[i]));
+      if (rc != hipSuccess) return dpm_set_error((int)rc, "hipEventElapsedTime(slot %d): %s", i, hipGetErrorString(rc));
+      t->used[(size_t)i] = 0;
+    }
+  }
+  return DPM_OK;
+}
+
+extern "C" void dpm_trace_destroy(dpm_trace* t) {
+  if (!t) return;
+  for (int i = 0; i < 2 * t->cap; ++i) (void)hipEventDestroy(static_cast<hipEvent_t>(t->starts[i]));
+  delete[] t->starts;
+  delete t;
+}
+
+// ---- prefetch: read buffers and drop the data (dpm_prefetch_launch)
+namespace {
+constexpr int PREFETCH_MAX = 8;
+struct PrefetchTab {
+  const u32x4* p[PREFETCH_MAX];
+  int64_t nvec[PREFETCH_MAX];
+};
+template <bool NT>
+__global__ __launch_bounds__(256) void prefetch_kernel(const PrefetchTab tab, int n_buf) {
+  for (int r = 0; r < n_buf; ++r) {
+    const u32x4* p = tab.p[r];
+    const int64_t nv = tab.nvec[r];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+      const u32x4 v = ld16<NT>(p + i);
+      asm volatile("" ::"v"(v));  // keeps the load; the data is not wanted
+    }
+  }
+}
+}  // namespace
+
+extern "C" int dpm_prefetch_launch(const void* const* bufs, const int64_t* bytes, int n_buf, int policy, void* stream) {
+  if (!bufs || !bytes || n_buf < 0 || n_buf > PREFETCH_MAX) return dpm_set_error(DPM_ERR_ARG, "prefetch: bad arguments (<= %d buffers)", PREFETCH_MAX);
+  PrefetchTab tab;
+  std::memset(&tab, 0, sizeof tab);
+  int64_t total = 0;
+  int k = 0;
+  for (int i = 0; i < n_buf; ++i) {
+    if (!bufs[i] || bytes[i] < 16) continue;
+    if (!aligned(bufs[i], 16)) return dpm_set_error(DPM_ERR_ALIGN, "prefetch: buffer %d is not 16-byte aligned", i);
+    tab.p[k] = static_cast<const u32x4*>(bufs[i]);
+    tab.nvec[k] = bytes[i] / 16;
+    total += tab.nvec[k];
+    ++k;
+  }
+  if (!k) return DPM_OK;
+  const DeviceInfo& di = device_info();
+  const int64_t cap = (int64_t)(di.n_cu > 0 ? di.n_cu : 256) * 4;
+  int64_t blocks = (total / k + 255) / 256;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (policy == 1)
+    hipLaunchKernelGGL(prefetch_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, tab, k);
+  else
+    hipLaunchKernelGGL(prefetch_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, tab, k);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return dpm_set_error((int)e, "prefetch launch failed: %s", hipGetErrorString(e));
+  return DPM_OK;
+}
+
 extern "C" size_t dpm_threshold_workspace_bytes(int64_t batch, int64_t per_sample) {
   if (batch < 1 || per_sample < 1) return 0;
   const DeviceInfo& di = device_info();

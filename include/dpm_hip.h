@@ -330,6 +330,22 @@ int dpm_plan_run(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model_cb mode
 int dpm_stage_launch_timed(const dpm_stage* st, const dpm_buffers* b, void* stream, float* ms);
 int dpm_plan_run_timed(const dpm_plan* p, const dpm_run_buffers* rb, void* stream, float* ms_per_stage, int* result);
 
+/* kernel durations INSIDE a real loop, without synchronising between launches: a trace owns `capacity` start/stop event
+   pairs; dpm_stage_launch_traced is dpm_stage_launch with the pair of `slot` bracketing the kernel itself
+   (hipExtLaunchKernelGGL), dpm_trace_read synchronises the stream once and fills ms[0..n) (-1 for slots never used).
+   What bench.py's `in_network_loop` and tools/in_loop.py use between the kernels of a torch network. */
+typedef struct dpm_trace dpm_trace;
+int dpm_trace_create(int capacity, dpm_trace** out);
+int dpm_stage_launch_traced(const dpm_stage* st, const dpm_buffers* b, void* stream, dpm_trace* t, int slot);
+int dpm_trace_read(dpm_trace* t, void* stream, float* ms, int n);
+void dpm_trace_destroy(dpm_trace* t);
+
+/* read `n_buf` device buffers (bytes[i] each, 16-byte aligned) and discard the data: pulls a later stage's inputs (x, the
+   cached model values) towards the memory-side cache from a side stream while the network's last layers still run
+   (ref :1195-1213 leaves a network call between two updates, so they are HBM-cold otherwise).  policy 0: default loads
+   (allocate in L2 and the Infinity Cache), 1: streaming loads.  Asynchronous on `stream`. */
+int dpm_prefetch_launch(const void* const* bufs, const int64_t* bytes, int n_buf, int policy, void* stream);
+
 /* several independent sampling requests advanced stage by stage (all requests stage s, then all stage s+1, ...)
    through dpm_stage_launch_multi: what a server holding n requests in flight does, and -- with a frozen model -- the
    HBM-cold measurement mode of bench.py: between two stages of one request the other n-1 requests stream their buffers

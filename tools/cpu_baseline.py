@@ -2,7 +2,13 @@
 """Time the unmodified reference (DPM_Solver.sample of $DPM_REFERENCE_DIR/dpm_solver_pytorch.py, default
 /root/reference) on this machine's host cores on bench.py's workload and write profiles/cpu_baseline_reference.json.
 The reference checkout exists in the build container only; bench.py attaches this file to its `cpu_baseline` when it
-runs where the reference is absent (the GPU box)."""
+runs where the reference is absent (the GPU box).
+
+On a GPU box: the reference file travels there as untracked, git-ignored scratch
+(`_refscratch/`, removed after the call; never committed) and only the RESULT is committed:
+    DPM_REFERENCE_DIR=_refscratch python tools/cpu_baseline.py --out gpurun_out/.../cpu_baseline_reference_gpubox.json \
+        --where "MI355X box host cores (gpurun)"
+"""
 import json
 import os
 import platform
@@ -14,17 +20,25 @@ import bench  # noqa: E402
 
 
 def main():
+    import argparse
+    import torch
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "cpu_baseline_reference.json"))
+    ap.add_argument("--where", default="build container (no GPU)")
+    ap.add_argument("--budget", type=float, default=30.0)
+    args = ap.parse_args()
     ref = bench.reference_dir()
     assert ref, "no reference checkout (DPM_REFERENCE_DIR)"
-    out = bench.cpu_baseline_reference(ref, bench.sd_alphas_cumprod(), budget_s=30.0)
+    out = bench.cpu_baseline_reference(ref, bench.sd_alphas_cumprod(), budget_s=args.budget)
     cpu = ""
     try:
         cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         pass
-    out["host"] = dict(cpu=cpu, cores=os.cpu_count(), machine=platform.machine(), where="build container (no GPU)")
-    p = os.path.join(ROOT, "profiles", "cpu_baseline_reference.json")
-    json.dump(out, open(p, "w"), indent=1)
+    gpu = torch.cuda.get_device_name(0) if torch.cuda.is_available() else None
+    out["host"] = dict(cpu=cpu, cores=os.cpu_count(), machine=platform.machine(), where=args.where, gpu=gpu,
+                       torch=torch.__version__)
+    json.dump(out, open(args.out, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 

@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""The 2M stage kernel inside a real torch network loop: DPM_Solver.sample() on one
+[256,4,64,64] request with a random-init torch network as model_fn (bench.LoopNet), the stage kernel's duration taken
+between the network's kernels, with and without the prefetch launch (x and the cached model value pulled towards the
+memory-side cache from a side stream while the network's last layer runs).
+
+    python tools/in_loop.py [--kinds gemm,conv] [--dtype fp16] [--out gpurun_out/in_loop.json]   # events, all variants
+    rocprofv3 --kernel-trace --stats -d DIR -o kt -- python tools/in_loop.py --trace-only [--prefetch 0]
+    python tools/in_loop.py --summarise DIR/kt [--md profiles/r03_in_loop.md]                     # rows of the trace
+"""
+import argparse
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def summarise(d, md=None, title=""):
+    """stage-kernel rows of a rocprofv3 kernel trace of `--trace-only`: duration, the kernel that ran before each, the gap"""
+    f = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+    assert f, "no *_results.db under %s" % d
+    cur = sqlite3.connect(f[0]).cursor()
+    rows = cur.execute("select name, start, duration from kernels order by start").fetchall()
+    out = ["# %s\n\n" % (title or "stage kernel inside a torch network loop (rocprofv3 --kernel-trace)")]
+    names = [r[0] for r in rows]
+    st = np.array([r[1] for r in rows], dtype=np.float64)
+    du = np.array([r[2] for r in rows], dtype=np.float64)
+    is_stage = np.array(["stage_kernel" in n for n in names])
+    idx = np.nonzero(is_stage)[0]
+    out.append("%d kernel rows, %d stage-kernel rows\n\n" % (len(rows), len(idx)))
+    # per distinct stage kernel
+    out.append("| stage kernel | rows | mean us | median us | p10 | p90 |\n|---|---|---|---|---|---|\n")
+    for n in sorted(set(names[i] for i in idx)):
+        v = du[[i for i in idx if names[i] == n]] / 1e3
+        out.append("| `%s` | %d | %.3f | %.3f | %.3f | %.3f |\n" % (n[:150].replace("|", "/"), len(v), v.mean(), np.median(v),
+                                                                  np.percentile(v, 10), np.percentile(v, 90)))
+    # what runs right before / after a stage kernel, and the gaps
+    prev = {}
+    gaps_b, gaps_a = [], []
+    for i in idx:
+        if i > 0:
+            prev.setdefault(names[i - 1][:110], []).append(du[i - 1] / 1e3)
+            gaps_b.append((st[i] - (st[i - 1] + du[i - 1])) / 1e3)
+        if i + 1 < len(rows):
+            gaps_a.append((st[i + 1] - (st[i] + du[i])) / 1e3)
+    out.append("\nkernel that ends right before a stage kernel starts (the network's last kernel):\n\n| kernel | times | its mean us |\n|---|---|---|\n")
+    for n, v in sorted(prev.items(), key=lambda kv: -len(kv[1]))[:6]:
+        out.append("| `%s` | %d | %.2f |\n" % (n.replace("|", "/"), len(v), float(np.mean(v))))
+    if gaps_b:
+        out.append("\ngap previous kernel end -> stage kernel start: median %.2f us; stage kernel end -> next kernel start: "
+                   "median %.2f us\n" % (float(np.median(gaps_b)), float(np.median(gaps_a))))
+    # one steady-state step, row by row
+    if len(idx) > 12:
+        a, b = idx[10], idx[11]
+        out.append("\none solver step of the trace (stage kernel, the network call, next stage kernel):\n\n| kernel | start us (rel) | duration us |\n|---|---|---|\n")
+        for i in range(a, b + 1):
+            out.append("| `%s` | %.2f | %.2f |\n" % (names[i][:110].replace("|", "/"), (st[i] - st[a]) / 1e3, du[i] / 1e3))
+    pf = [i for i, n in enumerate(names) if "prefetch_kernel" in n]
+    if pf:
+        v = du[pf] / 1e3
+        out.append("\nprefetch kernel: %d rows, mean %.2f us\n" % (len(v), v.mean()))
+    text = "".join(out)
+    if md:
+        open(md, "w").write(text)
+    print(text)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kinds", default="gemm")
+    ap.add_argument("--dtype", default="fp16")
+    ap.add_argument("--width", type=int, default=256)
+    ap.add_argument("--trajectories", type=int, default=8)
+    ap.add_argument("--prefetch", default=None, help="trace-only mode: None | 0 | 1")
+    ap.add_argument("--trace-only", action="store_true")
+    ap.add_argument("--summarise", default=None)
+    ap.add_argument("--md", default=None)
+    ap.add_argument("--title", default="")
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    if args.summarise:
+        return summarise(args.summarise, args.md, args.title)
+    import torch
+    import bench
+    import dpm_solver_amd as D
+    from dpm_solver_amd import _lib as L
+    dev = torch.device("cuda", 0)
+    dtype = bench._DT[args.dtype]
+    ns = D.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(bench.sd_alphas_cumprod()))
+    res = []
+    for kind in args.kinds.split(","):
+        if args.trace_only:
+            pf = None if args.prefetch in (None, "None", "none") else int(args.prefetch)
+            r = bench.in_network_loop(D, L, ns, dev, dtype, kind=kind, width=args.width, trajectories=args.trajectories, prefetch=pf)
+            r["variant"] = "%s prefetch=%s (under the profiler)" % (kind, pf)
+            res.append(r)
+            continue
+        for pf in (None, 0, 1):
+            r = bench.in_network_loop(D, L, ns, dev, dtype, kind=kind, width=args.width, trajectories=args.trajectories, prefetch=pf)
+            r["variant"] = "%s prefetch=%s" % (kind, pf)
+            res.append(r)
+            print(json.dumps(r), flush=True)
+    if args.out:
+        json.dump(res, open(args.out, "w"), indent=1)
+    if args.trace_only:
+        print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
