@@ -132,20 +132,30 @@ def cpu_baseline_reference(ref, ac, budget_s=8.0):
     cores = os.cpu_count() or 1
     out = {}
     before = torch.get_num_threads()
+    # 1 thread, then doubling thread counts up to all host cores: on a many-core host the reference's ~10 small ATen
+    # kernels per step stop scaling long before the core count (and collapse when oversubscribed), so the best count is
+    # searched, not assumed; a count that is more than twice as slow as the best so far ends the sweep
+    counts = sorted({1, cores} | {c for c in (4, 8, 16, 32, 64, 128) if c < cores})
+    per = max(budget_s / (len(counts) + 1), 1.0)
     try:
-        for th in sorted({1, cores}):
+        for th in counts:
             torch.set_num_threads(th)
-            n, el = _time_loop(run, budget_s / 2)
+            n, el = _time_loop(run, per, min_runs=2 if th == 1 else 1)
             out[th] = dict(value=round(B * n / el / 1e6, 6), unit="Msamples/s", threads=th, trajectories=n,
                            seconds=round(el, 2), ms_per_trajectory=round(el / n * 1e3, 2))
+            best_ms = min(v["ms_per_trajectory"] for v in out.values())
+            if out[th]["ms_per_trajectory"] > 2.0 * best_ms and th != 1:
+                break
     finally:
         torch.set_num_threads(before)
-    best = out[cores]
-    return dict(value=best["value"], unit="Msamples/s", cores=cores, threads=cores, kind="reference",
+    best = max(out.values(), key=lambda v: v["value"])
+    return dict(value=best["value"], unit="Msamples/s", cores=best["threads"], threads=best["threads"], host_cores=cores,
+                kind="reference",
                 sample="%d trajectories of [%d,4,64,64] fp32, DPM_Solver.sample(steps=20, order=2, multistep) of the "
-                       "unmodified reference dpm_solver_pytorch.py on CPU tensors, frozen eps, torch %s, %d threads, %.1f s"
-                       % (best["trajectories"], B, torch.__version__, cores, best["seconds"]),
-                single_thread=out[1], all_cores=best)
+                       "unmodified reference dpm_solver_pytorch.py on CPU tensors, frozen eps, torch %s, best of the thread "
+                       "counts %s: %d threads of the host's %d cores, %.1f s"
+                       % (best["trajectories"], B, torch.__version__, sorted(out), best["threads"], cores, best["seconds"]),
+                single_thread=out[1], best=best, by_threads=[out[k] for k in sorted(out)])
 
 
 def cpu_baseline_port(ac, budget_s=8.0):
@@ -224,7 +234,7 @@ class LoopNet(torch.nn.Module):
             self.c1 = torch.nn.Conv2d(4, c, 3, padding=1).to(device, dtype)
             self.c2 = torch.nn.Conv2d(c, c, 3, padding=1).to(device, dtype)
             self.c3 = torch.nn.Conv2d(c, 4, 3, padding=1).to(device, dtype)
-        self.before_last = None        # hook called right before the last layer is enqueued (prefetch experiment)
+        self.before_last = None        # hook called right before the call's last kernel is enqueued (prefetch experiment)
 
     def forward(self, x, t):
         B, C, H, W = x.shape
@@ -235,9 +245,10 @@ class LoopNet(torch.nn.Module):
             h = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
             h = F.silu(h @ self.w1 + temb[:, None, :])
             h = F.silu(h @ self.w2)
+            o = (h @ self.w3).reshape(B, H, W, C).permute(0, 3, 1, 2)
             if self.before_last is not None:
-                self.before_last()
-            return (h @ self.w3).reshape(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+                self.before_last()                  # the last kernel of the call: the layout copy that writes eps
+            return o.contiguous()
         h = F.silu(self.c1(x) + temb[:, :, None, None])
         h = F.silu(self.c2(h))
         if self.before_last is not None:
@@ -286,6 +297,9 @@ def in_network_loop(D, L, ns, dev, dtype, kind="gemm", width=256, trajectories=6
             L.check(L.lib.dpm_prefetch_launch(arr, nb, len(ptrs), int(prefetch), C.c_void_p(side.cuda_stream)))
 
         net.before_last = pull if prefetch is not None else None
+        if prefetch is not None:          # x and the cached model value are expected in the memory-side cache then
+            for b in fr.bufs[1:]:
+                b.inputs_resident = 1
         try:
             S._stage_launch_raw = traced
             for _ in range(trajectories):
@@ -321,6 +335,8 @@ def in_network_loop(D, L, ns, dev, dtype, kind="gemm", width=256, trajectories=6
         t_solver = timed(lambda: dpm.sample(x_T, steps=STEPS_SOLVER, order=2), k)
         t_net = timed(net_only, k)
         net.before_last = None
+        for b in fr.bufs:
+            b.inputs_resident = 0
     n_el = B * int(np.prod(SHAPE))
     ssz = x_T.element_size()
     alg = 5 * n_el * ssz
@@ -348,8 +364,9 @@ def main():
     ap.add_argument("--trajectories-per-step", type=int, default=30,
                     help="a step = this many 20-stage trajectories of the requests in flight (30 x 32 x 256 samples, ~0.125 s): "
                          "the driver's --steps 20 is then a sustained 2.5 s region")
-    ap.add_argument("--loop-net", default="gemm", choices=["gemm", "conv", "none"],
-                    help="network of the in_network_loop secondary measurement")
+    ap.add_argument("--loop-net", default="conv", choices=["gemm", "conv", "none"],
+                    help="network of the in_network_loop secondary measurement (conv: MIOpen 3x3 conv stack, falls back to "
+                         "gemm: hipBLASLt per-pixel MLP)")
     ap.add_argument("--requests", type=int, default=32,
                     help="independent [256,4,64,64] sampling requests in flight, advanced stage by stage (one fused "
                          "launch per stage); 32 x 42 MB per stage > the 256 MiB Infinity Cache")
@@ -652,10 +669,18 @@ def main():
 
     # ---- the stage kernel inside a real torch network loop (one request, the drop-in sample() call) ------------------
     if not args.no_secondary and args.loop_net != "none" and world == 1:
-        try:
-            roofline["in_network_loop"] = in_network_loop(D, L, ns, dev, dtype, kind=args.loop_net)
-        except Exception as e:                                          # a secondary must not cost the headline
-            roofline["in_network_loop"] = dict(error="%s: %s" % (type(e).__name__, e))
+        for kind in ([args.loop_net, "gemm"] if args.loop_net != "gemm" else ["gemm"]):
+            try:
+                roofline["in_network_loop"] = in_network_loop(D, L, ns, dev, dtype, kind=kind)
+                break
+            except Exception as e:                                      # a secondary must not cost the headline
+                roofline["in_network_loop"] = dict(error="%s: %s" % (type(e).__name__, e))
+        try:        # the same loop under rocprofv3 (kernel rows, not event intervals): committed, attached for the record
+            rows = json.load(open(os.path.join(ROOT, "profiles", "in_loop.json"))).get(args.dtype)
+            if rows and "error" not in roofline["in_network_loop"]:
+                roofline["in_network_loop"]["rocprofv3_kernel_rows"] = rows
+        except Exception:
+            pass
 
     if rank == 0:
         samples = world * steps * P * R * B

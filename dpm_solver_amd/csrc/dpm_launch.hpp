@@ -381,11 +381,14 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
             b->n % EPT == 0 && ext.mask_period % EPT == 0 &&
             (!ext.eps_stride || (ext.per_sample % EPT == 0 && ext.eps_stride % EPT == 0));
     // what the streaming family instantiates (binary size: one kernel per combination and dtype pair):
-    //   * a separate evaluation state (xe != x) only occurs in the singlestep mid / final stages: forms TWO and SS3T;
+    //   * a separate evaluation state (xe != x) occurs in the singlestep mid / final stages -- forms TWO and SS3T -- and
+    //     in the FIRST stage of a multistep run with a corrector on x_t (mask blend, any correcting_xt_fn): the network saw
+    //     the raw x_T, the update starts from the corrected state (ref :1179-1183) -- form LIN1, unguided or CFG;
     //   * the compile-time prologues (noise-prediction network) for the forms samplers spend their time in -- LIN1, TWO,
     //     MS3; SS3T and DENOISE run the general prologue (true division: the same bits);
     //   everything else goes through the one-element-per-lane kernel.
-    constexpr bool COMBO_BUILT = !XE || FORM == DPM_FORM_TWO || FORM == DPM_FORM_SS3T;
+    constexpr bool COMBO_BUILT = !XE || FORM == DPM_FORM_TWO || FORM == DPM_FORM_SS3T ||
+                                 (FORM == DPM_FORM_LIN1 && GUIDE != DPM_GUIDE_CLASSIFIER);
     constexpr bool SPEC_BUILT = FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3;
     // device-resident coefficients (adaptive solver): DYN kernels exist for the forms it launches -- first-order,
     // second-order and the singlestep-3 'taylor' combination -- without the KExt extensions; anything else takes the

@@ -171,6 +171,46 @@ def test_maskblend_fused_equals_closure_stochastic(method, order, steps, mask_sh
     assert torch.equal(D.MaskBlend(ns, mask, x0=x0, noise=noise)(x, t, 3), closure(x, t, 3))
 
 
+@pytest.mark.parametrize("mask_shape", [(64, 64), (1, 4, 64, 64), (8, 4, 64, 64)])
+@pytest.mark.parametrize("sdt", [torch.float32, torch.float16])
+@pytest.mark.parametrize("cfg", [False, True])
+def test_maskblend_first_stage_takes_the_vector_kernel(mask_shape, sdt, cfg, monkeypatch):
+    """The first stage of a multistep run with a corrector has a separate evaluation state (the network saw the raw x_T,
+    the update starts from the blended state, ref :1179-1183): first-order form + xe != x.  At whole-tile sizes it runs
+    the streaming kernel (split-tile layout for fp32) -- bit-equal to the Python closure and to the kernel double."""
+    from kernel_double import install_cpu_double
+    shape = (8, 4, 64, 64)
+    ns = make_schedule("sd")
+    x, x0, noise, mask = _blend_setup(shape, mask_shape, seed=11)
+    xs = x.to(sdt)
+
+    def mk(dev, corr):
+        if cfg:
+            c = torch.ones(shape[0], device=dev)
+            fn = D.model_wrapper(lambda xx, t, cc: xx * (0.4 + 0.1 * cc.reshape(-1, 1, 1, 1)).to(xx.dtype), ns,
+                                 guidance_type="classifier-free", condition=c, unconditional_condition=c * 0, guidance_scale=2.0)
+        else:
+            fn = D.model_wrapper(lambda xx, t: xx * 0.5, ns)
+        return D.DPM_Solver(fn, ns, correcting_xt_fn=corr, state_dtype=sdt)
+
+    helper = mk(DEV, None)
+    closure = lambda xt, t, step: (xt * mask.to(sdt) + (1 - mask.to(sdt)) * helper.add_noise(
+        x0.to(sdt), t.reshape(1), noise=noise.to(sdt).unsqueeze(0))).to(sdt)
+    spy = LaunchSpy(monkeypatch)
+    got, gi = mk(DEV, D.MaskBlend(ns, mask, x0=x0, noise=noise)).sample(xs, steps=6, order=2, return_intermediate=True)
+    first = spy.calls[0]
+    assert first["form"] == L.FORM_LIN1 and (first["flags"] & L.F_BLEND)
+    if sdt is torch.float32:          # the closure's half-precision products round differently; fp32 is exact
+        want, wi = mk(DEV, closure).sample(xs, steps=6, order=2, return_intermediate=True)
+        assert torch.equal(got, want) and all(torch.equal(a, b) for a, b in zip(gi, wi))
+    with monkeypatch.context() as m:
+        install_cpu_double(m, S, D)
+        dbl, di = mk("cpu", D.MaskBlend(ns, mask.cpu(), x0=x0.cpu(), noise=noise.cpu())).sample(
+            xs.cpu(), steps=6, order=2, return_intermediate=True)
+    assert got.dtype == sdt and torch.equal(got.cpu(), dbl)
+    assert all(torch.equal(a.cpu(), b) for a, b in zip(gi, di))
+
+
 def test_maskblend_against_reference_callback_goldens(golden):
     """goldens produced by the real reference with the closure xt*mask + (1-mask)*(0.25*step) as correcting_xt_fn"""
     case = C.E2E_BY_NAME["cfg1_small"]
