@@ -256,17 +256,19 @@ class LoopNet(torch.nn.Module):
         return self.c3(h)
 
 
-def in_network_loop(D, L, ns, dev, dtype, kind="gemm", width=256, trajectories=6, prefetch=None):
+def in_network_loop(D, L, ns, dev, dtype, kind="gemm", width=256, trajectories=6, prefetch=None, net_dtype=None):
     """DPM_Solver.sample() (2M++, 20 steps) on one [256,4,64,64] request with LoopNet as the network.  Returns the
     kernel-only duration of the steady-state stage kernel inside the loop (start/stop events attached to each launch,
     no synchronisation between launches: dpm_stage_launch_traced) and the wall time the solver stages add to the network
     calls.  prefetch = None | 0 | 1: pull the next stage's x and cached model value towards the memory-side cache from a
     side stream while the network's last layer runs (dpm_prefetch_launch, default / streaming loads)."""
     import dpm_solver_amd.solver as S
-    net = LoopNet(kind, width, dtype, dev)
+    net_dtype = net_dtype or dtype                  # fp16 network under an fp32 state: SD under autocast
+    net = LoopNet(kind, width, net_dtype, dev)
     g = torch.Generator(device="cpu").manual_seed(4321)
     x_T = torch.randn((B,) + SHAPE, generator=g).to(dev, dtype)
-    dpm = D.DPM_Solver(D.model_wrapper(net, ns), ns, algorithm_type="dpmsolver++", state_dtype=dtype)
+    model = net if net_dtype == dtype else (lambda x, t: net(x.to(net_dtype), t))
+    dpm = D.DPM_Solver(D.model_wrapper(model, ns), ns, algorithm_type="dpmsolver++", state_dtype=dtype)
     with torch.no_grad():
         out0 = dpm.sample(x_T, steps=STEPS_SOLVER, order=2)              # builds the launch records, warms the allocator
         torch.cuda.synchronize(dev)
@@ -330,7 +332,7 @@ def in_network_loop(D, L, ns, dev, dtype, kind="gemm", width=256, trajectories=6
 
         def net_only():
             for i in range(n_st):
-                net(x_T, tin[i])
+                model(x_T, tin[i])
         k = max(3, trajectories)
         t_solver = timed(lambda: dpm.sample(x_T, steps=STEPS_SOLVER, order=2), k)
         t_net = timed(net_only, k)
@@ -339,7 +341,7 @@ def in_network_loop(D, L, ns, dev, dtype, kind="gemm", width=256, trajectories=6
             b.inputs_resident = 0
     n_el = B * int(np.prod(SHAPE))
     ssz = x_T.element_size()
-    alg = 5 * n_el * ssz
+    alg = n_el * (4 * ssz + torch.empty((), dtype=net_dtype).element_size())
     med = float(np.median(steady))
     added = (t_solver - t_net) / n_st
     return dict(network="LoopNet(%s, width %d): %.2f ms per call" % (kind, width, t_net / n_st / 1e3),

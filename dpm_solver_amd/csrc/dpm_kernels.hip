@@ -943,7 +943,8 @@ extern "C" int dpm_calib_launch(int kind, int block, int blocks_per_cu, int nt, 
 extern "C" int dpm_tuning_set(int knob, int value) {
   switch (knob) {
     case DPM_TUNE_UNROLL:
-      if (value != 0 && value != 1 && value != 2) return dpm_set_error(DPM_ERR_ARG, "unroll must be 0 (default), 1 or 2");
+      if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
+        return dpm_set_error(DPM_ERR_ARG, "unroll must be 0 (default), 1, 2, 4 or 8 (4 and 8: tuning builds only)");
       g_tuning.unroll = value;
       return DPM_OK;
     case DPM_TUNE_NONTEMPORAL: g_tuning.nontemporal = value < 0 ? -1 : (value & 7); return DPM_OK;

@@ -447,8 +447,7 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
           // the north-star kernels (2M / 1st-order update, no guidance): (tiles per iteration, nt mask) by situation and
           // dtypes, from profiles/r01_tuning_v3.txt / r01_tuning_v4.txt:
           //   inputs cache-resident: default policy, two tiles per iteration when there is work for it
-          //   inputs from HBM:       2-byte state (1, nt loads); fp32 + fp32 (1 | 2, nt loads + nt m store);
-          //                          fp32 state + 2-byte network output (1 | 2, nt loads)  [SD under autocast]
+          //   inputs from HBM:       one tile per iteration, nt loads (+ nt m store for fp32 + fp32), see below
           const bool resident = b->inputs_resident != 0 || tn.assume_resident != 0;
           constexpr int CNT = sizeof(TS) == 2 ? 1 : (sizeof(TE) == 4 ? 5 : 1);  // nt mask of the HBM situation
 #ifdef DPM_TUNING_VARIANTS  // tools/tune.py single: every (tiles per iteration, nt mask)
@@ -460,16 +459,24 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
               case 16 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 2, 0, false); break;
               case 16 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 2, 1, false); break;
               case 16 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 2, 5, false); break;
+              case 32 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 4, 0, false); break;
+              case 32 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 4, 1, false); break;
+              case 32 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 4, 5, false); break;
+              case 64 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 8, 0, false); break;
+              case 64 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 8, 1, false); break;
+              case 64 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 8, 5, false); break;
               default: DPM_LAUNCH(SPEC_NOISE_X0, DEF_U, DefNT<TS>::value, false); break;
             }
           } else
 #endif
           if (resident) {
             if (big) DPM_LAUNCH(SPEC_NOISE_X0, 2, 0, false); else DPM_LAUNCH(SPEC_NOISE_X0, 1, 0, false);
-          } else if (sizeof(TS) == 2 || !big) {
-            DPM_LAUNCH(SPEC_NOISE_X0, 1, CNT, false);
           } else {
-            DPM_LAUNCH(SPEC_NOISE_X0, 2, CNT, false);
+            // from HBM: ONE tile per workgroup for every dtype pair.  Round 1 picked two tiles for 4-byte states from the
+            // interleaved-requests emulation (15.4 vs 15.6 us); INSIDE a torch network loop (profiles/r03_in_loop.md,
+            // rocprofv3 rows, 342 launches each) one tile is 15.0 us against 16.3, and four / eight tiles -- fewer, fatter
+            // wavefronts with every load issued up front, the emulation's favourite at 14.4 us -- are 15.2 / 23.8 us.
+            DPM_LAUNCH(SPEC_NOISE_X0, 1, CNT, false);
           }
         } else {
           DPM_LAUNCH(SPEC_NOISE_X0, DEF_U, DefNT<TS>::value, false);

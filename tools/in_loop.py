@@ -83,6 +83,10 @@ def main():
     ap.add_argument("--md", default=None)
     ap.add_argument("--title", default="")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--sweep", action="store_true", help="tuning build: (tiles per workgroup, nt mask) of the 2M kernel INSIDE "
+                    "the loop, for fp16, fp32 and fp32 state + fp16 network (events)")
+    ap.add_argument("--unroll", type=int, default=0, help="tuning build only: tiles per workgroup of the 2M stage kernel")
+    ap.add_argument("--nt", type=int, default=-1, help="tuning build only: nt mask")
     args = ap.parse_args()
     if args.summarise:
         return summarise(args.summarise, args.md, args.title)
@@ -93,6 +97,21 @@ def main():
     dev = torch.device("cuda", 0)
     dtype = bench._DT[args.dtype]
     ns = D.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(bench.sd_alphas_cumprod()))
+    if args.sweep:
+        for sname, ename in (("fp16", "fp16"), ("fp32", "fp32"), ("fp32", "fp16")):
+            for u in (1, 2, 4):
+                for nt in (0, 1, 5):
+                    L.check(L.lib.dpm_tuning_set(L.TUNE_UNROLL, u))
+                    L.check(L.lib.dpm_tuning_set(L.TUNE_NONTEMPORAL, nt))
+                    r = bench.in_network_loop(D, L, ns, dev, bench._DT[sname], kind=args.kinds.split(",")[0], width=args.width,
+                                              trajectories=args.trajectories, net_dtype=bench._DT[ename])
+                    print("%s state / %s network  U=%d nt=%d   stage kernel in the loop %7.3f us (events; %.3f of peak)   "
+                          "added wall per stage %7.3f us" % (sname, ename, u, nt, r["stage_kernel_us"], r["frac"],
+                                                            r["stage_added_wall_us"]), flush=True)
+        return
+    if args.unroll:
+        L.check(L.lib.dpm_tuning_set(L.TUNE_UNROLL, args.unroll))
+        L.check(L.lib.dpm_tuning_set(L.TUNE_NONTEMPORAL, args.nt if args.nt >= 0 else 1))
     res = []
     for kind in args.kinds.split(","):
         if args.trace_only:

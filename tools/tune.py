@@ -2,7 +2,8 @@
 """Launch-shape sweeps of the stage kernels on the GPU (run via gpurun).  One tool, two sweeps; both need a library
 built with every (tiles per iteration, nt mask) variant:
 
-    DPM_EXTRA_HIPCC_FLAGS=-DDPM_TUNING_VARIANTS python __graft_entry__.py --force
+    python -c "import __graft_entry__ as g; g.build_variant('tune', ['-DDPM_TUNING_VARIANTS'])"
+    export DPM_SOLVER_AMD_LIB=tools/_variants/tune/libdpm_hip.so
     python tools/tune.py multi  [--requests 32]      > profiles/rNN_tune_multi.txt     # fused multi-request launches
     python tools/tune.py single [--dtypes fp16,fp32] > profiles/rNN_tune_single.txt    # one request per launch
 
@@ -115,7 +116,7 @@ def sweep_single(args):
         res, resm = C.c_int(-1), (C.c_int * len(sets))()
         buf, msb = (C.c_float * nst)(), (C.c_float * (len(sets) * nst))()
         alg = n_el * (4 * torch.empty((), dtype=sd).element_size() + torch.empty((), dtype=ed).element_size())
-        for u in (1, 2):
+        for u in (1, 2, 4, 8):     # tiles per workgroup, all loads issued up front (4, 8: fewer, fatter wavefronts)
             for nt in (0, 1, 5):
                 L.lib.dpm_tuning_set(L.TUNE_UNROLL, u)
                 L.lib.dpm_tuning_set(L.TUNE_NONTEMPORAL, nt)
