@@ -33,7 +33,9 @@ SRC_STATE, SRC_TMP = 0, 1
 TUNE_UNROLL, TUNE_NONTEMPORAL, TUNE_BLOCKS_PER_CU, TUNE_ASSUME_RESIDENT = 0, 1, 2, 3
 TUNE_MULTI_FUSE, TUNE_MULTI_BLOCKS_PER_CU, TUNE_CLUSTER_IN_GRAPH, TUNE_CLUSTER_ONE_HOP = 4, 5, 6, 7
 TUNE_MULTI_XCD_REMAP = 8
+TUNE_THR_PREDICT = 9
 MULTI_MAX = 32
+THR_HINT_WORDS = 4
 
 
 class Stage(C.Structure):
@@ -63,7 +65,7 @@ class Buffers(C.Structure):
         ("state_dtype", C.c_int32), ("eps_dtype", C.c_int32),
         ("x_out2", C.c_void_p), ("eps_stride", C.c_int64), ("mask", C.c_void_p), ("blend_a", C.c_void_p),
         ("blend_b", C.c_void_p), ("mask_period", C.c_int64),
-        ("inputs_resident", C.c_int32), ("reserved", C.c_int32),
+        ("inputs_resident", C.c_int32), ("reserved", C.c_int32), ("thr_hint", C.c_void_p),
     ]
 
 
@@ -83,7 +85,7 @@ class RunBuffers(C.Structure):
         ("xbuf", C.c_void_p * 4), ("hist", C.c_void_p * 3), ("e0", C.c_void_p), ("e1", C.c_void_p),
         ("workspace", C.c_void_p), ("n", C.c_int64), ("batch", C.c_int64),
         ("state_dtype", C.c_int32), ("eps_dtype", C.c_int32),
-        ("eps_stride", C.c_int64), ("dup_state", C.c_int32), ("reserved", C.c_int32),
+        ("eps_stride", C.c_int64), ("dup_state", C.c_int32), ("reserved", C.c_int32), ("thr_hint", C.c_void_p),
     ]
 
 

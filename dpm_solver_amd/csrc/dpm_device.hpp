@@ -52,6 +52,7 @@ struct Tuning {
   int multi_xcd_remap = -1; // fused launch maps workgroup b to tile (b % 8) * span + b / 8 (one contiguous eighth of the
                             // tile space per XCD): 1 on, 0 off, -1 per dtype (on for 2-byte states: +1.4 %; fp32: -3 %)
   int multi_blocks_per_cu = 0;  // grid cap of the fused launch in workgroups per CU; 0 = one super-tile per workgroup
+  int thr_predict = 1;      // clustered thresholding: predict the select bound from the previous stages (thr_hint)
 };
 extern Tuning g_tuning;     // defined in dpm_kernels.hip
 // device-wide chain of clustered thresholding launches (see launch_typed): one instance per device for the library

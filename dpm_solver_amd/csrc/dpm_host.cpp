@@ -618,6 +618,7 @@ static int plan_run_impl(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model
     b.x_out = rb->xbuf[out];
     b.m_out = st.m_slot >= 0 ? rb->hist[st.m_slot] : nullptr;
     b.workspace = rb->workspace;
+    b.thr_hint = rb->thr_hint;
     b.n = rb->n;
     b.batch = rb->batch;
     b.state_dtype = rb->state_dtype;
@@ -695,6 +696,7 @@ extern "C" int dpm_plan_run_multi(const dpm_plan* p, const dpm_run_buffers* rbs,
       b.x_out = rb.xbuf[out];
       b.m_out = st.m_slot >= 0 ? rb.hist[st.m_slot] : nullptr;
       b.workspace = rb.workspace;
+      b.thr_hint = rb.thr_hint;
       b.n = rb.n;
       b.batch = rb.batch;
       b.state_dtype = rb.state_dtype;

@@ -957,6 +957,7 @@ extern "C" int dpm_tuning_set(int knob, int value) {
     case DPM_TUNE_CLUSTER_IN_GRAPH: g_tuning.cluster_in_graph = value != 0; return DPM_OK;
     case DPM_TUNE_MULTI_XCD_REMAP: g_tuning.multi_xcd_remap = value < 0 ? -1 : (value != 0); return DPM_OK;
     case DPM_TUNE_CLUSTER_ONE_HOP: g_tuning.cluster_one_hop = value < 0 ? 0 : (value > 2 ? 2 : value); return DPM_OK;
+    case DPM_TUNE_THR_PREDICT: g_tuning.thr_predict = value != 0; return DPM_OK;
     case DPM_TUNE_MULTI_BLOCKS_PER_CU:
       if (value < 0 || value > 4096) return dpm_set_error(DPM_ERR_ARG, "multi_blocks_per_cu must be in 0..4096");
       g_tuning.multi_blocks_per_cu = value;
@@ -976,6 +977,7 @@ extern "C" int dpm_tuning_get(int knob) {
     case DPM_TUNE_MULTI_XCD_REMAP: return g_tuning.multi_xcd_remap;
     case DPM_TUNE_CLUSTER_ONE_HOP: return g_tuning.cluster_one_hop;
     case DPM_TUNE_MULTI_BLOCKS_PER_CU: return g_tuning.multi_blocks_per_cu;
+    case DPM_TUNE_THR_PREDICT: return g_tuning.thr_predict;
   }
   return -1;
 }

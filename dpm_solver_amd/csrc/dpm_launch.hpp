@@ -84,7 +84,8 @@ inline ThrPlan thr_plan(int64_t batch, int64_t per_sample, int n_cu) {
   return ThrPlan{k, chunk};
 }
 // words per sample: the merged histograms / lists / counters of the general route + one slot per workgroup of the cluster
-inline int64_t thr_ws_stride(int64_t k) { return (int64_t)THR_WS_WORDS + k * (int64_t)THR_SLOTW; }
+// (two slot areas: the attempt with a predicted bound and the one with a searched bound each publish into their own)
+inline int64_t thr_ws_stride(int64_t k) { return (int64_t)THR_WS_WORDS + 2 * k * (int64_t)THR_SLOTW; }
 inline int64_t thr_ws_bytes(int64_t batch, int64_t per_sample, int n_cu) {
   const ThrPlan pl = thr_plan(batch, per_sample, n_cu);
   return pl.k > 1 ? batch * thr_ws_stride(pl.k) * 4 : 0;
@@ -351,6 +352,16 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
                              "workspace must be zero-filled again");
       }
       tp.fault = fault;
+      // the select bound predicted from the previous stages (dpm_buffers.thr_hint): single requests on the one-exchange route
+      // -- where it pays: a small K (the wanted rank from the top), so that the predicted union (~1.3-1.9 K entries instead
+      // of k * quota) is finished by rank counting.  Measured (tools/thr_routes.py): [32,3,64,64] (K = 63) 11.3 -> 10.7 us per
+      // stage, union 236 -> 116 entries, every stage from the third on predicted; [64,3,256,256] (K = 983) 53 -> 59 us -- a
+      // 10-step trajectory changes the statistic by 2.5x per stage, the extrapolation lands low and the union GROWS.
+      if (!multi && tp.quota > 0 && b->thr_hint && tp.kbig <= 128) {
+        tp.hint = b->thr_hint;
+        tp.hint_reset = st->index <= 0;
+        tp.hint_predict = g_tuning.thr_predict;
+      }
       // Two clustered launches on different streams could each hold part of the CUs with spinning workgroups and
       // starve the other's missing peers.  Within this process they are therefore chained device-wide: wait for the
       // previous clustered launch (whatever its stream), record after this one.  (Not under stream capture, where an

@@ -57,6 +57,10 @@ constexpr int THR_SLOTW = THR_SLOT_CAP + THR_SLOT_HDR;
 constexpr uint32_t THR_TAG = 0x80000000u;    // |x0| bit patterns have bit 31 clear: a tagged word is never 0
 constexpr uint32_t THR_OVERFLOW = 0x40000000u;
 constexpr int THR_WS_DONE = THR_WS_CNT + 12; // workgroups of the cluster that are through with the workspace
+constexpr int THR_HINT_W = DPM_THR_HINT_WORDS;
+// the predicted bound sits this far below the extrapolated order statistic: with the statistic within a few percent of
+// its extrapolation the union stays ~1.3 K entries (K = the wanted rank from the top) and holds the K-th largest
+constexpr float THR_HINT_MARGIN = 0.94f;
 constexpr uint32_t THR_SPIN_LIMIT = 1u << 22; // polls (about a microsecond each) before a wait gives up: seconds
 
 struct ThrParams {
@@ -82,6 +86,10 @@ struct ThrParams {
   int64_t ws_stride; // words per sample in ws
   uint32_t* ws;    // k > 1: batch x ws_stride words, all zero between launches (the kernel cleans up after itself)
   uint32_t* fault; // host-mapped word: set when a cluster wait timed out (the launch's results are then garbage)
+  float* hint;     // dpm_buffers.thr_hint (THR_HINT_W floats per sample) or null: the selected order statistic of the
+                   // previous two stages -> predicted select bound of this one (cluster_select_once, `pbound`)
+  int32_t hint_reset; // this is the first stage of a trajectory: the stored values are stale, overwrite without reading
+  int32_t hint_predict; // 0: maintain the hint but do not use it (DPM_TUNE_THR_PREDICT)
 #ifdef DPM_THR_TIMING
   uint64_t* tdbg;  // 16 timestamps per workgroup (tools/thr_timeline.py)
 #endif
@@ -491,7 +499,13 @@ template <int T>
 __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, bool vec, uint32_t m1, uint32_t m2,
                                                     uint32_t m3, uint32_t m4, bool has, uint32_t* hist, uint32_t* misc,
                                                     uint32_t* cand, uint32_t* slots, const ThrParams& tp, uint32_t k, int c,
-                                                    int tid, uint32_t& a_out, uint32_t& b_out, bool stamp) {
+                                                    int tid, uint32_t& a_out, uint32_t& b_out, bool stamp,
+                                                    const uint32_t pbound = 0u) {
+  // pbound != 0 (bit pattern of a positive float): the bound is PREDICTED from the previous stages' thresholds (same value
+  // in every workgroup of the cluster) instead of searched in the histogram of the per-thread maxima: no histogram, no
+  // locate_bin, and a union of ~1.3 K entries instead of k * quota.  Every element >= pbound of every chunk is published,
+  // so the answer is exact whenever the union holds at least K entries; fewer (the prediction was too high), a slot
+  // overflow or a union beyond the list capacity (too low) fail the attempt exactly like the searched bound does.
 #ifdef DPM_THR_TIMING
 #define DPM_R1STAMP(j) \
   if (tid == 0 && stamp) tp.tdbg[(int64_t)blockIdx.x * 16 + (j)] = wall_clock64();
@@ -511,21 +525,29 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
     const uint32_t d = u >> THR_FSHIFT;
     return d > dbase ? d - dbase : 0u;
   };
-  // 2. histogram of one value per thread, bound = digit of the quota-th largest maximum
-  if (has) atomicAdd(&hist[digit(m1)], 1u);
-  __syncthreads();
-  const int P = vec ? (n + 3) / 4 : n;  // threads that produced at least one element
-  const uint32_t Pl = (uint32_t)(P < T ? P : T);
-  locate_bin<T>(hist, misc, Pl > (uint32_t)tp.quota ? Pl - (uint32_t)tp.quota : 0u, tid);
-  const uint32_t bin_lo = Pl ? misc[0] : 0u;
+  // 2. histogram of one value per thread, bound = digit of the quota-th largest maximum (or the predicted bound)
+  uint32_t bin_lo = 0u;
+  if (!pbound) {
+    if (has) atomicAdd(&hist[digit(m1)], 1u);
+    __syncthreads();
+    const int P = vec ? (n + 3) / 4 : n;  // threads that produced at least one element
+    const uint32_t Pl = (uint32_t)(P < T ? P : T);
+    locate_bin<T>(hist, misc, Pl > (uint32_t)tp.quota ? Pl - (uint32_t)tp.quota : 0u, tid);
+    bin_lo = Pl ? misc[0] : 0u;
+  }
+  // does |x0| pattern u belong to this chunk's candidates?
+  auto qual = [&](uint32_t u) { return pbound ? u >= pbound : digit(u) >= bin_lo; };
   DPM_R1STAMP(8)
   // 3. this chunk's candidates: a thread's are among its four largest values unless even the fourth qualifies
   {
     const int mine = vec ? (has ? 4 * ((n - tid * 4 + T * 4 - 1) / (T * 4)) : 0) : (has ? (n - tid + T - 1) / T : 0);
-    const bool c1 = mine > 0 && digit(m1) >= bin_lo, c2 = mine > 1 && digit(m2) >= bin_lo;
-    const bool c3 = mine > 2 && digit(m3) >= bin_lo, c4 = mine > 3 && digit(m4) >= bin_lo;
+    const bool c1 = mine > 0 && qual(m1), c2 = mine > 1 && qual(m2);
+    const bool c3 = mine > 2 && qual(m3), c4 = mine > 3 && qual(m4);
     if (__ballot(c4 && mine > 4)) {
-      (void)compact_candidates<T, true>(sx0, n, bin_lo, misc, cand, tid, THR_FSHIFT, dbase);
+      if (pbound)  // digit = the whole pattern: d >= bin is u >= pbound
+        (void)compact_candidates<T, true>(sx0, n, pbound, misc, cand, tid, 0, 0u);
+      else
+        (void)compact_candidates<T, true>(sx0, n, bin_lo, misc, cand, tid, THR_FSHIFT, dbase);
     } else {
       const uint32_t cnt = (c1 ? 1u : 0u) + (c2 ? 1u : 0u) + (c3 ? 1u : 0u) + (c4 ? 1u : 0u);
       const uint32_t incl = wave_incl_scan(cnt);
@@ -556,7 +578,8 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
                          __HIP_MEMORY_SCOPE_AGENT);
   }
   if (tid == 0) {
-    const uint32_t bound = bin_lo ? (bin_lo + dbase) << THR_FSHIFT : 0u;  // smallest |x0| with that digit; digit 0 = everything
+    // smallest |x0| this workgroup would have published: the predicted bound, or the first pattern of the digit (0 = everything)
+    const uint32_t bound = pbound ? pbound : (bin_lo ? (bin_lo + dbase) << THR_FSHIFT : 0u);
     __hip_atomic_store(&mine_slot[2], cmax | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&mine_slot[1], bound | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&mine_slot[0], (over ? THR_OVERFLOW : ncl) | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -676,7 +699,7 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
   if (valid) {
     uint32_t a, b;
     const uint32_t rank = total - K;  // ascending
-    if (total <= 64u) {
+    if (total <= 192u) {  // rank counting is quadratic but three wavefronts' worth of it beats a histogram level
       rank_select<T>(cand, total, rank, misc, tid);
       a = misc[6];
       b = rank + 1u < total ? misc[7] : a;
@@ -692,12 +715,17 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
     // an unpublished element of some chunk could be among the K largest when the K-th of the union is below a bound
     valid = a >= bound_max && !tp.debug_reject;
   }
-  if (!valid) {  // the general route expects its LDS state: hist all zero, no candidates
+  if (!valid) {  // the next attempt / the general route expect their LDS state: hist all zero, no candidates
     if (leftovers) {
       hist[tid] = 0u;
       hist[tid + T] = 0u;
     }
-    if (tid == 0) misc[4] = 0u;
+    if (tid == 0) {
+      misc[4] = 0u;
+      misc[9] = 0u;   // k > 64 accumulates these with atomics
+      misc[10] = 0u;
+      misc[12] = 0u;
+    }
     __syncthreads();
   }
   return valid;
@@ -795,6 +823,17 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
 #pragma unroll
     for (int j = 0; j < BPT; ++j) hist[j * T + tid] = 0u;
     if (tid == 0) {
+      // predicted select bound of this sample (clusters with the single-exchange route only): the geometric extrapolation
+      // of the selected order statistic of the previous two thresholded stages, lowered by THR_HINT_MARGIN
+      uint32_t pb = 0u;
+      if (route1 && tp.hint && !tp.hint_reset && tp.hint_predict) {
+        const float h1v = tp.hint[(int64_t)s_idx * THR_HINT_W], h2v = tp.hint[(int64_t)s_idx * THR_HINT_W + 1];
+        if (h1v > 1e-30f && h2v > 1e-30f && h1v < 1e30f && h2v < 1e30f) {
+          const float r = h1v / h2v;
+          if (r > 0.25f && r < 4.f) pb = __float_as_uint((h1v * r) * THR_HINT_MARGIN);
+        }
+      }
+      misc[25] = pb;
       misc[4] = 0u;   // candidate counter
       misc[3] = ABS;  // smallest value above the selected top digit (cluster exchange)
       misc[8] = 0u;   // cluster_select_once: chunk maximum, largest bound, bad-slot flag, maximum of the sample
@@ -901,8 +940,19 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     // clusters first try to settle the sample with ONE exchange (cluster_select_once); the general route below is the
     // fallback for samples whose large values sit in one chunk, and the only route when the quantile is not near 1
     uint32_t a1 = 0u, b1 = 0u;
-    const bool solved = route1 && cluster_select_once<T>(sx0, n, vec, m1, m2, m3, m4, has, hist, misc, cand,
-                                                         ws + THR_WS_WORDS, tp, k, c, tid, a1, b1, s_idx == grp);
+    bool solved = false;
+    uint32_t route = 4u;  // diagnostics (hint word 2): 1 predicted bound, 2 prediction rejected, then 3 single exchange / 4 general
+    const uint32_t pbound = route1 ? misc[25] : 0u;  // cluster-uniform: every workgroup read the same hint words
+    if (pbound) {  // the predicted attempt has a slot area of its own (a rejected one leaves its slots dirty)
+      solved = cluster_select_once<T>(sx0, n, vec, m1, m2, m3, m4, has, hist, misc, cand,
+                                      ws + THR_WS_WORDS + (size_t)k * THR_SLOTW, tp, k, c, tid, a1, b1, s_idx == grp, pbound);
+      route = solved ? 1u : 2u;
+    }
+    if (route1 && !solved) {
+      solved = cluster_select_once<T>(sx0, n, vec, m1, m2, m3, m4, has, hist, misc, cand, ws + THR_WS_WORDS, tp, k, c, tid,
+                                      a1, b1, s_idx == grp && !pbound);
+      if (solved && route != 2u) route = 3u;
+    }
     const bool general = !solved;                // the general route runs (for clusters: it dirties the merged histograms)
 
     if (general && topk) {
@@ -1146,6 +1196,14 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
       }
     }
     DPM_TSTAMP(2)
+    if (tp.hint && c == 0 && tid == 0) {  // this stage's statistic for the next stage's prediction
+      float* hw = tp.hint + (int64_t)s_idx * THR_HINT_W;
+      const float prev = tp.hint_reset ? 0.f : hw[0];
+      hw[1] = prev;
+      hw[0] = a;
+      hw[2] = (float)(solved ? route : (route == 2u ? 2u : 4u));
+      hw[3] = (float)misc[24];  // diagnostics: entries of the last union this workgroup gathered
+    }
     // This workgroup is through with the sample's workspace.  The last of the cluster to say so puts every word it and
     // its peers dirtied back to zero (end of the sample loop): the workspace is all zero between launches, so no launch
     // has to clear it first.  The returning atomic is in flight during phase 3.
@@ -1232,8 +1290,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
       if (tid == 0) misc[11] = done_old == k - 1u ? 1u : 0u;
       __syncthreads();
       if (misc[11]) {
-        uint32_t* slots = ws + THR_WS_WORDS;
-        for (uint32_t i = tid; i < k * (uint32_t)THR_SLOTW; i += T) slots[i] = 0u;
+        uint32_t* slots = ws + THR_WS_WORDS;  // both slot areas when the predicted attempt ran (cluster-uniform)
+        for (uint32_t i = tid; i < (pbound ? 2u : 1u) * k * (uint32_t)THR_SLOTW; i += T) slots[i] = 0u;
         if (general || !route1) {
           for (uint32_t i = tid; i < (uint32_t)THR_WS_WORDS; i += T) ws[i] = 0u;
         } else if (tid == 0) {

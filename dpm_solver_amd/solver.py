@@ -421,6 +421,7 @@ class _FastRun:
         self.xbuf = [None] + [t[:B] for t in self.xfull[1:]]
         self.hist = [torch.empty(shape, dtype=sd, device=device) for _ in range(plan.slots)]
         self.ws = None
+        self.thr_hint = None
         nstg = len(plan.stages)
         self.stages, self.bufs, self.refs = [], [], []
         esz = torch.empty((), dtype=sd).element_size()
@@ -451,7 +452,11 @@ class _FastRun:
                     if self.ws is None:      # zero-filled once; every launch leaves it zero-filled
                         self.ws = torch.zeros(nb, dtype=torch.uint8, device=device)
                         _WS_LIVE.add(self.ws)
+                        # per-sample state the clustered kernel carries from stage to stage (dpm_buffers.thr_hint): the
+                        # previous thresholds, from which it predicts the next select bound; stage 0 resets it
+                        self.thr_hint = torch.zeros(L.THR_HINT_WORDS * max(B, 1), dtype=torch.float32, device=device)
                     b.workspace = self.ws.data_ptr()
+                    b.thr_hint = self.thr_hint.data_ptr()
             self.stages.append(st)
             self.bufs.append(b)
             self.refs.append((C.byref(st), C.byref(b)))

@@ -141,6 +141,14 @@ typedef struct dpm_buffers {
                           wrote them (frozen-model loops; dpm_plan_run sets it when there is no model callback) ->
                           default cache policy, they are expected in the 256 MiB Infinity Cache                  */
   int32_t reserved;
+  float* thr_hint;     /* DPM_F_THRESH, optional (NULL = off): DPM_THR_HINT_WORDS floats per sample that persist from stage
+                          to stage of ONE trajectory -- the kernel's private state (content undefined to the caller; no
+                          initialisation needed: the stage with index 0 resets it).  [0], [1]: the selected order statistic
+                          of |x0| in the previous two thresholded stages, from which a clustered launch predicts this
+                          stage's select bound (a correct prediction saves the bound search and shrinks the exchange; a
+                          wrong one is detected and costs one extra exchange, never exactness); [2]: route taken
+                          (diagnostics: 1 predicted, 2 prediction rejected, 3 single exchange, 4 general); [3]: entries of
+                          the last union gathered (diagnostics)                                                      */
 } dpm_buffers;
 
 /* ---- noise schedule (NoiseScheduleVP, ref :6-167) --------------------------------------- */
@@ -239,6 +247,7 @@ int dpm_stage_launch_multi(const dpm_stage* st, const dpm_buffers* bs, int n_req
    every launch leaves it zero-filled again (the last workgroup of a cluster cleans up), so no launch pays for a clear.
    Launches that share a workspace must be ordered (same stream).  After DPM_ERR_FAULT zero-fill it again. */
 size_t dpm_threshold_workspace_bytes(int64_t batch, int64_t per_sample);
+#define DPM_THR_HINT_WORDS 4   /* floats per sample of dpm_buffers.thr_hint / dpm_run_buffers.thr_hint */
 /* x_t = alpha_t*x + sigma_t*noise for nt times (add_noise, ref :1012-1030); out is [nt, n] */
 int dpm_add_noise_launch(const dpm_schedule* s, const float* t_host, int nt, const void* x, const void* noise,
                          void* out, int64_t n, int dtype, void* stream);
@@ -320,6 +329,7 @@ typedef struct dpm_run_buffers {
                           callback of a classifier-free-guidance network receives its [2B,...] input ready-made
                           (xbuf[0] must already hold x_T twice)                                                  */
   int32_t reserved;
+  float* thr_hint;     /* as dpm_buffers.thr_hint (DPM_THR_HINT_WORDS floats per sample, or NULL)                */
 } dpm_run_buffers;
 int dpm_plan_run(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model_cb model, void* user, void* stream,
                  int* result);
@@ -375,8 +385,10 @@ enum {
   DPM_TUNE_CLUSTER_IN_GRAPH = 6,    /* 1: thresholding keeps workgroup clusters under stream capture for samples that
                                        fit one workgroup too (default 0: one workgroup per sample there)           */
   DPM_TUNE_CLUSTER_ONE_HOP = 7,     /* 0: clusters skip the single-exchange select (testing the general route)     */
-  DPM_TUNE_MULTI_XCD_REMAP = 8      /* fused launch gives every XCD one contiguous eighth of the tiles: 1 on, 0 off,
+  DPM_TUNE_MULTI_XCD_REMAP = 8,     /* fused launch gives every XCD one contiguous eighth of the tiles: 1 on, 0 off,
                                        -1 (default) on for 2-byte states only (measured +1.4 % fp16, -3 % fp32)    */
+  DPM_TUNE_THR_PREDICT = 9          /* 1 (default): clustered thresholding launches predict the select bound from
+                                       dpm_buffers.thr_hint; 0: the hint is still maintained but never used          */
 };
 int dpm_tuning_set(int knob, int value);
 int dpm_tuning_get(int knob);

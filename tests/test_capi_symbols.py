@@ -30,9 +30,9 @@ def test_struct_layouts_match_header():
     for i, t in enumerate((L.Stage, L.Buffers, L.PlanDesc, L.RunBuffers, L.AdaptiveDesc)):
         assert L.lib.dpm_sizeof(i) == ctypes.sizeof(t), t.__name__
     assert ctypes.sizeof(L.Stage) == 12 * 4 + 20 * 4                       # 12 int32 + 20 float
-    assert ctypes.sizeof(L.Buffers) == 14 * 8 + 4 * 8 + 4 * 4              # 14 pointers, 4 int64, 4 int32
+    assert ctypes.sizeof(L.Buffers) == 15 * 8 + 4 * 8 + 4 * 4              # 15 pointers, 4 int64, 4 int32
     assert ctypes.sizeof(L.PlanDesc) == 12 * 4 + 5 * 8
-    assert ctypes.sizeof(L.RunBuffers) == 10 * 8 + 2 * 8 + 2 * 4 + 8 + 2 * 4
+    assert ctypes.sizeof(L.RunBuffers) == 10 * 8 + 2 * 8 + 2 * 4 + 8 + 2 * 4 + 8      # + thr_hint
     assert ctypes.sizeof(L.AdaptiveDesc) == 6 * 4 + 8 * 8
 
 

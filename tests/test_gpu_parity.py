@@ -225,7 +225,8 @@ def test_thresholded_sampling_random_sweep():
         p, mv = float(rng.choice([0.5, 0.9, 0.95, 0.99, 0.995, 0.999, 1.0])), float(rng.choice([0.5, 1.0, 2.0]))
         sname = str(rng.choice(["ddpm", "sd"]))
         order = int(rng.integers(1, 4))
-        steps = int(rng.integers(order, 8))
+        # (DPM_THR_SWEEP_STEPS raises the trajectory length: more stages that select with a predicted bound)
+        steps = int(rng.integers(order, int(os.environ.get("DPM_THR_SWEEP_STEPS", "8"))))
         x = (rng.standard_normal((B, Cc, H, W)) * float(rng.choice([0.3, 1.0, 2.0]))).astype(F32)
         scale = F32(rng.choice([0.5, 0.9, 1.3]))
         ns, osch = make_schedule(sname), TO.make_schedule(sname)
@@ -620,3 +621,83 @@ def test_half_precision_stores_round_to_nearest_even(sdt):
         out, _ = S._launch_stage(st, x, None, torch.zeros_like(x), None, None, None, None, sdt, want_m=False)
         want = (x.float() * np.float32(cx)).to(sdt)
         assert torch.equal(out.view(torch.int16), want.view(torch.int16)), cx
+
+
+# ------------------------------------------------------------------------------------------------
+# clustered thresholding: the select bound predicted from the previous stages (dpm_buffers.thr_hint)
+# ------------------------------------------------------------------------------------------------
+def _routes_per_stage(dpm, x, monkeypatch, **kw):
+    """sample() with the route word of the hint buffer (1 predicted, 2 prediction rejected, 3 single exchange, 4 general)
+    read back after every stage launch"""
+    routes = []
+    real = S._stage_launch_raw
+
+    def spy(st, b, stream):
+        rc = real(st, b, stream)
+        torch.cuda.synchronize()
+        fr = [v for v in dpm._fast.values() if getattr(v, "thr_hint", None) is not None]
+        if fr:
+            routes.append(fr[-1].thr_hint.view(-1, L.THR_HINT_WORDS)[:, 2].cpu().numpy().copy())
+        return rc
+    with monkeypatch.context() as m:
+        m.setattr(S, "_stage_launch_raw", spy)
+        out = dpm.sample(x, **kw)
+    torch.cuda.synchronize()
+    return out, routes
+
+
+@pytest.mark.parametrize("shape", [(4, 3, 64, 64), (32, 3, 64, 64), (3, 3, 80, 80)])
+def test_threshold_bound_prediction_is_taken_and_exact(shape, monkeypatch):
+    """A smooth trajectory: from the third thresholded stage on the clusters select with the PREDICTED bound (route 1);
+    the results equal the run with the prediction switched off, bit for bit, and the reference-style quantile."""
+    ns = make_schedule("ddpm")
+    rng = np.random.default_rng(31)
+    x = torch.from_numpy(rng.standard_normal(shape).astype(F32)).to(DEV)
+    mk = lambda: D.DPM_Solver(D.model_wrapper(lambda xx, t: xx * 0.5, ns), ns, correcting_x0_fn="dynamic_thresholding")
+    assert L.lib.dpm_threshold_workspace_bytes(shape[0], int(np.prod(shape[1:]))) > 0        # a clustered shape
+    got, routes = _routes_per_stage(mk(), x, monkeypatch, steps=12, order=2)
+    assert len(routes) == 12
+    assert np.all(routes[0] >= 3) and np.all(routes[1] >= 3)                  # no history yet
+    taken = np.mean([np.mean(r == 1) for r in routes[2:]])
+    assert taken >= 0.8, (taken, [r.tolist() for r in routes])
+    L.lib.dpm_tuning_set(L.TUNE_THR_PREDICT, 0)
+    try:
+        want, routes0 = _routes_per_stage(mk(), x, monkeypatch, steps=12, order=2)
+    finally:
+        L.lib.dpm_tuning_set(L.TUNE_THR_PREDICT, 1)
+    assert all(np.all(r >= 3) for r in routes0)
+    assert torch.equal(got, want)
+    if shape[0] * int(np.prod(shape[1:])) <= 1 << 18:      # and the numpy double of the kernel (torch.quantile semantics)
+        ncpu = make_schedule("ddpm")
+        dbl = _double_on_cpu(monkeypatch, lambda: D.DPM_Solver(D.model_wrapper(lambda xx, t: xx * 0.5, ncpu), ncpu,
+                                                               correcting_x0_fn="dynamic_thresholding").sample(x.cpu(), steps=12, order=2))
+        assert torch.equal(got.cpu(), dbl)
+    again = mk()
+    assert torch.equal(again.sample(x, steps=12, order=2), want) and torch.equal(again.sample(x, steps=12, order=2), want)
+
+
+def test_threshold_bound_misprediction_is_detected():
+    """A network whose output scale jumps from stage to stage: predictions that are too high (union smaller than K) or
+    too low (slot overflow / oversized union) are rejected by every workgroup alike and the searched bound takes over --
+    identical results with the prediction on and off, per-sample scales included."""
+    shape = (6, 3, 64, 64)
+    ns = make_schedule("ddpm")
+    rng = np.random.default_rng(32)
+    x = torch.from_numpy(rng.standard_normal(shape).astype(F32)).to(DEV)
+    scales = [1.0, 0.9, 0.8, 3.0, 0.2, 0.21, 0.22, 5.0, 5.1, 0.01, 0.5, 0.5, 0.55, 40.0, 0.5]
+    per_sample = torch.tensor([1.0, 0.3, 2.0, 1.0, 7.0, 0.05], device=DEV).reshape(-1, 1, 1, 1)
+
+    def run():
+        calls = [0]
+
+        def net(xx, t):
+            calls[0] += 1
+            return xx * (scales[(calls[0] - 1) % len(scales)] * (per_sample if calls[0] % 3 == 0 else 1.0))
+        return D.DPM_Solver(D.model_wrapper(net, ns), ns, correcting_x0_fn="dynamic_thresholding").sample(x, steps=15, order=2)
+    got = run()
+    L.lib.dpm_tuning_set(L.TUNE_THR_PREDICT, 0)
+    try:
+        want = run()
+    finally:
+        L.lib.dpm_tuning_set(L.TUNE_THR_PREDICT, 1)
+    assert torch.isfinite(got).all() and torch.equal(got, want)
