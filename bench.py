@@ -470,10 +470,11 @@ def main():
         wall = time.perf_counter() - t0
         region_us = ev0.elapsed_time(ev1) * 1e3         # GPU time of the K steps = K * P * 20 fused launches
         h1_us, h2_us = ev0.elapsed_time(evm) * 1e3, evm.elapsed_time(ev1) * 1e3
+        wall_min = wall
         if dist is not None:
-            tw = torch.tensor([wall], dtype=torch.float64, device=dev)
-            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-            wall = float(tw.item())
+            tw = torch.tensor([wall, -wall], dtype=torch.float64, device=dev)
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)                 # max over ranks (and, negated, the min)
+            wall, wall_min = float(tw[0].item()), -float(tw[1].item())
         if wall >= MIN_REGION_S:
             break
         steps = int(steps * max(2.0, 1.3 * MIN_REGION_S / max(wall, 1e-6))) + 1   # too short to report: time more steps
@@ -711,6 +712,7 @@ def main():
             "python_api_requests_ms_per_trajectory": None if py_req_ms is None else round(py_req_ms, 4),
             "roofline": roofline,
             "gather_ms": None if gather_ms is None else round(gather_ms, 4),
+            "per_rank_wall_s": {"min": round(wall_min, 4), "max": round(wall, 4)},   # value uses the max
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ac)

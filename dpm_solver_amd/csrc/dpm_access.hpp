@@ -165,20 +165,36 @@ __device__ __forceinline__ void load_tile(const T* __restrict__ p, int64_t gi, b
       return;
     }
   } else {
-    if (split) {  // 2-byte network output next to a 4-byte state: the same elements as two 8-byte accesses
-      typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-      const u32x2_t* q = reinterpret_cast<const u32x2_t*>(p) + (2 * gi - (int64_t)threadIdx.x);
-      const u32x2_t a = NT ? __builtin_nontemporal_load(q) : *q;
-      const u32x2_t b = NT ? __builtin_nontemporal_load(q + 256) : *(q + 256);
-      const uint32_t w[4] = {a[0], a[1], b[0], b[1]};
+    if (split) {
+      // 2-byte network output next to a 4-byte state.  The state's split layout gives lane t of the tile the elements
+      // [4t, 4t+4) and [1024+4t, +4): as two 8-byte accesses per lane (round 2) the network-output streams ran at the
+      // 8-byte rate of the load path (MI355X_MICROARCH.md: 0.54-0.70x the 16-byte rate).  Now ONE 16-byte access per lane:
+      // wavefront w needs two 512-byte runs of the tile, elements [256w, +256) and [1024+256w, +256); its lanes 0..31
+      // fetch the first run and lanes 32..63 the second, 8 consecutive elements each, and four ds_permute_b32 (the LDS
+      // crossbar, no LDS memory) hand every lane its two 4-element groups: source lane s < 32 owns what the even lane 2s
+      // (dwords 0, 1) and the odd lane 2s+1 (dwords 2, 3) need of the first run, lane 32+s the same of the second run; every
+      // permute moves one dword to each of the 64 lanes (first-run dwords to the even lanes while second-run dwords go to
+      // the odd ones, then the other way round).  Requires all 64 lanes active: load_tile runs in straight-line code.
+      const int l = (int)(threadIdx.x & 63u), w = (int)(threadIdx.x >> 6);
+      const bool lo = l < 32;
+      const u32x4* q = reinterpret_cast<const u32x4*>(p) + ((gi - (int64_t)threadIdx.x) + 32 * w + (lo ? l : l + 96));
+      const u32x4 v = ld16<NT>(q);
+      const int s2 = (lo ? l : l - 32) * 2;
+      const int to_a = (lo ? s2 : s2 + 1) * 4, to_b = (lo ? s2 + 1 : s2) * 4;  // byte address = destination lane * 4
+      const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_permute(to_a, (int)(lo ? v[0] : v[2]));
+      const uint32_t r2 = (uint32_t)__builtin_amdgcn_ds_permute(to_a, (int)(lo ? v[1] : v[3]));
+      const uint32_t r3 = (uint32_t)__builtin_amdgcn_ds_permute(to_b, (int)(lo ? v[2] : v[0]));
+      const uint32_t r4 = (uint32_t)__builtin_amdgcn_ds_permute(to_b, (int)(lo ? v[3] : v[1]));
+      const bool even = (l & 1) == 0;
+      const uint32_t w4[4] = {even ? r1 : r3, even ? r2 : r4, even ? r3 : r1, even ? r4 : r2};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if constexpr (std::is_same<T, __half>::value) {
-          out[2 * j] = __half2float(__ushort_as_half((unsigned short)(w[j] & 0xffffu)));
-          out[2 * j + 1] = __half2float(__ushort_as_half((unsigned short)(w[j] >> 16)));
+          out[2 * j] = __half2float(__ushort_as_half((unsigned short)(w4[j] & 0xffffu)));
+          out[2 * j + 1] = __half2float(__ushort_as_half((unsigned short)(w4[j] >> 16)));
         } else {
-          out[2 * j] = __uint_as_float(w[j] << 16);
-          out[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+          out[2 * j] = __uint_as_float(w4[j] << 16);
+          out[2 * j + 1] = __uint_as_float(w4[j] & 0xffff0000u);
         }
       }
       return;
