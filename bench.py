@@ -366,6 +366,8 @@ def main():
     ap.add_argument("--trajectories-per-step", type=int, default=30,
                     help="a step = this many 20-stage trajectories of the requests in flight (30 x 32 x 256 samples, ~0.125 s): "
                          "the driver's --steps 20 is then a sustained 2.5 s region")
+    ap.add_argument("--min-region-s", type=float, default=MIN_REGION_S,
+                    help="shortest timed region that is reported (profiling runs under rocprofv3 pass a small value)")
     ap.add_argument("--loop-net", default="conv", choices=["gemm", "conv", "none"],
                     help="network of the in_network_loop secondary measurement (conv: MIOpen 3x3 conv stack, falls back to "
                          "gemm: hipBLASLt per-pixel MLP)")
@@ -475,9 +477,9 @@ def main():
             tw = torch.tensor([wall, -wall], dtype=torch.float64, device=dev)
             dist.all_reduce(tw, op=dist.ReduceOp.MAX)                 # max over ranks (and, negated, the min)
             wall, wall_min = float(tw[0].item()), -float(tw[1].item())
-        if wall >= MIN_REGION_S:
+        if wall >= args.min_region_s:
             break
-        steps = int(steps * max(2.0, 1.3 * MIN_REGION_S / max(wall, 1e-6))) + 1   # too short to report: time more steps
+        steps = int(steps * max(2.0, 1.3 * args.min_region_s / max(wall, 1e-6))) + 1   # too short to report: time more steps
 
     # ---- roofline of the timed region ---------------------------------------------------------------------------
     n_el = B * int(np.prod(SHAPE))

@@ -1,16 +1,29 @@
 #!/bin/bash
-# One GPU call with everything a round's profiles/ need: tests, bench lines (fp16 / fp32 / bf16), rocprofv3 kernel trace and
-# memory-side counters of the headline command, the stage table.   usage (through gpurun): bash tools/gpu_round.sh r02
-TAG=${1:-r02}
+# One GPU call with everything a round's profiles/ need: tests (+ the long thresholding sweep), bench lines (fp16 / fp32 /
+# bf16 / fp32+fp16), rocprofv3 kernel trace (+ kernel_stats.csv) and memory-side counters of the headline command, the stage
+# kernel inside the torch network loop (events + rocprofv3 rows), the stage table.   usage (through gpurun): bash tools/gpu_round.sh r03
+TAG=${1:-r03}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/$TAG; mkdir -p $O
-timeout 900 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" $O/pytest.log | tail -2
+timeout 1200 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" $O/pytest.log | tail -2
+( time DPM_THR_SWEEP=20000 DPM_THR_SWEEP_STEPS=20 timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "random_sweep" ) > $O/pytest_thr_sweep_20000.log 2>&1; echo "thresholding sweep (20000 configurations, up to 19 steps) rc=$?"; grep -E "passed|failed|real" $O/pytest_thr_sweep_20000.log | tail -3
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
 # the launch line the driver uses for N > 1, with one rank (RCCL communicator, barrier, MAX all-reduce, final all-gather)
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $O/bench_torchrun_1rank.json 2> $O/bench_torchrun_1rank.err; echo "torchrun 1 rank rc=$?"
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > $O/bench_torchrun_1rank.json 2> $O/bench_torchrun_1rank.err; echo "torchrun 1 rank rc=$?"
 timeout 900 bash tools/profile_round.sh $TAG fp16 > $O/profile_fp16.log 2>&1; echo "profile rc=$?"; tail -32 $O/profile_fp16.log
 timeout 600 python bench.py --dtype fp32 --no-cpu-baseline > $O/bench_fp32.json 2> $O/bench_fp32.err; echo "bench fp32 rc=$?"
 timeout 600 python bench.py --dtype bf16 --no-cpu-baseline > $O/bench_bf16.json 2> $O/bench_bf16.err; echo "bench bf16 rc=$?"
 timeout 600 python bench.py --dtype fp32 --eps-dtype fp16 --no-cpu-baseline > $O/bench_fp32_fp16.json 2> $O/bench_fp32_fp16.err; echo "bench fp32/fp16 rc=$?"
+# the stage kernel inside the torch network loop: events for both networks, rocprofv3 rows (fp16 and fp32 state)
+timeout 600 python tools/in_loop.py --kinds gemm,conv --out $O/in_loop.json > $O/in_loop.log 2>&1; echo "in_loop rc=$?"
+for DT in fp16 fp32; do
+  timeout 420 rocprofv3 --kernel-trace --stats --output-format rocpd csv -d $O/kt_loop_$DT -o kt -- python tools/in_loop.py --dtype $DT --trace-only > $O/kt_loop_$DT.log 2>&1; echo "rocprof in-loop $DT rc=$?"
+  python tools/in_loop.py --summarise $O/kt_loop_$DT --md $O/in_loop_trace_$DT.md > /dev/null 2>&1
+  find $O/kt_loop_$DT -name "*kernel_stats.csv" -exec cp {} $O/in_loop_kernel_stats_$DT.csv \;
+  rm -rf $O/kt_loop_$DT
+  sed -n 5,9p $O/in_loop_trace_$DT.md
+done
 timeout 900 python tools/stage_bench.py --md $O/stage_table.md > $O/stage_bench.log 2>&1; echo "stage_bench rc=$?"; tail -8 $O/stage_bench.log
+timeout 300 python tools/thr_routes.py > $O/thr_routes.txt 2>&1; echo "thr_routes rc=$?"
+du -sh $O

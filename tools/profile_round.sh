@@ -11,8 +11,10 @@ export TMPDIR=/tmp
 P=$ROOT/gpurun_out/prof_${TAG}_$DT
 rm -rf "$P"; mkdir -p "$P"
 python bench.py --dtype $DT > "$P/bench.json" 2> "$P/bench.err"
-CMD="python bench.py --dtype $DT --steps 12 --warmup 2 --no-cpu-baseline --no-secondary"
-rocprofv3 --kernel-trace --stats -d "$P/kt" -o kt -- $CMD > "$P/bench_kt.json" 2> "$P/bench_kt.err"
+CMD="python bench.py --dtype $DT --steps 12 --warmup 2 --trajectories-per-step 2 --min-region-s 0.05 --no-cpu-baseline --no-secondary"
+rocprofv3 --kernel-trace --stats --output-format rocpd csv -d "$P/kt" -o kt -- $CMD > "$P/bench_kt.json" 2> "$P/bench_kt.err"
+find "$P/kt" -name "*kernel_stats.csv" -exec cp {} "$P/kernel_stats.csv" \;
+find "$P/kt" -name "*kernel_trace.csv" -delete
 for C in FETCH_SIZE WRITE_SIZE TCC_EA0_RDREQ_DRAM_32B_sum TCC_EA0_WRREQ_WRITE_DRAM_32B_sum TCC_EA0_RDREQ_32B_sum; do
   rocprofv3 --pmc $C -d "$P/pmc_$C" -o pmc -- $CMD > "$P/bench_$C.json" 2> "$P/bench_$C.err"
 done

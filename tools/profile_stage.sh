@@ -14,7 +14,9 @@ cd "$ROOT"
 export TMPDIR=/tmp
 P=$ROOT/gpurun_out/prof_${TAG}
 rm -rf "$P"; mkdir -p "$P"
-rocprofv3 --kernel-trace --stats -d "$P/kt" -o kt -- python tools/stage_bench.py --only "$ONLY" > "$P/kt.log" 2> "$P/kt.err"
+rocprofv3 --kernel-trace --stats --output-format rocpd csv -d "$P/kt" -o kt -- python tools/stage_bench.py --only "$ONLY" > "$P/kt.log" 2> "$P/kt.err"
+find "$P/kt" -name "*kernel_stats.csv" -exec cp {} "$P/kernel_stats.csv" \;
+find "$P/kt" -name "*kernel_trace.csv" -delete
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C -d "$P/pmc_$C" -o pmc -- python tools/stage_bench.py --only "$ONLY" > "$P/$C.log" 2> "$P/$C.err"
 done
