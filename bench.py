@@ -319,23 +319,28 @@ def in_network_loop(D, L, ns, dev, dtype, kind="gemm", width=256, trajectories=6
                            lower_order_final=True, denoise_to_zero=False, t_T=1.0, t_0=1.0 / ns.total_N).time_views(dev, B, False)
         tin = tb["t_input_b"]
 
-        def timed(fn, k):
-            fn()
+        def timed(fn):
             torch.cuda.synchronize(dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(k):
-                fn()
+            fn()
             e1.record()
             torch.cuda.synchronize(dev)
-            return e0.elapsed_time(e1) / k * 1e3                          # us per call of fn
+            return e0.elapsed_time(e1) * 1e3                              # us
 
         def net_only():
             for i in range(n_st):
                 model(x_T, tin[i])
-        k = max(3, trajectories)
-        t_solver = timed(lambda: dpm.sample(x_T, steps=STEPS_SOLVER, order=2), k)
-        t_net = timed(net_only, k)
+        with_solver = lambda: dpm.sample(x_T, steps=STEPS_SOLVER, order=2)
+        with_solver()
+        net_only()
+        # alternate the two (A B A B ...) and take medians: the network's own time drifts by more than the 20 stage
+        # kernels cost, so back-to-back blocks of each would measure the drift
+        ts, tn = [], []
+        for _ in range(max(8, 2 * trajectories)):
+            ts.append(timed(with_solver))
+            tn.append(timed(net_only))
+        t_solver, t_net = float(np.median(ts)), float(np.median(tn))
         net.before_last = None
         for b in fr.bufs:
             b.inputs_resident = 0
@@ -676,7 +681,7 @@ def main():
     if not args.no_secondary and args.loop_net != "none" and world == 1:
         for kind in ([args.loop_net, "gemm"] if args.loop_net != "gemm" else ["gemm"]):
             try:
-                roofline["in_network_loop"] = in_network_loop(D, L, ns, dev, dtype, kind=kind)
+                roofline["in_network_loop"] = in_network_loop(D, L, ns, dev, dtype, kind=kind, net_dtype=eps_dtype)
                 break
             except Exception as e:                                      # a secondary must not cost the headline
                 roofline["in_network_loop"] = dict(error="%s: %s" % (type(e).__name__, e))
