@@ -543,3 +543,69 @@ def guided_checks(golden, device, tol):
 
 def test_guided_diffusion_adapter_against_reference_goldens(golden):
     guided_checks(golden, "cpu", TOL)
+
+
+# ------------------------------------------------------------------------------------------------
+# round 3 host-side additions
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [False, True])
+def test_fresh_time_tensors_for_networks_that_write_into_t(cfg):
+    """The (batch,) time vectors are built once per plan and shared by every call; a network that edits its time argument
+    in place corrupts them unless DPM_Solver.fresh_time_tensors hands out clones (the reference makes a fresh tensor per
+    call, ref :404)."""
+    ns = make_schedule("sd")
+    x = torch.from_numpy(np.random.default_rng(3).standard_normal((3, 4, 8, 8)).astype(F32))
+
+    def make(mutate):
+        def net(xx, t, c=None):
+            scale = (t * 0.0005 + 0.25).reshape(-1, 1, 1, 1)
+            out = xx * scale
+            if mutate:
+                t.mul_(0.0)                         # what a careless network might do
+            return out
+        if cfg:
+            cond = torch.ones(3)
+            return D.model_wrapper(net, ns, guidance_type="classifier-free", condition=cond, unconditional_condition=cond * 0,
+                                   guidance_scale=2.0)
+        return D.model_wrapper(net, ns)
+    want = D.DPM_Solver(make(False), ns).sample(x, steps=6, order=2)
+    dpm = D.DPM_Solver(make(True), ns)
+    dpm.fresh_time_tensors = True
+    for _ in range(2):                              # the second call would see the first call's damage
+        assert torch.equal(dpm.sample(x, steps=6, order=2), want)
+    # correctors / intermediates take the general loop: same guarantee
+    got, inter = dpm.sample(x, steps=6, order=2, return_intermediate=True)
+    assert torch.equal(got, want) and len(inter) == 7
+
+
+def test_cluster_fault_evicts_and_zeroes_the_cached_workspaces():
+    """DPM_ERR_FAULT (a clustered thresholding launch gave up waiting): the workspace contract wants the dirty workspace
+    zero-filled again -- the fault hook evicts the per-stream cache and zeroes every workspace a launch record holds, before
+    the error reaches the caller."""
+    ws = torch.ones(64, dtype=torch.uint8)
+    S._WS_CACHE[("test", 0)] = torch.ones(16, dtype=torch.uint8)
+    S._WS_LIVE.add(ws)
+    L.lib.dpm_time_steps(None, 0, 1.0, 0.001, 5, None)          # leaves some error text behind
+    with pytest.raises(L.DpmError):
+        L.check(L.ERR_FAULT)
+    assert not S._WS_CACHE and not bool(ws.any())
+
+
+def test_plan_and_adaptive_caches_are_bounded():
+    ns = make_schedule("sd")
+    dpm = D.DPM_Solver(D.model_wrapper(lambda xx, t: xx * 0.5, ns), ns)
+    plan = dpm._get_plan(method="multistep", order=2, steps=5, skip_type="time_uniform", solver_type="dpmsolver",
+                         lower_order_final=True, denoise_to_zero=False, t_T=1.0, t_0=1e-3)
+    for b in range(1, 14):
+        plan.time_views("cpu", b, False)
+    assert len(plan._views) <= 8
+
+
+def test_numerical_clip_alpha_method_and_c_entry_agree():
+    ns = make_schedule("cosine1000")
+    raw = np.linspace(-1e-4, -9.0, 400).astype(np.float32)
+    keep = C_.c_int()
+    L.check(L.lib.dpm_numerical_clip_len_f32(raw.ctypes.data_as(C_.POINTER(C_.c_float)), 400, -5.1, C_.byref(keep)))
+    out = ns.numerical_clip_alpha(torch.from_numpy(raw))
+    assert out.shape[0] == keep.value and 0 < keep.value < 400
+    assert L.lib.dpm_numerical_clip_len_f32(None, 4, -5.1, C_.byref(keep)) == L.ERR_ARG
