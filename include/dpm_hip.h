@@ -241,7 +241,7 @@ int dpm_stage_launch(const dpm_stage* st, const dpm_buffers* b, void* stream);
 #define DPM_MULTI_MAX 32
 int dpm_stage_launch_multi(const dpm_stage* st, const dpm_buffers* bs, int n_req, void* stream);
 /* scratch needed by stages with DPM_F_THRESH on the current device: 0 when one workgroup per sample is the plan (the
-   sample lives in that workgroup's LDS), else ~40-60 KiB per sample of slots, histograms and counters through which the
+   sample lives in that workgroup's LDS), else ~45-80 KiB per sample of slots, histograms and counters through which the
    workgroup cluster of a sample exchanges its candidates (small batches, samples beyond 12288 elements).
    Pass it as dpm_buffers.workspace.  Contract: the caller ZERO-FILLS the workspace once (hipMemset) before its first use;
    every launch leaves it zero-filled again (the last workgroup of a cluster cleans up), so no launch pays for a clear.
