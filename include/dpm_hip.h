@@ -40,7 +40,7 @@ enum {
   DPM_OK = 0,
   DPM_ERR_ARG = -1,         /* bad argument value (ValueError at the Python layer)            */
   DPM_ERR_UNSUPPORTED = -2, /* valid in the reference, not (yet) built here -- never silent   */
-  DPM_ERR_ALIGN = -3,       /* reserved                                                      */
+  DPM_ERR_ALIGN = -3,       /* a buffer is not aligned as the entry point requires (dpm_prefetch_launch)     */
   DPM_ERR_NOMEM = -4,
   DPM_ERR_CALLBACK = -5,    /* the model callback of dpm_plan_run returned non-zero           */
   DPM_ERR_FAULT = -6        /* an earlier clustered thresholding launch gave up waiting for a peer

@@ -561,3 +561,63 @@ def test_adaptive_sharded_with_an_empty_shard_on_the_gpu():
     assert [r[1] for r in first] == [1, 1] and first[0][2] == first[1][2] > 0
     # pass 2: rank 0 owns the sample, rank 1 an empty shard
     assert [r[3][0] for r in second] == [1, 0] and all(r[4] for r in second), second
+
+
+# ------------------------------------------------------------------------------------------------
+# measurement entry points of the C ABI (round 3): event-bracketed launches without synchronisation, the prefetch kernel
+# ------------------------------------------------------------------------------------------------
+def test_traced_launches_time_the_kernel_and_change_nothing():
+    """dpm_stage_launch_traced = dpm_stage_launch with a start / stop event pair attached to the kernel itself; nothing
+    synchronises until dpm_trace_read.  Same results as the plain launches, positive durations for the slots used, -1 for
+    the others, argument errors for slots outside the trace."""
+    ns = make_schedule("sd")
+    rng = np.random.default_rng(41)
+    x = torch.from_numpy(rng.standard_normal((16, 4, 64, 64)).astype(F32)).to(DEV)
+    e = torch.from_numpy(rng.standard_normal((16, 4, 64, 64)).astype(F32)).to(DEV)
+    dpm = D.DPM_Solver(D.model_wrapper(lambda xx, t: e, ns), ns)
+    want = dpm.sample(x, steps=10, order=2)
+    trace = C_.c_void_p()
+    L.check(L.lib.dpm_trace_create(16, C_.byref(trace)))
+    count = [0]
+    real = S._stage_launch_raw
+
+    def traced(st, b, stream):
+        k = count[0]
+        count[0] += 1
+        return L.lib.dpm_stage_launch_traced(st, b, stream, trace, k)
+    try:
+        S._stage_launch_raw = traced
+        got = dpm.sample(x, steps=10, order=2)
+    finally:
+        S._stage_launch_raw = real
+    ms = (C_.c_float * 16)()
+    L.check(L.lib.dpm_trace_read(trace, C_.c_void_p(torch.cuda.current_stream().cuda_stream), ms, 16))
+    v = np.frombuffer(ms, dtype=np.float32)
+    assert count[0] == 10 and torch.equal(got, want)
+    assert np.all(v[:10] > 0) and np.all(v[:10] < 5.0) and np.all(v[10:] == -1.0), v
+    st, b = L.Stage(), L.Buffers()
+    assert L.lib.dpm_stage_launch_traced(C_.byref(st), C_.byref(b), None, trace, 16) == L.ERR_ARG
+    assert L.lib.dpm_trace_read(trace, None, ms, 16) == L.DPM_OK and np.all(np.frombuffer(ms, dtype=np.float32) == -1.0)
+    L.lib.dpm_trace_destroy(trace)
+    assert L.lib.dpm_trace_create(0, C_.byref(trace)) == L.ERR_ARG
+
+
+def test_prefetch_launch_reads_and_leaves_the_buffers_alone():
+    """dpm_prefetch_launch (the rejected experiment of DESIGN.md 4.3 stays callable): reads up to 8 buffers with either load
+    policy, writes nothing, rejects unaligned buffers and more than 8."""
+    a = torch.arange(1 << 20, dtype=torch.float32, device=DEV)
+    b = torch.ones(12345, dtype=torch.float16, device=DEV)
+    ca, cb = a.clone(), b.clone()
+    stream = C_.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for policy in (0, 1):
+        ptrs = (C_.c_void_p * 3)(a.data_ptr(), None, b.data_ptr())
+        nbytes = (C_.c_int64 * 3)(a.numel() * 4, 0, b.numel() * 2)
+        L.check(L.lib.dpm_prefetch_launch(ptrs, nbytes, 3, policy, stream))
+    torch.cuda.synchronize()
+    assert torch.equal(a, ca) and torch.equal(b, cb)
+    ptrs = (C_.c_void_p * 1)(a.data_ptr() + 4)
+    nbytes = (C_.c_int64 * 1)(1024)
+    assert L.lib.dpm_prefetch_launch(ptrs, nbytes, 1, 0, stream) == L.ERR_ALIGN
+    many = (C_.c_void_p * 9)(*[a.data_ptr()] * 9)
+    assert L.lib.dpm_prefetch_launch(many, (C_.c_int64 * 9)(*[64] * 9), 9, 0, stream) == L.ERR_ARG
+    assert L.lib.dpm_prefetch_launch(None, None, 0, 0, stream) == L.ERR_ARG
