@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def summarise(d, md=None, title=""):
+def summarise(d, md=None, title="", pattern="stage_kernel"):
     """stage-kernel rows of a rocprofv3 kernel trace of `--trace-only`: duration, the kernel that ran before each, the gap"""
     f = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
     assert f, "no *_results.db under %s" % d
@@ -31,7 +31,7 @@ def summarise(d, md=None, title=""):
     names = [r[0] for r in rows]
     st = np.array([r[1] for r in rows], dtype=np.float64)
     du = np.array([r[2] for r in rows], dtype=np.float64)
-    is_stage = np.array(["stage_kernel" in n for n in names])
+    is_stage = np.array([pattern in n for n in names])
     idx = np.nonzero(is_stage)[0]
     out.append("%d kernel rows, %d stage-kernel rows\n\n" % (len(rows), len(idx)))
     # per distinct stage kernel
@@ -83,13 +83,16 @@ def main():
     ap.add_argument("--md", default=None)
     ap.add_argument("--title", default="")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--calib", action="store_true", help="the NO-ARITHMETIC kernel of the same five streams (dpm_calib_launch) in "
+                    "the stage kernel's place in the loop: what the memory system alone charges a lone launch there")
+    ap.add_argument("--pattern", default="stage_kernel", help="--summarise: substring of the kernel rows to report")
     ap.add_argument("--sweep", action="store_true", help="tuning build: (tiles per workgroup, nt mask) of the 2M kernel INSIDE "
                     "the loop, for fp16, fp32 and fp32 state + fp16 network (events)")
     ap.add_argument("--unroll", type=int, default=0, help="tuning build only: tiles per workgroup of the 2M stage kernel")
     ap.add_argument("--nt", type=int, default=-1, help="tuning build only: nt mask")
     args = ap.parse_args()
     if args.summarise:
-        return summarise(args.summarise, args.md, args.title)
+        return summarise(args.summarise, args.md, args.title, args.pattern)
     import torch
     import bench
     import dpm_solver_amd as D
@@ -97,6 +100,26 @@ def main():
     dev = torch.device("cuda", 0)
     dtype = bench._DT[args.dtype]
     ns = D.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(bench.sd_alphas_cumprod()))
+    if args.calib:
+        import ctypes as C
+        net = bench.LoopNet(args.kinds.split(",")[0], args.width, dtype, dev)
+        g = torch.Generator(device="cpu").manual_seed(4321)
+        x = torch.randn((bench.B,) + bench.SHAPE, generator=g).to(dev, dtype)
+        bufs = [torch.empty_like(x) for _ in range(4)]          # x / m ping-pong: read the pair the previous launch wrote
+        tvec = torch.full((bench.B,), 500.0, device=dev)
+        sptr = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        nbytes = x.numel() * x.element_size()
+        with torch.no_grad():
+            xi, mi = x, bufs[0]
+            for it in range(20 * args.trajectories):
+                eps = net(xi, tvec)
+                xo, mo = (bufs[1], bufs[2]) if it % 2 == 0 else (bufs[3], bufs[0])
+                L.check(L.lib.dpm_calib_launch(1, 256, 8, 1, xi.data_ptr(), eps.data_ptr(), mi.data_ptr(), xo.data_ptr(), mo.data_ptr(),
+                                               nbytes, sptr, None))
+                xi, mi = xo, mo
+        torch.cuda.synchronize()
+        print("calib loop done: %d launches of the no-arithmetic kernel (3 read + 2 write streams of %d bytes)" % (20 * args.trajectories, nbytes))
+        return
     if args.sweep:
         for sname, ename in (("fp16", "fp16"), ("fp32", "fp32"), ("fp32", "fp16")):
             for u in (1, 2, 4):
