@@ -723,6 +723,14 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ac)
+        try:     # the unmodified reference on the same kind of GPU through PyTorch-ROCm eager (tools/gpu_reference.py; committed)
+            gr = json.load(open(os.path.join(ROOT, "profiles", "gpu_reference.json")))
+            line["reference_on_mi355x"] = dict(
+                source="profiles/gpu_reference.json (tools/gpu_reference.py through gpurun; committed, not measured in this run)",
+                what=gr["what"], rows=[{k: r[k] for k in ("case", "reference_on_gpu_ms", "engine_ms", "speedup",
+                                                          "rel_err_vs_reference_on_gpu")} for r in gr["rows"]])
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
