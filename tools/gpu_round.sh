@@ -26,4 +26,10 @@ for DT in fp16 fp32; do
 done
 timeout 900 python tools/stage_bench.py --md $O/stage_table.md > $O/stage_bench.log 2>&1; echo "stage_bench rc=$?"; tail -8 $O/stage_bench.log
 timeout 300 python tools/thr_routes.py > $O/thr_routes.txt 2>&1; echo "thr_routes rc=$?"
+# the unmodified reference, when it travelled here as git-ignored scratch (_refscratch/, removed after the call): its CPU timing
+# on this box's host cores and its timing + parity on this GPU
+if [ -f _refscratch/dpm_solver_pytorch.py ]; then
+  DPM_REFERENCE_DIR=_refscratch timeout 400 python tools/cpu_baseline.py --budget 40 --out $O/cpu_baseline_reference_gpubox.json --where "MI355X box host cores (gpurun)" > $O/cpu_baseline.log 2>&1; echo "cpu_baseline rc=$?"
+  DPM_REFERENCE_DIR=_refscratch timeout 400 python tools/gpu_reference.py --out $O/gpu_reference.json > $O/gpu_reference.log 2>&1; echo "gpu_reference rc=$?"
+fi
 du -sh $O
