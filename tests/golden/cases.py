@@ -274,3 +274,25 @@ GD_RUNS = [
     ("eps_clf_ss3", dict(sample_type="dpmsolver", use_clf=True, thresholding=False, denoise=False, scale=1.5,
                          method="singlestep", order=3, timesteps=9)),
 ]
+
+
+# --------------------------------------------------------------------------------------
+# ScoreSDE example (examples/score_sde_pytorch/sampling.py:505-555): stand-in score model and runs
+# --------------------------------------------------------------------------------------
+SCORE_SDE_SHAPE = (4, 3, 8, 8)
+SCORE_SDE_RUNS = [
+    ("default", dict()),                                                          # singlestep-3, logSNR, 10 steps, dpmsolver
+    ("denoise", dict(denoise=True, steps=12)),
+    # (thresholding=True cannot be a golden: the vendored older revision calls correcting_x0_fn(x0) with one argument and
+    #  its own dynamic_thresholding_fn(x0, t) then raises TypeError, examples/score_sde_pytorch/dpm_solver.py:449)
+    ("pp_ms2", dict(algorithm_type="dpmsolver++", method="multistep", order=2, skip_type="time_uniform", steps=15)),
+    ("adaptive", dict(method="adaptive", order=2)),
+]
+
+
+def score_sde_model(torch_mod):
+    """a small deterministic 'score model': model(x, labels) with labels = t * 999 (models/utils.py:148)"""
+    class M(torch_mod.nn.Module):
+        def forward(self, x, labels):
+            return x * (labels * 2e-4 + 0.35).reshape(-1, 1, 1, 1)
+    return M()

@@ -395,6 +395,31 @@ def gen_guided(out):
         out["guided/" + tag] = run(**kw).detach().numpy()
 
 
+def gen_score_sde(out):
+    """`get_dpm_solver_sampler` of the ScoreSDE example, imported unmodified together with its `sde_lib` and `models.utils`
+    (examples/score_sde_pytorch/sampling.py:505-555; its `from dpm_solver import ...` resolves to the older revision vendored
+    next to it): VP SDE, stand-in score model, prior samples from a seeded torch.randn"""
+    ex = os.path.join(REF_DIR, "examples", "score_sde_pytorch")
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k in ("dpm_solver", "sampling", "sde_lib", "models") or k.startswith("models.")}
+    sys.path.insert(0, ex)
+    try:
+        import sampling as SM
+        import sde_lib
+        sde = sde_lib.VPSDE(beta_min=0.1, beta_max=20., N=1000)
+        inverse_scaler = lambda x: (x + 1.) / 2.
+        for i, (tag, kw) in enumerate(C.SCORE_SDE_RUNS):
+            torch.manual_seed(100 + i)
+            fn = SM.get_dpm_solver_sampler(sde, C.SCORE_SDE_SHAPE, inverse_scaler, device="cpu", **kw)
+            y, nfe = fn(C.score_sde_model(torch))
+            out["score_sde/%s/x" % tag] = y.numpy()
+            out["score_sde/%s/nfe" % tag] = np.int64(nfe)
+    finally:
+        sys.path.remove(ex)
+        for k in [k for k in sys.modules if k in ("dpm_solver", "sampling", "sde_lib", "models") or k.startswith("models.")]:
+            sys.modules.pop(k)
+        sys.modules.update(saved)
+
+
 def gen_utils(out):
     """the module-level helpers interpolate_fn / expand_dims (ref :1253-1305) on seeded inputs: queries inside the
     keypoint range, on keypoints, beyond both ends (linear extrapolation), several channels"""
@@ -445,7 +470,7 @@ def gen_api(out):
 
 
 def main():
-    groups = dict(api=gen_api, clip=gen_clip, utils=gen_utils, guided=gen_guided, legacy=gen_legacy, schedules=gen_schedules, timesteps=gen_timesteps, updates=gen_updates,
+    groups = dict(score_sde=gen_score_sde, api=gen_api, clip=gen_clip, utils=gen_utils, guided=gen_guided, legacy=gen_legacy, schedules=gen_schedules, timesteps=gen_timesteps, updates=gen_updates,
                   quantile=gen_quantile, add_noise=gen_add_noise, e2e=gen_e2e,
                   callbacks=gen_callbacks, adaptive=gen_adaptive, sampler=gen_sampler)
     only = sys.argv[1:]

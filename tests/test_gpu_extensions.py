@@ -621,3 +621,10 @@ def test_prefetch_launch_reads_and_leaves_the_buffers_alone():
     many = (C_.c_void_p * 9)(*[a.data_ptr()] * 9)
     assert L.lib.dpm_prefetch_launch(many, (C_.c_int64 * 9)(*[64] * 9), 9, 0, stream) == L.ERR_ARG
     assert L.lib.dpm_prefetch_launch(None, None, 0, 0, stream) == L.ERR_ARG
+
+
+def test_score_sde_sampler_against_reference_goldens(golden, capsys):
+    """dpm_solver_amd.adapters.score_sde_get_dpm_solver_sampler on the HIP path vs goldens from the ScoreSDE example's own
+    sampler (singlestep-3 / logSNR default, denoise, dpmsolver++ multistep, adaptive)"""
+    from test_host_logic import run_score_sde_adapter
+    assert run_score_sde_adapter(DEV, golden, thresholding_too=True) < TOL

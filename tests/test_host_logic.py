@@ -609,3 +609,38 @@ def test_numerical_clip_alpha_method_and_c_entry_agree():
     out = ns.numerical_clip_alpha(torch.from_numpy(raw))
     assert out.shape[0] == keep.value and 0 < keep.value < 400
     assert L.lib.dpm_numerical_clip_len_f32(None, 4, -5.1, C_.byref(keep)) == L.ERR_ARG
+
+
+# ------------------------------------------------------------------------------------------------
+# the ScoreSDE example's sampler (examples/score_sde_pytorch/sampling.py:505-555)
+# ------------------------------------------------------------------------------------------------
+class _VPSDE:
+    """what get_dpm_solver_sampler reads of sde_lib.VPSDE: beta_0, beta_1, T, prior_sampling"""
+    beta_0, beta_1, T = 0.1, 20., 1
+
+    def prior_sampling(self, shape):
+        return torch.randn(*shape)
+
+
+def run_score_sde_adapter(device, golden, thresholding_too=False):
+    from dpm_solver_amd.adapters import score_sde_get_dpm_solver_sampler
+    worst = 0.0
+    for i, (tag, kw) in enumerate(C.SCORE_SDE_RUNS):
+        torch.manual_seed(100 + i)
+        fn = score_sde_get_dpm_solver_sampler(_VPSDE(), C.SCORE_SDE_SHAPE, lambda x: (x + 1.) / 2., device=device, **kw)
+        y, nfe = fn(C.score_sde_model(torch).to(device))
+        assert nfe == int(golden.get("score_sde", "score_sde/%s/nfe" % tag))
+        assert y.dtype == torch.float32 and str(y.device).startswith(str(device).split(":")[0])
+        worst = max(worst, rel_err(y.cpu().numpy(), golden.get("score_sde", "score_sde/%s/x" % tag)))
+    if thresholding_too:    # the reference's vendored revision raises TypeError with thresholding=True; the engine runs it
+        torch.manual_seed(7)
+        fn = score_sde_get_dpm_solver_sampler(_VPSDE(), C.SCORE_SDE_SHAPE, lambda x: x, device=device, thresholding=True,
+                                              algorithm_type="dpmsolver++", method="multistep", order=2, steps=8)
+        y, _ = fn(C.score_sde_model(torch).to(device))
+        assert torch.isfinite(y).all() and y.shape == C.SCORE_SDE_SHAPE
+    return worst
+
+
+def test_score_sde_sampler_against_reference_goldens(golden, capsys):
+    """goldens produced by the example's own sampling.get_dpm_solver_sampler (tests/golden/make_golden.py score_sde)"""
+    assert run_score_sde_adapter("cpu", golden, thresholding_too=True) < TOL
