@@ -435,19 +435,14 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
           launch(stage_kernel<TS, TE, FORM, GUIDE, XE, SPEC_GENERIC, 1, DefNT<TS>::value, false, true>, grid_for(1), dim3(256),
                  0, stream, x, xe, e0, e1, g, h1, h2, xo, mo, b->n, p, ext, stream.dyn, stream.skip);
       } else if (use_ext) {
-        // (tiles per iteration, nt mask) of the inputs-from-HBM table below; x_out stays cacheable (it is the next
-        // network input), so bit 1 is never set
-        constexpr int EU = (sizeof(TS) == 4 && sizeof(TE) == 2) ? 2 : 1;
+        // one tile per workgroup (round 2 launched two for an fp32 state with 2-byte outputs: CFG + duplicate store at
+        // [256,4,64,64] 18.1 / 20.3 us back-to-back / evicted against 17.3 / 19.3 with one, tools/stage_bench.py); nt mask of
+        // the inputs-from-HBM situation
         constexpr int ENT = sizeof(TS) == 2 ? 1 : (sizeof(TE) == 4 ? 5 : 1);
-        const bool two = EU == 2 && big && SPEC_BUILT;
         if (spec == SPEC_GENERIC) {
           DPM_LAUNCH(SPEC_GENERIC, 1, ENT, true);
         } else if constexpr (SPEC_BUILT) {
-          if (spec == SPEC_NOISE_X0) {
-            if (two) DPM_LAUNCH(SPEC_NOISE_X0, EU, ENT, true); else DPM_LAUNCH(SPEC_NOISE_X0, 1, ENT, true);
-          } else {
-            if (two) DPM_LAUNCH(SPEC_NOISE_EPS, EU, ENT, true); else DPM_LAUNCH(SPEC_NOISE_EPS, 1, ENT, true);
-          }
+          if (spec == SPEC_NOISE_X0) DPM_LAUNCH(SPEC_NOISE_X0, 1, ENT, true); else DPM_LAUNCH(SPEC_NOISE_EPS, 1, ENT, true);
         }
       } else if (spec == SPEC_GENERIC) {
         DPM_LAUNCH(SPEC_GENERIC, 1, DefNT<TS>::value, false);
