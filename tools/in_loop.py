@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--md", default=None)
     ap.add_argument("--title", default="")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--requests", type=int, default=0, help="trace-only: R requests advanced together by DPM_Solver.sample_requests "
+                    "with the real network (one fused stage launch per stage): rows of stage_kernel_multi inside the loop")
     ap.add_argument("--calib", action="store_true", help="the NO-ARITHMETIC kernel of the same five streams (dpm_calib_launch) in "
                     "the stage kernel's place in the loop: what the memory system alone charges a lone launch there")
     ap.add_argument("--pattern", default="stage_kernel", help="--summarise: substring of the kernel rows to report")
@@ -100,6 +102,19 @@ def main():
     dev = torch.device("cuda", 0)
     dtype = bench._DT[args.dtype]
     ns = D.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(bench.sd_alphas_cumprod()))
+    if args.requests:
+        net = bench.LoopNet(args.kinds.split(",")[0], args.width, dtype, dev)
+        g = torch.Generator(device="cpu").manual_seed(99)
+        xs = [torch.randn((bench.B,) + bench.SHAPE, generator=g).to(dev, dtype) for _ in range(args.requests)]
+        dpm = D.DPM_Solver(D.model_wrapper(net, ns), ns, algorithm_type="dpmsolver++", state_dtype=dtype)
+        with torch.no_grad():
+            want = [dpm.sample(x, steps=20, order=2) for x in xs[:2]]
+            for _ in range(max(2, args.trajectories // 2)):
+                got = dpm.sample_requests(xs, steps=20, order=2)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(got[:2], want))
+        print("sample_requests loop done: %d requests of [%d,4,64,64] %s, real network between the fused stage launches" % (args.requests, bench.B, args.dtype))
+        return
     if args.calib:
         import ctypes as C
         net = bench.LoopNet(args.kinds.split(",")[0], args.width, dtype, dev)
