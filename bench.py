@@ -21,6 +21,11 @@ raised until the region is long enough, and `steps` in the JSON line is the numb
 (`steps_requested` is what --steps asked for).  `sustained` carries the region's length and the throughput of its second
 half over its first half (a throttling check).
 
+Back-to-back fused launches are also the CONSERVATIVE regime: each launch finds the write-back Infinity Cache full of its
+predecessor's dirty stores and pays for them; behind a real network (reads) the cache is clean, absorbs up to 256 MB of the
+launch's stores and the same launch is 12-14 % shorter (tools/duty_cycle.py, profiles/r03_in_loop.md).  Every byte of the
+timed region is paid for inside it.
+
 One JSON line on rank 0:
   value            whole-job Msamples/s = N * K * R * 256 / wall, wall = barrier/sync-bracketed, max over ranks
   roofline         HBM roofline of the fused 2M stage kernel.  `achieved` = algorithmic bytes of the timed region
