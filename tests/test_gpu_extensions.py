@@ -628,3 +628,28 @@ def test_score_sde_sampler_against_reference_goldens(golden, capsys):
     sampler (singlestep-3 / logSNR default, denoise, dpmsolver++ multistep, adaptive)"""
     from test_host_logic import run_score_sde_adapter
     assert run_score_sde_adapter(DEV, golden, thresholding_too=True) < TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's own example call sites, source files unchanged (tools/dropin_examples.py).  The reference tree is not
+# part of this repository: the test runs when it travelled to the box as scratch ($DPM_REFERENCE_DIR, tools/ref_scratch.sh)
+# ------------------------------------------------------------------------------------------------
+def _dropin_tool():
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("dropin_examples", os.path.join(root, "tools", "dropin_examples.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("site", [0, 1, 2], ids=["stable-diffusion", "score-sde", "guided-diffusion"])
+def test_dropin_examples_on_the_gpu(site):
+    DE = _dropin_tool()
+    ex = DE.reference_examples()
+    if ex is None:
+        pytest.skip("no reference checkout on this box (DPM_REFERENCE_DIR)")
+    name, where, fn = DE.SITES[site]
+    row = DE.run_site(name, where, fn, DEV, ex)
+    assert row["passed"], {k: row[k] for k in ("max_rel_err", "integers_equal", "network_trace")}
