@@ -34,6 +34,7 @@ TUNE_UNROLL, TUNE_NONTEMPORAL, TUNE_BLOCKS_PER_CU, TUNE_ASSUME_RESIDENT = 0, 1, 
 TUNE_MULTI_FUSE, TUNE_MULTI_BLOCKS_PER_CU, TUNE_CLUSTER_IN_GRAPH, TUNE_CLUSTER_ONE_HOP = 4, 5, 6, 7
 TUNE_MULTI_XCD_REMAP = 8
 TUNE_THR_PREDICT = 9
+TUNE_THR_SPIN_LIMIT, TUNE_THR_DEBUG_FAULT = 10, 11
 MULTI_MAX = 32
 THR_HINT_WORDS = 4
 
@@ -170,6 +171,7 @@ _SIGNATURES = [
     ("dpm_tuning_get", C.c_int, [C.c_int]),
     ("dpm_calib_launch", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int64, C.c_void_p, _P(C.c_float)]),
+    ("dpm_cluster_timeout_poll", C.c_int, []),
     ("dpm_version", C.c_int, []),
     ("dpm_sizeof", C.c_size_t, [C.c_int]),
     ("dpm_last_error", C.c_char_p, []),
@@ -198,11 +200,19 @@ for _i, _t in enumerate((Stage, Buffers, PlanDesc, RunBuffers, AdaptiveDesc)):  
                           % (_t.__name__, C.sizeof(_t), lib.dpm_sizeof(_i)))
 
 
+if lib.dpm_version() < 102:
+    raise ImportError("dpm_solver_amd: libdpm_hip.so reports version %d, this binding needs >= 102 -- stale library, rebuild"
+                      % lib.dpm_version())
+
+
 class DpmError(RuntimeError):
     pass
 
 
-fault_hooks = []          # called on DPM_ERR_FAULT before it is raised (solver.py: re-zero the cluster workspaces)
+def cluster_timeout_poll():
+    """True when a wait between the workgroups of a thresholding cluster timed out since the last call (the kernel
+    recovered: results are unaffected; see include/dpm_hip.h).  Diagnostics for shared-GPU deployments."""
+    return bool(lib.dpm_cluster_timeout_poll())
 
 
 def check(rc):
@@ -211,9 +221,6 @@ def check(rc):
     if rc == DPM_OK:
         return
     msg = lib.dpm_last_error().decode("utf-8", "replace")
-    if rc == ERR_FAULT:
-        for hook in fault_hooks:
-            hook()
     if rc == ERR_ARG:
         raise ValueError(msg)
     if rc == ERR_UNSUPPORTED:

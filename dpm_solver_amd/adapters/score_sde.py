@@ -18,7 +18,11 @@ from ..solver import DPM_Solver
 
 def get_noise_fn(sde, model, train=False, continuous=True):
     """models/utils.py:129-155 for a continuously trained VP model: time labels are t * 999."""
-    if not continuous or not (hasattr(sde, "beta_0") and hasattr(sde, "beta_1")):
+    # the reference accepts `isinstance(sde, sde_lib.VPSDE)` only (models/utils.py:143) and raises otherwise.  sde_lib is the
+    # application's module, so the class is recognised by name along the MRO: subVPSDE -- which also carries beta_0 / beta_1
+    # but has another marginal std -- derives from SDE, not from VPSDE, and must be rejected, not sampled as a VP model
+    is_vp = any(k.__name__ == "VPSDE" for k in type(sde).__mro__)
+    if not continuous or not is_vp or not (hasattr(sde, "beta_0") and hasattr(sde, "beta_1")):
         raise NotImplementedError("SDE class %s not yet supported." % sde.__class__.__name__)
     if hasattr(model, "train"):
         model.train(bool(train))

@@ -53,6 +53,9 @@ struct Tuning {
                             // tile space per XCD): 1 on, 0 off, -1 per dtype (on for 2-byte states: +1.4 %; fp32: -3 %)
   int multi_blocks_per_cu = 0;  // grid cap of the fused launch in workgroups per CU; 0 = one super-tile per workgroup
   int thr_predict = 1;      // clustered thresholding: predict the select bound from the previous stages (thr_hint)
+  int thr_spin_limit = 1 << 12;  // clustered thresholding: polls before a wait on a peer gives up (THR_SPIN_LIMIT)
+  int thr_debug_fault = 0;  // testing: 1 = every cluster wait gives up at its first unsuccessful poll, 2 = workgroup 1 of
+                            // every cluster neither publishes nor arrives (its peers time out and recover)
 };
 extern Tuning g_tuning;     // defined in dpm_kernels.hip
 // device-wide chain of clustered thresholding launches (see launch_typed): one instance per device for the library
@@ -62,8 +65,8 @@ struct ClusterChain {
   bool recorded = false;
 };
 ClusterChain& cluster_chain(int dev);  // defined in dpm_kernels.hip
-// host-mapped word a clustered kernel raises when one of its waits timed out; nullptr until created (create = false
-// never allocates: stream capture)
+// host-mapped word a clustered kernel raises when one of its waits timed out (and was recovered from: diagnostics only);
+// nullptr until created (create = false never allocates: stream capture)
 uint32_t* cluster_fault_word(bool create);
 // bfloat16 storage (a named type with external linkage: it is a template argument of functions shared between
 // translation units, dpm_catchall_* below)

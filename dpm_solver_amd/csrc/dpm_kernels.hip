@@ -958,6 +958,14 @@ extern "C" int dpm_tuning_set(int knob, int value) {
     case DPM_TUNE_MULTI_XCD_REMAP: g_tuning.multi_xcd_remap = value < 0 ? -1 : (value != 0); return DPM_OK;
     case DPM_TUNE_CLUSTER_ONE_HOP: g_tuning.cluster_one_hop = value < 0 ? 0 : (value > 2 ? 2 : value); return DPM_OK;
     case DPM_TUNE_THR_PREDICT: g_tuning.thr_predict = value != 0; return DPM_OK;
+    case DPM_TUNE_THR_SPIN_LIMIT:
+      if (value < 0) return dpm_set_error(DPM_ERR_ARG, "thr_spin_limit must be >= 0");
+      g_tuning.thr_spin_limit = value;
+      return DPM_OK;
+    case DPM_TUNE_THR_DEBUG_FAULT:
+      if (value < 0 || value > 2) return dpm_set_error(DPM_ERR_ARG, "thr_debug_fault must be 0, 1 or 2");
+      g_tuning.thr_debug_fault = value;
+      return DPM_OK;
     case DPM_TUNE_MULTI_BLOCKS_PER_CU:
       if (value < 0 || value > 4096) return dpm_set_error(DPM_ERR_ARG, "multi_blocks_per_cu must be in 0..4096");
       g_tuning.multi_blocks_per_cu = value;
@@ -978,8 +986,17 @@ extern "C" int dpm_tuning_get(int knob) {
     case DPM_TUNE_CLUSTER_ONE_HOP: return g_tuning.cluster_one_hop;
     case DPM_TUNE_MULTI_BLOCKS_PER_CU: return g_tuning.multi_blocks_per_cu;
     case DPM_TUNE_THR_PREDICT: return g_tuning.thr_predict;
+    case DPM_TUNE_THR_SPIN_LIMIT: return g_tuning.thr_spin_limit;
+    case DPM_TUNE_THR_DEBUG_FAULT: return g_tuning.thr_debug_fault;
   }
   return -1;
+}
+
+extern "C" int dpm_cluster_timeout_poll(void) {
+  uint32_t* w = cluster_fault_word(false);
+  if (!w || !*w) return 0;
+  *w = 0u;
+  return 1;
 }
 
 extern "C" int dpm_device_info(int* n_cu, int* lds_bytes, char* arch, int arch_len) {

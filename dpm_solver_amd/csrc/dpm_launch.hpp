@@ -343,15 +343,11 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
       tp.ws_stride = thr_ws_stride(pl.k);
       grid = groups * pl.k;
       // No clearing of the workspace here: the caller hands it over zero-filled once, the kernel leaves it zero-filled
-      // (dpm_threshold_workspace_bytes).  A wait that timed out in an earlier clustered launch is reported now.
-      uint32_t* fault = cluster_fault_word(!capturing);
-      if (fault && *fault) {
-        *fault = 0u;
-        return dpm_set_error(DPM_ERR_FAULT, "a clustered dynamic-thresholding launch gave up waiting for a peer workgroup "
-                             "(another clustered launch held the GPU concurrently?); its results are invalid and its "
-                             "workspace must be zero-filled again");
-      }
-      tp.fault = fault;
+      // (dpm_threshold_workspace_bytes).  A wait on a peer that times out is recovered from inside the kernel (solo_select:
+      // same results, no error); the host-mapped word only records that it happened (dpm_cluster_timeout_poll).
+      tp.fault = cluster_fault_word(!capturing);
+      tp.spin_limit = g_tuning.thr_debug_fault == 1 ? 0u : (uint32_t)g_tuning.thr_spin_limit;
+      tp.debug_fault = g_tuning.thr_debug_fault;
       // the select bound predicted from the previous stages (dpm_buffers.thr_hint): single requests on the one-exchange route
       // -- where it pays: a small K (the wanted rank from the top), so that the predicted union (~1.3-1.9 K entries instead
       // of k * quota) is finished by rank counting.  Measured (tools/thr_routes.py): [32,3,64,64] (K = 63) 11.3 -> 10.7 us per

@@ -31,6 +31,11 @@ namespace {
 // within the number of co-resident workgroups, so waiting workgroups can always be joined by their peers.
 // ------------------------------------------------------------------------------------------------
 constexpr int THR_THREADS = 512;
+// wavefronts per SIMD the run-time dispatched catch-all thresholding kernel (HOT = 0) is compiled for: 4 = two workgroups per
+// CU at a 128-register budget (a handful of spills to scratch), 2 = no register limit, one workgroup per CU
+#ifndef DPM_THR_CATCHALL_WAVES
+#define DPM_THR_CATCHALL_WAVES 4
+#endif
 constexpr int THR_NB = 2048;                 // bins per radix level
 // workspace words per sample (k > 1): 3 level histograms, the histogram of the per-thread maxima and the candidate list
 // of the top-K front end, counters (a 256-byte multiple)
@@ -61,7 +66,11 @@ constexpr int THR_HINT_W = DPM_THR_HINT_WORDS;
 // the predicted bound sits this far below the extrapolated order statistic: with the statistic within a few percent of
 // its extrapolation the union stays ~1.3 K entries (K = the wanted rank from the top) and holds the K-th largest
 constexpr float THR_HINT_MARGIN = 0.94f;
-constexpr uint32_t THR_SPIN_LIMIT = 1u << 22; // polls (about a microsecond each) before a wait gives up: seconds
+constexpr int THR_WS_POISON = THR_WS_CNT + 16; // a workgroup of the cluster gave up a wait on this sample (see solo_select)
+// polls (a microsecond or two each: a dependent sc1 load + s_sleep) before a wait on a peer gives up -- milliseconds.
+// Giving up is safe (the workgroup then computes the sample's order statistics alone, solo_select), so the limit only
+// trades a stall against redundant work when the peers are off the chip (ThrParams.spin_limit, DPM_TUNE_THR_SPIN_LIMIT)
+constexpr uint32_t THR_SPIN_LIMIT = 1u << 12;
 
 struct ThrParams {
   int64_t per_sample;
@@ -85,7 +94,10 @@ struct ThrParams {
   int32_t debug_reject; // testing: run the single-exchange select but always take the general route afterwards
   int64_t ws_stride; // words per sample in ws
   uint32_t* ws;    // k > 1: batch x ws_stride words, all zero between launches (the kernel cleans up after itself)
-  uint32_t* fault; // host-mapped word: set when a cluster wait timed out (the launch's results are then garbage)
+  uint32_t* fault; // host-mapped word: set when a cluster wait timed out and was recovered from (diagnostics only:
+                   // dpm_cluster_timeout_poll; the launch's results are correct either way)
+  uint32_t spin_limit;  // polls before a wait on a peer gives up (THR_SPIN_LIMIT)
+  int32_t debug_fault;  // testing (DPM_TUNE_THR_DEBUG_FAULT): 2 = workgroup 1 of every cluster neither publishes nor arrives
   float* hint;     // dpm_buffers.thr_hint (THR_HINT_W floats per sample) or null: the selected order statistic of the
                    // previous two stages -> predicted select bound of this one (cluster_select_once, `pbound`)
   int32_t hint_reset; // this is the first stage of a trajectory: the stored values are stale, overwrite without reading
@@ -172,31 +184,41 @@ __device__ __forceinline__ void store4(bf16_t* __restrict__ p, int64_t i, const 
   st8<NT>(reinterpret_cast<u32x2*>(p + i), a);
 }
 
-// A wait on another workgroup gives up after THR_SPIN_LIMIT polls (seconds): the peers of a cluster are co-resident by
-// construction, so this only happens when something else keeps them off the chip that long (two clustered graphs
-// replayed concurrently on different streams) or on a true deadlock.  It never traps: the waiter raises the library's
-// host-mapped fault word, stops waiting for the rest of the launch (its results are garbage) and the kernel terminates;
-// the next clustered launch returns DPM_ERR_FAULT.
+// A wait on another workgroup gives up after ThrParams.spin_limit polls (milliseconds).  Within one process the peers of a
+// cluster are co-resident by construction (grid capped at the occupancy, clustered launches chained), so this happens
+// when something else keeps them off the chip: another PROCESS running clusters on the same GPU, two clustered graphs
+// replayed concurrently, a kernel of another stream holding the CUs.  Giving up is harmless and local: the workgroup
+// marks the sample (THR_WS_POISON: peers on the general route may have read merged data it left incomplete), stops
+// waiting for the rest of the launch, and computes the sample's order statistics ALONE from global memory
+// (solo_select) -- the stage's results are the same bits as without the timeout, nothing is reported to the caller
+// except the host-mapped diagnostic word (dpm_cluster_timeout_poll).  The reference cannot fail here (ref :416-425);
+// neither can this.
 __device__ __forceinline__ void raise_fault(uint32_t* fault) {
   if (fault) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// `dead` (LDS word): this workgroup gave up a wait -- do not wait again in this launch
+__device__ __forceinline__ void give_up(uint32_t* dead, uint32_t* poison, uint32_t* fault) {
+  *dead = 1u;
+  raise_fault(fault);
+  // the mark must be visible before anything this workgroup contributes from here on (peers check it after reading)
+  __hip_atomic_store(poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // all workgroups of a cluster meet here; `cnt` is a zero-initialised single-use counter.  Everything the cluster
 // shares travels as agent-scope atomics and sc1 loads, so no cache write-back / invalidate is needed: drain this
 // wave's atomics, arrive with a relaxed atomic, poll with relaxed sc1 loads (MI355X_MICROARCH.md, barrier-counter).
-// `dead` (LDS word): a previous wait of this workgroup timed out -- do not wait again.
-__device__ __forceinline__ void cluster_barrier(uint32_t* cnt, uint32_t k, uint32_t* dead, uint32_t* fault) {
+// `dead` (LDS word): a previous wait of this workgroup timed out -- do not wait again.  `ws`: the sample's workspace.
+__device__ __forceinline__ void cluster_barrier(uint32_t* cnt, uint32_t k, uint32_t* dead, uint32_t* ws, const ThrParams& tp,
+                                                bool silent = false) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!silent) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t spins = 0;
     while (!*dead && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > THR_SPIN_LIMIT) {
-        *dead = 1u;
-        raise_fault(fault);
-      }
+      if (++spins > tp.spin_limit) give_up(dead, ws + THR_WS_POISON, tp.fault);
     }
   }
   __syncthreads();
@@ -500,7 +522,7 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
                                                     uint32_t m3, uint32_t m4, bool has, uint32_t* hist, uint32_t* misc,
                                                     uint32_t* cand, uint32_t* slots, const ThrParams& tp, uint32_t k, int c,
                                                     int tid, uint32_t& a_out, uint32_t& b_out, bool stamp,
-                                                    const uint32_t pbound = 0u) {
+                                                    uint32_t* poison, const uint32_t pbound = 0u) {
   // pbound != 0 (bit pattern of a positive float): the bound is PREDICTED from the previous stages' thresholds (same value
   // in every workgroup of the cluster) instead of searched in the histogram of the per-thread maxima: no histogram, no
   // locate_bin, and a union of ~1.3 K entries instead of k * quota.  Every element >= pbound of every chunk is published,
@@ -571,13 +593,14 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
   // the first `pub` entries of a slot are always written -- the tag alone beyond the count -- so that readers can wait
   // for them without knowing the count (step 5)
   const uint32_t pub = (uint32_t)tp.slot_pub;
-  {
+  const bool silent = tp.debug_fault == 2 && c == 1;  // testing: this workgroup's peers must get by without it
+  if (!silent) {
     const uint32_t nv = over ? 0u : ncl, nw = nv > pub ? nv : pub;
     for (uint32_t i = tid; i < nw; i += T)
       __hip_atomic_store(&mine_slot[THR_SLOT_HDR + i], (i < nv ? cand[i] : 0u) | THR_TAG, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (tid == 0) {
+  if (tid == 0 && !silent) {
     // smallest |x0| this workgroup would have published: the predicted bound, or the first pattern of the digit (0 = everything)
     const uint32_t bound = pbound ? pbound : (bin_lo ? (bin_lo + dbase) << THR_FSHIFT : 0u);
     __hip_atomic_store(&mine_slot[2], cmax | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -623,10 +646,7 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
       for (int j = 0; j < PER; ++j) all &= w[j];
       if ((all & THR_TAG) || misc[30]) break;
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > THR_SPIN_LIMIT) {
-        misc[30] = 1u;
-        raise_fault(tp.fault);
-      }
+      if (++spins > tp.spin_limit) give_up(misc + 30, poison, tp.fault);
     }
 #pragma unroll
     for (int j = 0; j < PER; ++j)
@@ -682,10 +702,7 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
         while (!(w[j] & THR_TAG) && !misc[30]) {
           __builtin_amdgcn_s_sleep(1);
           w[j] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (++spins > THR_SPIN_LIMIT) {
-            misc[30] = 1u;
-            raise_fault(tp.fault);
-          }
+          if (++spins > tp.spin_limit) give_up(misc + 30, poison, tp.fault);
         }
         cand[sc[k + sl] + i] = w[j] & ~THR_TAG;
       }
@@ -731,13 +748,63 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
   return valid;
 }
 
+// The order statistics of a whole sample by ONE workgroup from global memory, for a workgroup whose cluster cannot be
+// relied on (a wait on a peer timed out, give_up): `bits_at(i)` recomputes |x0| of element i of the sample -- the
+// same prologue arithmetic as phase 1, hence the same bits --, three radix levels (11 / 11 / 9 bits) find the element of
+// ascending rank `rank`, one more pass its successor.  No peers, no workspace; hist may hold anything on entry and is
+// left zeroed.  Slow (four passes over the sample through L2) and rare.
+template <int T, typename F>
+__device__ __forceinline__ void solo_select(F&& bits_at, int n, uint32_t rank, bool need_next, uint32_t* hist,
+                                            uint32_t* misc, int tid, uint32_t& a, uint32_t& b) {
+#pragma unroll
+  for (int j = 0; j < THR_NB / T; ++j) hist[j * T + tid] = 0u;
+  __syncthreads();
+  uint32_t prefix = 0u, known = 0u, cnt_sel = 0u;
+#pragma unroll 1
+  for (int pass = 0; pass < 3; ++pass) {
+    const int shift = pass == 0 ? 20 : pass == 1 ? 9 : 0;
+    const uint32_t dmask = pass == 2 ? 0x1ffu : 0x7ffu;
+#pragma unroll 1
+    for (int i = tid; i < n; i += T) {
+      const uint32_t u = bits_at(i);
+      if ((u & known) == prefix) atomicAdd(&hist[(u >> shift) & dmask], 1u);
+    }
+    __syncthreads();
+    locate_bin<T>(hist, misc, rank, tid);
+    prefix |= misc[0] << shift;
+    known |= dmask << shift;
+    rank = misc[1];
+    cnt_sel = misc[2];
+  }
+  a = prefix;
+  b = prefix;
+  if (need_next && rank + 1u >= cnt_sel) {  // the successor is the smallest element above a (if any)
+    if (tid == 0) misc[12] = 0x7fffffffu;
+    __syncthreads();
+    uint32_t m = 0x7fffffffu;
+#pragma unroll 1
+    for (int i = tid; i < n; i += T) {
+      const uint32_t u = bits_at(i);
+      if (u > prefix && u < m) m = u;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint32_t o = __shfl_xor(m, d, 64);
+      m = o < m ? o : m;
+    }
+    if ((tid & 63) == 0) atomicMin(&misc[12], m);
+    __syncthreads();
+    if (misc[12] != 0x7fffffffu) b = misc[12];
+  }
+}
+
 // HOT != 0: the usual configuration fixed at compile time -- 16-byte accesses legal, noise-prediction network with the
 // division by the invariant alpha, no mask blend; HOT = 1 with the top-K front end, HOT = 2 with the full level-0
 // histogram -- so that the load and store loops are straight-line code without the wave-uniform branches of the general
 // prologue and their operands (the kernel is as sensitive to its instruction count as to HBM).
 // Everything else runs the same source with HOT = 0.
 template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int T, int HOT>
-__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void stage_thresh_kernel(
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 : DPM_THR_CATCHALL_WAVES, 4))) void stage_thresh_kernel(
     const TS* __restrict__ x_1, const TS* __restrict__ xe_1, const TE* __restrict__ e0_1, const TE* __restrict__ e1_1,
     const TE* __restrict__ g, const TS* __restrict__ h1_1, const TS* __restrict__ h2_1, TS* __restrict__ xo_1,
     TS* __restrict__ mo_1, KParams p, ThrParams tp, KExt ext, const ThrTab tab) {
@@ -745,6 +812,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
   const bool nx = form_needs_x<FORM>(p), nh1 = form_needs_h1<FORM>(p), nh2 = form_needs_h2<FORM>(p);
   const bool g_cfg = guide_is<GUIDE>(DPM_GUIDE_CFG, p), g_cls = guide_is<GUIDE>(DPM_GUIDE_CLASSIFIER, p);
   constexpr int BPT = THR_NB / T;  // histogram bins per thread when all threads touch the histogram
+  // tile rows a thread keeps in flight in the streaming phases: THR_ROWS in the specialised kernels; ONE in the run-time
+  // dispatched catch-all kernel, whose extra operands (mask blend, run-time form / guidance) otherwise push it past the
+  // 128 registers two workgroups per CU leave a wavefront (round 3: 14-19 registers spilled to scratch)
+  constexpr int ROWS = HOT != 0 ? THR_ROWS : 1;
   constexpr uint32_t ABS = 0x7fffffffu;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   float* sx0 = reinterpret_cast<float*>(lds_raw);                    // [chunk]
@@ -787,7 +858,13 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     uint32_t* ws_base = tp.ws;
     int64_t s_loc = s_idx;
     if (tp.bpr > 0) {
-      const uint32_t r = (uint32_t)s_idx / (uint32_t)tp.bpr;
+      // request r = s_idx / bpr, r < MULTI_MAX = 32: five scalar compare-and-add steps instead of a division (whose
+      // reciprocal set-up the compiler hoists out of the sample loop into a register that lives through the whole kernel)
+      static_assert(MULTI_MAX <= 32, "five binary-search steps");
+      uint32_t r = 0u;
+#pragma unroll
+      for (uint32_t bit = 16u; bit; bit >>= 1)
+        if ((uint64_t)(r + bit) * (uint32_t)tp.bpr <= (uint64_t)(uint32_t)s_idx) r += bit;
       s_loc = (int64_t)((uint32_t)s_idx - r * (uint32_t)tp.bpr);
       x = xe = static_cast<const TS*>(tab.x[r]);
       e0 = static_cast<const TE*>(tab.e0[r]);
@@ -834,6 +911,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         }
       }
       misc[25] = pb;
+      // a workgroup that gave up a wait on an earlier sample does not wait on this one either: tell the peers
+      if (k > 1 && misc[30]) __hip_atomic_store(ws + THR_WS_POISON, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       misc[4] = 0u;   // candidate counter
       misc[3] = ABS;  // smallest value above the selected top digit (cluster exchange)
       misc[8] = 0u;   // cluster_select_once: chunk maximum, largest bound, bad-slot flag, maximum of the sample
@@ -844,12 +923,12 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     __syncthreads();
     uint32_t m1 = 0u, m2 = 0u, m3 = 0u, m4 = 0u;  // top-K: the four largest |x0| bit patterns this thread produced
     if (vec) {
-      // THR_ROWS tile rows per iteration, the loads of all of them issued before the first use: the phase is bound by
+      // ROWS tile rows per iteration, the loads of all of them issued before the first use: the phase is bound by
       // the bytes one workgroup keeps in flight (two workgroups per CU, and while one of them selects only one streams)
-      for (int i0 = tid * 4; i0 < n; i0 += THR_ROWS * T * 4) {
-        float vx[THR_ROWS][4], v0[THR_ROWS][4], v1[THR_ROWS][4], vg[THR_ROWS][4];
+      for (int i0 = tid * 4; i0 < n; i0 += ROWS * T * 4) {
+        float vx[ROWS][4], v0[ROWS][4], v1[ROWS][4], vg[ROWS][4];
 #pragma unroll
-        for (int r = 0; r < THR_ROWS; ++r) {
+        for (int r = 0; r < ROWS; ++r) {
           const int ir = i0 + r * T * 4 < n ? i0 + r * T * 4 : i0;  // clamped: loads are unconditional
           load4(XE ? xe : x, base + ir, vx[r]);
           load4<true>(e0, ebase + ir, v0[r]);                     // the network outputs are dead after this kernel
@@ -857,7 +936,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
           if (g_cls) load4<true>(g, base + ir, vg[r]);
         }
 #pragma unroll
-        for (int r = 0; r < THR_ROWS; ++r) {
+        for (int r = 0; r < ROWS; ++r) {
           const int i = i0 + r * T * 4;
           if (r == 0 || i < n) {
             float o[4];
@@ -918,10 +997,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
 
     // phase 3's first operand rows do not depend on the threshold: their loads are issued here and land while the
     // select runs (a sample's select is 4-9 us of barriers and exchanges during which this workgroup moves no data)
-    float vx[THR_ROWS][4], vh1[THR_ROWS][4], vh2[THR_ROWS][4];
+    float vx[ROWS][4], vh1[ROWS][4], vh2[ROWS][4];
     auto fetch_rows = [&](int i0) {  // rows i0, i0 + 4T, ... of this thread; lanes past the end re-read a valid group
 #pragma unroll
-      for (int r = 0; r < THR_ROWS; ++r) {
+      for (int r = 0; r < ROWS; ++r) {
         const int i = i0 + r * T * 4;
         const int64_t gi = base + (i < n ? i : (i0 < n ? i0 : 0));
         if (nx) load4<true>(x, gi, vx[r]);                 // last use of x and of the cached model values
@@ -945,15 +1024,17 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
     const uint32_t pbound = route1 ? misc[25] : 0u;  // cluster-uniform: every workgroup read the same hint words
     if (pbound) {  // the predicted attempt has a slot area of its own (a rejected one leaves its slots dirty)
       solved = cluster_select_once<T>(sx0, n, vec, m1, m2, m3, m4, has, hist, misc, cand,
-                                      ws + THR_WS_WORDS + (size_t)k * THR_SLOTW, tp, k, c, tid, a1, b1, s_idx == grp, pbound);
+                                      ws + THR_WS_WORDS + (size_t)k * THR_SLOTW, tp, k, c, tid, a1, b1, s_idx == grp,
+                                      ws + THR_WS_POISON, pbound);
       route = solved ? 1u : 2u;
     }
     if (route1 && !solved) {
       solved = cluster_select_once<T>(sx0, n, vec, m1, m2, m3, m4, has, hist, misc, cand, ws + THR_WS_WORDS, tp, k, c, tid,
-                                      a1, b1, s_idx == grp && !pbound);
+                                      a1, b1, s_idx == grp && !pbound, ws + THR_WS_POISON);
       if (solved && route != 2u) route = 3u;
     }
     const bool general = !solved;                // the general route runs (for clusters: it dirties the merged histograms)
+    const bool silent = tp.debug_fault == 2 && c == 1;  // testing: this workgroup arrives at no cluster barrier
 
     if (general && topk) {
       // Top-K front end (the usual case: ratio close to 1, K = n - lo elements at or above the wanted one, K much smaller
@@ -971,7 +1052,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
           const uint32_t v = hist[j * T + tid];
           if (v) __hip_atomic_fetch_add(&gh[j * T + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        cluster_barrier(ws + THR_WS_CNT + 4, k, misc + 30, tp.fault);
+        cluster_barrier(ws + THR_WS_CNT + 4, k, misc + 30, ws, tp, silent);
 #pragma unroll
         for (int j = 0; j < BPT; ++j)
           hist[j * T + tid] = __hip_atomic_load(&gh[j * T + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1015,7 +1096,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         if (ok && slot0 <= (uint32_t)THR_GCAP && nc <= (uint32_t)THR_GCAP - slot0)
           for (uint32_t i = tid; i < nc; i += T)
             __hip_atomic_store(&gl[slot0 + i], cand[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cluster_barrier(ws + THR_WS_CNT + 5, k, misc + 30, tp.fault);
+        cluster_barrier(ws + THR_WS_CNT + 5, k, misc + 30, ws, tp, silent);
         const uint32_t total = __hip_atomic_load(gcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = total <= (uint32_t)THR_GCAP;
         if (ok) {
@@ -1071,7 +1152,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
           const uint32_t v = hist[j * T + tid];
           if (v) __hip_atomic_fetch_add(&gh[j * T + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        cluster_barrier(ws + THR_WS_CNT + pass, k, misc + 30, tp.fault);
+        cluster_barrier(ws + THR_WS_CNT + pass, k, misc + 30, ws, tp, silent);
 #pragma unroll
         for (int j = 0; j < BPT; ++j)
           hist[j * T + tid] = __hip_atomic_load(&gh[j * T + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1113,7 +1194,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
           const uint32_t slot0 = misc[5];
           for (uint32_t i = tid; i < nc; i += T)
             __hip_atomic_store(&gl[slot0 + i], cand[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          cluster_barrier(ws + THR_WS_CNT + 1, k, misc + 30, tp.fault);
+          cluster_barrier(ws + THR_WS_CNT + 1, k, misc + 30, ws, tp, silent);
           nc = cnt_sel;
           for (uint32_t i = tid; i < nc; i += T)
             cand[i] = __hip_atomic_load(&gl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1188,11 +1269,39 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
         if (!local_only) {  // workspace words start at zero: keep the minimum as a maximum of the complement
           uint32_t* gm = ws + THR_WS_CNT + 8;
           if (tid == 0) __hip_atomic_fetch_max(gm, ABS - misc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          cluster_barrier(ws + THR_WS_CNT + 3, k, misc + 30, tp.fault);
+          cluster_barrier(ws + THR_WS_CNT + 3, k, misc + 30, ws, tp, silent);
           b = __uint_as_float(ABS - __hip_atomic_load(gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         } else {
           b = __uint_as_float(misc[3]);
         }
+      }
+    }
+    if (k > 1 && general) {
+      // A wait of this workgroup timed out (misc[30]), or -- general route only: the single exchange reads nothing a peer
+      // writes after its own wait -- a peer gave one up and the merged histograms / lists this workgroup read may be
+      // incomplete (THR_WS_POISON, set before the peer went on): the cluster cannot be relied on for this sample.  The
+      // workgroup computes the two order statistics alone (solo_select): same bits, no peers.
+      if (tid == 0) misc[29] = misc[30] | __hip_atomic_load(ws + THR_WS_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (misc[29]) {
+        // wave-uniform bases + a 32-bit element index (a clustered sample has at most THR_KMAX chunks: < 2^31 elements)
+        const int64_t sx = s_loc * tp.per_sample, se = s_loc * (eps_stride ? eps_stride : tp.per_sample);
+        const TS* __restrict__ xs = (XE ? xe : x) + sx;
+        const TE* __restrict__ e0s = e0 + se;
+        const TE* __restrict__ e1s = g_cfg ? e1 + se : e0 + se;
+        const TE* __restrict__ gs = g_cls ? g + sx : e0 + se;
+        auto bits_at = [&](int i) -> uint32_t {
+          const float o = prologue<GUIDE>(to_f32(xs[i]), to_f32(e0s[i]), g_cfg ? to_f32(e1s[i]) : 0.f,
+                                          g_cls ? to_f32(gs[i]) : 0.f, p);
+          return __float_as_uint(o) & ABS;
+        };
+        uint32_t sa, sb;
+        solo_select<T>(bits_at, (int)tp.per_sample, (uint32_t)tp.lo, tp.hi != tp.lo, hist, misc, tid, sa, sb);
+        a = __uint_as_float(sa);
+        b = __uint_as_float(sb);
+        // the operand rows fetched before the select are re-fetched here: not live across this (rare) detour, which
+        // would otherwise cost every launch registers
+        if (vec && n > 0) fetch_rows(tid * 4);
       }
     }
     DPM_TSTAMP(2)
@@ -1221,11 +1330,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
 
     // phase 3: clamp, scale, combine, epilogue, store
     if (vec) {
-      // THR_ROWS tile rows per iteration, the loads of all issued before the first use (explicit: the write-through
+      // ROWS tile rows per iteration, the loads of all issued before the first use (explicit: the write-through
       // stores are assembly the loop unroller will not duplicate)
-      for (int i0 = tid * 4; i0 < n; i0 += THR_ROWS * T * 4) {  // (the first rows were fetched before the select)
+      for (int i0 = tid * 4; i0 < n; i0 += ROWS * T * 4) {  // (the first rows were fetched before the select)
 #pragma unroll
-        for (int r = 0; r < THR_ROWS; ++r) {
+        for (int r = 0; r < ROWS; ++r) {
           const int i = i0 + r * T * 4;
           if (r == 0 || i < n) {  // per lane: a later row may end before this lane
             const int64_t gi = base + i;
@@ -1269,7 +1378,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
             if (store_m) store4<true>(mo, gi, om);                  // read again only after the next network call
           }
         }
-        if (i0 + THR_ROWS * T * 4 < n) fetch_rows(i0 + THR_ROWS * T * 4);  // the next iteration's operands
+        if (i0 + ROWS * T * 4 < n) fetch_rows(i0 + ROWS * T * 4);  // the next iteration's operands
       }
     } else {
       for (int i = tid; i < n; i += T) {
@@ -1296,6 +1405,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) void 
           for (uint32_t i = tid; i < (uint32_t)THR_WS_WORDS; i += T) ws[i] = 0u;
         } else if (tid == 0) {
           ws[THR_WS_DONE] = 0u;
+          ws[THR_WS_POISON] = 0u;  // (a peer that gave up takes the general route itself, its solved peers end up here)
         }
       }
     }

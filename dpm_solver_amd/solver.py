@@ -13,7 +13,6 @@ methods.  What differs is where the work happens:
 """
 import ctypes as C
 import inspect
-import weakref
 
 import numpy as np
 import torch
@@ -62,13 +61,44 @@ _stage_launch_raw = L.lib.dpm_stage_launch
 _stage_launch_multi_raw = L.lib.dpm_stage_launch_multi
 
 
-def _conv(t, dt):
-    """`t` as a contiguous tensor of dtype `dt` (no copy when it already is one)"""
+def _mf_of(t):
+    """The memory format of a dense tensor that is NOT laid out in the default order: torch.channels_last (4-D, NHWC) /
+    torch.channels_last_3d (5-D); None = default-contiguous, or neither.  The stage kernels are elementwise over the flat
+    storage and thresholding only needs every sample to be one contiguous block -- both hold for these formats -- so a
+    trajectory whose network works in NHWC (MIOpen's preferred layout on gfx9) runs on the network's storage untouched,
+    where the reference's ATen kernels would read the outputs strided (ref :439, :827-831 are layout-agnostic)."""
+    if t.is_contiguous():
+        return None
+    d = t.dim()
+    if d == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return torch.channels_last
+    if d == 5 and t.is_contiguous(memory_format=torch.channels_last_3d):
+        return torch.channels_last_3d
+    return None
+
+
+def _conv(t, dt, mf=None):
+    """`t` as a dense tensor of dtype `dt` in memory format `mf` (None: default-contiguous); no copy when it already is one"""
     if t is None:
         return None
     if t.dtype != dt:
         t = t.to(dt)
-    return t if t.is_contiguous() else t.contiguous()
+    if mf is None:
+        return t if t.is_contiguous() else t.contiguous()
+    return t if t.is_contiguous(memory_format=mf) else t.contiguous(memory_format=mf)
+
+
+def _empty(shape, dt, dev, mf=None):
+    return torch.empty(shape, dtype=dt, device=dev, memory_format=mf if mf is not None else torch.contiguous_format)
+
+
+def _in_layout_of(t, ref):
+    """`t` in the memory format of `ref` (what ATen's elementwise kernels would have returned for an update whose first
+    operand is `ref`); a no-op when it already is, or when `ref` is in neither of the two formats"""
+    if ref.is_contiguous():
+        return _conv(t, t.dtype)
+    mf = _mf_of(ref)
+    return t if mf is None else _conv(t, t.dtype, mf)
 
 
 def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=None):
@@ -81,33 +111,37 @@ def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=No
     ref_t = x if x is not None else xe
     dev = ref_t.device
     sd = state_dtype
-    x, xe, h1, h2 = _conv(x, sd), _conv(xe, sd), _conv(h1, sd), _conv(h2, sd)
+    # the network's layout decides the launch's: a channels_last output is consumed in place and every other operand is
+    # brought to that order (no-ops from the second stage on, the states this function hands out are in it).  The mask
+    # blend's operands are indexed with a flat period in the default order: such launches stay there.
+    mf = _mf_of(e0) if (e0.shape == ref_t.shape and not (ext is not None and ext.get("blend") is not None)) else None
+    x, xe, h1, h2 = _conv(x, sd, mf), _conv(xe, sd, mf), _conv(h1, sd, mf), _conv(h2, sd, mf)
     ed = e0.dtype
     if ed not in _DT or (sd != torch.float32 and ed != sd):
         ed = sd  # only (fp32 state, any eps) and equal low-precision pairs have kernels
     eps_stride = 0
-    if e0.dtype == ed and not e0.is_contiguous() and _sample_strided(e0) and e0.shape == ref_t.shape and (
+    if mf is None and e0.dtype == ed and not e0.is_contiguous() and _sample_strided(e0) and e0.shape == ref_t.shape and (
             e1 is None or (e1.dtype == ed and _sample_strided(e1) and e1.stride(0) == e0.stride(0))):
         eps_stride = int(e0.stride(0))          # read the slice in place: no .contiguous() copy
         g = _conv(g, ed)
     else:
-        e0, e1, g = _conv(e0, ed), _conv(e1, ed), _conv(g, ed)
+        e0, e1, g = _conv(e0, ed, mf), _conv(e1, ed, mf), _conv(g, ed, mf)
     shape = ref_t.shape
     B = int(shape[0]) if len(shape) > 0 else 1
     b = L.Buffers()                               # zero-initialised
     x2 = None
     if ext is not None and ext.get("dup") and len(shape) > 0:
-        x2 = torch.empty((2 * B,) + tuple(shape[1:]), dtype=sd, device=dev)
+        x2 = _empty((2 * B,) + tuple(shape[1:]), sd, dev, mf)
         x_out = x2[:B]
         ext["x2"] = x2
         b.x_out2 = x2.data_ptr() + x_out.numel() * x_out.element_size()
     else:
-        x_out = torch.empty(shape, dtype=sd, device=dev)
+        x_out = _empty(shape, sd, dev, mf)
     store = bool(st.flags & L.F_STORE_M) if want_m is None else want_m
     m_out = None
     if store:
         st.flags |= L.F_STORE_M
-        m_out = torch.empty(shape, dtype=sd, device=dev)
+        m_out = _empty(shape, sd, dev, mf)
         b.m_out = m_out.data_ptr()
     else:
         st.flags &= ~L.F_STORE_M
@@ -153,22 +187,6 @@ def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=No
 
 
 _WS_CACHE = {}
-_WS_LIVE = weakref.WeakSet()          # every thresholding workspace handed to a launch record (_FastRun)
-
-
-def _on_cluster_fault():
-    """DPM_ERR_FAULT: a clustered thresholding launch gave up waiting for a peer; the workspace it used is dirty and the
-    contract (dpm_threshold_workspace_bytes) wants it zero-filled again.  The fault word does not say which one, so
-    every cached workspace is evicted / zeroed before the error reaches the caller."""
-    _WS_CACHE.clear()
-    for ws in list(_WS_LIVE):
-        try:
-            ws.zero_()
-        except Exception:
-            pass
-
-
-L.fault_hooks.append(_on_cluster_fault)
 
 
 def _cluster_workspace(dev, idx, stream, nbytes):
@@ -230,6 +248,7 @@ class _Plan:
             self.stages.append(st)
         self._dev = {}
         self._views = {}
+        self.times_written = False
         # static buffer roles per stage, as plan_run_impl (dpm_host.cpp) rotates them: indices into
         # [x_T, scratch 1, scratch 2, scratch 3] for the update's x, the state the network saw, and the output
         self.roles = []
@@ -256,26 +275,42 @@ class _Plan:
 
     def time_views(self, device, batch, cfg):
         """per stage: 0-dim t_eval / t_out, t_eval and t_input expanded to (batch,) and, under classifier-free
-        guidance, t_input expanded to (2*batch,) -- views of times(), built once per (device, batch)"""
+        guidance, t_input expanded to (2*batch,) -- views of times(), built once per (device, batch).
+
+        The vectors are SHARED by every later call of the plan (the reference hands the network a fresh tensor per call,
+        ref :404).  A network or callback that writes into its time argument in place (`t.mul_(1000)`) is detected through
+        the tensors' version counters: the next call finds them changed, rebuilds the vectors from the host plan and sets
+        `times_written` -- DPM_Solver then hands out clones (`fresh_time_tensors`).  Inside one trajectory every row is
+        handed out once, so the trajectory during which the first write happens is still correct."""
         key = (str(device), int(batch), bool(cfg))
         hit = self._views.get(key)
+        if hit is not None and tuple(t._version for t in hit["base"]) != hit["ver"]:
+            self._views.pop(key)
+            self._dev.pop(str(device), None)
+            self.times_written = True
+            hit = None
         if hit is None:
             T = self.times(device)
             n = len(self.stages)
             # contiguous (batch,) vectors like the reference hands to the network (t.expand(B) of a fresh tensor,
             # torch.cat([t] * 2) under CFG) for models that need contiguous inputs.  Materialised once per (plan, batch)
-            # -- two small kernels here, none per step -- and SHARED by every later call of the plan: a network must not
-            # write into its time argument (DPM_Solver.fresh_time_tensors = True hands out a clone per call instead).
-            te = T[0].reshape(n, 1).expand(n, batch).contiguous()
-            ti = T[1].reshape(n, 1).expand(n, 2 * batch if cfg else batch).contiguous()
+            # -- two small kernels here, none per step.  `repeat` always copies: the vectors never alias times().
+            te = T[0].reshape(n, 1).repeat(1, batch)
+            ti = T[1].reshape(n, 1).repeat(1, 2 * batch if cfg else batch)
             if len(self._views) >= 8:                 # bounded: one entry per (device, batch, cfg)
                 self._views.pop(next(iter(self._views)))
             hit = dict(t_eval=[T[0, i] for i in range(n)], t_out=[T[2, i] for i in range(n)],
                        t_eval_b=[te[i] for i in range(n)],
                        t_input_b=[ti[i, :batch] for i in range(n)],
-                       t_input_2b=[ti[i] for i in range(n)] if cfg else None)
+                       t_input_2b=[ti[i] for i in range(n)] if cfg else None,
+                       base=(T, te, ti))
+            hit["ver"] = tuple(t._version for t in hit["base"])
             self._views[key] = hit
         return hit
+
+    def written(self, V):
+        """True when a network / callback wrote into the shared time tensors of `V` since they were built"""
+        return tuple(t._version for t in V["base"]) != V["ver"]
 
     def __del__(self):
         if getattr(self, "handle", None):
@@ -296,15 +331,22 @@ class _Cloning:
         return self._items[i].clone()
 
 
-def _bind_outputs(b, e0, e1, g, sd, shape):
+def _bind_outputs(b, e0, e1, g, sd, shape, mf=None):
     """Point a launch record at the fresh network outputs (e0 / e1 / g): choose the eps dtype the kernels have
     ((fp32 state, any eps) and equal low-precision pairs), read channel slices of a wider output in place
-    (eps_stride), convert / copy only when there is no kernel for the layout.  Returns the tensors to keep alive."""
+    (eps_stride), convert / copy only when there is no kernel for the layout.  `mf`: the memory format the run's
+    buffers are in (None: default-contiguous; channels_last when the network works in NHWC, see _mf_of) -- outputs in
+    that format are bound as they are.  Returns the tensors to keep alive."""
     ed = e0.dtype
     if ed is not sd and (sd is not torch.float32 or ed not in _DT):
         ed = sd
     stride = 0
-    if e0.dtype is ed and e0.is_contiguous() and (e1 is None or (e1.dtype is ed and e1.is_contiguous())) \
+    if mf is not None:
+        dense = lambda t: t.is_contiguous(memory_format=mf)
+        if not (e0.dtype is ed and dense(e0) and (e1 is None or (e1.dtype is ed and dense(e1)))
+                and (g is None or (g.dtype is ed and dense(g)))):
+            e0, e1, g = _conv(e0, ed, mf), _conv(e1, ed, mf), _conv(g, ed, mf)
+    elif e0.dtype is ed and e0.is_contiguous() and (e1 is None or (e1.dtype is ed and e1.is_contiguous())) \
             and (g is None or (g.dtype is ed and g.is_contiguous())):
         pass
     elif e0.dtype is ed and not e0.is_contiguous() and _sample_strided(e0) and e0.shape == shape and (
@@ -410,16 +452,18 @@ class _FastRun:
     Scratch buffers are internal (never handed out), so reusing them across calls on the same stream is safe; the
     result of a call is always a fresh tensor."""
 
-    def __init__(self, solver, plan, shape, sd, device, dup):
+    def __init__(self, solver, plan, shape, sd, device, dup, mf=None):
         B = int(shape[0])
         n = 1
         for d in shape:
             n *= int(d)
-        self.shape, self.sd, self.dup, self.n = tuple(shape), sd, dup, n
+        self.shape, self.sd, self.dup, self.n, self.mf = tuple(shape), sd, dup, n, mf
         full = ((2 * B,) + tuple(shape[1:])) if dup else tuple(shape)
-        self.xfull = [None] + [torch.empty(full, dtype=sd, device=device) for _ in range(3)]   # [2B,...] under CFG
+        # scratch states and cached model values in the run's memory format (_mf_of): the network is handed states in
+        # the layout it answers in, the kernels see flat storage either way
+        self.xfull = [None] + [_empty(full, sd, device, mf) for _ in range(3)]   # [2B,...] under CFG
         self.xbuf = [None] + [t[:B] for t in self.xfull[1:]]
-        self.hist = [torch.empty(shape, dtype=sd, device=device) for _ in range(plan.slots)]
+        self.hist = [_empty(shape, sd, device, mf) for _ in range(plan.slots)]
         self.ws = None
         self.thr_hint = None
         nstg = len(plan.stages)
@@ -451,7 +495,6 @@ class _FastRun:
                 if nb:
                     if self.ws is None:      # zero-filled once; every launch leaves it zero-filled
                         self.ws = torch.zeros(nb, dtype=torch.uint8, device=device)
-                        _WS_LIVE.add(self.ws)
                         # per-sample state the clustered kernel carries from stage to stage (dpm_buffers.thr_hint): the
                         # previous thresholds, from which it predicts the next select bound; stage 0 resets it
                         self.thr_hint = torch.zeros(L.THR_HINT_WORDS * max(B, 1), dtype=torch.float32, device=device)
@@ -463,6 +506,15 @@ class _FastRun:
 
 
 class DPM_Solver:
+    # Engine options (extensions; class-level defaults, settable per instance).
+    # adaptive solver: controller on the device (no host synchronisation per iteration); False = the reference's host
+    # loop (one .item() per iteration, ref :1002).  With the device controller the host enqueues `adaptive_lookahead`
+    # iterations ahead of the device's decisions: up to that many iterations enqueued after t_end was reached still call
+    # the network (their solver kernels are no-ops) -- the reported NFE and the result do not change, the number of
+    # network calls can be (lookahead + 1) * order larger than the reference's.
+    adaptive_on_device = True
+    adaptive_lookahead = 1
+
     def __init__(self, model_fn, noise_schedule, algorithm_type="dpmsolver++", correcting_x0_fn=None,
                  correcting_xt_fn=None, thresholding_max_val=1., dynamic_thresholding_ratio=0.995,
                  state_dtype=None):
@@ -497,8 +549,9 @@ class DPM_Solver:
         self.thresholding_max_val = thresholding_max_val
         self._state_dtype = state_dtype
         # The (batch,) time vectors handed to the network are built once per (plan, batch) and shared by every call
-        # (the reference makes a fresh tensor per call, ref :404).  A network that writes into its time argument needs
-        # fresh_time_tensors = True: a clone per call.
+        # (the reference makes a fresh tensor per call, ref :404).  A network that writes into its time argument gets a
+        # clone per call: fresh_time_tensors = True, switched on automatically when such a write is detected
+        # (_Plan.time_views).
         self.fresh_time_tensors = False
         self._plans = {}
         self._fast = {}
@@ -507,9 +560,6 @@ class DPM_Solver:
         self._adaptive_handles = {}
         # adaptive solver: optional hook applied to the 0-dim batch-maximum error before the controller reads it
         self.error_reduce = None
-        # adaptive solver: controller on the device (no host synchronisation per iteration); False = the host loop
-        self.adaptive_on_device = True
-        self.adaptive_lookahead = 1          # iterations the host enqueues ahead of the device's decisions
         self.adaptive_max_iterations = None  # bound of the loop (required knowledge under hipGraph capture: default 64)
 
     # ------------------------------------------------------------------------------------------
@@ -548,6 +598,13 @@ class DPM_Solver:
     def _tt(self, value, device, shape1=False):
         t = torch.full((1,) if shape1 else (), float(value), dtype=torch.float32, device=device)
         return t
+
+    def _time_views(self, plan, device, batch, cfg):
+        """plan.time_views; a network that was caught writing into the shared time vectors gets clones from now on"""
+        V = plan.time_views(device, batch, cfg)
+        if plan.times_written and not self.fresh_time_tensors:
+            self.fresh_time_tensors = True
+        return V
 
     def _call_x0(self, x0, t):
         if self._user_x0_nargs == 1:
@@ -1098,7 +1155,7 @@ class DPM_Solver:
         device = xs[0].device
         stream, idx, capturing, other = _launch_ctx(device)
         R, shape = len(xs), xs[0].shape
-        V = plan.time_views(device, shape[0], cfg)
+        V = self._time_views(plan, device, shape[0], cfg)
         tb, ti, t2 = V["t_eval_b"], V["t_input_b"], V["t_input_2b"]
         if self.fresh_time_tensors:
             tb, ti, t2 = _Cloning(tb), _Cloning(ti), (_Cloning(t2) if cfg else None)
@@ -1108,12 +1165,19 @@ class DPM_Solver:
             if wrapped is not None:
                 return wrapped.raw_outputs(x_t, tb[i], ti[i], t2[i] if cfg else None, x_in2=x2)
             return model_fn(x_t, tb[i]), None, None
-        first = [net(x, 0) for x in xs]          # on the callers' x_T (ref :1179, :1222); decides the state dtype
+        first0 = net(xs[0], 0)                   # on the callers' x_T (ref :1179, :1222); decides the state dtype
+        if not self.fresh_time_tensors and plan.written(V):
+            # the network edits its time argument in place and the requests of a stage share one row: clones from here on
+            self.fresh_time_tensors = True
+            V = self._time_views(plan, device, shape[0], cfg)
+            tb, ti, t2 = _Cloning(V["t_eval_b"]), _Cloning(V["t_input_b"]), (_Cloning(V["t_input_2b"]) if cfg else None)
+        first = [first0] + [net(x, 0) for x in xs[1:]]
         sd = self._promoted(sd, first[0][0])
-        key = (id(plan), tuple(shape), sd, idx, stream, cfg, R)
+        mf = _mf_of(first[0][0]) if first[0][0].shape == shape else None
+        key = (id(plan), tuple(shape), sd, idx, stream, cfg, R, mf)
         grp = None if capturing else self._fast_groups.get(key)
         if grp is None:
-            runs = [_FastRun(self, plan, shape, sd, device, cfg) for _ in range(R)]
+            runs = [_FastRun(self, plan, shape, sd, device, cfg, mf) for _ in range(R)]
             arrs = []
             for i in range(len(plan.stages)):
                 a = (L.Buffers * R)()
@@ -1126,8 +1190,8 @@ class DPM_Solver:
                     self._fast_groups.pop(next(iter(self._fast_groups)))
                 self._fast_groups[key] = grp
         runs, arrs = grp
-        x0s = [_conv(x, sd) for x in xs]
-        outs = [torch.empty(shape, dtype=sd, device=device) for _ in range(R)]
+        x0s = [_conv(x, sd, mf) for x in xs]
+        outs = [_empty(shape, sd, device, mf) for _ in range(R)]
         last, roles = runs[0].last, plan.roles
         launch = _stage_launch_multi_raw
         for i, a in enumerate(arrs):
@@ -1147,7 +1211,7 @@ class DPM_Solver:
                 if i == last:
                     b.x_out = outs[r].data_ptr()
                 e = first[r] if i == 0 else net(xe_t, i, x2)
-                keep.append(_bind_outputs(b, e[0], e[1], e[2], sd, shape))
+                keep.append(_bind_outputs(b, e[0], e[1], e[2], sd, shape, mf))
             st_ref = runs[0].refs[i][0]
             if other:
                 with torch.cuda.device(idx):
@@ -1156,7 +1220,7 @@ class DPM_Solver:
                 rc = launch(st_ref, a, R, stream)
             if rc:
                 L.check(rc)
-        return outs
+        return [_in_layout_of(o, x) for o, x in zip(outs, xs)]
 
     def capture(self, x, warmup=2, **sample_kwargs):
         """hipGraph-capture `sample(x, **sample_kwargs)` for a fixed shape (extension).
@@ -1182,7 +1246,7 @@ class DPM_Solver:
         device = x.device
         stream, idx, capturing, other = _launch_ctx(device)
         B = x.shape[0]
-        V = plan.time_views(device, B, cfg)
+        V = self._time_views(plan, device, B, cfg)
         tb, ti, t2 = V["t_eval_b"], V["t_input_b"], V["t_input_2b"]
         wrapped = self._wrapped
         model_fn = self._model_fn
@@ -1195,17 +1259,20 @@ class DPM_Solver:
         else:
             first = (model_fn(x, tb[0]), None, None)
         sd = self._promoted(sd, first[0])
-        key = (id(plan), tuple(x.shape), sd, idx, stream, cfg)
+        # the network's layout is the run's (see _mf_of): an NHWC network gets NHWC states and its outputs are bound as
+        # they are; x_T is brought there once and the result goes back to x_T's layout, like ATen would return it
+        mf = _mf_of(first[0]) if first[0].shape == x.shape else None
+        key = (id(plan), tuple(x.shape), sd, idx, stream, cfg, mf)
         fr = None if capturing else self._fast.get(key)      # a captured graph bakes its buffers in: give it its own
         if fr is None:
-            fr = _FastRun(self, plan, x.shape, sd, device, cfg)
+            fr = _FastRun(self, plan, x.shape, sd, device, cfg, mf)
             if not capturing:
                 if len(self._fast) >= 8:
                     self._fast.pop(next(iter(self._fast)))
                 self._fast[key] = fr
-        x0 = _conv(x, sd)
+        x0 = _conv(x, sd, mf)
         p0 = x0.data_ptr()
-        out = torch.empty(x.shape, dtype=sd, device=device)
+        out = _empty(x.shape, sd, device, mf)
         bufs, refs, roles = fr.bufs, fr.refs, plan.roles
         bufs[fr.last].x_out = out.data_ptr()
         xbuf, xfull = fr.xbuf, fr.xfull
@@ -1226,7 +1293,7 @@ class DPM_Solver:
                 e0, e1, g = wrapped.raw_outputs(xe_t, tb[i], ti[i], t2[i] if cfg else None, x_in2=x2)
             else:
                 e0, e1, g = model_fn(xe_t, tb[i]), None, None
-            keep = _bind_outputs(b, e0, e1, g, sd, x.shape)
+            keep = _bind_outputs(b, e0, e1, g, sd, x.shape, mf)
             if other:
                 with torch.cuda.device(idx):
                     rc = launch(refs[i][0], refs[i][1], stream)
@@ -1234,7 +1301,7 @@ class DPM_Solver:
                 rc = launch(refs[i][0], refs[i][1], stream)
             if rc:
                 L.check(rc)
-        return out
+        return out if (mf is None and x.is_contiguous()) else _in_layout_of(out, x)
 
     def _run_plan(self, plan, x, method, cxt, keep, intermediates):
         device = x.device
@@ -1244,7 +1311,7 @@ class DPM_Solver:
             if self._group is not None:
                 return self._run_plan_group(plan, self._group, sd, cfg)
             return self._run_plan_fast(plan, x, sd, cfg)
-        V = plan.time_views(device, x.shape[0] if x.dim() > 0 else 1, cfg)
+        V = self._time_views(plan, device, x.shape[0] if x.dim() > 0 else 1, cfg)
         if self.fresh_time_tensors:
             V = dict(V, t_eval_b=_Cloning(V["t_eval_b"]), t_input_b=_Cloning(V["t_input_b"]),
                      t_input_2b=_Cloning(V["t_input_2b"]) if cfg else None)
@@ -1289,12 +1356,12 @@ class DPM_Solver:
                     t_cb = V["t_out"][i].reshape(1) if st.form == L.FORM_DENOISE else V["t_out"][i]
                     x_out = cxt(x_out, t_cb, st.outer_step)
                 if keep:
-                    intermediates.append(x_out)
+                    intermediates.append(_in_layout_of(x_out, x))
                 state, state2 = x_out, ext.get("x2")
                 tmp, tmp2 = None, None
             else:
                 tmp, tmp2 = x_out, ext.get("x2")
-        return state
+        return _in_layout_of(state, x) if x.dim() > 0 else state
 
 
 class GraphedSample:

@@ -99,6 +99,13 @@ int main(int argc, char** argv) {
   for (int64_t i = 0; i < n; ++i) hx[i] = pseudo_normal(&seed);
   for (int64_t i = 0; i < n; ++i) he[i] = pseudo_normal(&seed);
 
+  /* load-time checks of the ABI (include/dpm_hip.h): library not older than the header, struct layouts as compiled */
+  if (dpm_version() < DPM_HIP_VERSION || dpm_sizeof(DPM_SIZEOF_RUN_BUFFERS) != sizeof(dpm_run_buffers) ||
+      dpm_sizeof(DPM_SIZEOF_STAGE) != sizeof(dpm_stage) || dpm_sizeof(DPM_SIZEOF_PLAN_DESC) != sizeof(dpm_plan_desc)) {
+    fprintf(stderr, "libdpm_hip.so (version %d) does not match the header this host was built against (%d)\n", dpm_version(),
+            DPM_HIP_VERSION);
+    return 5;
+  }
   hipStream_t stream;
   CHECK_HIP(hipStreamCreate(&stream));
   dpm_run_buffers rb;

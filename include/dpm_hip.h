@@ -33,7 +33,13 @@
 extern "C" {
 #endif
 
-#define DPM_HIP_VERSION 100 /* major*10000 + minor*100 + patch */
+/* major*10000 + minor*100 + patch.  History: 100 rounds 1-2; 101 dpm_buffers / dpm_run_buffers gained the trailing
+   `thr_hint` pointer; 102 dpm_cluster_timeout_poll, DPM_TUNE_THR_SPIN_LIMIT / _DEBUG_FAULT, DPM_ERR_FAULT retired.
+   The structs grow at their END only.  A host MUST zero-initialise every struct it passes (memset / = {0}: new trailing
+   fields then read as "absent") and SHOULD check at load time that dpm_version() >= the version it was built against and
+   that dpm_sizeof(DPM_SIZEOF_*) == its own sizeof() -- a host compiled against an older header passes shorter structs,
+   and the library would read past their end (examples/native_host.c and dpm_solver_amd/_lib.py do both checks). */
+#define DPM_HIP_VERSION 102
 
 /* ---- status --------------------------------------------------------------------------- */
 enum {
@@ -43,8 +49,10 @@ enum {
   DPM_ERR_ALIGN = -3,       /* a buffer is not aligned as the entry point requires (dpm_prefetch_launch)     */
   DPM_ERR_NOMEM = -4,
   DPM_ERR_CALLBACK = -5,    /* the model callback of dpm_plan_run returned non-zero           */
-  DPM_ERR_FAULT = -6        /* an earlier clustered thresholding launch gave up waiting for a peer
-                               workgroup (bounded wait, never a trap): its results are invalid    */
+  DPM_ERR_FAULT = -6        /* retired (version 102): a clustered thresholding launch whose wait on a peer
+                               workgroup times out now recovers inside the kernel -- the workgroup computes
+                               the sample's order statistics alone, results unchanged -- and no entry point
+                               returns this code any more; see dpm_cluster_timeout_poll                      */
 };
 
 /* ---- enumerations (values are ABI) ----------------------------------------------------- */
@@ -245,8 +253,16 @@ int dpm_stage_launch_multi(const dpm_stage* st, const dpm_buffers* bs, int n_req
    workgroup cluster of a sample exchanges its candidates (small batches, samples beyond 12288 elements).
    Pass it as dpm_buffers.workspace.  Contract: the caller ZERO-FILLS the workspace once (hipMemset) before its first use;
    every launch leaves it zero-filled again (the last workgroup of a cluster cleans up), so no launch pays for a clear.
-   Launches that share a workspace must be ordered (same stream).  After DPM_ERR_FAULT zero-fill it again. */
+   Launches that share a workspace must be ordered (same stream).
+   Cluster waits are bounded (DPM_TUNE_THR_SPIN_LIMIT polls, milliseconds).  When the peers of a cluster are kept off the
+   chip that long -- another process running clusters on the same GPU, two clustered graphs replayed concurrently -- the
+   waiting workgroup gives up, computes the order statistics of its sample alone from global memory and carries on:
+   the launch's results are the same bits, the workspace is left zero-filled as always, nothing is reported as an error. */
 size_t dpm_threshold_workspace_bytes(int64_t batch, int64_t per_sample);
+/* diagnostics: 1 when a cluster wait of any clustered thresholding launch of this process timed out (and was recovered
+   from) since the last call, else 0.  Reads and clears a host-mapped word; meaningful after the launches in question
+   have completed (no synchronisation here). */
+int dpm_cluster_timeout_poll(void);
 #define DPM_THR_HINT_WORDS 4   /* floats per sample of dpm_buffers.thr_hint / dpm_run_buffers.thr_hint */
 /* x_t = alpha_t*x + sigma_t*noise for nt times (add_noise, ref :1012-1030); out is [nt, n] */
 int dpm_add_noise_launch(const dpm_schedule* s, const float* t_host, int nt, const void* x, const void* noise,
@@ -387,8 +403,13 @@ enum {
   DPM_TUNE_CLUSTER_ONE_HOP = 7,     /* 0: clusters skip the single-exchange select (testing the general route)     */
   DPM_TUNE_MULTI_XCD_REMAP = 8,     /* fused launch gives every XCD one contiguous eighth of the tiles: 1 on, 0 off,
                                        -1 (default) on for 2-byte states only (measured +1.4 % fp16, -3 % fp32)    */
-  DPM_TUNE_THR_PREDICT = 9          /* 1 (default): clustered thresholding launches predict the select bound from
+  DPM_TUNE_THR_PREDICT = 9,         /* 1 (default): clustered thresholding launches predict the select bound from
                                        dpm_buffers.thr_hint; 0: the hint is still maintained but never used          */
+  DPM_TUNE_THR_SPIN_LIMIT = 10,     /* polls (a microsecond or two each) before a wait on a cluster peer gives up and
+                                       the workgroup finishes its sample alone; default 4096                          */
+  DPM_TUNE_THR_DEBUG_FAULT = 11     /* testing.  1: every cluster wait gives up at its first unsuccessful poll;
+                                       2: workgroup 1 of every cluster neither publishes nor arrives (its peers time
+                                       out).  Results must not change.  0 (default): off                              */
 };
 int dpm_tuning_set(int knob, int value);
 int dpm_tuning_get(int knob);

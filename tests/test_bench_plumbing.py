@@ -1,0 +1,78 @@
+"""bench.py's N > 1 plumbing under two gloo ranks on CPU: the driver launches
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`
+on an 8-GPU node that no round has had so far.  With DPM_BENCH_STUB=1 the same file runs its rank / world handling, the
+process group, the barrier-bracketed timed region with the MAX over ranks, `per_rank_wall_s`, the final all-gather and
+`gather_ms`, and prints its JSON line -- with the timed region replaced by a sleep (slower on rank 1) and every measurement
+field nulled ("stub": true)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("world", [2, 1])
+def test_bench_multi_rank_plumbing_with_a_stubbed_timed_region(world):
+    env = dict(os.environ, DPM_BENCH_STUB="1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4", "--warmup", "1",
+           "--requests", "2", "--trajectories-per-step", "3", "--min-region-s", "0.002", "--no-secondary", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # ONE JSON line, from rank 0
+    line = json.loads(lines[0])
+    assert line["stub"] is True and line["value"] is None and line["roofline"] is None
+    assert line["n_gpus"] == world and line["steps"] >= 4 and line["steps_requested"] == 4 and line["warmup"] == 1
+    assert line["scaling"] == "weak" and line["higher_is_better"] is True and line["vs_baseline"] is None
+    assert line["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    cfg = line["config"]
+    assert cfg["requests_in_flight_per_gpu"] == 2 and cfg["trajectories_per_step"] == 3
+    assert cfg["parallelism"].startswith("batch-sharded x%d" % world) and "model" not in cfg
+    w = line["per_rank_wall_s"]
+    assert 0 < w["min"] <= w["max"]
+    # the reported time is the slowest rank's: ms_per_step * steps == per_rank_wall_s.max
+    assert abs(line["ms_per_step"] * line["steps"] / 1e3 - w["max"]) < 2e-3 * max(1.0, w["max"])
+    # rank r sleeps (1 + r) x 0.2 ms per trajectory and the region ends with a barrier: the reported time covers the SLOWEST
+    # rank's work (every rank waits for it, so min and max agree to the barrier's skew)
+    assert w["max"] >= line["steps"] * 3 * 2e-4 * world, (w, line["steps"])
+    assert line["gather_ms"] is not None and line["gather_ms"] >= 0     # the single end-of-sampling collective, timed apart
+    assert "cpu_baseline" not in line                                   # rank 0 at N = 1 only, and not with --no-cpu-baseline
+
+
+def test_cpu_baseline_record_carries_the_reference_figure_on_top():
+    """where the reference is absent (the GPU box) `cpu_baseline` leads with the reference's own
+    figure from the committed MI355X-box measurement, marked as not measured in this run; the live port timing sits below."""
+    sys.path.insert(0, ROOT)
+    import bench
+    old = os.environ.get("DPM_REFERENCE_DIR")
+    os.environ["DPM_REFERENCE_DIR"] = "/nonexistent"
+    port_fn = bench.cpu_baseline_port
+    bench.cpu_baseline_port = lambda ac, budget_s=8.0: dict(value=0.0016, unit="Msamples/s", cores=1, kind="port", sample="stub")
+    try:
+        out = bench.cpu_baseline(bench.sd_alphas_cumprod())
+    finally:
+        bench.cpu_baseline_port = port_fn
+        if old is None:
+            os.environ.pop("DPM_REFERENCE_DIR")
+        else:
+            os.environ["DPM_REFERENCE_DIR"] = old
+    assert out["kind"] == "reference" and out["measured_in_this_run"] is False
+    assert out["source"].startswith("profiles/cpu_baseline_reference_gpubox.json")
+    assert out["cores"] == out["threads"] == out["best"]["threads"] and out["host_cores"] >= out["cores"]
+    assert out["unit"] == "Msamples/s" and out["value"] == out["best"]["value"]
+    assert out["port_live"]["kind"] == "port" and out["port_live"]["measured_in_this_run"] is True

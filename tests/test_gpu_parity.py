@@ -701,3 +701,102 @@ def test_threshold_bound_misprediction_is_detected():
     finally:
         L.lib.dpm_tuning_set(L.TUNE_THR_PREDICT, 1)
     assert torch.isfinite(got).all() and torch.equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------------
+# round 4: a cluster wait that times out is recovered from inside the kernel
+# ------------------------------------------------------------------------------------------------
+class _Tuned:
+    """dpm_tuning_set for the duration of a `with` block"""
+
+    def __init__(self, **knobs):
+        self.knobs = {getattr(L, "TUNE_" + k.upper()): v for k, v in knobs.items()}
+
+    def __enter__(self):
+        self.old = {k: L.lib.dpm_tuning_get(k) for k in self.knobs}
+        for k, v in self.knobs.items():
+            L.check(L.lib.dpm_tuning_set(k, v))
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            L.lib.dpm_tuning_set(k, v)
+
+
+def _thr_solver(ns, model=lambda xx, t: xx * 0.5, **kw):
+    return D.DPM_Solver(D.model_wrapper(model, ns, **kw), ns, correcting_x0_fn="dynamic_thresholding")
+
+
+@pytest.mark.parametrize("shape", [(32, 3, 64, 64), (5, 3, 64, 64), (2, 3, 160, 160)])
+@pytest.mark.parametrize("mode,one_hop", [(1, 1), (2, 1), (1, 0), (2, 0)])
+def test_cluster_wait_timeout_is_recovered_inside_the_kernel(shape, mode, one_hop):
+    """Forced faults -- mode 1: every wait on a peer gives up at its first unsuccessful poll; mode 2: workgroup 1 of every
+    cluster neither publishes nor arrives, so its peers run into the (shortened) timeout -- on the single-exchange route
+    and on the general route (merged histograms).  A workgroup that cannot rely on its cluster computes the sample's order
+    statistics alone from global memory: the trajectory's bits do not change, nothing raises, the workspace is left
+    zero-filled, and only the diagnostic word says that it happened."""
+    ns = make_schedule("ddpm")
+    x = torch.from_numpy(np.random.default_rng(41).standard_normal(shape).astype(F32)).to(DEV)
+    assert L.lib.dpm_threshold_workspace_bytes(shape[0], int(np.prod(shape[1:]))) > 0        # a clustered shape
+    torch.cuda.synchronize()
+    L.cluster_timeout_poll()                                                                  # clear
+    want = _thr_solver(ns).sample(x, steps=8, order=2)
+    torch.cuda.synchronize()
+    assert not L.cluster_timeout_poll()                                                       # a healthy run reports nothing
+    dpm = _thr_solver(ns)
+    with _Tuned(thr_debug_fault=mode, thr_spin_limit=48, cluster_one_hop=one_hop):
+        got = dpm.sample(x, steps=8, order=2)
+        torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert L.cluster_timeout_poll()
+    for fr in dpm._fast.values():
+        if getattr(fr, "ws", None) is not None:
+            assert not bool(fr.ws.any()), "the workspace must be all zero between launches"
+    # and the same launch records keep working afterwards (nothing to re-zero, nothing evicted)
+    assert torch.equal(dpm.sample(x, steps=8, order=2), want)
+    torch.cuda.synchronize()
+    assert not L.cluster_timeout_poll()
+
+
+def test_cluster_wait_timeout_with_cfg_half_state_and_requests_in_flight():
+    """the recovery path recomputes x0 with the launch's own prologue: classifier-free guidance, fp16 state, fp32 state with
+    fp16 outputs; and a fused multi-request launch of clustered shapes (a workspace per request)"""
+    ns = make_schedule("ddpm")
+    shape = (4, 3, 64, 64)
+    g = torch.Generator().manual_seed(43)
+    cond = torch.ones(shape[0], device=DEV)
+    for sdt, edt in ((torch.float32, None), (torch.float16, None), (torch.float32, torch.float16)):
+        x = torch.randn(shape, generator=g).to(DEV, sdt)
+        net = lambda xx, t, c: (xx.float() * (0.4 + 0.2 * c.reshape(-1, 1, 1, 1))).to(edt or xx.dtype)
+        mk = lambda: D.DPM_Solver(D.model_wrapper(net, ns, guidance_type="classifier-free", condition=cond,
+                                                  unconditional_condition=cond * 0, guidance_scale=3.0), ns,
+                                  correcting_x0_fn="dynamic_thresholding", **({"state_dtype": sdt} if sdt is not torch.float32 else {}))
+        want = mk().sample(x, steps=6, order=2)
+        wants = [mk().sample(x * s, steps=6, order=2) for s in (1.0, 0.5, 2.0)]
+        with _Tuned(thr_debug_fault=2, thr_spin_limit=48):
+            assert torch.equal(mk().sample(x, steps=6, order=2), want)
+            for got, w in zip(mk().sample_requests([x, x * 0.5, x * 2.0], steps=6, order=2), wants):
+                assert torch.equal(got, w)
+        torch.cuda.synchronize()
+    assert L.cluster_timeout_poll()
+
+
+def test_two_processes_run_clustered_thresholding_on_one_gpu():
+    """Two PROCESSES, each running clustered thresholding trajectories on cuda:0 at the same time: the library can only
+    chain the clustered launches of its own process, so the two grids may hold the chip against each other.  Both must
+    finish (bounded waits + recovery inside the kernel) with the bits of an undisturbed run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    here = os.path.dirname(os.path.abspath(__file__))
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = [subprocess.Popen([sys.executable, os.path.join(here, "cluster_pair_worker.py"), tmp, str(r), "2"],
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+        outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    res = [json.loads(so.strip().splitlines()[-1]) for so, _ in outs]
+    for r in res:
+        assert r["ok"], r
+        assert r["trajectories"] >= 20 and r["overlapped"], r

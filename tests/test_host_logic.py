@@ -578,17 +578,57 @@ def test_fresh_time_tensors_for_networks_that_write_into_t(cfg):
     assert torch.equal(got, want) and len(inter) == 7
 
 
-def test_cluster_fault_evicts_and_zeroes_the_cached_workspaces():
-    """DPM_ERR_FAULT (a clustered thresholding launch gave up waiting): the workspace contract wants the dirty workspace
-    zero-filled again -- the fault hook evicts the per-stream cache and zeroes every workspace a launch record holds, before
-    the error reaches the caller."""
-    ws = torch.ones(64, dtype=torch.uint8)
-    S._WS_CACHE[("test", 0)] = torch.ones(16, dtype=torch.uint8)
-    S._WS_LIVE.add(ws)
-    L.lib.dpm_time_steps(None, 0, 1.0, 0.001, 5, None)          # leaves some error text behind
-    with pytest.raises(L.DpmError):
-        L.check(L.ERR_FAULT)
-    assert not S._WS_CACHE and not bool(ws.any())
+@pytest.mark.parametrize("cfg", [False, True])
+def test_a_network_that_writes_into_t_is_detected_and_gets_clones(cfg):
+    """without anyone setting fresh_time_tensors, a network that edits its time argument in place must not
+    corrupt later calls: the version counters of the shared vectors give the write away, the vectors are rebuilt from the host
+    plan and the solver hands out clones from then on -- every call equals the reference-style result."""
+    ns = make_schedule("sd")
+    x = torch.from_numpy(np.random.default_rng(4).standard_normal((2, 4, 8, 8)).astype(F32))
+
+    def make(mutate):
+        def net(xx, t, c=None):
+            out = xx * (t * 0.0005 + 0.25).reshape(-1, 1, 1, 1)
+            if mutate:
+                t.mul_(1000.0)
+            return out
+        if cfg:
+            cond = torch.ones(2)
+            return D.model_wrapper(net, ns, guidance_type="classifier-free", condition=cond, unconditional_condition=cond * 0,
+                                   guidance_scale=2.0)
+        return D.model_wrapper(net, ns)
+    want = D.DPM_Solver(make(False), ns).sample(x, steps=6, order=2)
+    dpm = D.DPM_Solver(make(True), ns)
+    assert not dpm.fresh_time_tensors
+    for _ in range(3):
+        assert torch.equal(dpm.sample(x, steps=6, order=2), want)
+    assert dpm.fresh_time_tensors                     # switched on by the detection, not by the caller
+    got, inter = dpm.sample(x, steps=6, order=2, return_intermediate=True)
+    assert torch.equal(got, want)
+    # requests in flight share one row per stage: the write is caught after the first request's first call
+    dpm2 = D.DPM_Solver(make(True), ns)
+    xs = [x, x * 0.5, x + 0.25]
+    ref = D.DPM_Solver(make(False), ns)
+    for _ in range(2):
+        for got, xx in zip(dpm2.sample_requests(xs, steps=6, order=2), xs):
+            assert torch.equal(got, ref.sample(xx, steps=6, order=2))
+    # singlestep with a batch of one (expand would alias the plan's own table there)
+    x1 = x[:1]
+    want1 = D.DPM_Solver(make(False), ns).sample(x1, steps=7, order=3, method="singlestep")
+    dpm3 = D.DPM_Solver(make(True), ns)
+    for _ in range(3):
+        assert torch.equal(dpm3.sample(x1, steps=7, order=3, method="singlestep"), want1)
+
+
+def test_abi_version_and_load_time_checks():
+    """the structs grew (thr_hint) -- the version says so, and a binding can verify its layout at load time
+    (dpm_sizeof); DPM_ERR_FAULT is retired: no hook machinery is left in the binding."""
+    assert L.lib.dpm_version() >= 102
+    import ctypes
+    for i, t in enumerate((L.Stage, L.Buffers, L.PlanDesc, L.RunBuffers, L.AdaptiveDesc)):
+        assert L.lib.dpm_sizeof(i) == ctypes.sizeof(t)
+    assert not hasattr(L, "fault_hooks")
+    assert L.cluster_timeout_poll() is False            # no clustered launch has run in this process
 
 
 def test_plan_and_adaptive_caches_are_bounded():
@@ -614,12 +654,38 @@ def test_numerical_clip_alpha_method_and_c_entry_agree():
 # ------------------------------------------------------------------------------------------------
 # the ScoreSDE example's sampler (examples/score_sde_pytorch/sampling.py:505-555)
 # ------------------------------------------------------------------------------------------------
-class _VPSDE:
-    """what get_dpm_solver_sampler reads of sde_lib.VPSDE: beta_0, beta_1, T, prior_sampling"""
+class VPSDE:
+    """what get_dpm_solver_sampler reads of sde_lib.VPSDE: beta_0, beta_1, T, prior_sampling (the adapter recognises the
+    class by its name, like the reference's isinstance(sde, sde_lib.VPSDE))"""
     beta_0, beta_1, T = 0.1, 20., 1
 
     def prior_sampling(self, shape):
         return torch.randn(*shape)
+
+
+_VPSDE = VPSDE
+
+
+class subVPSDE:
+    """sde_lib.subVPSDE has the same attributes but another marginal distribution: not a VP model"""
+    beta_0, beta_1, T = 0.1, 20., 1
+
+    def prior_sampling(self, shape):
+        return torch.randn(*shape)
+
+
+def test_score_sde_adapter_rejects_sdes_that_are_not_vp():
+    """the reference raises NotImplementedError for anything but a VPSDE (models/utils.py:143-153); an SDE
+    that merely carries beta_0 / beta_1 (subVPSDE) must not be sampled with the VP noise parametrisation"""
+    from dpm_solver_amd.adapters import score_sde_get_dpm_solver_sampler
+    fn = score_sde_get_dpm_solver_sampler(subVPSDE(), C.SCORE_SDE_SHAPE, lambda x: x, device="cpu")
+    with pytest.raises(NotImplementedError, match="subVPSDE"):
+        fn(C.score_sde_model(torch))
+
+    class Derived(VPSDE):
+        pass
+    y, nfe = score_sde_get_dpm_solver_sampler(Derived(), C.SCORE_SDE_SHAPE, lambda x: x, device="cpu")(C.score_sde_model(torch))
+    assert nfe == 10 and torch.isfinite(y).all()
 
 
 def run_score_sde_adapter(device, golden, thresholding_too=False):
@@ -644,3 +710,85 @@ def run_score_sde_adapter(device, golden, thresholding_too=False):
 def test_score_sde_sampler_against_reference_goldens(golden, capsys):
     """goldens produced by the example's own sampling.get_dpm_solver_sampler (tests/golden/make_golden.py score_sde)"""
     assert run_score_sde_adapter("cpu", golden, thresholding_too=True) < TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# round 4: channels_last (NHWC) networks run on their own storage (VERDICT round 3, item 4)
+# ------------------------------------------------------------------------------------------------
+class _CopySpy:
+    """counts the layout / dtype conversions the solver makes (calls of S._conv that return a new tensor)"""
+
+    def __init__(self, monkeypatch):
+        self.copies = 0
+        real = S._conv
+
+        def conv(t, dt, mf=None):
+            out = real(t, dt, mf)
+            if t is not None and out is not t:
+                self.copies += 1
+            return out
+        monkeypatch.setattr(S, "_conv", conv)
+
+
+def _nhwc_model(ns, cfg, thr_scale=False, fmt=torch.channels_last):
+    def net(xx, t, c=None):
+        scale = (t * 0.0005 + 0.25).reshape(-1, 1, 1, 1)
+        if c is not None:
+            scale = scale * (1.0 + 0.1 * c.reshape(-1, 1, 1, 1))
+        out = xx * scale
+        return out.contiguous(memory_format=fmt) if fmt is not None else out.contiguous()
+    if cfg:
+        cond = torch.ones(3)
+        return D.model_wrapper(net, ns, guidance_type="classifier-free", condition=cond, unconditional_condition=cond * 0,
+                               guidance_scale=3.0)
+    return D.model_wrapper(net, ns)
+
+
+@pytest.mark.parametrize("cfg", [False, True])
+@pytest.mark.parametrize("thr", [False, True])
+@pytest.mark.parametrize("x_nhwc", [False, True])
+def test_channels_last_network_runs_on_its_own_storage(cfg, thr, x_nhwc, monkeypatch):
+    """A network that answers in channels_last: the launch records point at its outputs as they are, the scratch states
+    are NHWC too (the network is handed the layout it works in), x_T is converted at most once and the result comes back
+    in x_T's layout -- bit-identical to the default-layout run (the kernels are elementwise over the flat storage, and the
+    thresholding quantile is a per-sample order statistic)."""
+    ns = make_schedule("sd")
+    x = torch.from_numpy(np.random.default_rng(5).standard_normal((3, 4, 8, 8)).astype(F32))
+    kw = dict(correcting_x0_fn="dynamic_thresholding") if thr else {}
+    want = D.DPM_Solver(_nhwc_model(ns, cfg, fmt=None), ns, **kw).sample(x, steps=8, order=2)
+    xin = x.contiguous(memory_format=torch.channels_last) if x_nhwc else x
+    seen = []
+    model = _nhwc_model(ns, cfg)
+    inner = model.model
+
+    def spy_net(xx, t, *a):
+        seen.append(xx.is_contiguous(memory_format=torch.channels_last))
+        return inner(xx, t, *a)
+    model.model = spy_net
+    dpm = D.DPM_Solver(model, ns, **kw)
+    spy = _CopySpy(monkeypatch)
+    got = dpm.sample(xin, steps=8, order=2)
+    assert torch.equal(got, want)
+    assert got.is_contiguous(memory_format=torch.channels_last) == x_nhwc and (x_nhwc or got.is_contiguous())
+    # conversions: x_T into the network's layout and the result back into x_T's -- none per stage
+    assert spy.copies == (0 if x_nhwc else 2), spy.copies
+    # from the second evaluation on the network is handed NHWC states (the first one sees the caller's x_T)
+    assert all(seen[1:]) and seen[0] == x_nhwc
+    # requests in flight and the general loop (intermediates) keep the guarantee
+    outs = dpm.sample_requests([xin, xin * 0.5], steps=8, order=2)
+    assert torch.equal(outs[0], want) and outs[0].is_contiguous(memory_format=torch.channels_last) == x_nhwc
+    got2, inter = dpm.sample(xin, steps=8, order=2, return_intermediate=True)
+    assert torch.equal(got2, want) and len(inter) == 9
+    assert all(v.is_contiguous(memory_format=torch.channels_last) == x_nhwc for v in inter[1:])
+
+
+def test_channels_last_x_T_with_a_default_layout_network(monkeypatch):
+    """the other mixed case: x_T in NHWC, the network answers in the default layout -> the run stays in the network's
+    layout, x_T is converted once, the result returns in NHWC"""
+    ns = make_schedule("sd")
+    x = torch.from_numpy(np.random.default_rng(6).standard_normal((2, 4, 8, 8)).astype(F32))
+    want = D.DPM_Solver(_nhwc_model(ns, False, fmt=None), ns).sample(x, steps=5, order=2)
+    spy = _CopySpy(monkeypatch)
+    got = D.DPM_Solver(_nhwc_model(ns, False, fmt=None), ns).sample(x.contiguous(memory_format=torch.channels_last), steps=5, order=2)
+    assert torch.equal(got, want) and got.is_contiguous(memory_format=torch.channels_last)
+    assert spy.copies == 2

@@ -71,6 +71,94 @@ def summarise(d, md=None, title="", pattern="stage_kernel"):
     print(text)
 
 
+# The kernels of the other BASELINE configs inside a real torch network loop: DPM_Solver.sample() with a random-init conv
+# network (MIOpen) as the model, to be run under `rocprofv3 --kernel-trace --stats` and summarised with --summarise.
+#   shape, state dtype, network dtype, CFG scale (None: unguided), thresholding, sample() kwargs, schedule, network width,
+#   memory format of network and x_T
+CASES = {
+    # classifier-free guidance 7.5 + the duplicate store of the [2B,...] network input, SD under autocast (ref :322-330)
+    "cfg_sd64": dict(shape=(64, 4, 64, 64), state="fp32", net="fp16", cfg=7.5, thr=False, kw=dict(steps=20, order=2), sched="sd", width=256),
+    "cfg_sd8": dict(shape=(8, 4, 64, 64), state="fp32", net="fp16", cfg=7.5, thr=False, kw=dict(steps=20, order=2), sched="sd", width=256),
+    # BASELINE cfg5: dynamic thresholding, pixel space, 25 steps (ref :416-425)
+    "cfg5": dict(shape=(32, 3, 64, 64), state="fp32", net="fp32", cfg=None, thr=True, kw=dict(steps=25, order=2), sched="ddpm", width=128),
+    # BASELINE cfg3: DPM-Solver-3 singlestep, 15 NFE, CFG 7.5 (ref :675-794)
+    "cfg3": dict(shape=(64, 3, 256, 256), state="fp32", net="fp32", cfg=7.5, thr=False,
+                 kw=dict(steps=15, order=3, method="singlestep"), sched="ddpm", algo="dpmsolver", width=32),
+    # the plain 2M kernel behind a conv network in the default layout and in channels_last
+    "nchw": dict(shape=(256, 4, 64, 64), state="fp16", net="fp16", cfg=None, thr=False, kw=dict(steps=20, order=2), sched="sd", width=256),
+    "nhwc": dict(shape=(256, 4, 64, 64), state="fp16", net="fp16", cfg=None, thr=False, kw=dict(steps=20, order=2), sched="sd", width=256,
+                 channels_last=True),
+}
+
+
+def run_case(name, trajectories):
+    import time
+    import torch
+    import bench
+    import dpm_solver_amd as D
+    c = CASES[name]
+    dev = torch.device("cuda", 0)
+    sd, nd = bench._DT[c["state"]], bench._DT[c["net"]]
+    shape = c["shape"]
+    if c["sched"] == "sd":
+        ns = D.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(bench.sd_alphas_cumprod()))
+    else:
+        ns = D.NoiseScheduleVP("discrete", betas=torch.linspace(1e-4, 0.02, 1000, dtype=torch.float64))
+    net = bench.LoopNet("conv", c["width"], nd, dev, channels=shape[1])
+    cl = bool(c.get("channels_last"))
+    if cl:
+        net = net.to(memory_format=torch.channels_last)
+    scale = 0.5 if c["thr"] else 1.0
+    if c["cfg"] is not None:
+        cond = torch.ones(shape[0], device=dev)
+        model = D.model_wrapper(lambda x, t, cc: net(x.to(nd), t) * scale, ns, guidance_type="classifier-free", condition=cond,
+                                unconditional_condition=cond * 0, guidance_scale=c["cfg"])
+    else:
+        model = D.model_wrapper(lambda x, t: net(x.to(nd), t) * scale, ns)
+    kwargs = dict(algorithm_type=c.get("algo", "dpmsolver++"))
+    if c["thr"]:
+        kwargs["correcting_x0_fn"] = "dynamic_thresholding"
+    if sd is not torch.float32:
+        kwargs["state_dtype"] = sd
+    dpm = D.DPM_Solver(model, ns, **kwargs)
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    x = torch.randn(shape, generator=g).to(dev, sd)
+    if cl:
+        x = x.to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        out = dpm.sample(x, **c["kw"])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(trajectories):
+            out = dpm.sample(x, **c["kw"])
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / trajectories
+        # the same network calls alone (same inputs, same number): what the solver adds to a trajectory
+        calls = []
+        inner = model.model
+        model.model = lambda *a: (calls.append(a), inner(*a))[1]
+        dpm.sample(x, **c["kw"])
+        model.model = inner
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(trajectories):
+            for a in calls:
+                inner(*a)
+        torch.cuda.synchronize()
+        wall_net = (time.perf_counter() - t0) / trajectories
+    n = 1
+    for d in shape:
+        n *= d
+    assert torch.isfinite(out.float()).all()
+    print(json.dumps(dict(case=name, shape=list(shape), state=c["state"], network=c["net"], cfg=c["cfg"], thresholding=c["thr"],
+                          sample_kwargs=c["kw"], channels_last=cl, elements=n, network_calls=len(calls),
+                          trajectory_ms=round(wall * 1e3, 4), network_calls_alone_ms=round(wall_net * 1e3, 4),
+                          solver_added_us_per_call=round((wall - wall_net) / max(len(calls), 1) * 1e6, 2),
+                          network_ms_per_call=round(wall_net / max(len(calls), 1) * 1e3, 4),
+                          out_channels_last=bool(out.dim() == 4 and out.is_contiguous(memory_format=torch.channels_last)
+                                                 and not out.is_contiguous()))), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--kinds", default="gemm")
@@ -90,11 +178,15 @@ def main():
     ap.add_argument("--pattern", default="stage_kernel", help="--summarise: substring of the kernel rows to report")
     ap.add_argument("--sweep", action="store_true", help="tuning build: (tiles per workgroup, nt mask) of the 2M kernel INSIDE "
                     "the loop, for fp16, fp32 and fp32 state + fp16 network (events)")
+    ap.add_argument("--case", default=None, choices=sorted(CASES), help="trace-only runs of the OTHER kernels the BASELINE configs "
+                    "launch, each inside a real torch network loop (VERDICT round 3, item 5): see CASES")
     ap.add_argument("--unroll", type=int, default=0, help="tuning build only: tiles per workgroup of the 2M stage kernel")
     ap.add_argument("--nt", type=int, default=-1, help="tuning build only: nt mask")
     args = ap.parse_args()
     if args.summarise:
         return summarise(args.summarise, args.md, args.title, args.pattern)
+    if args.case:
+        return run_case(args.case, args.trajectories)
     import torch
     import bench
     import dpm_solver_amd as D
