@@ -172,6 +172,10 @@ _SIGNATURES = [
     ("dpm_calib_launch", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int64, C.c_void_p, _P(C.c_float)]),
     ("dpm_cluster_timeout_poll", C.c_int, []),
+    ("dpm_resident_create", C.c_int, [_P(Stage), _P(Buffers), C.c_int, C.c_int, C.c_int, _P(C.c_void_p)]),
+    ("dpm_resident_start", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("dpm_resident_signal", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    ("dpm_resident_destroy", None, [C.c_void_p]),
     ("dpm_version", C.c_int, []),
     ("dpm_sizeof", C.c_size_t, [C.c_int]),
     ("dpm_last_error", C.c_char_p, []),

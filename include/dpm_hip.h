@@ -418,6 +418,19 @@ int dpm_tuning_get(int knob);
 int dpm_calib_launch(int kind, int block, int blocks_per_cu, int nt, const void* a, const void* b, const void* c,
                      void* d, void* e, int64_t nbytes, void* stream, float* ms);
 
+/* ---- EXPERIMENT: a resident stage kernel woken by a stream-ordered write -----------------
+   Not used by any loop of the library or by DPM_Solver; kept for the measurement in profiles/r04_resident.md
+   (tools/in_loop.py --resident).  One launch per trajectory on a side stream keeps `workgroups` workgroups on the chip;
+   per stage the host enqueues dpm_resident_signal behind the network's last kernel: hipStreamWriteValue64 of the
+   output's address wakes the workgroups, hipStreamWaitValue32 holds the stream until the stage's last workgroup is
+   through.  Covers what the unguided 20-step DPM-Solver++(2M) trajectory launches: noise-prediction network, forms LIN1 /
+   TWO, equal fp16 or fp32 dtypes, n a multiple of 2048.  `stages` / `bufs`: the n_stages records a dpm_stage_launch loop
+   would use (static buffers; e0 is supplied per stage by dpm_resident_signal). */
+int dpm_resident_create(const dpm_stage* stages, const dpm_buffers* bufs, int n_stages, int workgroups, int sleep, void** out);
+int dpm_resident_start(void* handle, const void* x_first, void* x_last_out, void* side_stream);
+int dpm_resident_signal(void* handle, int stage, const void* eps, void* stream);
+void dpm_resident_destroy(void* handle);
+
 /* ---- misc ---------------------------------------------------------------------------------- */
 int dpm_version(void);
 /* sizeof() of the ABI structs as compiled, so a binding can verify its own layout at load time */

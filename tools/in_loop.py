@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def summarise(d, md=None, title="", pattern="stage_kernel"):
+def summarise(d, md=None, title="", pattern="stage_"):
     """stage-kernel rows of a rocprofv3 kernel trace of `--trace-only`: duration, the kernel that ran before each, the gap"""
     f = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
     assert f, "no *_results.db under %s" % d
@@ -111,10 +111,12 @@ def run_case(name, trajectories):
     scale = 0.5 if c["thr"] else 1.0
     if c["cfg"] is not None:
         cond = torch.ones(shape[0], device=dev)
-        model = D.model_wrapper(lambda x, t, cc: net(x.to(nd), t) * scale, ns, guidance_type="classifier-free", condition=cond,
+        model = D.model_wrapper(lambda x, t, cc: net(x.to(nd), t), ns, guidance_type="classifier-free", condition=cond,
                                 unconditional_condition=cond * 0, guidance_scale=c["cfg"])
-    else:
+    elif c["thr"]:
         model = D.model_wrapper(lambda x, t: net(x.to(nd), t) * scale, ns)
+    else:
+        model = D.model_wrapper(lambda x, t: net(x.to(nd), t), ns)    # the network's last kernel is its last convolution
     kwargs = dict(algorithm_type=c.get("algo", "dpmsolver++"))
     if c["thr"]:
         kwargs["correcting_x0_fn"] = "dynamic_thresholding"
@@ -159,6 +161,115 @@ def run_case(name, trajectories):
                                                  and not out.is_contiguous()))), flush=True)
 
 
+def resident_experiment(kind, dtype_name, width, trajectories, configs):
+    """EXPERIMENT: the resident stage kernel (dpm_resident_*: woken by
+    hipStreamWriteValue64 behind the network's last kernel, the next network call held by hipStreamWaitValue32) against the
+    dispatched stage kernel of DPM_Solver.sample(), same network, same [256,4,64,64] request, same arithmetic (the results
+    must be equal).  Reports per configuration (workgroups, sleep): the wall time a solver stage adds to a network call and
+    what the parked pollers cost the network.  Keep criterion: added wall per stage drops by >= 1.5 us AND the network
+    call gets < 0.5 % slower."""
+    import ctypes as C
+    import torch
+    import bench
+    import dpm_solver_amd as D
+    from dpm_solver_amd import _lib as L
+    dev = torch.device("cuda", 0)
+    dtype = bench._DT[dtype_name]
+    ns = D.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(bench.sd_alphas_cumprod()))
+    net = bench.LoopNet(kind, width, dtype, dev)
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    x_T = torch.randn((bench.B,) + bench.SHAPE, generator=g).to(dev, dtype)
+    dpm = D.DPM_Solver(D.model_wrapper(net, ns), ns, algorithm_type="dpmsolver++", state_dtype=dtype)
+    n_st = bench.STEPS_SOLVER
+    rows = []
+    with torch.no_grad():
+        want = dpm.sample(x_T, steps=n_st, order=2)
+        torch.cuda.synchronize()
+        fr = next(iter(dpm._fast.values()))
+        plan = dpm._get_plan(method="multistep", order=2, steps=n_st, skip_type="time_uniform", solver_type="dpmsolver",
+                             lower_order_final=True, denoise_to_zero=False, t_T=1.0, t_0=1.0 / ns.total_N)
+        roles = plan.roles
+        tin = plan.time_views(dev, bench.B, False)["t_input_b"]
+        stages = (L.Stage * n_st)(*fr.stages)
+        bufs = (L.Buffers * n_st)(*fr.bufs)
+        out = torch.empty_like(want)
+        main = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+
+        def timed(fn):
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3
+
+        def net_only():
+            for i in range(n_st):
+                net(x_T, tin[i])
+        dispatched = lambda: dpm.sample(x_T, steps=n_st, order=2)
+        for wgs, sleep in configs:
+            h = C.c_void_p()
+            L.check(L.lib.dpm_resident_create(stages, bufs, n_st, wgs, sleep, C.byref(h)))
+
+            def start():
+                side.wait_stream(main)
+                L.check(L.lib.dpm_resident_start(h, x_T.data_ptr(), out.data_ptr(), C.c_void_p(side.cuda_stream)))
+
+            def resident():
+                start()
+                keep = []
+                for i in range(n_st):
+                    xe = x_T if roles[i][1] == 0 else fr.xbuf[roles[i][1]]
+                    eps = net(xe, tin[i])
+                    keep.append(eps)
+                    L.check(L.lib.dpm_resident_signal(h, i, eps.data_ptr(), C.c_void_p(main.cuda_stream)))
+                main.wait_stream(side)
+                return keep
+
+            net_ms = [None]
+
+            def parked():
+                """the network calls alone while the resident kernel sits on the chip polling (then let it run out)"""
+                start()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                net_only()
+                e1.record()
+                eps = net(x_T, tin[0])
+                for i in range(n_st):
+                    L.check(L.lib.dpm_resident_signal(h, i, eps.data_ptr(), C.c_void_p(main.cuda_stream)))
+                main.wait_stream(side)
+                torch.cuda.synchronize()
+                net_ms[0] = e0.elapsed_time(e1) * 1e3
+
+            resident()
+            torch.cuda.synchronize()
+            equal = bool(torch.equal(out, want))
+            t_res, t_dis, t_net, t_park = [], [], [], []
+            for _ in range(max(6, trajectories)):
+                t_res.append(timed(resident))
+                t_dis.append(timed(dispatched))
+                t_net.append(timed(net_only))
+                parked()
+                t_park.append(net_ms[0])
+            med = lambda v: float(np.median(v))
+            row = dict(workgroups=wgs, sleep_x_s_sleep64=sleep, result_equals_dispatched=equal,
+                       network_ms_per_call=round(med(t_net) / n_st / 1e3, 4),
+                       network_ms_per_call_with_pollers_parked=round(med(t_park) / n_st / 1e3, 4),
+                       network_slowdown_pct=round((med(t_park) / med(t_net) - 1.0) * 100.0, 3),
+                       stage_added_wall_us_dispatched=round((med(t_dis) - med(t_net)) / n_st, 3),
+                       stage_added_wall_us_resident=round((med(t_res) - med(t_net)) / n_st, 3),
+                       trajectory_ms_dispatched=round(med(t_dis) / 1e3, 4), trajectory_ms_resident=round(med(t_res) / 1e3, 4))
+            row["gain_us_per_stage"] = round(row["stage_added_wall_us_dispatched"] - row["stage_added_wall_us_resident"], 3)
+            row["keep"] = bool(equal and row["gain_us_per_stage"] >= 1.5 and row["network_slowdown_pct"] < 0.5)
+            rows.append(row)
+            print(json.dumps(row), flush=True)
+            L.lib.dpm_resident_destroy(h)
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--kinds", default="gemm")
@@ -175,11 +286,13 @@ def main():
                     "with the real network (one fused stage launch per stage): rows of stage_kernel_multi inside the loop")
     ap.add_argument("--calib", action="store_true", help="the NO-ARITHMETIC kernel of the same five streams (dpm_calib_launch) in "
                     "the stage kernel's place in the loop: what the memory system alone charges a lone launch there")
-    ap.add_argument("--pattern", default="stage_kernel", help="--summarise: substring of the kernel rows to report")
+    ap.add_argument("--pattern", default="stage_", help="--summarise: substring of the kernel rows to report")
     ap.add_argument("--sweep", action="store_true", help="tuning build: (tiles per workgroup, nt mask) of the 2M kernel INSIDE "
                     "the loop, for fp16, fp32 and fp32 state + fp16 network (events)")
     ap.add_argument("--case", default=None, choices=sorted(CASES), help="trace-only runs of the OTHER kernels the BASELINE configs "
                     "launch, each inside a real torch network loop (VERDICT round 3, item 5): see CASES")
+    ap.add_argument("--resident", default=None, help="EXPERIMENT: resident stage kernel vs the dispatched one; comma list of "
+                    "workgroups:sleep, e.g. 512:1,1024:1,2048:1,1024:4")
     ap.add_argument("--unroll", type=int, default=0, help="tuning build only: tiles per workgroup of the 2M stage kernel")
     ap.add_argument("--nt", type=int, default=-1, help="tuning build only: nt mask")
     args = ap.parse_args()
@@ -187,6 +300,12 @@ def main():
         return summarise(args.summarise, args.md, args.title, args.pattern)
     if args.case:
         return run_case(args.case, args.trajectories)
+    if args.resident:
+        cfgs = [tuple(int(v) for v in c.split(":")) for c in args.resident.split(",")]
+        rows = resident_experiment(args.kinds.split(",")[0], args.dtype, args.width, args.trajectories, cfgs)
+        if args.out:
+            json.dump(rows, open(args.out, "w"), indent=1)
+        return
     import torch
     import bench
     import dpm_solver_amd as D
