@@ -58,7 +58,7 @@ constexpr int THR_KMAX = 256;                // largest cluster the single-excha
 constexpr int THR_MISC = 32 + 2 * THR_KMAX;  // scalar LDS words of the thresholding kernel (see stage_thresh_kernel)
 constexpr int THR_SLOT_CAP = 256;            // values one workgroup may publish
 constexpr int THR_SLOT_HDR = 8;              // [0] tag | count (or overflow), [1] tag | bound, [2] tag | chunk maximum
-constexpr int THR_SLOTW = THR_SLOT_CAP + THR_SLOT_HDR;
+constexpr int THR_SLOTW = THR_SLOT_CAP + THR_SLOT_HDR;  // (128-byte aligned slots, 288 words, were measured: no difference)
 constexpr uint32_t THR_TAG = 0x80000000u;    // |x0| bit patterns have bit 31 clear: a tagged word is never 0
 constexpr uint32_t THR_OVERFLOW = 0x40000000u;
 constexpr int THR_WS_DONE = THR_WS_CNT + 12; // workgroups of the cluster that are through with the workspace
@@ -346,18 +346,52 @@ __device__ __forceinline__ uint32_t wave_max_to_lane63(uint32_t v) {
 // largest candidate when there is none).  One pass -- instead of three histogram levels + a min search.
 // rank_count expects misc[6] = misc[7] = 0 and 32 sentinels (0xffffffff: never smaller than anything, the list becomes a
 // multiple of 32) behind the list, both visible to the workgroup (a barrier behind the writes); one barrier at its end.
+// `part` (optional: T zeroed words, visible like the sentinels): short lists -- the union of a small cluster is ~120
+// entries, two wavefronts' worth of candidates -- are counted by ALL eight wavefronts: the 64-candidate groups are
+// replicated over the wavefronts and every replica counts against its own part of the list (the counting is the longest
+// single step of a small cluster's select: nc compare-and-add pairs per candidate), the partial counts meet in `part`
+// through LDS atomics; one more barrier.
 template <int T>
-__device__ __forceinline__ void rank_count(const uint32_t* cand, uint32_t nc, uint32_t rank, uint32_t* misc, int tid) {
+__device__ __forceinline__ void rank_count(const uint32_t* cand, uint32_t nc, uint32_t rank, uint32_t* misc, int tid,
+                                           uint32_t* part = nullptr) {
+  static_assert(T / 64 == 8, "eight wavefronts");
+  const uint32_t groups = (nc + 63u) >> 6;  // wavefronts' worth of candidates
+  const uint32_t gp = groups <= 1u ? 1u : (groups <= 2u ? 2u : (groups <= 4u ? 4u : 8u));
+  const uint32_t P = part ? 8u / gp : 1u;   // replicas of every group = parts of the list
+  uint32_t lt = 0u;
+  if (P > 1u) {
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t g = wave & (gp - 1u), pr = wave / gp;
+    const uint32_t ci = g * 64u + (uint32_t)(tid & 63);
+    if (g * 64u < nc) {
+      const uint32_t my = ci < nc ? cand[ci] : 0xffffffffu;
+      const uint32_t nchunk = (nc + 31u) >> 5, per = (nchunk + P - 1u) / P;
+      const uint32_t j1 = (pr + 1u) * per < nchunk ? (pr + 1u) * per : nchunk;
+      for (uint32_t j = pr * per * 32u; j < j1 * 32u; j += 32u) {
+        u32x4 q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[e] = *reinterpret_cast<const u32x4*>(cand + j + 4 * e);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          lt += (q[e][0] < my ? 1u : 0u) + (q[e][1] < my ? 1u : 0u) + (q[e][2] < my ? 1u : 0u) + (q[e][3] < my ? 1u : 0u);
+      }
+      if (ci < nc && lt) atomicAdd(&part[ci], lt);
+    }
+    __syncthreads();
+  }
   if ((uint32_t)(tid & ~63) < nc) {  // wavefronts beyond the list have nothing to do
     const uint32_t my = (uint32_t)tid < nc ? cand[tid] : 0xffffffffu;
-    uint32_t lt = 0u;
-    for (uint32_t j = 0; j < nc; j += 32) {  // broadcast reads, eight in flight
-      u32x4 q[8];
+    if (P > 1u) {
+      lt = (uint32_t)tid < nc ? part[tid] : 0u;
+    } else {
+      for (uint32_t j = 0; j < nc; j += 32) {  // broadcast reads, eight in flight
+        u32x4 q[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) q[e] = *reinterpret_cast<const u32x4*>(cand + j + 4 * e);
+        for (int e = 0; e < 8; ++e) q[e] = *reinterpret_cast<const u32x4*>(cand + j + 4 * e);
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        lt += (q[e][0] < my ? 1u : 0u) + (q[e][1] < my ? 1u : 0u) + (q[e][2] < my ? 1u : 0u) + (q[e][3] < my ? 1u : 0u);
+        for (int e = 0; e < 8; ++e)
+          lt += (q[e][0] < my ? 1u : 0u) + (q[e][1] < my ? 1u : 0u) + (q[e][2] < my ? 1u : 0u) + (q[e][3] < my ? 1u : 0u);
+      }
     }
     const uint32_t ma = wave_max_to_lane63(((uint32_t)tid < nc && lt <= rank) ? my : 0u);
     const uint32_t mb = wave_max_to_lane63(((uint32_t)tid < nc && lt <= rank + 1u) ? my : 0u);
@@ -369,6 +403,10 @@ __device__ __forceinline__ void rank_count(const uint32_t* cand, uint32_t nc, ui
   __syncthreads();
 }
 
+// scratch of rank_count's partial counts inside cand[]: behind the longest list rank_select is called with (T entries + 32
+// sentinels)
+constexpr int THR_PART_OFF = 2048;
+
 template <int T>
 __device__ __forceinline__ void rank_select(uint32_t* cand, uint32_t nc, uint32_t rank, uint32_t* misc, int tid) {
   if (tid == 0) {
@@ -376,8 +414,10 @@ __device__ __forceinline__ void rank_select(uint32_t* cand, uint32_t nc, uint32_
     misc[7] = 0u;
   }
   if (tid < 32) cand[nc + tid] = 0xffffffffu;
+  const bool split = nc <= (uint32_t)(T / 2);  // (workgroup-uniform) lists that leave wavefronts without candidates
+  if (split) cand[THR_PART_OFF + tid] = 0u;
   __syncthreads();
-  rank_count<T>(cand, nc, rank, misc, tid);
+  rank_count<T>(cand, nc, rank, misc, tid, split ? cand + THR_PART_OFF : nullptr);
 }
 
 // workgroup-wide exclusive prefix sum of one value per thread (wavefront scan + the wavefront totals through misc[16..]);
@@ -1028,6 +1068,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
                                       ws + THR_WS_POISON, pbound);
       route = solved ? 1u : 2u;
     }
+    const bool searched = route1 && !solved;     // the searched-bound attempt runs (and dirties the first slot area)
     if (route1 && !solved) {
       solved = cluster_select_once<T>(sx0, n, vec, m1, m2, m3, m4, has, hist, misc, cand, ws + THR_WS_WORDS, tp, k, c, tid,
                                       a1, b1, s_idx == grp && !pbound, ws + THR_WS_POISON);
@@ -1316,8 +1357,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
     // This workgroup is through with the sample's workspace.  The last of the cluster to say so puts every word it and
     // its peers dirtied back to zero (end of the sample loop): the workspace is all zero between launches, so no launch
     // has to clear it first.  The returning atomic is in flight during phase 3.
+    // (a workgroup that gave up a wait says so in the upper half of the counter: it may have left words dirty that the
+    // last workgroup's own route knows nothing about, see the clean-up)
     uint32_t done_old = 0u;
-    if (k > 1 && tid == 0) done_old = __hip_atomic_fetch_add(ws + THR_WS_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k > 1 && tid == 0)
+      done_old = __hip_atomic_fetch_add(ws + THR_WS_DONE, 1u + (misc[30] ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // torch.quantile 'linear' = ATen lerp(a, b, w)
     const float diff = b - a;
     const float q = tp.w < 0.5f ? a + tp.w * diff : b - diff * (1.f - tp.w);
@@ -1396,12 +1440,31 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
       }
     }
     if (k > 1) {
-      if (tid == 0) misc[11] = done_old == k - 1u ? 1u : 0u;
+      if (tid == 0) {
+        misc[11] = (done_old & 0xffffu) == k - 1u ? 1u : 0u;
+        misc[28] = ((done_old >> 16) != 0u || misc[30]) ? 1u : 0u;  // some workgroup of the cluster gave up a wait
+      }
       __syncthreads();
       if (misc[11]) {
-        uint32_t* slots = ws + THR_WS_WORDS;  // both slot areas when the predicted attempt ran (cluster-uniform)
-        for (uint32_t i = tid; i < (pbound ? 2u : 1u) * k * (uint32_t)THR_SLOTW; i += T) slots[i] = 0u;
-        if (general || !route1) {
+        const bool any_dead = misc[28] != 0u;  // then: everything any route can have written
+        // Only the slot areas an attempt of this sample published into, and of their slots the header and the slot_cap
+        // value words (round 3 cleared both areas at their full stride whatever had run: 12.7 KB per sample of cfg5's
+        // launch, 0.4 MB of its 3.5 MB of writes; a predicted attempt that solves the sample now leaves 1.7 KB to clear).
+        // Flat, unconditional stores: clearing exactly max(slot_pub, count) words per slot was measured too -- 10 % fewer
+        // bytes again, but the count comes from LDS and the loop sits on the critical path of the cluster's next sample
+        // (+0.2 us per stage at cfg5's size, +1.5 us at [64,3,256,256], profiles/r04_thresholding.md).
+        uint32_t* slots = ws + THR_WS_WORDS;
+        const int zshift = tp.slot_shift;
+        const uint32_t zw = 1u << zshift, zwords = k << zshift;  // slot_cap is a power of two
+        for (uint32_t area = 0; area < 2u; ++area) {
+          const bool used = area == 0u ? (searched || (any_dead && route1)) : pbound != 0u;
+          if (!used) continue;
+          uint32_t* as = slots + (size_t)area * k * THR_SLOTW;
+          for (uint32_t q = tid; q < zwords; q += T) as[(size_t)(q >> zshift) * THR_SLOTW + THR_SLOT_HDR + (q & (zw - 1u))] = 0u;
+          for (uint32_t i = tid; i < k * (uint32_t)THR_SLOT_HDR; i += T)
+            as[(size_t)(i / THR_SLOT_HDR) * THR_SLOTW + (i % THR_SLOT_HDR)] = 0u;
+        }
+        if (general || !route1 || any_dead) {
           for (uint32_t i = tid; i < (uint32_t)THR_WS_WORDS; i += T) ws[i] = 0u;
         } else if (tid == 0) {
           ws[THR_WS_DONE] = 0u;

@@ -49,7 +49,8 @@ for shape, steps in (((32, 3, 64, 64), 25), ((64, 3, 256, 256), 10)):
     for model in ("frozen", "half"):
         for predict in (1, 0):
             rows = run(shape, steps, predict, model)
-            print("shape %s model %s predict %d" % (shape, model, predict))
+            print("shape %s model %s predict %d   median of the stages >= 2: %.2f us" % (
+                shape, model, predict, float(np.median([r[0] for r in rows[2:]]))))
             for i, (us, route, tot, a) in enumerate(rows):
                 cnt = {int(k): int((route == k).sum()) for k in np.unique(route)}
                 print("  stage %2d  %7.2f us  routes %s  union median %5.0f max %5.0f  a[0] %.4f" % (i, us, cnt, np.median(tot), tot.max(), a[0]))
