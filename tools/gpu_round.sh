@@ -6,7 +6,8 @@ TAG=${1:-r03}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/$TAG; mkdir -p $O
-timeout 1200 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" $O/pytest.log | tail -2
+[ -f _refscratch/dpm_solver_pytorch.py ] && export DPM_REFERENCE_DIR=_refscratch
+timeout 1500 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" $O/pytest.log | tail -2
 ( time DPM_THR_SWEEP=20000 DPM_THR_SWEEP_STEPS=20 timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "random_sweep" ) > $O/pytest_thr_sweep_20000.log 2>&1; echo "thresholding sweep (20000 configurations, up to 19 steps) rc=$?"; grep -E "passed|failed|real" $O/pytest_thr_sweep_20000.log | tail -3
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
 # the launch line the driver uses for N > 1, with one rank (RCCL communicator, barrier, MAX all-reduce, final all-gather)
@@ -32,4 +33,29 @@ if [ -f _refscratch/dpm_solver_pytorch.py ]; then
   DPM_REFERENCE_DIR=_refscratch timeout 400 python tools/cpu_baseline.py --budget 40 --out $O/cpu_baseline_reference_gpubox.json --where "MI355X box host cores (gpurun)" > $O/cpu_baseline.log 2>&1; echo "cpu_baseline rc=$?"
   DPM_REFERENCE_DIR=_refscratch timeout 400 python tools/gpu_reference.py --out $O/gpu_reference.json > $O/gpu_reference.log 2>&1; echo "gpu_reference rc=$?"
 fi
+# the reference's own example call sites, unchanged, on the engine (needs the scratch tree)
+if [ -d _refscratch/examples ]; then
+  DPM_REFERENCE_DIR=_refscratch timeout 300 python tools/dropin_examples.py --device cuda:0 --out $O/dropin.json > $O/dropin.log 2>&1; echo "dropin rc=$?"; tail -4 $O/dropin.log
+fi
+# the other BASELINE kernels inside a real torch network loop (rocprofv3 rows), channels_last vs default layout
+for CASE in nchw nhwc cfg_sd64 cfg_sd8 cfg5 cfg3; do
+  TR=6; [ $CASE = cfg3 ] && TR=3
+  timeout 420 rocprofv3 --kernel-trace --stats --output-format rocpd csv -d $O/kt_$CASE -o kt -- python tools/in_loop.py --case $CASE --trajectories $TR > $O/case_$CASE.log 2>&1; echo "rocprof $CASE rc=$?"
+  grep '^{' $O/case_$CASE.log | tail -1 | cut -c1-400
+  python tools/in_loop.py --summarise $O/kt_$CASE --md $O/in_loop_$CASE.md --title "BASELINE kernel inside a torch network loop: case $CASE (rocprofv3 --kernel-trace --stats -- python tools/in_loop.py --case $CASE)" > /dev/null 2>&1
+  find $O/kt_$CASE -name "*kernel_stats.csv" -exec cp {} $O/in_loop_${CASE}_kernel_stats.csv \;
+  rm -rf $O/kt_$CASE
+  sed -n 5,9p $O/in_loop_$CASE.md | cut -c1-200
+done
+# cfg5's own size under the profiler: kernel rows + memory-side traffic (separate --pmc passes)
+P=$O/prof_thr32; mkdir -p $P
+rocprofv3 --kernel-trace --stats --output-format rocpd csv -d $P/kt -o kt -- python tools/stage_bench.py --only "cfg5 2M++ thr B=32" > $P/kt.log 2>&1; echo "rocprof thr32 kt rc=$?"
+find $P/kt -name "*kernel_stats.csv" -exec cp {} $P/kernel_stats.csv \;
+find $P/kt -name "*kernel_trace.csv" -delete
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C -d $P/pmc_$C -o pmc -- python tools/stage_bench.py --only "cfg5 2M++ thr B=32" > $P/pmc_$C.log 2>&1; echo "pmc $C rc=$?"
+done
+python tools/rocprof_summary.py $P "stage_thresh_kernel<float, float, 1, 0, false, 512, 1" $P/summary.md "$TAG: rocprofv3 ... -- python tools/stage_bench.py --only 'cfg5 2M++ thr B=32' (cfg5's own size [32,3,64,64])" > /dev/null 2>&1
+tail -12 $P/summary.md
+find $O -name "*.db" -size +20M -delete
 du -sh $O
