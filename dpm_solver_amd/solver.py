@@ -233,6 +233,15 @@ def _adaptive_error(x_lower, x_higher, x_prev, atol, rtol):
     return e_dev[B]
 
 
+def _versions(tensors):
+    """version counters of `tensors` (in-place writes bump them); None where they are not tracked -- tensors created under
+    torch.inference_mode() -- which switches the detection of writes into the shared time vectors off (never an error)"""
+    try:
+        return tuple(t._version for t in tensors)
+    except RuntimeError:
+        return None
+
+
 class _Plan:
     """A frozen `dpm_plan` plus the per-device time tensors handed to the network / callbacks."""
 
@@ -284,7 +293,7 @@ class _Plan:
         handed out once, so the trajectory during which the first write happens is still correct."""
         key = (str(device), int(batch), bool(cfg))
         hit = self._views.get(key)
-        if hit is not None and tuple(t._version for t in hit["base"]) != hit["ver"]:
+        if hit is not None and hit["ver"] is not None and _versions(hit["base"]) != hit["ver"]:
             self._views.pop(key)
             self._dev.pop(str(device), None)
             self.times_written = True
@@ -304,13 +313,13 @@ class _Plan:
                        t_input_b=[ti[i, :batch] for i in range(n)],
                        t_input_2b=[ti[i] for i in range(n)] if cfg else None,
                        base=(T, te, ti))
-            hit["ver"] = tuple(t._version for t in hit["base"])
+            hit["ver"] = _versions(hit["base"])
             self._views[key] = hit
         return hit
 
     def written(self, V):
         """True when a network / callback wrote into the shared time tensors of `V` since they were built"""
-        return tuple(t._version for t in V["base"]) != V["ver"]
+        return V["ver"] is not None and _versions(V["base"]) != V["ver"]
 
     def __del__(self):
         if getattr(self, "handle", None):

@@ -620,6 +620,23 @@ def test_a_network_that_writes_into_t_is_detected_and_gets_clones(cfg):
         assert torch.equal(dpm3.sample(x1, steps=7, order=3, method="singlestep"), want1)
 
 
+def test_sampling_under_inference_mode():
+    """tensors created under torch.inference_mode() do not track version counters: the write detection of the shared time
+    vectors switches itself off there instead of raising (SD pipelines sample under inference_mode)"""
+    ns = make_schedule("sd")
+    x = torch.from_numpy(np.random.default_rng(8).standard_normal((2, 4, 8, 8)).astype(F32))
+    model = D.model_wrapper(lambda xx, t: xx * (t * 0.0005 + 0.25).reshape(-1, 1, 1, 1), ns)
+    want = D.DPM_Solver(model, ns).sample(x, steps=6, order=2)
+    dpm = D.DPM_Solver(model, ns)
+    with torch.inference_mode():
+        for _ in range(2):
+            got = dpm.sample(x, steps=6, order=2)
+            assert torch.equal(got, want)
+        outs = dpm.sample_requests([x, x * 0.5], steps=6, order=2)
+        assert torch.equal(outs[0], want)
+    assert torch.equal(dpm.sample(x, steps=6, order=2), want)       # and the same solver keeps working outside
+
+
 def test_abi_version_and_load_time_checks():
     """the structs grew (thr_hint) -- the version says so, and a binding can verify its layout at load time
     (dpm_sizeof); DPM_ERR_FAULT is retired: no hook machinery is left in the binding."""
