@@ -23,7 +23,7 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("world", [2, 1])
+@pytest.mark.parametrize("world", [2, 8, 1])       # 8: the node the driver scales to
 def test_bench_multi_rank_plumbing_with_a_stubbed_timed_region(world):
     env = dict(os.environ, DPM_BENCH_STUB="1", OMP_NUM_THREADS="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
