@@ -67,6 +67,19 @@ def main():
         assert all(torch.equal(y, solver.sample(x, steps=20, order=2)) for x, y in zip(xs, ys))
     print("sample_requests: %d requests, identical to sample() of each" % len(ys))
 
+    # a network in channels_last (NHWC, MIOpen's preferred layout): the solver runs on the network's own storage -- its
+    # scratch states are allocated in that layout, nothing is copied per stage -- and returns x_T's layout
+    net_cl = TinyEps().to(dev).eval()
+    net_cl.load_state_dict(net.state_dict())
+    net_cl = net_cl.to(memory_format=torch.channels_last)
+    solver_cl = DPM_Solver(model_wrapper(net_cl, ns, model_type="noise", guidance_type="classifier-free", condition=cond,
+                                         unconditional_condition=uncond, guidance_scale=7.5), ns, algorithm_type="dpmsolver++")
+    with torch.no_grad():
+        y_cl = solver_cl.sample(x_T.to(memory_format=torch.channels_last), steps=20, order=2)
+    rel = ((y_cl - x0).abs().max() / x0.abs().max()).item()
+    print("channels_last: result in channels_last = %s, differs from the NCHW run by %.2g of its scale (other MIOpen kernels)"
+          % (y_cl.is_contiguous(memory_format=torch.channels_last), rel))
+
     # DiffEdit / inpainting: keep the masked-out region on the known image, noised to the current level
     mask = (torch.rand(64, 64, device=dev) > 0.5).float()
     known = torch.randn(B, 4, 64, 64, device=dev)

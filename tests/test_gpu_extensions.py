@@ -767,3 +767,16 @@ def test_escape_hatch_build_without_write_through_stores():
                        env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
     assert " passed" in r.stdout and "failed" not in r.stdout.splitlines()[-1], r.stdout[-500:]
+
+
+def test_quickstart_example_runs():
+    """examples/quickstart.py end to end (reference calling convention, capture, requests in flight, channels_last, inpainting)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "quickstart.py")], cwd=root, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    for needle in ("sample:", "captured", "sample_requests: 8 requests", "channels_last: result in channels_last = True", "inpaint:"):
+        assert needle in r.stdout, r.stdout[-2000:]
