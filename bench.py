@@ -432,6 +432,9 @@ def main():
     if world > 1 or "RANK" in os.environ:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # the host driver of these boxes only supports dmabuf IPC: without this RCCL's cross-process buffer sharing fails
+        # with `hipIpcGetMemHandle: invalid argument` (already exported on the GPU boxes; kept for any other launcher)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RCCL prints a version banner on stdout when NCCL_DEBUG=VERSION (set on the GPU boxes): keep stdout for the
         # one JSON line by pointing fd 1 at stderr while the communicator is created
         sys.stdout.flush()

@@ -301,14 +301,19 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
     // the compile-time specialisation exists for the forms / guidance kinds samplers combine with thresholding
     constexpr bool HOT_BUILT = (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3) &&
                                (GUIDE == DPM_GUIDE_NONE || GUIDE == DPM_GUIDE_CFG) && !XE;
-    const bool hot = HOT_BUILT && tp.vec && tp.fastdiv && !ext.mask;
+    const bool hot = HOT_BUILT && tp.vec && !ext.mask;
+    const bool front = tp.topk > 0 || tp.quota > 0;  // the select starts from the per-thread maxima (quantile close to 1)
     // the general kernel reads form / guidance from the stage record and always takes the evaluation state through xe
     using ThrKernel = decltype(&stage_thresh_kernel<TS, TE, FORM_RT, GUIDE_RT, true, THR_THREADS, 0>);
     auto kern = reinterpret_cast<ThrKernel>(const_cast<void*>(dpm_catchall_thresh<TS, TE>()));
     if constexpr (HOT_BUILT) {
-      if (hot)
-        kern = (tp.topk > 0 || tp.quota > 0) ? stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 1>
-                                            : stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 2>;
+      // noise-prediction network + division by the invariant alpha: the compile-time prologue (HOT 1 / 2); any other
+      // parameterisation with the usual near-1 quantile: the run-time prologue (HOT 3); the rest: the catch-all kernel
+      if (hot && tp.fastdiv)
+        kern = front ? stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 1>
+                     : stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 2>;
+      else if (hot && front)
+        kern = stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 3>;
     }
     if (!xe) xe = x;
     int64_t grid = batch;

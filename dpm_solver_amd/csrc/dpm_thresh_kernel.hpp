@@ -838,11 +838,14 @@ __device__ __forceinline__ void solo_select(F&& bits_at, int n, uint32_t rank, b
   }
 }
 
-// HOT != 0: the usual configuration fixed at compile time -- 16-byte accesses legal, noise-prediction network with the
-// division by the invariant alpha, no mask blend; HOT = 1 with the top-K front end, HOT = 2 with the full level-0
-// histogram -- so that the load and store loops are straight-line code without the wave-uniform branches of the general
-// prologue and their operands (the kernel is as sensitive to its instruction count as to HBM).
-// Everything else runs the same source with HOT = 0.
+// HOT != 0: the usual configuration fixed at compile time -- 16-byte accesses legal, no mask blend, form and guidance kind
+// known -- so that the load and store loops are straight-line code without the wave-uniform branches of the run-time form
+// and guidance and their operands (the kernel is as sensitive to its instruction count as to HBM):
+//   HOT = 1  noise-prediction network with the division by the invariant alpha, top-K front end of the select;
+//   HOT = 2  the same with the full level-0 histogram;
+//   HOT = 3  like 1, the prologue chosen per sample at run time: x_start / v / score networks and divisors that fail the
+//            guard of the division by an invariant (round 4: those ran the catch-all kernel, 14-19 % slower).
+// Everything else runs the same source with HOT = 0 (run-time form, guidance, evaluation state, mask blend).
 template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int T, int HOT>
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 : DPM_THR_CATCHALL_WAVES, 4))) void stage_thresh_kernel(
     const TS* __restrict__ x_1, const TS* __restrict__ xe_1, const TE* __restrict__ e0_1, const TE* __restrict__ e1_1,
@@ -868,9 +871,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
   const bool vec = HOT != 0 || tp.vec != 0;
   const uint32_t k = (uint32_t)tp.k;
   const bool route1 = k > 1 && tp.quota > 0;                              // single-exchange cluster select
-  const bool track = HOT == 1 || (HOT == 0 && (tp.topk > 0 || route1));  // phase 1 keeps every thread's four largest |x0|
+  const bool track = HOT == 1 || HOT == 3 || (HOT == 0 && (tp.topk > 0 || route1));  // phase 1 keeps every thread's four largest |x0|
   const bool topk = track && tp.topk > 0;                                 // top-K front end of the general route
-  const bool fastdiv = HOT != 0 || tp.fastdiv != 0;
+  constexpr bool FAST_ONLY = HOT == 1 || HOT == 2;  // the launch guarantees tp.fastdiv there
+  const bool fastdiv = FAST_ONLY || tp.fastdiv != 0;
   const int64_t eps_stride = ext.eps_stride;
   const int grp = k == 1 ? (int)blockIdx.x : (int)(blockIdx.x / k);
   const int c = k == 1 ? 0 : (int)(blockIdx.x % k);
@@ -964,7 +968,13 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
     uint32_t m1 = 0u, m2 = 0u, m3 = 0u, m4 = 0u;  // top-K: the four largest |x0| bit patterns this thread produced
     if (vec) {
       // ROWS tile rows per iteration, the loads of all of them issued before the first use: the phase is bound by
-      // the bytes one workgroup keeps in flight (two workgroups per CU, and while one of them selects only one streams)
+      // the bytes one workgroup keeps in flight (two workgroups per CU, and while one of them selects only one streams).
+      // FAST = noise-prediction network with the division by the invariant alpha (the common case, branch-free packed
+      // arithmetic: the only loop of the HOT = 1 / 2 kernels); otherwise the general prologue (x_start / v / score
+      // networks, divisors that fail the guard).  HOT = 3 and the catch-all kernel hold both loops and choose once per
+      // sample (v-prediction at [1024,3,64,64]: 54.5 -> 44.3 us per stage against the catch-all kernel).
+      auto load_phase = [&](auto fast_tag) {
+      constexpr bool FAST = decltype(fast_tag)::value;
       for (int i0 = tid * 4; i0 < n; i0 += ROWS * T * 4) {
         float vx[ROWS][4], v0[ROWS][4], v1[ROWS][4], vg[ROWS][4];
 #pragma unroll
@@ -980,7 +990,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
           const int i = i0 + r * T * 4;
           if (r == 0 || i < n) {
             float o[4];
-            if (fastdiv) {  // uniform: the common parameterisation, division by the invariant alpha (3 VALU ops for ~12)
+            if constexpr (FAST) {  // the common parameterisation, division by the invariant alpha (3 VALU ops for ~12)
 #pragma unroll
               for (int j = 0; j < 4; j += 2) {  // adjacent pairs: packed fp32 instructions
                 const f32x2 z = {0.f, 0.f};
@@ -1012,6 +1022,15 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
             }
           }
         }
+      }
+      };
+      if constexpr (FAST_ONLY) {
+        load_phase(std::true_type{});
+      } else {
+        if (fastdiv)
+          load_phase(std::true_type{});
+        else
+          load_phase(std::false_type{});
       }
     } else {
 #pragma unroll 4

@@ -1,6 +1,6 @@
 """build()'s ISA check (__graft_entry__.scan_disassembly) on synthetic disassembly: it must accept the shape the
 library has and reject the two regressions it exists for -- a write-through store separated from its `s_nop`, and a
-compile-time specialised stage kernel that spills to scratch."""
+stage kernel (specialised or catch-all) that spills to scratch."""
 import os
 import sys
 
@@ -19,7 +19,6 @@ GOOD = """
 	global_store_dwordx4 v[10:11], v[4:7], off sc0 sc1         // 000000001018: DC000000
 	s_nop 1
 0000000000002000 <_ZN12_GLOBAL__N_119stage_thresh_kernelIffLin1ELin1ELb1ELi512ELi0EEEvPKT_>:
-	scratch_store_dword off, v40, s32                          // 000000002000: DC000000
 	global_store_dwordx4 v[10:11], v[0:3], off sc0 sc1
 	s_nop 1
 0000000000003000 <_ZN12_GLOBAL__N_116add_noise_kernelIfLb1EEEvPKT_>:
@@ -30,7 +29,7 @@ GOOD = """
 def test_accepts_the_expected_shape():
     n_wt, n_kernels, spilled = G.scan_disassembly(GOOD)
     assert (n_wt, n_kernels) == (3, 2)
-    assert len(spilled) == 1 and "Lin1ELin1E" in next(iter(spilled))
+    assert not spilled
 
 
 def test_rejects_a_store_without_its_nop():
@@ -44,6 +43,14 @@ def test_rejects_a_store_without_its_nop():
 
 def test_rejects_scratch_in_a_specialised_kernel():
     bad = GOOD[:2] + ["\tscratch_load_dword v1, off, s32"] + GOOD[2:]
+    with pytest.raises(AssertionError, match="spills to scratch"):
+        G.scan_disassembly(bad)
+
+
+def test_rejects_scratch_in_the_catch_all_thresholding_kernel_too():
+    """round 4: no kernel of the library spills any more, the run-time dispatched thresholding kernel included"""
+    i = next(i for i, ln in enumerate(GOOD) if "stage_thresh_kernel" in ln)
+    bad = GOOD[:i + 1] + ["\tscratch_store_dword off, v40, s32"] + GOOD[i + 1:]
     with pytest.raises(AssertionError, match="spills to scratch"):
         G.scan_disassembly(bad)
 
