@@ -299,8 +299,10 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
 #endif
     const size_t lds_bytes = (size_t)pl.chunk * 4 + THR_NB * 4 + THR_MISC * 4 + (THR_CAP + 32) * 4;
     // the compile-time specialisation exists for the forms / guidance kinds samplers combine with thresholding
-    constexpr bool HOT_BUILT = (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3) &&
-                               (GUIDE == DPM_GUIDE_NONE || GUIDE == DPM_GUIDE_CFG) && !XE;
+    // (classifier guidance -- the reference's own ImageNet-256 example samples with it AND thresholding, sample.sh:40-50 --
+    // has the HOT = 3 flavour only: its two load loops cover the noise fast path and everything else)
+    constexpr bool HOT_BUILT = (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3) && !XE;
+    constexpr bool HOT12_BUILT = HOT_BUILT && (GUIDE == DPM_GUIDE_NONE || GUIDE == DPM_GUIDE_CFG);
     const bool hot = HOT_BUILT && tp.vec && !ext.mask;
     const bool front = tp.topk > 0 || tp.quota > 0;  // the select starts from the per-thread maxima (quantile close to 1)
     // the general kernel reads form / guidance from the stage record and always takes the evaluation state through xe
@@ -309,11 +311,15 @@ int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& str
     if constexpr (HOT_BUILT) {
       // noise-prediction network + division by the invariant alpha: the compile-time prologue (HOT 1 / 2); any other
       // parameterisation with the usual near-1 quantile: the run-time prologue (HOT 3); the rest: the catch-all kernel
-      if (hot && tp.fastdiv)
-        kern = front ? stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 1>
-                     : stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 2>;
-      else if (hot && front)
-        kern = stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 3>;
+      bool chosen = false;
+      if constexpr (HOT12_BUILT) {
+        if (hot && tp.fastdiv) {
+          kern = front ? stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 1>
+                       : stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 2>;
+          chosen = true;
+        }
+      }
+      if (!chosen && hot && front) kern = stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 3>;
     }
     if (!xe) xe = x;
     int64_t grid = batch;
