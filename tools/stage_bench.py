@@ -236,6 +236,17 @@ def main():
     s = D.DPM_Solver(D.model_wrapper(lambda x, t: e6[:, :3], dd), dd)
     rows += run("guided-diffusion 2M++ 6ch B=1024", s, torch.randn(shape, device=DEV), steps=25, order=2)
     del e6
+    # the reference's own ImageNet-256 example (examples/ddpm_and_guided-diffusion/sample.sh:40-50): dpmsolver++ 2M, 20 steps,
+    # classifier guidance scale 8, dynamic thresholding, learned-variance (6-channel) network output read in place
+    shape = (16, 3, 256, 256)
+    e6 = torch.randn((16, 6, 256, 256), device=DEV)
+    gfix = torch.randn(shape, device=DEV) * 0.01
+    s = D.DPM_Solver(D.model_wrapper(lambda x, t: e6[:, :3], dd, guidance_type="classifier", condition=torch.zeros(16, device=DEV),
+                                     guidance_scale=8.0, classifier_fn=lambda x, t, c: (x * gfix).sum(dim=(1, 2, 3))), dd,
+                     correcting_x0_fn="dynamic_thresholding")
+    rows += run("guided-diffusion ImageNet-256 example: 2M++ thr 6ch classifier [16,3,256,256]", s, torch.randn(shape, device=DEV),
+                reps=3, steps=20, order=2)
+    del e6, gfix
     # large-sample thresholding [64,3,256,256]
     shape = (64, 3, 256, 256)
     e, = frozen(shape, torch.float32)
