@@ -44,23 +44,37 @@ def gather_samples(x_local, batch=None, group=None):
     world = dist.get_world_size(group)
     if world == 1:
         return x_local
-    n_local = torch.tensor([x_local.shape[0]], device=x_local.device, dtype=torch.int64)
+    # a channels_last shard (the solver returns x_T's layout) is gathered as it lies in memory: the batch is the outermost
+    # dimension of both layouts, so the collective sees each sample's block unchanged -- viewed [N,H,W,C] it is a plain
+    # contiguous tensor -- and the full batch comes back in channels_last as well (no layout copy before the all-gather).
+    # Every rank must read the gathered buffer the same way: an EMPTY shard has no layout of its own, so ragged batches
+    # exchange the flag together with the shard sizes.
+    nd = x_local.dim()
+    cl = False
+    if nd in (4, 5) and x_local.numel() > 0 and not x_local.is_contiguous():
+        cl = x_local.is_contiguous(memory_format=torch.channels_last if nd == 4 else torch.channels_last_3d)
+    n_local = torch.tensor([x_local.shape[0], int(cl)], device=x_local.device, dtype=torch.int64)
     if batch is not None and batch % world == 0:
         sizes = [batch // world] * world
     else:
         all_n = [torch.zeros_like(n_local) for _ in range(world)]
         dist.all_gather(all_n, n_local, group=group)
-        sizes = [int(v.item()) for v in all_n]
+        sizes = [int(v[0].item()) for v in all_n]
+        cl = any(int(v[1].item()) for v in all_n)
     mx = max(sizes)
-    xl = x_local.contiguous()
+    perm = (0,) + tuple(range(2, nd)) + (1,) if cl else None
+    xl = (x_local.permute(perm) if perm is not None else x_local).contiguous()   # (no copy for a dense channels_last shard)
     if xl.shape[0] != mx:
         pad = torch.zeros((mx - xl.shape[0],) + tuple(xl.shape[1:]), dtype=xl.dtype, device=xl.device)
         xl = torch.cat([xl, pad])
     out = torch.empty((world * mx,) + tuple(xl.shape[1:]), dtype=xl.dtype, device=xl.device)
     dist.all_gather_into_tensor(out, xl, group=group)
-    if all(s == mx for s in sizes):
-        return out
-    return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)])
+    if not all(s == mx for s in sizes):
+        out = torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)])
+    if perm is not None:
+        inv = (0, len(perm) - 1) + tuple(range(1, len(perm) - 1))
+        out = out.permute(inv)
+    return out
 
 
 def sample_sharded(solver, x_T, group=None, gather=True, **sample_kwargs):

@@ -58,6 +58,10 @@ def _worker(rank, world, port, batch, q):
             loc = torch.arange(nb * 6, dtype=torch.float32).reshape(nb, 2, 3)[lo2:hi2]
             got = DD.gather_samples(loc, batch=nb)
             ok = ok and bool(torch.equal(got, torch.arange(nb * 6, dtype=torch.float32).reshape(nb, 2, 3)))
+        # a channels_last batch: the shards and the gathered result keep the layout, values as in the default layout
+        xcl = x.contiguous(memory_format=torch.channels_last)
+        ocl = DD.sample_sharded(build_solver(scase, "cpu"), xcl, **kw)
+        ok = ok and bool(torch.equal(ocl, full)) and ocl.is_contiguous(memory_format=torch.channels_last) and ocl.shape == full.shape
         # a batch smaller than the world: the rank with the empty shard still joins every collective (adaptive: the
         # MAX all-reduce of every iteration; then the gather)
         x1 = xa[:1]
