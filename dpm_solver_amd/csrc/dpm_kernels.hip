@@ -963,7 +963,7 @@ extern "C" int dpm_tuning_set(int knob, int value) {
       g_tuning.thr_spin_limit = value;
       return DPM_OK;
     case DPM_TUNE_THR_DEBUG_FAULT:
-      if (value < 0 || value > 2) return dpm_set_error(DPM_ERR_ARG, "thr_debug_fault must be 0, 1 or 2");
+      if (value < 0 || value > 3) return dpm_set_error(DPM_ERR_ARG, "thr_debug_fault must be 0 .. 3");
       g_tuning.thr_debug_fault = value;
       return DPM_OK;
     case DPM_TUNE_MULTI_BLOCKS_PER_CU:

@@ -66,7 +66,7 @@ constexpr int THR_HINT_W = DPM_THR_HINT_WORDS;
 // the predicted bound sits this far below the extrapolated order statistic: with the statistic within a few percent of
 // its extrapolation the union stays ~1.3 K entries (K = the wanted rank from the top) and holds the K-th largest
 constexpr float THR_HINT_MARGIN = 0.94f;
-constexpr int THR_WS_POISON = THR_WS_CNT + 16; // a workgroup of the cluster gave up a wait on this sample (see solo_select)
+constexpr int THR_WS_POISON = THR_WS_CNT + 16; // a workgroup of the cluster is out of the protocol on this sample (see give_up)
 // polls (a microsecond or two each: a dependent sc1 load + s_sleep) before a wait on a peer gives up -- milliseconds.
 // Giving up is safe (the workgroup then computes the sample's order statistics alone, solo_select), so the limit only
 // trades a stall against redundant work when the peers are off the chip (ThrParams.spin_limit, DPM_TUNE_THR_SPIN_LIMIT)
@@ -97,7 +97,7 @@ struct ThrParams {
   uint32_t* fault; // host-mapped word: set when a cluster wait timed out and was recovered from (diagnostics only:
                    // dpm_cluster_timeout_poll; the launch's results are correct either way)
   uint32_t spin_limit;  // polls before a wait on a peer gives up (THR_SPIN_LIMIT)
-  int32_t debug_fault;  // testing (DPM_TUNE_THR_DEBUG_FAULT): 2 = workgroup 1 of every cluster neither publishes nor arrives
+  int32_t debug_fault;  // testing (DPM_TUNE_THR_DEBUG_FAULT): 2 / 3 = workgroup 1 of every cluster takes no part in its cluster
   float* hint;     // dpm_buffers.thr_hint (THR_HINT_W floats per sample) or null: the selected order statistic of the
                    // previous two stages -> predicted select bound of this one (cluster_select_once, `pbound`)
   int32_t hint_reset; // this is the first stage of a trajectory: the stored values are stale, overwrite without reading
@@ -187,41 +187,55 @@ __device__ __forceinline__ void store4(bf16_t* __restrict__ p, int64_t i, const 
 // A wait on another workgroup gives up after ThrParams.spin_limit polls (milliseconds).  Within one process the peers of a
 // cluster are co-resident by construction (grid capped at the occupancy, clustered launches chained), so this happens
 // when something else keeps them off the chip: another PROCESS running clusters on the same GPU, two clustered graphs
-// replayed concurrently, a kernel of another stream holding the CUs.  Giving up is harmless and local: the workgroup
-// marks the sample (THR_WS_POISON: peers on the general route may have read merged data it left incomplete), stops
-// waiting for the rest of the launch, and computes the sample's order statistics ALONE from global memory
-// (solo_select) -- the stage's results are the same bits as without the timeout, nothing is reported to the caller
-// except the host-mapped diagnostic word (dpm_cluster_timeout_poll).  The reference cannot fail here (ref :416-425);
-// neither can this.
+// replayed concurrently, a kernel of another stream holding the CUs.  Giving up is harmless and local.  The workgroup
+// LEAVES the cluster protocol for the rest of the launch: it writes nothing more into any sample's workspace, arrives at
+// no further barrier, and computes the order statistics of its samples ALONE from global memory (solo_select) -- the
+// same bits as without the timeout.  What it contributed before (always complete: every contribution precedes the
+// wait it belongs to) stays valid for the peers; peers that wait for something it will no longer deliver give up in
+// turn -- at once when they see the sample's THR_WS_POISON mark, which only shortens their wait, after their own polls
+// otherwise.  Nothing is reported to the caller except the host-mapped diagnostic word (dpm_cluster_timeout_poll).
+// The reference cannot fail here (ref :416-425); neither can this.
+// (Round 4 first let such a workgroup run on through the protocol with whatever it had read and discard its result:
+// the forced-fault sweeps found a neighbouring chunk changed once in a few thousand launches and workspace words left
+// dirty, profiles/r04_thresholding.md.)
 __device__ __forceinline__ void raise_fault(uint32_t* fault) {
   if (fault) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// `dead` (LDS word): this workgroup gave up a wait -- do not wait again in this launch
+// `dead` (LDS word): this workgroup gave up a wait -- it is out of the protocol for the rest of the launch
 __device__ __forceinline__ void give_up(uint32_t* dead, uint32_t* poison, uint32_t* fault) {
   *dead = 1u;
   raise_fault(fault);
-  // the mark must be visible before anything this workgroup contributes from here on (peers check it after reading)
-  __hip_atomic_store(poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __hip_atomic_store(poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the peers need not poll to the end
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (landed long before this workgroup reports itself done)
+}
+// the `spins`-th unsuccessful poll of a wait: time to give up?  (the mark of a peer that did is looked at every 8th poll)
+__device__ __forceinline__ bool wait_is_over(uint32_t spins, const uint32_t* poison, const ThrParams& tp) {
+  if (spins > tp.spin_limit) return true;
+  return (spins & 7u) == 0u && __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
 }
 
 // all workgroups of a cluster meet here; `cnt` is a zero-initialised single-use counter.  Everything the cluster
 // shares travels as agent-scope atomics and sc1 loads, so no cache write-back / invalidate is needed: drain this
 // wave's atomics, arrive with a relaxed atomic, poll with relaxed sc1 loads (MI355X_MICROARCH.md, barrier-counter).
-// `dead` (LDS word): a previous wait of this workgroup timed out -- do not wait again.  `ws`: the sample's workspace.
-__device__ __forceinline__ void cluster_barrier(uint32_t* cnt, uint32_t k, uint32_t* dead, uint32_t* ws, const ThrParams& tp,
-                                                bool silent = false) {
+// Returns false when the wait was given up (`dead`, an LDS word, is set): the caller leaves the cluster protocol -- it
+// contributes nothing and arrives nowhere from then on.  Hence the invariant the peers rely on: a counter that reaches
+// k was reached by k workgroups that were each still in the protocol, with every contribution of theirs drained.
+__device__ __forceinline__ bool cluster_barrier(uint32_t* cnt, uint32_t k, uint32_t* dead, uint32_t* ws, const ThrParams& tp) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (!silent) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t spins = 0;
-    while (!*dead && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k) {
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > tp.spin_limit) give_up(dead, ws + THR_WS_POISON, tp.fault);
+      if (wait_is_over(++spins, ws + THR_WS_POISON, tp)) {
+        give_up(dead, ws + THR_WS_POISON, tp.fault);
+        break;
+      }
     }
   }
   __syncthreads();
+  return *dead == 0u;
 }
 
 // keep m1 >= m2 >= m3 >= m4, the four largest values seen so far (duplicates are separate entries): inserting u into a
@@ -633,14 +647,13 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
   // the first `pub` entries of a slot are always written -- the tag alone beyond the count -- so that readers can wait
   // for them without knowing the count (step 5)
   const uint32_t pub = (uint32_t)tp.slot_pub;
-  const bool silent = tp.debug_fault == 2 && c == 1;  // testing: this workgroup's peers must get by without it
-  if (!silent) {
+  {
     const uint32_t nv = over ? 0u : ncl, nw = nv > pub ? nv : pub;
     for (uint32_t i = tid; i < nw; i += T)
       __hip_atomic_store(&mine_slot[THR_SLOT_HDR + i], (i < nv ? cand[i] : 0u) | THR_TAG, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (tid == 0 && !silent) {
+  if (tid == 0) {
     // smallest |x0| this workgroup would have published: the predicted bound, or the first pattern of the digit (0 = everything)
     const uint32_t bound = pbound ? pbound : (bin_lo ? (bin_lo + dbase) << THR_FSHIFT : 0u);
     __hip_atomic_store(&mine_slot[2], cmax | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -686,7 +699,7 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
       for (int j = 0; j < PER; ++j) all &= w[j];
       if ((all & THR_TAG) || misc[30]) break;
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > tp.spin_limit) give_up(misc + 30, poison, tp.fault);
+      if (wait_is_over(++spins, poison, tp)) give_up(misc + 30, poison, tp.fault);
     }
 #pragma unroll
     for (int j = 0; j < PER; ++j)
@@ -742,7 +755,7 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
         while (!(w[j] & THR_TAG) && !misc[30]) {
           __builtin_amdgcn_s_sleep(1);
           w[j] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (++spins > tp.spin_limit) give_up(misc + 30, poison, tp.fault);
+          if (wait_is_over(++spins, poison, tp)) give_up(misc + 30, poison, tp.fault);
         }
         cand[sc[k + sl] + i] = w[j] & ~THR_TAG;
       }
@@ -882,7 +895,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
   const TS* ba = HOT != 0 ? nullptr : static_cast<const TS*>(ext.ba);
   const TS* bb = HOT != 0 ? nullptr : static_cast<const TS*>(ext.bb);
   TS* xo2 = static_cast<TS*>(ext.xo2);
-  if (threadIdx.x == 0) misc[30] = 0u;  // set when a wait on a peer workgroup timed out (see raise_fault)
+  // misc[30]: this workgroup gave up a wait on a peer and is out of the cluster protocol (give_up).  Testing
+  // (ThrParams.debug_fault 2 / 3): workgroup 1 of every cluster is out from the start, with / without the sample mark.
+  if (threadIdx.x == 0) misc[30] = (k > 1 && tp.debug_fault >= 2 && c == 1) ? 1u : 0u;
   for (int s_idx = grp; s_idx < tp.batch; s_idx += tp.groups) {
     // The thread index is re-materialised per sample: otherwise the compiler hoists every per-thread predicate of the
     // body (dozens of 64-bit lane masks) out of this loop, runs out of SGPRs and pays v_readlane pairs all over the select.
@@ -955,8 +970,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
         }
       }
       misc[25] = pb;
-      // a workgroup that gave up a wait on an earlier sample does not wait on this one either: tell the peers
-      if (k > 1 && misc[30]) __hip_atomic_store(ws + THR_WS_POISON, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // a workgroup that gave up a wait on an earlier sample takes no part in this one either: tell the peers
+      if (k > 1 && misc[30] && tp.debug_fault != 3)
+        __hip_atomic_store(ws + THR_WS_POISON, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       misc[4] = 0u;   // candidate counter
       misc[3] = ABS;  // smallest value above the selected top digit (cluster exchange)
       misc[8] = 0u;   // cluster_select_once: chunk maximum, largest bound, bad-slot flag, maximum of the sample
@@ -1081,22 +1097,25 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
     bool solved = false;
     uint32_t route = 4u;  // diagnostics (hint word 2): 1 predicted bound, 2 prediction rejected, then 3 single exchange / 4 general
     const uint32_t pbound = route1 ? misc[25] : 0u;  // cluster-uniform: every workgroup read the same hint words
-    if (pbound) {  // the predicted attempt has a slot area of its own (a rejected one leaves its slots dirty)
+    bool lost = k > 1 && misc[30] != 0u;  // out of the cluster protocol (give_up): straight to solo_select
+    if (pbound && !lost) {  // the predicted attempt has a slot area of its own (a rejected one leaves its slots dirty)
       solved = cluster_select_once<T>(sx0, n, vec, m1, m2, m3, m4, has, hist, misc, cand,
                                       ws + THR_WS_WORDS + (size_t)k * THR_SLOTW, tp, k, c, tid, a1, b1, s_idx == grp,
                                       ws + THR_WS_POISON, pbound);
       route = solved ? 1u : 2u;
+      lost = !solved && misc[30] != 0u;
     }
-    const bool searched = route1 && !solved;     // the searched-bound attempt runs (and dirties the first slot area)
-    if (route1 && !solved) {
+    const bool searched = route1 && !solved && !lost;  // the searched-bound attempt runs (and dirties the first slot area)
+    if (searched) {
       solved = cluster_select_once<T>(sx0, n, vec, m1, m2, m3, m4, has, hist, misc, cand, ws + THR_WS_WORDS, tp, k, c, tid,
                                       a1, b1, s_idx == grp && !pbound, ws + THR_WS_POISON);
       if (solved && route != 2u) route = 3u;
+      lost = !solved && misc[30] != 0u;
     }
     const bool general = !solved;                // the general route runs (for clusters: it dirties the merged histograms)
-    const bool silent = tp.debug_fault == 2 && c == 1;  // testing: this workgroup arrives at no cluster barrier
 
-    if (general && topk) {
+    // (a lambda for its early exits: a cluster wait that is given up ends the front end -- returns false)
+    auto topk_front = [&]() -> bool {
       // Top-K front end (the usual case: ratio close to 1, K = n - lo elements at or above the wanted one, K much smaller
       // than the number of threads).  The K-th largest element of the sample is at least the K-th largest of the
       // per-thread maxima (those are K distinct elements), so every element that can still matter has a top digit >=
@@ -1112,7 +1131,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
           const uint32_t v = hist[j * T + tid];
           if (v) __hip_atomic_fetch_add(&gh[j * T + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        cluster_barrier(ws + THR_WS_CNT + 4, k, misc + 30, ws, tp, silent);
+        if (!cluster_barrier(ws + THR_WS_CNT + 4, k, misc + 30, ws, tp)) return false;
 #pragma unroll
         for (int j = 0; j < BPT; ++j)
           hist[j * T + tid] = __hip_atomic_load(&gh[j * T + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1156,7 +1175,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
         if (ok && slot0 <= (uint32_t)THR_GCAP && nc <= (uint32_t)THR_GCAP - slot0)
           for (uint32_t i = tid; i < nc; i += T)
             __hip_atomic_store(&gl[slot0 + i], cand[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cluster_barrier(ws + THR_WS_CNT + 5, k, misc + 30, ws, tp, silent);
+        if (!cluster_barrier(ws + THR_WS_CNT + 5, k, misc + 30, ws, tp)) return false;
         const uint32_t total = __hip_atomic_load(gcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok = total <= (uint32_t)THR_GCAP;
         if (ok) {
@@ -1177,14 +1196,16 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
         if (tid == 0) misc[4] = 0u;
       }
       hist_ready = false;
-    }
+      return true;
+    };
+    if (general && topk && !lost) lost = !topk_front();
 
     // 11 + 11 + 9-bit radix select over the candidates, or over the whole chunk.  In the latter case the elements
     // that share the selected top digit -- the only ones levels 1, 2 and the min-above search can still care about --
     // are compacted into `cand` after level 0 (wave-aggregated append); everything above that digit only matters
     // through its minimum, kept per lane in `hi`.
 #pragma unroll 1
-    for (int pass = 0; pass < 3 && !fast && general; ++pass) {
+    for (int pass = 0; pass < 3 && !fast && general && !lost; ++pass) {
       const int shift = pass == 0 ? 20 : pass == 1 ? 9 : 0;
       const uint32_t dmask = pass == 2 ? 0x1ffu : 0x7ffu;
       if (pass > 0 || !hist_ready) {  // the histogram is all zero here (sample start / locate_bin)
@@ -1212,7 +1233,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
           const uint32_t v = hist[j * T + tid];
           if (v) __hip_atomic_fetch_add(&gh[j * T + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        cluster_barrier(ws + THR_WS_CNT + pass, k, misc + 30, ws, tp, silent);
+        if (!cluster_barrier(ws + THR_WS_CNT + pass, k, misc + 30, ws, tp)) {
+          lost = true;
+          break;
+        }
 #pragma unroll
         for (int j = 0; j < BPT; ++j)
           hist[j * T + tid] = __hip_atomic_load(&gh[j * T + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1252,9 +1276,16 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
           }
           __syncthreads();
           const uint32_t slot0 = misc[5];
-          for (uint32_t i = tid; i < nc; i += T)
+          // (the counts of the cluster add up to cnt_sel <= THR_GCAP: every workgroup that gets here is in the protocol
+          // and read the same complete histogram; the bound is defensive)
+          const uint32_t room = slot0 < (uint32_t)THR_GCAP ? (uint32_t)THR_GCAP - slot0 : 0u;
+          const uint32_t nput = nc < room ? nc : room;
+          for (uint32_t i = tid; i < nput; i += T)
             __hip_atomic_store(&gl[slot0 + i], cand[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          cluster_barrier(ws + THR_WS_CNT + 1, k, misc + 30, ws, tp, silent);
+          if (!cluster_barrier(ws + THR_WS_CNT + 1, k, misc + 30, ws, tp)) {
+            lost = true;
+            break;
+          }
           nc = cnt_sel;
           for (uint32_t i = tid; i < nc; i += T)
             cand[i] = __hip_atomic_load(&gl[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1271,6 +1302,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
     if (solved) {
       a = __uint_as_float(a1);
       b = tp.hi != tp.lo ? __uint_as_float(b1) : a;
+    } else if (lost) {
+      a = b = 0.f;  // (solo_select below)
     } else if (fast) {
       // the candidates hold the wanted element at ascending position `rank`, and -- unless it is their largest -- the next
       // order statistic too; otherwise that one is the smallest value of the higher digits
@@ -1329,21 +1362,19 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
         if (!local_only) {  // workspace words start at zero: keep the minimum as a maximum of the complement
           uint32_t* gm = ws + THR_WS_CNT + 8;
           if (tid == 0) __hip_atomic_fetch_max(gm, ABS - misc[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          cluster_barrier(ws + THR_WS_CNT + 3, k, misc + 30, ws, tp, silent);
-          b = __uint_as_float(ABS - __hip_atomic_load(gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          if (cluster_barrier(ws + THR_WS_CNT + 3, k, misc + 30, ws, tp))
+            b = __uint_as_float(ABS - __hip_atomic_load(gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          else
+            lost = true;
         } else {
           b = __uint_as_float(misc[3]);
         }
       }
     }
-    if (k > 1 && general) {
-      // A wait of this workgroup timed out (misc[30]), or -- general route only: the single exchange reads nothing a peer
-      // writes after its own wait -- a peer gave one up and the merged histograms / lists this workgroup read may be
-      // incomplete (THR_WS_POISON, set before the peer went on): the cluster cannot be relied on for this sample.  The
-      // workgroup computes the two order statistics alone (solo_select): same bits, no peers.
-      if (tid == 0) misc[29] = misc[30] | __hip_atomic_load(ws + THR_WS_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      if (misc[29]) {
+    if (lost) {
+      // This workgroup is out of the cluster protocol (a wait of its own timed out, on this sample or an earlier one): it
+      // computes the sample's two order statistics alone (solo_select): same bits, no peers, no workspace.
+      {
         // wave-uniform bases + a 32-bit element index (a clustered sample has at most THR_KMAX chunks: < 2^31 elements)
         const int64_t sx = s_loc * tp.per_sample, se = s_loc * (eps_stride ? eps_stride : tp.per_sample);
         const TS* __restrict__ xs = (XE ? xe : x) + sx;
@@ -1487,7 +1518,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
           for (uint32_t i = tid; i < (uint32_t)THR_WS_WORDS; i += T) ws[i] = 0u;
         } else if (tid == 0) {
           ws[THR_WS_DONE] = 0u;
-          ws[THR_WS_POISON] = 0u;  // (a peer that gave up takes the general route itself, its solved peers end up here)
+          ws[THR_WS_POISON] = 0u;
         }
       }
     }

@@ -408,8 +408,9 @@ enum {
   DPM_TUNE_THR_SPIN_LIMIT = 10,     /* polls (a microsecond or two each) before a wait on a cluster peer gives up and
                                        the workgroup finishes its sample alone; default 4096                          */
   DPM_TUNE_THR_DEBUG_FAULT = 11     /* testing.  1: every cluster wait gives up at its first unsuccessful poll;
-                                       2: workgroup 1 of every cluster neither publishes nor arrives (its peers time
-                                       out).  Results must not change.  0 (default): off                              */
+                                       2 / 3: workgroup 1 of every cluster takes no part in its cluster from the start,
+                                       with / without marking its samples (the peers see the mark / run out of polls).
+                                       Results must not change.  0 (default): off                                     */
 };
 int dpm_tuning_set(int knob, int value);
 int dpm_tuning_get(int knob);

@@ -217,6 +217,26 @@ def test_thresholded_sampling_random_sweep():
     rng = np.random.default_rng(7)
     done = 0
     total = int(os.environ.get("DPM_THR_SWEEP", "250"))
+    # DPM_THR_SWEEP_FAULT=1|2|3 runs the sweep with forced cluster faults (every wait gives up at once / workgroup 1 of
+    # every cluster out of the protocol, marked or not; short timeout), DPM_THR_SWEEP_ONE_HOP=0 on the general route only:
+    # the in-kernel recovery must reproduce the oracle's bits on every configuration
+    fault = int(os.environ.get("DPM_THR_SWEEP_FAULT", "0"))
+    one_hop = int(os.environ.get("DPM_THR_SWEEP_ONE_HOP", "1"))
+    if fault:
+        L.check(L.lib.dpm_tuning_set(L.TUNE_THR_DEBUG_FAULT, fault))
+        L.check(L.lib.dpm_tuning_set(L.TUNE_THR_SPIN_LIMIT, 32))
+    L.check(L.lib.dpm_tuning_set(L.TUNE_CLUSTER_ONE_HOP, one_hop))
+    try:
+        _thr_sweep(rng, total)
+    finally:
+        L.lib.dpm_tuning_set(L.TUNE_CLUSTER_ONE_HOP, 1)
+        if fault:
+            L.lib.dpm_tuning_set(L.TUNE_THR_DEBUG_FAULT, 0)
+            L.lib.dpm_tuning_set(L.TUNE_THR_SPIN_LIMIT, 4096)
+
+
+def _thr_sweep(rng, total):
+    done = 0
     while done < total:
         B = int(rng.choice([1, 2, 3, 5, 8, 17, 40, 130, 600]))
         Cc, H, W = int(rng.integers(1, 4)), int(rng.choice([4, 7, 16, 31, 32, 64, 96])), int(rng.choice([4, 9, 16, 32, 64, 128]))
@@ -727,13 +747,14 @@ def _thr_solver(ns, model=lambda xx, t: xx * 0.5, **kw):
 
 
 @pytest.mark.parametrize("shape", [(32, 3, 64, 64), (5, 3, 64, 64), (2, 3, 160, 160)])
-@pytest.mark.parametrize("mode,one_hop", [(1, 1), (2, 1), (1, 0), (2, 0)])
+@pytest.mark.parametrize("mode,one_hop", [(1, 1), (2, 1), (3, 1), (1, 0), (2, 0), (3, 0)])
 def test_cluster_wait_timeout_is_recovered_inside_the_kernel(shape, mode, one_hop):
-    """Forced faults -- mode 1: every wait on a peer gives up at its first unsuccessful poll; mode 2: workgroup 1 of every
-    cluster neither publishes nor arrives, so its peers run into the (shortened) timeout -- on the single-exchange route
-    and on the general route (merged histograms).  A workgroup that cannot rely on its cluster computes the sample's order
-    statistics alone from global memory: the trajectory's bits do not change, nothing raises, the workspace is left
-    zero-filled, and only the diagnostic word says that it happened."""
+    """Forced faults -- mode 1: every wait on a peer gives up at its first unsuccessful poll; modes 2 / 3: workgroup 1 of
+    every cluster takes no part in it from the start, with / without marking its samples, so its peers see the mark or run
+    into the (shortened) timeout -- on the single-exchange route and on the general route (merged histograms).  A
+    workgroup whose wait timed out leaves the cluster protocol and computes the order statistics of its samples alone from
+    global memory: the trajectory's bits do not change, nothing raises, the workspace is left zero-filled, and only the
+    diagnostic word says that it happened."""
     ns = make_schedule("ddpm")
     x = torch.from_numpy(np.random.default_rng(41).standard_normal(shape).astype(F32)).to(DEV)
     assert L.lib.dpm_threshold_workspace_bytes(shape[0], int(np.prod(shape[1:]))) > 0        # a clustered shape
@@ -755,6 +776,31 @@ def test_cluster_wait_timeout_is_recovered_inside_the_kernel(shape, mode, one_ho
     assert torch.equal(dpm.sample(x, steps=8, order=2), want)
     torch.cuda.synchronize()
     assert not L.cluster_timeout_poll()
+
+
+@pytest.mark.parametrize("mode,one_hop,spin", [(1, 0, 0), (3, 0, 32), (2, 0, 32), (3, 1, 32), (3, 0, 512)])
+def test_staggered_timeouts_in_a_twelve_workgroup_cluster(mode, one_hop, spin):
+    """The case the forced-fault sweep (DPM_THR_SWEEP_FAULT) caught in the first version of the recovery: [40, 3, 64, 128]
+    = clusters of 12 workgroups whose waits run out at different moments (a short limit).  Workgroups that had given up
+    used to run on through the exchange with half-merged histograms and discard the outcome: a neighbouring chunk came
+    out wrong once in a few launches and workspace words stayed dirty.  Now they leave the protocol.  Every intermediate
+    state of several repetitions equals the undisturbed run; the workspace is all zero after every trajectory."""
+    ns = make_schedule("sd")
+    shape = (40, 3, 64, 128)
+    x = torch.from_numpy(np.random.default_rng(123).standard_normal(shape).astype(F32)).to(DEV)
+    mk = lambda: D.DPM_Solver(D.model_wrapper(lambda xx, t: xx * 0.9, ns), ns, correcting_x0_fn="dynamic_thresholding",
+                              thresholding_max_val=0.5, dynamic_thresholding_ratio=0.995)
+    _, want = mk().sample(x, steps=10, order=2, return_intermediate=True)
+    import dpm_solver_amd.solver as S
+    for rep in range(4):
+        with _Tuned(thr_debug_fault=mode, thr_spin_limit=spin, cluster_one_hop=one_hop):
+            _, got = mk().sample(x, steps=10, order=2, return_intermediate=True)
+            torch.cuda.synchronize()
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert torch.equal(a, b), (rep, i)
+        for ws in S._WS_CACHE.values():
+            assert not bool(ws.any()), "the workspace must be all zero between launches"
+    assert L.cluster_timeout_poll()
 
 
 def test_cluster_wait_timeout_with_cfg_half_state_and_requests_in_flight():
