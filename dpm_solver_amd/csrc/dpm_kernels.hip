@@ -876,7 +876,9 @@ extern "C" void dpm_graph_destroy(dpm_graph* g) {
 
 // ------------------------------------------------------------------------------------------------
 // calibration kernels: what the memory system sustains for this access pattern and size, with no arithmetic.
-// kind 0: copy (1 read + 1 write stream); kind 1: 3 read + 2 write streams (the 2M stage's pattern).
+// kind 0: copy (1 read + 1 write stream); kind 1: 3 read + 2 write streams (the 2M stage's pattern); kind 2: 4 read + 1 write
+// streams (the same bytes: what a 2M stage would move that re-derives the previous model value from the previous state and
+// network output instead of storing it -- `e` is read).
 // ------------------------------------------------------------------------------------------------
 namespace {
 template <int BLOCK, int KIND, int NT>
@@ -887,6 +889,10 @@ __global__ __launch_bounds__(BLOCK) void calib_kernel(const u32x4* __restrict__ 
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < nvec; i += stride) {
     if (KIND == 0) {
       st16<(NT & 2) != 0>(d + i, ld16<(NT & 1) != 0>(a + i));
+    } else if (KIND == 2) {
+      const u32x4 va = ld16<(NT & 1) != 0>(a + i), vb = ld16<(NT & 1) != 0>(b + i), vc = ld16<(NT & 1) != 0>(c + i);
+      const u32x4 ve = ld16<(NT & 1) != 0>(e + i);
+      st16<(NT & 2) != 0>(d + i, (va ^ vb) ^ (vc ^ ve));
     } else {
       const u32x4 va = ld16<(NT & 1) != 0>(a + i), vb = ld16<(NT & 1) != 0>(b + i), vc = ld16<(NT & 1) != 0>(c + i);
       st16<(NT & 2) != 0>(d + i, va ^ vb);
@@ -909,7 +915,7 @@ void calib_nt(int nt, dim3 grid, const LaunchCtx& c, const u32x4* a, const u32x4
 
 extern "C" int dpm_calib_launch(int kind, int block, int blocks_per_cu, int nt, const void* a, const void* b, const void* c,
                                 void* d, void* e, int64_t nbytes, void* stream, float* ms) {
-  if (!a || !d || nbytes < 16 || (kind == 1 && (!b || !c || !e))) return dpm_set_error(DPM_ERR_ARG, "calib: bad arguments");
+  if (!a || !d || nbytes < 16 || (kind >= 1 && (!b || !c || !e))) return dpm_set_error(DPM_ERR_ARG, "calib: bad arguments");
   const int64_t nvec = nbytes / 16;
   const DeviceInfo& di = device_info();
   int64_t blocks = (nvec + block - 1) / block;
@@ -932,6 +938,9 @@ extern "C" int dpm_calib_launch(int kind, int block, int blocks_per_cu, int nt, 
   else if (kind == 1 && block == 256) calib_nt<256, 1>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
   else if (kind == 1 && block == 512) calib_nt<512, 1>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
   else if (kind == 1 && block == 1024) calib_nt<1024, 1>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
+  else if (kind == 2 && block == 256) calib_nt<256, 2>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
+  else if (kind == 2 && block == 512) calib_nt<512, 2>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
+  else if (kind == 2 && block == 1024) calib_nt<1024, 2>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
   else rc = dpm_set_error(DPM_ERR_ARG, "calib: kind %d / block %d not built", kind, block);
   if (ms) {
     int rc2 = dpm_timing_end(1, starts, stops, stream, rc ? nullptr : ms, nullptr);

@@ -415,7 +415,7 @@ enum {
 int dpm_tuning_set(int knob, int value);
 int dpm_tuning_get(int knob);
 /* memory-system calibration with no arithmetic (kind 0: copy; kind 1: 3 read + 2 write streams, the 2M stage's
-   pattern) over nbytes per stream; block in {256,512,1024}; nt mask as DPM_TUNE_NONTEMPORAL; ms = kernel time. */
+   pattern; kind 2: 4 read + 1 write streams, `e` read) over nbytes per stream; block in {256,512,1024}; nt mask as DPM_TUNE_NONTEMPORAL; ms = kernel time. */
 int dpm_calib_launch(int kind, int block, int blocks_per_cu, int nt, const void* a, const void* b, const void* c,
                      void* d, void* e, int64_t nbytes, void* stream, float* ms);
 

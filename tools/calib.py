@@ -17,7 +17,7 @@ def main():
     for nbytes, tag in [(8 << 20, "8MiB/stream (fp16 [256,4,64,64])"), (16 << 20, "16MiB/stream (fp32)"), (256 << 20, "256MiB/stream")]:
         nsets = 8 if nbytes <= (16 << 20) else 2
         sets = [[torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 255) for _ in range(5)] for _ in range(nsets)]
-        for kind, streams in [(0, 2), (1, 5)]:
+        for kind, streams in [(0, 2), (1, 5), (2, 5)]:
             for block in (256, 512, 1024):
                 for bpc in (2048 // block, 4096 // block):
                     for nt in (0, 1, 5, 7):
@@ -33,7 +33,7 @@ def main():
                                 if it >= 8:
                                     t.append(ms.value)
                             res[mode] = float(np.mean(t) * 1e3)
-                        print(json.dumps(dict(size=tag, kind="copy" if kind == 0 else "3r2w", block=block, bpc=bpc, nt=nt,
+                        print(json.dumps(dict(size=tag, kind=("copy", "3r2w", "4r1w")[kind], block=block, bpc=bpc, nt=nt,
                                               warm_us=round(res["warm"], 2), cold_us=round(res["cold"], 2),
                                               warm_GBs=round(streams * nbytes / res["warm"] / 1e3), cold_GBs=round(streams * nbytes / res["cold"] / 1e3))),
                               flush=True)
