@@ -475,6 +475,8 @@ def main():
 
     import dpm_solver_amd as D
     from dpm_solver_amd import _lib as L
+    if os.environ.get("DPM_BENCH_BLOCK_THREADS") and not STUB:      # experiments only (tools/gpu_r04_s.sh)
+        L.check(L.lib.dpm_tuning_set(L.TUNE_BLOCK_THREADS, int(os.environ["DPM_BENCH_BLOCK_THREADS"])))
 
     ac = sd_alphas_cumprod()
     ns = D.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(ac))

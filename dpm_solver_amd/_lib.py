@@ -34,7 +34,7 @@ TUNE_UNROLL, TUNE_NONTEMPORAL, TUNE_BLOCKS_PER_CU, TUNE_ASSUME_RESIDENT = 0, 1, 
 TUNE_MULTI_FUSE, TUNE_MULTI_BLOCKS_PER_CU, TUNE_CLUSTER_IN_GRAPH, TUNE_CLUSTER_ONE_HOP = 4, 5, 6, 7
 TUNE_MULTI_XCD_REMAP = 8
 TUNE_THR_PREDICT = 9
-TUNE_THR_SPIN_LIMIT, TUNE_THR_DEBUG_FAULT = 10, 11
+TUNE_THR_SPIN_LIMIT, TUNE_THR_DEBUG_FAULT, TUNE_BLOCK_THREADS = 10, 11, 12
 MULTI_MAX = 32
 THR_HINT_WORDS = 4
 

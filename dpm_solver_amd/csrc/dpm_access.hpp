@@ -145,7 +145,12 @@ __device__ __forceinline__ void store_pack(bf16_t* __restrict__ p, int64_t group
   st16<NT>(reinterpret_cast<u32x4*>(p) + group, a);
 }
 
-// Tile-level access for the streaming kernel.  A tile is the 2048 elements of one workgroup iteration (256 lanes x 8).
+// A tile belongs to 256 consecutive lanes.  The streaming kernel may be launched with 256 or 512 threads: every
+// 256-lane group of a workgroup then takes tiles of its own (stage_kernel) -- fewer, larger workgroups for the dispatcher
+// to place, the same lanes doing the same work.  (In a kernel bounded to 256 threads the mask folds away.)
+__device__ __forceinline__ uint32_t tile_lane() { return threadIdx.x & 255u; }
+
+// Tile-level access for the streaming kernel.  A tile is the 2048 elements of one 256-lane group's iteration (256 lanes x 8).
 // `split` (4-byte state, tile complete): lane t takes elements [4t, 4t+4) and [1024+4t, 1024+4t+4) of the tile, so
 // each of the two global_load_dwordx4 of a wavefront covers 1 KiB of consecutive addresses; otherwise lane t takes the
 // 8 consecutive elements [8t, 8t+8) (one 16-byte access for 2-byte types, two adjacent ones for fp32).  The op is
@@ -155,7 +160,7 @@ template <bool NT, typename T>
 __device__ __forceinline__ void load_tile(const T* __restrict__ p, int64_t gi, bool split, float (&out)[EPT]) {
   if constexpr (sizeof(T) == 4) {
     if (split) {
-      const u32x4* q = reinterpret_cast<const u32x4*>(p) + (2 * gi - (int64_t)threadIdx.x);
+      const u32x4* q = reinterpret_cast<const u32x4*>(p) + (2 * gi - (int64_t)tile_lane());
       const u32x4 a = ld16<NT>(q), b = ld16<NT>(q + 256);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -175,9 +180,9 @@ __device__ __forceinline__ void load_tile(const T* __restrict__ p, int64_t gi, b
       // (dwords 0, 1) and the odd lane 2s+1 (dwords 2, 3) need of the first run, lane 32+s the same of the second run; every
       // permute moves one dword to each of the 64 lanes (first-run dwords to the even lanes while second-run dwords go to
       // the odd ones, then the other way round).  Requires all 64 lanes active: load_tile runs in straight-line code.
-      const int l = (int)(threadIdx.x & 63u), w = (int)(threadIdx.x >> 6);
+      const int l = (int)(threadIdx.x & 63u), w = (int)(tile_lane() >> 6);
       const bool lo = l < 32;
-      const u32x4* q = reinterpret_cast<const u32x4*>(p) + ((gi - (int64_t)threadIdx.x) + 32 * w + (lo ? l : l + 96));
+      const u32x4* q = reinterpret_cast<const u32x4*>(p) + ((gi - (int64_t)tile_lane()) + 32 * w + (lo ? l : l + 96));
       const u32x4 v = ld16<NT>(q);
       const int s2 = (lo ? l : l - 32) * 2;
       const int to_a = (lo ? s2 : s2 + 1) * 4, to_b = (lo ? s2 + 1 : s2) * 4;  // byte address = destination lane * 4
@@ -212,7 +217,7 @@ __device__ __forceinline__ void store_tile(T* __restrict__ p, int64_t gi, bool s
         a[j] = __float_as_uint(in[j]);
         b[j] = __float_as_uint(in[4 + j]);
       }
-      u32x4* q = reinterpret_cast<u32x4*>(p) + (2 * gi - (int64_t)threadIdx.x);
+      u32x4* q = reinterpret_cast<u32x4*>(p) + (2 * gi - (int64_t)tile_lane());
       st16<NT>(q, a);
       st16<NT>(q + 256, b);
       return;

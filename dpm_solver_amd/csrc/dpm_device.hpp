@@ -54,6 +54,7 @@ struct Tuning {
   int multi_blocks_per_cu = 0;  // grid cap of the fused launch in workgroups per CU; 0 = one super-tile per workgroup
   int thr_predict = 1;      // clustered thresholding: predict the select bound from the previous stages (thr_hint)
   int thr_spin_limit = 1 << 12;  // clustered thresholding: polls before a wait on a peer gives up (THR_SPIN_LIMIT)
+  int block_threads = 0;    // streaming kernel: threads per workgroup (256 / 512); 0 = by size (launch_stream)
   int thr_debug_fault = 0;  // testing: 1 = every cluster wait gives up at its first unsuccessful poll, 2 / 3 = workgroup 1 of
                             // every cluster takes no part from the start, with / without marking the sample (its peers
                             // see the mark / time out by their own polls, and recover)

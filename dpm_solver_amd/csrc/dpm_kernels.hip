@@ -975,6 +975,11 @@ extern "C" int dpm_tuning_set(int knob, int value) {
       if (value < 0 || value > 3) return dpm_set_error(DPM_ERR_ARG, "thr_debug_fault must be 0 .. 3");
       g_tuning.thr_debug_fault = value;
       return DPM_OK;
+    case DPM_TUNE_BLOCK_THREADS:
+      if (value != 0 && value != 256 && value != 512)
+        return dpm_set_error(DPM_ERR_ARG, "block_threads must be 0 (by size), 256 or 512");
+      g_tuning.block_threads = value;
+      return DPM_OK;
     case DPM_TUNE_MULTI_BLOCKS_PER_CU:
       if (value < 0 || value > 4096) return dpm_set_error(DPM_ERR_ARG, "multi_blocks_per_cu must be in 0..4096");
       g_tuning.multi_blocks_per_cu = value;
@@ -997,6 +1002,7 @@ extern "C" int dpm_tuning_get(int knob) {
     case DPM_TUNE_THR_PREDICT: return g_tuning.thr_predict;
     case DPM_TUNE_THR_SPIN_LIMIT: return g_tuning.thr_spin_limit;
     case DPM_TUNE_THR_DEBUG_FAULT: return g_tuning.thr_debug_fault;
+    case DPM_TUNE_BLOCK_THREADS: return g_tuning.block_threads;
   }
   return -1;
 }

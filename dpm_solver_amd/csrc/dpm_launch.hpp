@@ -138,369 +138,420 @@ void launch(K kern, dim3 grid, dim3 block, size_t lds, const LaunchCtx& c, Args.
 // prologue, buffers) has no fused variant: the caller then launches the requests one by one
 constexpr int MULTI_NOT_BUILT = -1000;
 
-template <typename TS, typename TE, int FORM, int GUIDE, bool XE>
-int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& stream) {
-  const KParams p = make_params(st);
-  const TS* x = static_cast<const TS*>(b->x);
-  const TS* xe = static_cast<const TS*>(b->xe);
-  const TE* e0 = static_cast<const TE*>(b->e0);
-  const TE* e1 = static_cast<const TE*>(b->e1);
-  const TE* g = static_cast<const TE*>(b->g);
-  const TS* h1 = static_cast<const TS*>(b->h1);
-  const TS* h2 = static_cast<const TS*>(b->h2);
-  TS* xo = static_cast<TS*>(b->x_out);
-  TS* mo = static_cast<TS*>(b->m_out);
-  const DeviceInfo& di = device_info();
-  const int n_cu = di.n_cu > 0 ? di.n_cu : 256;
-  KExt ext;
-  std::memset(&ext, 0, sizeof ext);
-  const bool blend = (st->flags & DPM_F_BLEND) != 0;
-  ext.xo2 = b->x_out2;
-  ext.mask = blend ? b->mask : nullptr;
-  ext.ba = blend ? b->blend_a : nullptr;
-  ext.bb = blend ? b->blend_b : nullptr;
-  ext.mask_period = blend ? b->mask_period : 0;
-  ext.per_sample = b->n / b->batch;
-  ext.eps_stride = (b->eps_stride == ext.per_sample) ? 0 : b->eps_stride;
-  ext.blend_alpha = st->blend_alpha;
-  ext.blend_sigma = st->blend_sigma;
-  const bool use_ext = ext.xo2 || ext.mask || ext.eps_stride;
+// the operands of one single-request launch, typed: what both kernel families (streaming, thresholding) start from
+template <typename TS, typename TE>
+struct Operands {
+  KParams p;
+  const TS *x, *xe, *h1, *h2;
+  const TE *e0, *e1, *g;
+  TS *xo, *mo;
+  KExt ext;       // duplicate output, mask blend, channel-sliced network output
+  bool use_ext;
+  int n_cu;
+  Operands(const dpm_stage* st, const dpm_buffers* b)
+      : p(make_params(st)),
+        x(static_cast<const TS*>(b->x)),
+        xe(static_cast<const TS*>(b->xe)),
+        h1(static_cast<const TS*>(b->h1)),
+        h2(static_cast<const TS*>(b->h2)),
+        e0(static_cast<const TE*>(b->e0)),
+        e1(static_cast<const TE*>(b->e1)),
+        g(static_cast<const TE*>(b->g)),
+        xo(static_cast<TS*>(b->x_out)),
+        mo(static_cast<TS*>(b->m_out)) {
+    const DeviceInfo& di = device_info();
+    n_cu = di.n_cu > 0 ? di.n_cu : 256;
+    std::memset(&ext, 0, sizeof ext);
+    const bool blend = (st->flags & DPM_F_BLEND) != 0;
+    ext.xo2 = b->x_out2;
+    ext.mask = blend ? b->mask : nullptr;
+    ext.ba = blend ? b->blend_a : nullptr;
+    ext.bb = blend ? b->blend_b : nullptr;
+    ext.mask_period = blend ? b->mask_period : 0;
+    ext.per_sample = b->n / b->batch;
+    ext.eps_stride = (b->eps_stride == ext.per_sample) ? 0 : b->eps_stride;
+    ext.blend_alpha = st->blend_alpha;
+    ext.blend_sigma = st->blend_sigma;
+    use_ext = ext.xo2 || ext.mask || ext.eps_stride;
+  }
+};
 
-  if (st->flags & DPM_F_THRESH) {
-    if (stream.dyn) return dpm_set_error(DPM_ERR_UNSUPPORTED, "dynamic thresholding with device-resident coefficients");
-    const int64_t per_sample = b->n / b->batch;
-    // several requests in one launch: one batch of n_multi * batch samples -- more samples per launch, smaller (or no)
-    // clusters -- whose sample s lives in the tensors of request s / batch (ThrTab)
-    const bool multi = stream.multi != nullptr;
-    const int64_t batch = multi ? (int64_t)stream.n_multi * b->batch : b->batch;
-    if (batch > 0x7fffffff || per_sample > ((int64_t)1 << 40))
-      return dpm_set_error(DPM_ERR_UNSUPPORTED, "thresholding: batch / sample size out of range");
-    ThrPlan pl = thr_plan(batch, per_sample, n_cu);
-    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(stream.stream, &cap_status);
-    const bool capturing = cap_status != hipStreamCaptureStatusNone;
-    // Clusters wait for each other inside the kernel, which is only safe while no OTHER clustered launch can hold part of
-    // the chip at the same time.  Eager launches of this process are chained device-wide (below); a captured graph is
-    // replayed outside that chain, possibly next to another graph on another stream.  Under capture a sample that fits
-    // one workgroup's LDS therefore takes the cluster-free shape (one workgroup per sample) unless the caller opts in
-    // (DPM_TUNE_CLUSTER_IN_GRAPH); larger samples have no such shape and keep their clusters, with bounded waits.
-    if (capturing && pl.k > 1 && per_sample <= THR_CHUNK_MAX && !g_tuning.cluster_in_graph) {
-      pl.k = 1;
-      pl.chunk = (per_sample + 3) / 4 * 4;
+// ---- a thresholded stage (stage_thresh_kernel): cluster shape, select parameters, kernel flavour, the launch
+template <typename TS, typename TE, int FORM, int GUIDE, bool XE>
+int launch_thresh(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& stream, const Operands<TS, TE>& op) {
+  const KParams& p = op.p;
+  const TS *x = op.x, *xe = op.xe, *h1 = op.h1, *h2 = op.h2;
+  const TE *e0 = op.e0, *e1 = op.e1, *g = op.g;
+  TS *xo = op.xo, *mo = op.mo;
+  const KExt& ext = op.ext;
+  const int n_cu = op.n_cu;
+  if (stream.dyn) return dpm_set_error(DPM_ERR_UNSUPPORTED, "dynamic thresholding with device-resident coefficients");
+  const int64_t per_sample = b->n / b->batch;
+  // several requests in one launch: one batch of n_multi * batch samples -- more samples per launch, smaller (or no)
+  // clusters -- whose sample s lives in the tensors of request s / batch (ThrTab)
+  const bool multi = stream.multi != nullptr;
+  const int64_t batch = multi ? (int64_t)stream.n_multi * b->batch : b->batch;
+  if (batch > 0x7fffffff || per_sample > ((int64_t)1 << 40))
+    return dpm_set_error(DPM_ERR_UNSUPPORTED, "thresholding: batch / sample size out of range");
+  ThrPlan pl = thr_plan(batch, per_sample, n_cu);
+  hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(stream.stream, &cap_status);
+  const bool capturing = cap_status != hipStreamCaptureStatusNone;
+  // Clusters wait for each other inside the kernel, which is only safe while no OTHER clustered launch can hold part of
+  // the chip at the same time.  Eager launches of this process are chained device-wide (below); a captured graph is
+  // replayed outside that chain, possibly next to another graph on another stream.  Under capture a sample that fits
+  // one workgroup's LDS therefore takes the cluster-free shape (one workgroup per sample) unless the caller opts in
+  // (DPM_TUNE_CLUSTER_IN_GRAPH); larger samples have no such shape and keep their clusters, with bounded waits.
+  if (capturing && pl.k > 1 && per_sample <= THR_CHUNK_MAX && !g_tuning.cluster_in_graph) {
+    pl.k = 1;
+    pl.chunk = (per_sample + 3) / 4 * 4;
+  }
+  ThrParams tp;
+  std::memset(&tp, 0, sizeof tp);
+  tp.per_sample = per_sample;
+  // torch.quantile: rank = q * (n - 1) evaluated in fp32 (q is an fp32 tensor)
+  const float rank = st->thr_ratio * (float)(per_sample - 1);
+  tp.lo = (int32_t)floorf(rank);
+  tp.hi = (int32_t)ceilf(rank);
+  tp.w = rank - (float)tp.lo;
+  tp.max_val = st->thr_max;
+  tp.chunk = (int32_t)pl.chunk;
+  tp.k = (int32_t)pl.k;
+  tp.batch = (int32_t)batch;
+  tp.fastdiv = st->model_type == DPM_MODEL_NOISE && (st->flags & DPM_F_TO_X0) && div_invariant_ok(st->alpha_e);
+  const size_t a4s = sizeof(TS) * 4, a4e = sizeof(TE) * 4;
+  tp.vec = per_sample % 4 == 0 && ext.eps_stride % 4 == 0 && ext.mask_period % 4 == 0 && aligned(x, a4s) &&
+           aligned(xe, a4s) && aligned(h1, a4s) && aligned(h2, a4s) && aligned(xo, a4s) && aligned(mo, a4s) &&
+           aligned(ext.xo2, a4s) && aligned(ext.mask, a4s) && aligned(ext.ba, a4s) && aligned(ext.bb, a4s) &&
+           aligned(e0, a4e) && aligned(e1, a4e) && aligned(g, a4e);
+  static const ThrTab no_tab = {};
+  ThrTab tab_multi;
+  if (multi) {
+    // the fused launch serves plain requests: no extensions, the evaluation state is the state, distinct workspaces
+    // (clusters of different requests run side by side); anything else is launched request by request
+    if (XE || GUIDE == DPM_GUIDE_CLASSIFIER || stream.n_multi > MULTI_MAX) return MULTI_NOT_BUILT;
+    std::memset(&tab_multi, 0, sizeof tab_multi);
+    tp.bpr = (int32_t)b->batch;
+    for (int r = 0; r < stream.n_multi; ++r) {
+      const dpm_buffers& q = stream.multi[r];
+      if (!q.x || (q.xe && q.xe != q.x) || q.x_out2 || (q.eps_stride && q.eps_stride != per_sample)) return MULTI_NOT_BUILT;
+      if (pl.k > 1) {
+        if (!q.workspace) return MULTI_NOT_BUILT;
+        for (int r2 = 0; r2 < r; ++r2)
+          if (stream.multi[r2].workspace == q.workspace) return MULTI_NOT_BUILT;
+      }
+      tp.vec = tp.vec && aligned(q.x, a4s) && aligned(q.h1, a4s) && aligned(q.h2, a4s) && aligned(q.x_out, a4s) &&
+               aligned(q.m_out, a4s) && aligned(q.e0, a4e) && aligned(q.e1, a4e);
+      tab_multi.x[r] = q.x;
+      tab_multi.e0[r] = q.e0;
+      tab_multi.e1[r] = q.e1;
+      tab_multi.h1[r] = q.h1;
+      tab_multi.h2[r] = q.h2;
+      tab_multi.xo[r] = q.x_out;
+      tab_multi.mo[r] = q.m_out;
+      tab_multi.ws[r] = static_cast<uint32_t*>(q.workspace);
     }
-    ThrParams tp;
-    std::memset(&tp, 0, sizeof tp);
-    tp.per_sample = per_sample;
-    // torch.quantile: rank = q * (n - 1) evaluated in fp32 (q is an fp32 tensor)
-    const float rank = st->thr_ratio * (float)(per_sample - 1);
-    tp.lo = (int32_t)floorf(rank);
-    tp.hi = (int32_t)ceilf(rank);
-    tp.w = rank - (float)tp.lo;
-    tp.max_val = st->thr_max;
-    tp.chunk = (int32_t)pl.chunk;
-    tp.k = (int32_t)pl.k;
-    tp.batch = (int32_t)batch;
-    tp.fastdiv = st->model_type == DPM_MODEL_NOISE && (st->flags & DPM_F_TO_X0) && div_invariant_ok(st->alpha_e);
-    const size_t a4s = sizeof(TS) * 4, a4e = sizeof(TE) * 4;
-    tp.vec = per_sample % 4 == 0 && ext.eps_stride % 4 == 0 && ext.mask_period % 4 == 0 && aligned(x, a4s) &&
-             aligned(xe, a4s) && aligned(h1, a4s) && aligned(h2, a4s) && aligned(xo, a4s) && aligned(mo, a4s) &&
-             aligned(ext.xo2, a4s) && aligned(ext.mask, a4s) && aligned(ext.ba, a4s) && aligned(ext.bb, a4s) &&
-             aligned(e0, a4e) && aligned(e1, a4e) && aligned(g, a4e);
-    static const ThrTab no_tab = {};
-    ThrTab tab_multi;
-    if (multi) {
-      // the fused launch serves plain requests: no extensions, the evaluation state is the state, distinct workspaces
-      // (clusters of different requests run side by side); anything else is launched request by request
-      if (XE || GUIDE == DPM_GUIDE_CLASSIFIER || stream.n_multi > MULTI_MAX) return MULTI_NOT_BUILT;
-      std::memset(&tab_multi, 0, sizeof tab_multi);
-      tp.bpr = (int32_t)b->batch;
-      for (int r = 0; r < stream.n_multi; ++r) {
-        const dpm_buffers& q = stream.multi[r];
-        if (!q.x || (q.xe && q.xe != q.x) || q.x_out2 || (q.eps_stride && q.eps_stride != per_sample)) return MULTI_NOT_BUILT;
-        if (pl.k > 1) {
-          if (!q.workspace) return MULTI_NOT_BUILT;
-          for (int r2 = 0; r2 < r; ++r2)
-            if (stream.multi[r2].workspace == q.workspace) return MULTI_NOT_BUILT;
-        }
-        tp.vec = tp.vec && aligned(q.x, a4s) && aligned(q.h1, a4s) && aligned(q.h2, a4s) && aligned(q.x_out, a4s) &&
-                 aligned(q.m_out, a4s) && aligned(q.e0, a4e) && aligned(q.e1, a4e);
-        tab_multi.x[r] = q.x;
-        tab_multi.e0[r] = q.e0;
-        tab_multi.e1[r] = q.e1;
-        tab_multi.h1[r] = q.h1;
-        tab_multi.h2[r] = q.h2;
-        tab_multi.xo[r] = q.x_out;
-        tab_multi.mo[r] = q.m_out;
-        tab_multi.ws[r] = static_cast<uint32_t*>(q.workspace);
+  }
+  const ThrTab& tab = multi ? tab_multi : no_tab;
+  {
+    // top-K front end: a = the K-th largest element.  It needs at most one wanted element per contributing thread and
+    // pays when the K-th largest per-thread maximum sits in the sparse upper tail (K a small part of the threads) and
+    // the candidates (a small multiple of K) fit the rank-counting finish (<= THR_THREADS of them).
+    const int64_t K = per_sample - (int64_t)tp.lo;
+    int64_t P = 0;
+    for (int64_t c = 0; c < pl.k; ++c) {
+      const int64_t n_c = std::max<int64_t>(0, std::min<int64_t>(pl.chunk, per_sample - c * pl.chunk));
+      P += std::min<int64_t>(THR_THREADS, tp.vec ? (n_c + 3) / 4 : n_c);
+    }
+    if (K >= 1 && K <= P / 4 && K <= THR_THREADS / 4) {  // beyond: the candidates outgrow the rank-counting finish
+      tp.topk = (int32_t)K;
+      tp.mrank = (int32_t)(P - K);
+    }
+    // single-exchange cluster route (cluster_select_once): a chunk's share of the K largest is ~ K/k; publishing the
+    // ~quota = K/k + 6 sigma + 8 largest values of every chunk makes the one-hop answer exact except for samples whose
+    // large values sit in one chunk (those fall back inside the kernel).  Needs room in the slots for the 14-bit digit's
+    // granularity (x1.5) and a union that fits the LDS list.
+    if (pl.k > 1 && pl.k <= THR_KMAX && K >= 1 && K < ((int64_t)1 << 30)) {
+      const double mu = (double)K / (double)pl.k;
+      const int64_t quota = (int64_t)std::ceil(mu + 6.0 * std::sqrt(mu) + 8.0);
+      // slot size: the smallest power of two >= 64 with room for the quota and the digit granularity (fewer words to
+      // fetch per slot); at most THR_SLOT_CAP and THR_CAP / k
+      int slot_shift = 6;
+      while (((int64_t)1 << slot_shift) < quota * 3 / 2 && slot_shift < 8) ++slot_shift;
+      while (slot_shift > 0 && ((int64_t)1 << slot_shift) > std::min<int64_t>(THR_SLOT_CAP, THR_CAP / pl.k)) --slot_shift;
+      const int64_t slot_cap = (int64_t)1 << slot_shift;
+      if (quota * 3 / 2 <= slot_cap && g_tuning.cluster_one_hop) {
+        tp.quota = (int32_t)quota;
+        tp.kbig = (int32_t)K;
+        tp.slot_cap = (int32_t)slot_cap;
+        tp.slot_pub = (int32_t)std::min<int64_t>(slot_cap, quota + quota / 4 + 4);
+        tp.slot_shift = slot_shift;
+        tp.debug_reject = g_tuning.cluster_one_hop == 2;
       }
     }
-    const ThrTab& tab = multi ? tab_multi : no_tab;
-    {
-      // top-K front end: a = the K-th largest element.  It needs at most one wanted element per contributing thread and
-      // pays when the K-th largest per-thread maximum sits in the sparse upper tail (K a small part of the threads) and
-      // the candidates (a small multiple of K) fit the rank-counting finish (<= THR_THREADS of them).
-      const int64_t K = per_sample - (int64_t)tp.lo;
-      int64_t P = 0;
-      for (int64_t c = 0; c < pl.k; ++c) {
-        const int64_t n_c = std::max<int64_t>(0, std::min<int64_t>(pl.chunk, per_sample - c * pl.chunk));
-        P += std::min<int64_t>(THR_THREADS, tp.vec ? (n_c + 3) / 4 : n_c);
-      }
-      if (K >= 1 && K <= P / 4 && K <= THR_THREADS / 4) {  // beyond: the candidates outgrow the rank-counting finish
-        tp.topk = (int32_t)K;
-        tp.mrank = (int32_t)(P - K);
-      }
-      // single-exchange cluster route (cluster_select_once): a chunk's share of the K largest is ~ K/k; publishing the
-      // ~quota = K/k + 6 sigma + 8 largest values of every chunk makes the one-hop answer exact except for samples whose
-      // large values sit in one chunk (those fall back inside the kernel).  Needs room in the slots for the 14-bit digit's
-      // granularity (x1.5) and a union that fits the LDS list.
-      if (pl.k > 1 && pl.k <= THR_KMAX && K >= 1 && K < ((int64_t)1 << 30)) {
-        const double mu = (double)K / (double)pl.k;
-        const int64_t quota = (int64_t)std::ceil(mu + 6.0 * std::sqrt(mu) + 8.0);
-        // slot size: the smallest power of two >= 64 with room for the quota and the digit granularity (fewer words to
-        // fetch per slot); at most THR_SLOT_CAP and THR_CAP / k
-        int slot_shift = 6;
-        while (((int64_t)1 << slot_shift) < quota * 3 / 2 && slot_shift < 8) ++slot_shift;
-        while (slot_shift > 0 && ((int64_t)1 << slot_shift) > std::min<int64_t>(THR_SLOT_CAP, THR_CAP / pl.k)) --slot_shift;
-        const int64_t slot_cap = (int64_t)1 << slot_shift;
-        if (quota * 3 / 2 <= slot_cap && g_tuning.cluster_one_hop) {
-          tp.quota = (int32_t)quota;
-          tp.kbig = (int32_t)K;
-          tp.slot_cap = (int32_t)slot_cap;
-          tp.slot_pub = (int32_t)std::min<int64_t>(slot_cap, quota + quota / 4 + 4);
-          tp.slot_shift = slot_shift;
-          tp.debug_reject = g_tuning.cluster_one_hop == 2;
-        }
-      }
-    }
+  }
 #ifdef DPM_THR_TIMING
-    // debug build only: the DPM_THR_TIMING_LAUNCH-th thresholding launch of the process (default 40) is synchronised
-    // and its stamps are written to $DPM_THR_TIMING_FILE, one line of 16 values per workgroup
-    static uint64_t* t_dev = nullptr;
-    static int t_launches = 0;
-    if (!t_dev) (void)hipMalloc(&t_dev, 4096 * 16 * sizeof(uint64_t));
-    tp.tdbg = t_dev;
-    auto t_dump = [&](int64_t wgs) {
-      const char* path = getenv("DPM_THR_TIMING_FILE");
-      const char* at = getenv("DPM_THR_TIMING_LAUNCH");
-      if (!path || ++t_launches != (at ? atoi(at) : 40) || wgs > 4096) return;
-      (void)hipStreamSynchronize(stream.stream);
-      std::vector<uint64_t> h((size_t)wgs * 16);
-      (void)hipMemcpy(h.data(), t_dev, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
-      if (FILE* f = fopen(path, "w")) {
-        for (int64_t i = 0; i < wgs; ++i) {
-          for (int j = 0; j < 16; ++j) fprintf(f, "%llu ", (unsigned long long)h[(size_t)i * 16 + j]);
-          fprintf(f, "\n");
-        }
-        fclose(f);
+  // debug build only: the DPM_THR_TIMING_LAUNCH-th thresholding launch of the process (default 40) is synchronised
+  // and its stamps are written to $DPM_THR_TIMING_FILE, one line of 16 values per workgroup
+  static uint64_t* t_dev = nullptr;
+  static int t_launches = 0;
+  if (!t_dev) (void)hipMalloc(&t_dev, 4096 * 16 * sizeof(uint64_t));
+  tp.tdbg = t_dev;
+  auto t_dump = [&](int64_t wgs) {
+    const char* path = getenv("DPM_THR_TIMING_FILE");
+    const char* at = getenv("DPM_THR_TIMING_LAUNCH");
+    if (!path || ++t_launches != (at ? atoi(at) : 40) || wgs > 4096) return;
+    (void)hipStreamSynchronize(stream.stream);
+    std::vector<uint64_t> h((size_t)wgs * 16);
+    (void)hipMemcpy(h.data(), t_dev, h.size() * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    if (FILE* f = fopen(path, "w")) {
+      for (int64_t i = 0; i < wgs; ++i) {
+        for (int j = 0; j < 16; ++j) fprintf(f, "%llu ", (unsigned long long)h[(size_t)i * 16 + j]);
+        fprintf(f, "\n");
       }
-    };
-#else
-    auto t_dump = [](int64_t) {};
-#endif
-    const size_t lds_bytes = (size_t)pl.chunk * 4 + THR_NB * 4 + THR_MISC * 4 + (THR_CAP + 32) * 4;
-    // the compile-time specialisation exists for the forms / guidance kinds samplers combine with thresholding
-    // (classifier guidance -- the reference's own ImageNet-256 example samples with it AND thresholding, sample.sh:40-50 --
-    // has the HOT = 3 flavour only: its two load loops cover the noise fast path and everything else)
-    constexpr bool HOT_BUILT = (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3) && !XE;
-    constexpr bool HOT12_BUILT = HOT_BUILT && (GUIDE == DPM_GUIDE_NONE || GUIDE == DPM_GUIDE_CFG);
-    const bool hot = HOT_BUILT && tp.vec && !ext.mask;
-    const bool front = tp.topk > 0 || tp.quota > 0;  // the select starts from the per-thread maxima (quantile close to 1)
-    // the general kernel reads form / guidance from the stage record and always takes the evaluation state through xe
-    using ThrKernel = decltype(&stage_thresh_kernel<TS, TE, FORM_RT, GUIDE_RT, true, THR_THREADS, 0>);
-    auto kern = reinterpret_cast<ThrKernel>(const_cast<void*>(dpm_catchall_thresh<TS, TE>()));
-    if constexpr (HOT_BUILT) {
-      // noise-prediction network + division by the invariant alpha: the compile-time prologue (HOT 1 / 2); any other
-      // parameterisation with the usual near-1 quantile: the run-time prologue (HOT 3); the rest: the catch-all kernel
-      bool chosen = false;
-      if constexpr (HOT12_BUILT) {
-        if (hot && tp.fastdiv) {
-          kern = front ? stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 1>
-                       : stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 2>;
-          chosen = true;
-        }
-      }
-      if (!chosen && hot && front) kern = stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 3>;
+      fclose(f);
     }
-    if (!xe) xe = x;
-    int64_t grid = batch;
-    tp.groups = (int32_t)batch;
-    if (pl.k > 1) {
-      // clusters synchronise through spin barriers: every workgroup of the grid must be resident at once
-      static thread_local int occ_dev = -1, occ = 0;
-      static thread_local size_t occ_lds = 0;
+  };
+#else
+  auto t_dump = [](int64_t) {};
+#endif
+  const size_t lds_bytes = (size_t)pl.chunk * 4 + THR_NB * 4 + THR_MISC * 4 + (THR_CAP + 32) * 4;
+  // the compile-time specialisation exists for the forms / guidance kinds samplers combine with thresholding
+  // (classifier guidance -- the reference's own ImageNet-256 example samples with it AND thresholding, sample.sh:40-50 --
+  // has the HOT = 3 flavour only: its two load loops cover the noise fast path and everything else)
+  constexpr bool HOT_BUILT = (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3) && !XE;
+  constexpr bool HOT12_BUILT = HOT_BUILT && (GUIDE == DPM_GUIDE_NONE || GUIDE == DPM_GUIDE_CFG);
+  const bool hot = HOT_BUILT && tp.vec && !ext.mask;
+  const bool front = tp.topk > 0 || tp.quota > 0;  // the select starts from the per-thread maxima (quantile close to 1)
+  // the general kernel reads form / guidance from the stage record and always takes the evaluation state through xe
+  using ThrKernel = decltype(&stage_thresh_kernel<TS, TE, FORM_RT, GUIDE_RT, true, THR_THREADS, 0>);
+  auto kern = reinterpret_cast<ThrKernel>(const_cast<void*>(dpm_catchall_thresh<TS, TE>()));
+  if constexpr (HOT_BUILT) {
+    // noise-prediction network + division by the invariant alpha: the compile-time prologue (HOT 1 / 2); any other
+    // parameterisation with the usual near-1 quantile: the run-time prologue (HOT 3); the rest: the catch-all kernel
+    bool chosen = false;
+    if constexpr (HOT12_BUILT) {
+      if (hot && tp.fastdiv) {
+        kern = front ? stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 1>
+                     : stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 2>;
+        chosen = true;
+      }
+    }
+    if (!chosen && hot && front) kern = stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 3>;
+  }
+  if (!xe) xe = x;
+  int64_t grid = batch;
+  tp.groups = (int32_t)batch;
+  if (pl.k > 1) {
+    // clusters synchronise through spin barriers: every workgroup of the grid must be resident at once
+    static thread_local int occ_dev = -1, occ = 0;
+    static thread_local size_t occ_lds = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev != occ_dev || lds_bytes != occ_lds) {
+      int nb = 0;
+      hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), THR_THREADS,
+                                                                  lds_bytes);
+      if (e != hipSuccess) return dpm_set_error((int)e, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s", hipGetErrorString(e));
+      occ_dev = dev;
+      occ_lds = lds_bytes;
+      occ = nb;
+    }
+    const int64_t cap = (int64_t)n_cu * (occ < 1 ? 1 : (occ > 2 ? 2 : occ));
+    if (pl.k > cap)
+      return dpm_set_error(DPM_ERR_UNSUPPORTED, "dynamic thresholding: a sample of %lld elements needs %lld co-resident "
+                           "workgroups, the device holds %lld", (long long)per_sample, (long long)pl.k, (long long)cap);
+    if (!b->workspace)
+      return dpm_set_error(DPM_ERR_ARG,
+                           "dynamic thresholding of %lld samples x %lld elements needs a workspace of "
+                           "dpm_threshold_workspace_bytes() = %lld bytes",
+                           (long long)b->batch, (long long)per_sample, (long long)thr_ws_bytes(b->batch, per_sample, n_cu));
+    const int64_t groups = std::min<int64_t>(batch, cap / pl.k);
+    tp.groups = (int32_t)groups;
+    tp.ws = static_cast<uint32_t*>(b->workspace);
+    tp.ws_stride = thr_ws_stride(pl.k);
+    grid = groups * pl.k;
+    // No clearing of the workspace here: the caller hands it over zero-filled once, the kernel leaves it zero-filled
+    // (dpm_threshold_workspace_bytes).  A wait on a peer that times out is recovered from inside the kernel (solo_select:
+    // same results, no error); the host-mapped word only records that it happened (dpm_cluster_timeout_poll).
+    tp.fault = cluster_fault_word(!capturing);
+    tp.spin_limit = g_tuning.thr_debug_fault == 1 ? 0u : (uint32_t)g_tuning.thr_spin_limit;
+    tp.debug_fault = g_tuning.thr_debug_fault;
+    // the select bound predicted from the previous stages (dpm_buffers.thr_hint): single requests on the one-exchange route
+    // -- where it pays: a small K (the wanted rank from the top), so that the predicted union (~1.3-1.9 K entries instead
+    // of k * quota) is finished by rank counting.  Measured (tools/thr_routes.py): [32,3,64,64] (K = 63) 11.3 -> 10.7 us per
+    // stage, union 236 -> 116 entries, every stage from the third on predicted; [64,3,256,256] (K = 983) 53 -> 59 us -- a
+    // 10-step trajectory changes the statistic by 2.5x per stage, the extrapolation lands low and the union GROWS.
+    if (!multi && tp.quota > 0 && b->thr_hint && tp.kbig <= 128) {
+      tp.hint = b->thr_hint;
+      tp.hint_reset = st->index <= 0;
+      tp.hint_predict = g_tuning.thr_predict;
+    }
+    // Two clustered launches on different streams could each hold part of the CUs with spinning workgroups and
+    // starve the other's missing peers.  Within this process they are therefore chained device-wide: wait for the
+    // previous clustered launch (whatever its stream), record after this one.  (Not under stream capture, where an
+    // event recorded outside the capture cannot be waited on; see above.)
+    if (!capturing) {
       int dev = 0;
       (void)hipGetDevice(&dev);
-      if (dev != occ_dev || lds_bytes != occ_lds) {
-        int nb = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), THR_THREADS,
-                                                                    lds_bytes);
-        if (e != hipSuccess) return dpm_set_error((int)e, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s", hipGetErrorString(e));
-        occ_dev = dev;
-        occ_lds = lds_bytes;
-        occ = nb;
-      }
-      const int64_t cap = (int64_t)n_cu * (occ < 1 ? 1 : (occ > 2 ? 2 : occ));
-      if (pl.k > cap)
-        return dpm_set_error(DPM_ERR_UNSUPPORTED, "dynamic thresholding: a sample of %lld elements needs %lld co-resident "
-                             "workgroups, the device holds %lld", (long long)per_sample, (long long)pl.k, (long long)cap);
-      if (!b->workspace)
-        return dpm_set_error(DPM_ERR_ARG,
-                             "dynamic thresholding of %lld samples x %lld elements needs a workspace of "
-                             "dpm_threshold_workspace_bytes() = %lld bytes",
-                             (long long)b->batch, (long long)per_sample, (long long)thr_ws_bytes(b->batch, per_sample, n_cu));
-      const int64_t groups = std::min<int64_t>(batch, cap / pl.k);
-      tp.groups = (int32_t)groups;
-      tp.ws = static_cast<uint32_t*>(b->workspace);
-      tp.ws_stride = thr_ws_stride(pl.k);
-      grid = groups * pl.k;
-      // No clearing of the workspace here: the caller hands it over zero-filled once, the kernel leaves it zero-filled
-      // (dpm_threshold_workspace_bytes).  A wait on a peer that times out is recovered from inside the kernel (solo_select:
-      // same results, no error); the host-mapped word only records that it happened (dpm_cluster_timeout_poll).
-      tp.fault = cluster_fault_word(!capturing);
-      tp.spin_limit = g_tuning.thr_debug_fault == 1 ? 0u : (uint32_t)g_tuning.thr_spin_limit;
-      tp.debug_fault = g_tuning.thr_debug_fault;
-      // the select bound predicted from the previous stages (dpm_buffers.thr_hint): single requests on the one-exchange route
-      // -- where it pays: a small K (the wanted rank from the top), so that the predicted union (~1.3-1.9 K entries instead
-      // of k * quota) is finished by rank counting.  Measured (tools/thr_routes.py): [32,3,64,64] (K = 63) 11.3 -> 10.7 us per
-      // stage, union 236 -> 116 entries, every stage from the third on predicted; [64,3,256,256] (K = 983) 53 -> 59 us -- a
-      // 10-step trajectory changes the statistic by 2.5x per stage, the extrapolation lands low and the union GROWS.
-      if (!multi && tp.quota > 0 && b->thr_hint && tp.kbig <= 128) {
-        tp.hint = b->thr_hint;
-        tp.hint_reset = st->index <= 0;
-        tp.hint_predict = g_tuning.thr_predict;
-      }
-      // Two clustered launches on different streams could each hold part of the CUs with spinning workgroups and
-      // starve the other's missing peers.  Within this process they are therefore chained device-wide: wait for the
-      // previous clustered launch (whatever its stream), record after this one.  (Not under stream capture, where an
-      // event recorded outside the capture cannot be waited on; see above.)
-      if (!capturing) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        ClusterChain& ch = cluster_chain(dev);
-        std::lock_guard<std::mutex> lk(ch.mu);
-        if (!ch.ev && hipEventCreateWithFlags(&ch.ev, hipEventDisableTiming) != hipSuccess) ch.ev = nullptr;
-        if (ch.ev && ch.recorded) (void)hipStreamWaitEvent(stream.stream, ch.ev, 0);
-        launch(kern, dim3((unsigned)grid), dim3(THR_THREADS), lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo, p, tp, ext, tab);
-        if (ch.ev && hipEventRecord(ch.ev, stream.stream) == hipSuccess) ch.recorded = true;
-        t_dump(grid);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return dpm_set_error((int)e, "stage kernel launch failed: %s", hipGetErrorString(e));
-        return DPM_OK;
-      }
+      ClusterChain& ch = cluster_chain(dev);
+      std::lock_guard<std::mutex> lk(ch.mu);
+      if (!ch.ev && hipEventCreateWithFlags(&ch.ev, hipEventDisableTiming) != hipSuccess) ch.ev = nullptr;
+      if (ch.ev && ch.recorded) (void)hipStreamWaitEvent(stream.stream, ch.ev, 0);
+      launch(kern, dim3((unsigned)grid), dim3(THR_THREADS), lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo, p, tp, ext, tab);
+      if (ch.ev && hipEventRecord(ch.ev, stream.stream) == hipSuccess) ch.recorded = true;
+      t_dump(grid);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return dpm_set_error((int)e, "stage kernel launch failed: %s", hipGetErrorString(e));
+      return DPM_OK;
     }
-    launch(kern, dim3((unsigned)grid), dim3(THR_THREADS), lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo, p, tp, ext, tab);
-    t_dump(grid);
-  } else {
-    const size_t as = sizeof(TS) * EPT, ae = sizeof(TE) * EPT;
-    bool vec = aligned(x, as) && aligned(xe, as) && aligned(h1, as) && aligned(h2, as) && aligned(xo, as) &&
-               aligned(mo, as) && aligned(e0, ae) && aligned(e1, ae) && aligned(g, ae);
-    if (use_ext)  // the extended vector kernel has no ragged tail and indexes whole 8-element groups
-      vec = vec && aligned(ext.xo2, as) && aligned(ext.mask, as) && aligned(ext.ba, as) && aligned(ext.bb, as) &&
-            b->n % EPT == 0 && ext.mask_period % EPT == 0 &&
-            (!ext.eps_stride || (ext.per_sample % EPT == 0 && ext.eps_stride % EPT == 0));
-    // what the streaming family instantiates (binary size: one kernel per combination and dtype pair):
-    //   * a separate evaluation state (xe != x) occurs in the singlestep mid / final stages -- forms TWO and SS3T -- and
-    //     in the FIRST stage of a multistep run with a corrector on x_t (mask blend, any correcting_xt_fn): the network saw
-    //     the raw x_T, the update starts from the corrected state (ref :1179-1183) -- form LIN1, unguided or CFG;
-    //   * the compile-time prologues (noise-prediction network) for the forms samplers spend their time in -- LIN1, TWO,
-    //     MS3; SS3T and DENOISE run the general prologue (true division: the same bits);
-    //   everything else goes through the one-element-per-lane kernel.
-    constexpr bool COMBO_BUILT = !XE || FORM == DPM_FORM_TWO || FORM == DPM_FORM_SS3T ||
-                                 (FORM == DPM_FORM_LIN1 && GUIDE != DPM_GUIDE_CLASSIFIER);
-    constexpr bool SPEC_BUILT = FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3;
-    // device-resident coefficients (adaptive solver): DYN kernels exist for the forms it launches -- first-order,
-    // second-order and the singlestep-3 'taylor' combination -- without the KExt extensions; anything else takes the
-    // one-element-per-lane kernel
-    constexpr bool DYN_BUILT = COMBO_BUILT && (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_SS3T);
-    const bool dyn_vec = stream.dyn && DYN_BUILT && !use_ext;
-    if (!vec || !COMBO_BUILT || (stream.dyn && !dyn_vec)) {
-      int64_t blocks = (b->n + 255) / 256;
-      const int64_t cap = (int64_t)n_cu * 16;
+  }
+  launch(kern, dim3((unsigned)grid), dim3(THR_THREADS), lds_bytes, stream, x, xe, e0, e1, g, h1, h2, xo, mo, p, tp, ext, tab);
+  t_dump(grid);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return dpm_set_error((int)e, "stage kernel launch failed: %s", hipGetErrorString(e));
+  return DPM_OK;
+}
+
+// ---- a stage of the streaming family (stage_kernel / the one-element-per-lane catch-all): variant and launch shape
+template <typename TS, typename TE, int FORM, int GUIDE, bool XE>
+int launch_stream(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& stream, const Operands<TS, TE>& op) {
+  const KParams& p = op.p;
+  const TS *x = op.x, *xe = op.xe, *h1 = op.h1, *h2 = op.h2;
+  const TE *e0 = op.e0, *e1 = op.e1, *g = op.g;
+  TS *xo = op.xo, *mo = op.mo;
+  const KExt& ext = op.ext;
+  const int n_cu = op.n_cu;
+  const bool use_ext = op.use_ext;
+  const size_t as = sizeof(TS) * EPT, ae = sizeof(TE) * EPT;
+  bool vec = aligned(x, as) && aligned(xe, as) && aligned(h1, as) && aligned(h2, as) && aligned(xo, as) &&
+             aligned(mo, as) && aligned(e0, ae) && aligned(e1, ae) && aligned(g, ae);
+  if (use_ext)  // the extended vector kernel has no ragged tail and indexes whole 8-element groups
+    vec = vec && aligned(ext.xo2, as) && aligned(ext.mask, as) && aligned(ext.ba, as) && aligned(ext.bb, as) &&
+          b->n % EPT == 0 && ext.mask_period % EPT == 0 &&
+          (!ext.eps_stride || (ext.per_sample % EPT == 0 && ext.eps_stride % EPT == 0));
+  // what the streaming family instantiates (binary size: one kernel per combination and dtype pair):
+  //   * a separate evaluation state (xe != x) occurs in the singlestep mid / final stages -- forms TWO and SS3T -- and
+  //     in the FIRST stage of a multistep run with a corrector on x_t (mask blend, any correcting_xt_fn): the network saw
+  //     the raw x_T, the update starts from the corrected state (ref :1179-1183) -- form LIN1, unguided or CFG;
+  //   * the compile-time prologues (noise-prediction network) for the forms samplers spend their time in -- LIN1, TWO,
+  //     MS3; SS3T and DENOISE run the general prologue (true division: the same bits);
+  //   everything else goes through the one-element-per-lane kernel.
+  constexpr bool COMBO_BUILT = !XE || FORM == DPM_FORM_TWO || FORM == DPM_FORM_SS3T ||
+                               (FORM == DPM_FORM_LIN1 && GUIDE != DPM_GUIDE_CLASSIFIER);
+  constexpr bool SPEC_BUILT = FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3;
+  // device-resident coefficients (adaptive solver): DYN kernels exist for the forms it launches -- first-order,
+  // second-order and the singlestep-3 'taylor' combination -- without the KExt extensions; anything else takes the
+  // one-element-per-lane kernel
+  constexpr bool DYN_BUILT = COMBO_BUILT && (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_SS3T);
+  const bool dyn_vec = stream.dyn && DYN_BUILT && !use_ext;
+  if (!vec || !COMBO_BUILT || (stream.dyn && !dyn_vec)) {
+    int64_t blocks = (b->n + 255) / 256;
+    const int64_t cap = (int64_t)n_cu * 16;
+    if (blocks > cap) blocks = cap;
+    using ScalarKernel = decltype(&stage_kernel_scalar<TS, TE, false>);  // the DYN = true variant has the same signature
+    const void* k = stream.dyn ? dpm_catchall_scalar<TS, TE, true>() : dpm_catchall_scalar<TS, TE, false>();
+    launch(reinterpret_cast<ScalarKernel>(const_cast<void*>(k)), dim3((unsigned)blocks), dim3(256), 0, stream, x, xe ? xe : x,
+           e0, e1, g, h1, h2, xo, mo, b->n, p, ext, stream.dyn, stream.skip);
+  } else if constexpr (COMBO_BUILT) {
+    const bool noise = SPEC_BUILT && !stream.dyn && st->model_type == DPM_MODEL_NOISE &&
+                       (!(st->flags & DPM_F_TO_X0) || div_invariant_ok(st->alpha_e));
+    const int spec = !noise ? SPEC_GENERIC : ((st->flags & DPM_F_TO_X0) ? SPEC_NOISE_X0 : SPEC_NOISE_EPS);
+    const int64_t ntiles = ((b->n / EPT) + 255) / 256;
+    const Tuning tn = g_tuning;
+    const bool big = ntiles >= 4 * (int64_t)n_cu;  // two tiles per iteration only when there is work for it
+    // launch shape: one 256-lane group per U tiles, capped per CU; two groups per workgroup (stage_kernel) when that still
+    // leaves two workgroups per CU: what larger workgroups save is dispatches ([256,4,64,64]: 2048 -> 1024), and a small
+    // launch needs every CU more than it needs that
+    auto shape_for = [&](int u) {
+      const int64_t iters = (ntiles + u - 1) / u;
+      int bt = 256;
+      if (tn.block_threads > 0) bt = tn.block_threads;
+      else if (iters >= 4 * (int64_t)n_cu) bt = STAGE_MAX_THREADS;
+      const int64_t per = bt / 256;
+      int64_t blocks = (iters + per - 1) / per;
+      const int64_t cap = std::max<int64_t>(1, (int64_t)n_cu * tn.blocks_per_cu / per);
       if (blocks > cap) blocks = cap;
-      using ScalarKernel = decltype(&stage_kernel_scalar<TS, TE, false>);  // the DYN = true variant has the same signature
-      const void* k = stream.dyn ? dpm_catchall_scalar<TS, TE, true>() : dpm_catchall_scalar<TS, TE, false>();
-      launch(reinterpret_cast<ScalarKernel>(const_cast<void*>(k)), dim3((unsigned)blocks), dim3(256), 0, stream, x, xe ? xe : x,
-             e0, e1, g, h1, h2, xo, mo, b->n, p, ext, stream.dyn, stream.skip);
-    } else if constexpr (COMBO_BUILT) {
-      const bool noise = SPEC_BUILT && !stream.dyn && st->model_type == DPM_MODEL_NOISE &&
-                         (!(st->flags & DPM_F_TO_X0) || div_invariant_ok(st->alpha_e));
-      const int spec = !noise ? SPEC_GENERIC : ((st->flags & DPM_F_TO_X0) ? SPEC_NOISE_X0 : SPEC_NOISE_EPS);
-      const int64_t ntiles = ((b->n / EPT) + 255) / 256;
-      const Tuning tn = g_tuning;
-      const bool big = ntiles >= 4 * (int64_t)n_cu;  // two tiles per iteration only when there is work for it
-      auto grid_for = [&](int u) {
-        int64_t blocks = (ntiles + u - 1) / u;
-        const int64_t cap = (int64_t)n_cu * tn.blocks_per_cu;
-        if (blocks > cap) blocks = cap;
-        return dim3((unsigned)(blocks < 1 ? 1 : blocks));
-      };
-#define DPM_LAUNCH(SPEC_, U_, NT_, EXT_)                                                                             \
-  launch(stage_kernel<TS, TE, FORM, GUIDE, XE, SPEC_, U_, NT_, EXT_>, grid_for(U_), dim3(256), 0, stream, x, xe, e0, e1, \
-         g, h1, h2, xo, mo, b->n, p, ext, stream.dyn, stream.skip)
-      if (dyn_vec) {
-        if constexpr (DYN_BUILT)
-          launch(stage_kernel<TS, TE, FORM, GUIDE, XE, SPEC_GENERIC, 1, DefNT<TS>::value, false, true>, grid_for(1), dim3(256),
-                 0, stream, x, xe, e0, e1, g, h1, h2, xo, mo, b->n, p, ext, stream.dyn, stream.skip);
-      } else if (use_ext) {
-        // one tile per workgroup (round 2 launched two for an fp32 state with 2-byte outputs: CFG + duplicate store at
-        // [256,4,64,64] 18.1 / 20.3 us back-to-back / evicted against 17.3 / 19.3 with one, tools/stage_bench.py); nt mask of
-        // the inputs-from-HBM situation
-        constexpr int ENT = sizeof(TS) == 2 ? 1 : (sizeof(TE) == 4 ? 5 : 1);
-        if (spec == SPEC_GENERIC) {
-          DPM_LAUNCH(SPEC_GENERIC, 1, ENT, true);
-        } else if constexpr (SPEC_BUILT) {
-          if (spec == SPEC_NOISE_X0) DPM_LAUNCH(SPEC_NOISE_X0, 1, ENT, true); else DPM_LAUNCH(SPEC_NOISE_EPS, 1, ENT, true);
-        }
-      } else if (spec == SPEC_GENERIC) {
-        DPM_LAUNCH(SPEC_GENERIC, 1, DefNT<TS>::value, false);
-      } else if constexpr (SPEC_BUILT) {
-        if (spec == SPEC_NOISE_EPS) {
-          DPM_LAUNCH(SPEC_NOISE_EPS, DEF_U, DefNT<TS>::value, false);
-        } else if constexpr (HotCombo<FORM, GUIDE, XE>::value) {
-          // the north-star kernels (2M / 1st-order update, no guidance): (tiles per iteration, nt mask) by situation and
-          // dtypes, from profiles/r01_tuning_v3.txt / r01_tuning_v4.txt:
-          //   inputs cache-resident: default policy, two tiles per iteration when there is work for it
-          //   inputs from HBM:       one tile per iteration, nt loads (+ nt m store for fp32 + fp32), see below
-          const bool resident = b->inputs_resident != 0 || tn.assume_resident != 0;
-          constexpr int CNT = sizeof(TS) == 2 ? 1 : (sizeof(TE) == 4 ? 5 : 1);  // nt mask of the HBM situation
-#ifdef DPM_TUNING_VARIANTS  // tools/tune.py single: every (tiles per iteration, nt mask)
-          if (tn.unroll > 0 && tn.nontemporal >= 0) {
-            switch (tn.unroll * 8 + (tn.nontemporal & 7)) {
-              case 8 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 1, 0, false); break;
-              case 8 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 1, 1, false); break;
-              case 8 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 1, 5, false); break;
-              case 16 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 2, 0, false); break;
-              case 16 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 2, 1, false); break;
-              case 16 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 2, 5, false); break;
-              case 32 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 4, 0, false); break;
-              case 32 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 4, 1, false); break;
-              case 32 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 4, 5, false); break;
-              case 64 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 8, 0, false); break;
-              case 64 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 8, 1, false); break;
-              case 64 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 8, 5, false); break;
-              default: DPM_LAUNCH(SPEC_NOISE_X0, DEF_U, DefNT<TS>::value, false); break;
-            }
-          } else
-#endif
-          if (resident) {
-            if (big) DPM_LAUNCH(SPEC_NOISE_X0, 2, 0, false); else DPM_LAUNCH(SPEC_NOISE_X0, 1, 0, false);
-          } else {
-            // from HBM: ONE tile per workgroup for every dtype pair.  Round 1 picked two tiles for 4-byte states from the
-            // interleaved-requests emulation (15.4 vs 15.6 us); INSIDE a torch network loop (profiles/r03_in_loop.md,
-            // rocprofv3 rows, 342 launches each) one tile is 15.0 us against 16.3, and four / eight tiles -- fewer, fatter
-            // wavefronts with every load issued up front, the emulation's favourite at 14.4 us -- are 15.2 / 23.8 us.
-            DPM_LAUNCH(SPEC_NOISE_X0, 1, CNT, false);
-          }
-        } else {
-          DPM_LAUNCH(SPEC_NOISE_X0, DEF_U, DefNT<TS>::value, false);
-        }
+      return std::make_pair(dim3((unsigned)(blocks < 1 ? 1 : blocks)), dim3((unsigned)bt));
+    };
+#define DPM_LAUNCH(SPEC_, U_, NT_, EXT_)                                                                                 \
+  do {                                                                                                                   \
+    const auto sh_ = shape_for(U_);                                                                                      \
+    launch(stage_kernel<TS, TE, FORM, GUIDE, XE, SPEC_, U_, NT_, EXT_>, sh_.first, sh_.second, 0, stream, x, xe, e0, e1, \
+           g, h1, h2, xo, mo, b->n, p, ext, stream.dyn, stream.skip);                                                    \
+  } while (0)
+    if (dyn_vec) {
+      if constexpr (DYN_BUILT) {
+        const auto sh = shape_for(1);
+        launch(stage_kernel<TS, TE, FORM, GUIDE, XE, SPEC_GENERIC, 1, DefNT<TS>::value, false, true>, sh.first, sh.second, 0,
+               stream, x, xe, e0, e1, g, h1, h2, xo, mo, b->n, p, ext, stream.dyn, stream.skip);
       }
-#undef DPM_LAUNCH
+    } else if (use_ext) {
+      // one tile per workgroup (round 2 launched two for an fp32 state with 2-byte outputs: CFG + duplicate store at
+      // [256,4,64,64] 18.1 / 20.3 us back-to-back / evicted against 17.3 / 19.3 with one, tools/stage_bench.py); nt mask of
+      // the inputs-from-HBM situation
+      constexpr int ENT = sizeof(TS) == 2 ? 1 : (sizeof(TE) == 4 ? 5 : 1);
+      if (spec == SPEC_GENERIC) {
+        DPM_LAUNCH(SPEC_GENERIC, 1, ENT, true);
+      } else if constexpr (SPEC_BUILT) {
+        if (spec == SPEC_NOISE_X0) DPM_LAUNCH(SPEC_NOISE_X0, 1, ENT, true); else DPM_LAUNCH(SPEC_NOISE_EPS, 1, ENT, true);
+      }
+    } else if (spec == SPEC_GENERIC) {
+      DPM_LAUNCH(SPEC_GENERIC, 1, DefNT<TS>::value, false);
+    } else if constexpr (SPEC_BUILT) {
+      if (spec == SPEC_NOISE_EPS) {
+        DPM_LAUNCH(SPEC_NOISE_EPS, DEF_U, DefNT<TS>::value, false);
+      } else if constexpr (HotCombo<FORM, GUIDE, XE>::value) {
+        // the north-star kernels (2M / 1st-order update, no guidance): (tiles per iteration, nt mask) by situation and
+        // dtypes, from profiles/r01_tuning_v3.txt / r01_tuning_v4.txt:
+        //   inputs cache-resident: default policy, two tiles per iteration when there is work for it
+        //   inputs from HBM:       one tile per iteration, nt loads (+ nt m store for fp32 + fp32), see below
+        const bool resident = b->inputs_resident != 0 || tn.assume_resident != 0;
+        constexpr int CNT = sizeof(TS) == 2 ? 1 : (sizeof(TE) == 4 ? 5 : 1);  // nt mask of the HBM situation
+#ifdef DPM_TUNING_VARIANTS  // tools/tune.py single: every (tiles per iteration, nt mask)
+        if (tn.unroll > 0 && tn.nontemporal >= 0) {
+          switch (tn.unroll * 8 + (tn.nontemporal & 7)) {
+            case 8 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 1, 0, false); break;
+            case 8 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 1, 1, false); break;
+            case 8 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 1, 5, false); break;
+            case 16 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 2, 0, false); break;
+            case 16 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 2, 1, false); break;
+            case 16 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 2, 5, false); break;
+            case 32 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 4, 0, false); break;
+            case 32 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 4, 1, false); break;
+            case 32 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 4, 5, false); break;
+            case 64 + 0: DPM_LAUNCH(SPEC_NOISE_X0, 8, 0, false); break;
+            case 64 + 1: DPM_LAUNCH(SPEC_NOISE_X0, 8, 1, false); break;
+            case 64 + 5: DPM_LAUNCH(SPEC_NOISE_X0, 8, 5, false); break;
+            default: DPM_LAUNCH(SPEC_NOISE_X0, DEF_U, DefNT<TS>::value, false); break;
+          }
+        } else
+#endif
+        if (resident) {
+          if (big) DPM_LAUNCH(SPEC_NOISE_X0, 2, 0, false); else DPM_LAUNCH(SPEC_NOISE_X0, 1, 0, false);
+        } else {
+          // from HBM: ONE tile per workgroup for every dtype pair.  Round 1 picked two tiles for 4-byte states from the
+          // interleaved-requests emulation (15.4 vs 15.6 us); INSIDE a torch network loop (profiles/r03_in_loop.md,
+          // rocprofv3 rows, 342 launches each) one tile is 15.0 us against 16.3, and four / eight tiles -- fewer, fatter
+          // wavefronts with every load issued up front, the emulation's favourite at 14.4 us -- are 15.2 / 23.8 us.
+          DPM_LAUNCH(SPEC_NOISE_X0, 1, CNT, false);
+        }
+      } else {
+        DPM_LAUNCH(SPEC_NOISE_X0, DEF_U, DefNT<TS>::value, false);
+      }
     }
+#undef DPM_LAUNCH
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return dpm_set_error((int)e, "stage kernel launch failed: %s", hipGetErrorString(e));
   return DPM_OK;
+}
+
+template <typename TS, typename TE, int FORM, int GUIDE, bool XE>
+int launch_typed(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& stream) {
+  const Operands<TS, TE> op(st, b);
+  return (st->flags & DPM_F_THRESH) ? launch_thresh<TS, TE, FORM, GUIDE, XE>(st, b, stream, op)
+                                    : launch_stream<TS, TE, FORM, GUIDE, XE>(st, b, stream, op);
 }
 
 // Launch shape of the fused kernel (profiles/r02_tune_multi.txt, 32 x [256,4,64,64], kernel-only per request-stage):
@@ -512,6 +563,7 @@ template <typename TS, typename TE>
 struct MultiShape {
   static constexpr int U = (sizeof(TS) == 4) ? 2 : 1;
   static constexpr int NT = 1;
+  static constexpr int THREADS = 256;  // per workgroup (256 / 512: stage_kernel_multi)
 };
 
 // ---- fused multi-request launch of the streaming family (stage_kernel_multi); thresholded stages fuse inside
@@ -538,15 +590,17 @@ int launch_multi_spec(const dpm_stage* st, const dpm_buffers* bs, int n_req, con
   const int64_t ntiles = ((n / EPT) + 255) / 256;
   auto go = [&](auto kern, int u) {
     const int64_t spr = (ntiles + u - 1) / u;
-    int64_t blocks = spr * n_req;
+    const int64_t groups = spr * n_req;                     // 256-lane groups of work: one super-tile each
+    const int bt = tn.block_threads > 0 ? tn.block_threads : MultiShape<TS, TE>::THREADS;
+    const int64_t per = bt / 256;
     const bool remap = tn.multi_xcd_remap < 0 ? sizeof(TS) == 2 : tn.multi_xcd_remap != 0;
-    const uint32_t span = remap ? (uint32_t)((blocks + 7) / 8) : 0u;
-    if (span) blocks = (int64_t)span * 8;
+    const uint32_t span = remap ? (uint32_t)((groups + 7) / 8) : 0u;   // super-tiles per XCD
+    int64_t blocks = span ? 8 * (((int64_t)span + per - 1) / per) : (groups + per - 1) / per;
     if (tn.multi_blocks_per_cu > 0) {  // tuning hook: cap the grid, workgroups loop over the super-tiles
       const int64_t cap = (int64_t)n_cu * tn.multi_blocks_per_cu;
       if (blocks > cap) blocks = cap;
     }
-    launch(kern, dim3((unsigned)blocks), dim3(256), 0, c, tab, n, (uint32_t)n_req, (uint32_t)spr, p, span);
+    launch(kern, dim3((unsigned)blocks), dim3((unsigned)bt), 0, c, tab, n, (uint32_t)n_req, (uint32_t)spr, p, span);
   };
   constexpr int DU = MultiShape<TS, TE>::U, DN = MultiShape<TS, TE>::NT;
 #ifdef DPM_TUNING_VARIANTS  // tools/tune.py multi: every (tiles per iteration, nt mask) of the 2M kernel

@@ -298,7 +298,7 @@ __device__ __forceinline__ void stage_tiles(const TS* __restrict__ x, const TS* 
   // stay in straight-line code, so the loaded registers are consumed where they land (no copies at a join).
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const int64_t gr = (t0 + u) * 256 + threadIdx.x;
+    const int64_t gr = (t0 + u) * 256 + tile_lane();
     const int64_t gi = gr < ngroups ? gr : ngroups - 1;
     const bool split = can_split && (t0 + u) * 256 + 256 <= ngroups;
     int64_t ge = gi;  // group index into the network outputs
@@ -321,7 +321,7 @@ __device__ __forceinline__ void stage_tiles(const TS* __restrict__ x, const TS* 
       if (split) {  // mask, known image and noise in the state's split layout: whole 1 KiB runs per access
         const int64_t mtiles = mgroups / 256;
         const int64_t mt = small ? (int64_t)((uint32_t)(t0 + u) % (uint32_t)mtiles) : (t0 + u) % mtiles;
-        load_tile<false>(mask, mt * 256 + threadIdx.x, true, vm[u]);
+        load_tile<false>(mask, mt * 256 + tile_lane(), true, vm[u]);
         load_tile<(NT & 1) != 0>(ba, gi, true, va[u]);
         if (bb) load_tile<(NT & 1) != 0>(bb, gi, true, vb[u]);
       } else {
@@ -353,7 +353,7 @@ __device__ __forceinline__ void stage_tiles(const TS* __restrict__ x, const TS* 
 #undef DPM_MODELS
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const int64_t gi = (t0 + u) * 256 + threadIdx.x;
+    const int64_t gi = (t0 + u) * 256 + tile_lane();
     const bool split = can_split && (t0 + u) * 256 + 256 <= ngroups;
     float ox[EPT], om[EPT];
 #pragma unroll
@@ -382,8 +382,15 @@ __device__ __forceinline__ void stage_tiles(const TS* __restrict__ x, const TS* 
   }
 }
 
+// Launched with 256 or 512 threads: each 256-lane group of a workgroup walks tiles of its own, so the two shapes run the same
+// lanes over the same tiles and differ only in how many workgroups the dispatcher has to place -- 1024 instead of 2048 for
+// a [256,4,64,64] request.  Inside a network loop (rocprofv3 rows, same box, alternating runs, profiles/r04_block_threads.md)
+// the lone 2M launch takes 8.3-8.6 us instead of 8.6-8.7 (fp16), 14.2-14.3 instead of 14.5-14.7 (fp32), 13.1 instead of 13.6
+// (fp32 state, fp16 network); 1024 threads were measured too: no better for these, 1.6 % worse for the last, and a 128-VGPR
+// budget the extended kernels do not fit.
+constexpr int STAGE_MAX_THREADS = 512;
 template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int SPEC, int U, int NT, bool EXT, bool DYN = false>
-__global__ __launch_bounds__(256) void stage_kernel(const TS* __restrict__ x, const TS* __restrict__ xe,
+__global__ __launch_bounds__(STAGE_MAX_THREADS) void stage_kernel(const TS* __restrict__ x, const TS* __restrict__ xe,
                                                     const TE* __restrict__ e0, const TE* __restrict__ e1,
                                                     const TE* __restrict__ g, const TS* __restrict__ h1,
                                                     const TS* __restrict__ h2, TS* __restrict__ xo,
@@ -400,7 +407,9 @@ __global__ __launch_bounds__(256) void stage_kernel(const TS* __restrict__ x, co
   // a tile = 256 consecutive groups (one per lane of the workgroup); a workgroup iteration covers U tiles and
   // issues the loads of all of them before the first use
   const int64_t ntiles = (ngroups + 255) / 256;
-  for (int64_t t0 = (int64_t)blockIdx.x * U; t0 < ntiles; t0 += (int64_t)gridDim.x * U)
+  const uint32_t per = blockDim.x >> 8;                                                     // 256-lane groups per workgroup
+  const uint32_t sub = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));   // this wavefront's (wave-uniform)
+  for (int64_t t0 = ((int64_t)blockIdx.x * per + sub) * U; t0 < ntiles; t0 += (int64_t)gridDim.x * per * U)
     stage_tiles<TS, TE, FORM, GUIDE, XE, SPEC, U, NT, EXT>(x, xe, e0, e1, g, h1, h2, xo, mo, ngroups, t0, p, ext);
   if constexpr (!EXT) {
     // ragged tail (n % 8 elements): first lanes of block 0, scalar
@@ -440,14 +449,20 @@ struct MultiTab {
 };
 
 template <typename TS, typename TE, int FORM, int GUIDE, int SPEC, int U, int NT>
-__global__ __launch_bounds__(256) void stage_kernel_multi(const MultiTab tab, int64_t n, uint32_t nreq, uint32_t spr,
+__global__ __launch_bounds__(STAGE_MAX_THREADS) void stage_kernel_multi(const MultiTab tab, int64_t n, uint32_t nreq, uint32_t spr,
                                                           KParams p, uint32_t xcd_span) {
   const int64_t ngroups = n / EPT;
   KExt ext = {};
   const uint32_t total = nreq * spr;  // spr = super-tiles (U tiles) per request
-  for (uint32_t v0 = blockIdx.x; v0 < (xcd_span ? 8u * xcd_span : total); v0 += gridDim.x) {
+  // 256 or 512 threads per workgroup: every 256-lane group takes super-tiles of its own (see stage_kernel)
+  const uint32_t per = blockDim.x >> 8;
+  const uint32_t sub = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  const uint32_t wgs = xcd_span ? 8u * ((xcd_span + per - 1u) / per) : (total + per - 1u) / per;
+  for (uint32_t b = blockIdx.x; b < wgs; b += gridDim.x) {
     // xcd_span != 0 (tuning): workgroup b runs on XCD b % 8 -- give every XCD one contiguous eighth of the tile space
-    const uint32_t v = xcd_span ? (v0 & 7u) * xcd_span + (v0 >> 3) : v0;
+    const uint32_t in_xcd = (b >> 3) * per + sub;
+    if (xcd_span && in_xcd >= xcd_span) continue;
+    const uint32_t v = xcd_span ? (b & 7u) * xcd_span + in_xcd : b * per + sub;
     if (v >= total) continue;
     const uint32_t r = v / spr;
     const int64_t t0 = (int64_t)(v - r * spr) * U;

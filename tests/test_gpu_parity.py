@@ -456,6 +456,53 @@ def test_ragged_sizes_and_unaligned_views(shape):
     np.testing.assert_array_equal(xf2.cpu().numpy(), xf.cpu().numpy())
 
 
+def test_workgroup_size_of_the_streaming_kernel_does_not_change_a_bit():
+    """The streaming stage kernel runs with 256 or 512 threads per workgroup (every 256-lane group takes tiles of its own; by
+    default 512 when that leaves two workgroups per CU -- a [256,4,64,64] request).  The lanes do the same work on the
+    same tiles: every workgroup size forced through DPM_TUNE_BLOCK_THREADS gives the bits of the 256-thread launch -- fp32 / fp16 / bf16 states, half outputs next to an fp32 state (split layout + lane exchange),
+    ragged tiles, classifier-free guidance with the duplicate store, a mask blend, singlestep forms, a BASELINE-sized
+    request where the default picks 512."""
+    ns = make_schedule("sd")
+    g = torch.Generator().manual_seed(77)
+    cond = torch.ones(1, device=DEV)
+    xb, known, noise = (torch.randn((4, 4, 64, 64), generator=g).to(DEV) for _ in range(3))
+    mask = (torch.rand(64, 64, generator=g) > 0.5).float().to(DEV)
+
+    def runs():
+        out = []
+        for shape, sdt, edt in [((8, 4, 64, 64), torch.float32, None), ((8, 4, 64, 64), torch.float16, None),
+                                ((8, 4, 64, 64), torch.bfloat16, None), ((8, 4, 64, 64), torch.float32, torch.float16),
+                                ((3, 3, 33, 35), torch.float32, None), ((5, 4, 40, 40), torch.float16, None),
+                                ((256, 4, 64, 64), torch.float16, None)]:
+            x = torch.randn(shape, generator=torch.Generator().manual_seed(5)).to(DEV, sdt)
+            net = lambda xx, t: (xx.float() * 0.5).to(edt or xx.dtype)
+            kw = {} if sdt is torch.float32 else {"state_dtype": sdt}
+            dpm = D.DPM_Solver(D.model_wrapper(net, ns), ns, **kw)
+            out.append(dpm.sample(x, steps=6, order=2))
+            out.append(dpm.sample(x, steps=6, order=3, method="singlestep"))
+            if shape[0] <= 8:
+                c = cond.expand(shape[0])
+                cfg = D.DPM_Solver(D.model_wrapper(lambda xx, t, cc: (xx.float() * (0.3 + 0.2 * cc.reshape(-1, 1, 1, 1))).to(edt or xx.dtype),
+                                                   ns, guidance_type="classifier-free", condition=c,
+                                                   unconditional_condition=c * 0, guidance_scale=7.5), ns, **kw)
+                out.append(cfg.sample(x, steps=6, order=2))
+        edit = D.DPM_Solver(D.model_wrapper(lambda xx, t: xx * 0.5, ns), ns,
+                            correcting_xt_fn=D.MaskBlend(ns, mask, x0=known, noise=noise))
+        out.append(edit.sample(xb, steps=6, order=2))
+        # requests in flight: the fused multi-request kernel takes the same two workgroup sizes
+        for sdt in (torch.float16, torch.float32):
+            fl = D.DPM_Solver(D.model_wrapper(lambda xx, t: xx * 0.5, ns), ns, **({} if sdt is torch.float32 else {"state_dtype": sdt}))
+            out += fl.sample_requests([(xb * s).to(sdt) for s in (1.0, 0.5, 2.0, 1.5, 0.25)], steps=6, order=2)
+        return out
+    with _Tuned(block_threads=256):
+        want = runs()
+    for bt in (512, 0):
+        with _Tuned(block_threads=bt):
+            got = runs()
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert torch.equal(a, b), (bt, i)
+
+
 def test_empty_batch():
     ns = make_schedule("sd")
     dpm = D.DPM_Solver(D.model_wrapper(lambda x, t: x, ns), ns)

@@ -85,6 +85,8 @@ CASES = {
     "cfg3": dict(shape=(64, 3, 256, 256), state="fp32", net="fp32", cfg=7.5, thr=False,
                  kw=dict(steps=15, order=3, method="singlestep"), sched="ddpm", algo="dpmsolver", width=32),
     # the plain 2M kernel behind a conv network in the default layout and in channels_last
+    # SD-style autocast at the north-star size: fp32 state, fp16 network (the split layout + lane exchange of the 2-byte streams)
+    "autocast256": dict(shape=(256, 4, 64, 64), state="fp32", net="fp16", cfg=None, thr=False, kw=dict(steps=20, order=2), sched="sd", width=256),
     "nchw": dict(shape=(256, 4, 64, 64), state="fp16", net="fp16", cfg=None, thr=False, kw=dict(steps=20, order=2), sched="sd", width=256),
     "nhwc": dict(shape=(256, 4, 64, 64), state="fp16", net="fp16", cfg=None, thr=False, kw=dict(steps=20, order=2), sched="sd", width=256,
                  channels_last=True),
@@ -286,6 +288,8 @@ def main():
                     "with the real network (one fused stage launch per stage): rows of stage_kernel_multi inside the loop")
     ap.add_argument("--calib", action="store_true", help="the NO-ARITHMETIC kernel of the same five streams (dpm_calib_launch) in "
                     "the stage kernel's place in the loop: what the memory system alone charges a lone launch there")
+    ap.add_argument("--block-threads", type=int, default=-1, help="DPM_TUNE_BLOCK_THREADS for the run (0 = by size, the default)")
+    ap.add_argument("--calib-shape", default="256:8:1", help="--calib: threads per workgroup : workgroups per CU : nt mask")
     ap.add_argument("--pattern", default="stage_", help="--summarise: substring of the kernel rows to report")
     ap.add_argument("--sweep", action="store_true", help="tuning build: (tiles per workgroup, nt mask) of the 2M kernel INSIDE "
                     "the loop, for fp16, fp32 and fp32 state + fp16 network (events)")
@@ -298,6 +302,9 @@ def main():
     args = ap.parse_args()
     if args.summarise:
         return summarise(args.summarise, args.md, args.title, args.pattern)
+    if args.block_threads >= 0:
+        from dpm_solver_amd import _lib as L0
+        L0.check(L0.lib.dpm_tuning_set(L0.TUNE_BLOCK_THREADS, args.block_threads))
     if args.case:
         return run_case(args.case, args.trajectories)
     if args.resident:
@@ -335,12 +342,13 @@ def main():
         tvec = torch.full((bench.B,), 500.0, device=dev)
         sptr = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         nbytes = x.numel() * x.element_size()
+        cblk, cbpc, cnt = (int(v) for v in args.calib_shape.split(":"))
         with torch.no_grad():
             xi, mi = x, bufs[0]
             for it in range(20 * args.trajectories):
                 eps = net(xi, tvec)
                 xo, mo = (bufs[1], bufs[2]) if it % 2 == 0 else (bufs[3], bufs[0])
-                L.check(L.lib.dpm_calib_launch(1, 256, 8, 1, xi.data_ptr(), eps.data_ptr(), mi.data_ptr(), xo.data_ptr(), mo.data_ptr(),
+                L.check(L.lib.dpm_calib_launch(1, cblk, cbpc, cnt, xi.data_ptr(), eps.data_ptr(), mi.data_ptr(), xo.data_ptr(), mo.data_ptr(),
                                                nbytes, sptr, None))
                 xi, mi = xo, mo
         torch.cuda.synchronize()

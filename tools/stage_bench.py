@@ -161,7 +161,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--md", default=None)
     ap.add_argument("--only", default=None, help="substring filter on scenario names (skips the others and the loop timing)")
+    ap.add_argument("--block-threads", type=int, default=-1, help="DPM_TUNE_BLOCK_THREADS for the run (default: by size)")
     args = ap.parse_args()
+    if args.block_threads >= 0:
+        L.check(L.lib.dpm_tuning_set(L.TUNE_BLOCK_THREADS, args.block_threads))
     torch.manual_seed(0)
     global ONLY
     ONLY = args.only
