@@ -208,10 +208,12 @@ __device__ __forceinline__ void give_up(uint32_t* dead, uint32_t* poison, uint32
   __hip_atomic_store(poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the peers need not poll to the end
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (landed long before this workgroup reports itself done)
 }
-// the `spins`-th unsuccessful poll of a wait: time to give up?  (the mark of a peer that did is looked at every 8th poll)
-__device__ __forceinline__ bool wait_is_over(uint32_t spins, const uint32_t* poison, const ThrParams& tp) {
+// the `spins`-th unsuccessful poll of a wait: time to give up?  The mark of a peer that did is looked at every 8th poll, by
+// the workgroup's first wavefront only (`looks`): the others learn it through the LDS word give_up sets, and a wait in which
+// only they are left runs to its own limit (every wavefront looking cost 3 % more read traffic at cfg5's size).
+__device__ __forceinline__ bool wait_is_over(uint32_t spins, const uint32_t* poison, const ThrParams& tp, bool looks = true) {
   if (spins > tp.spin_limit) return true;
-  return (spins & 7u) == 0u && __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+  return looks && (spins & 7u) == 0u && __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
 }
 
 // all workgroups of a cluster meet here; `cnt` is a zero-initialised single-use counter.  Everything the cluster
@@ -699,7 +701,7 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
       for (int j = 0; j < PER; ++j) all &= w[j];
       if ((all & THR_TAG) || misc[30]) break;
       __builtin_amdgcn_s_sleep(1);
-      if (wait_is_over(++spins, poison, tp)) give_up(misc + 30, poison, tp.fault);
+      if (wait_is_over(++spins, poison, tp, tid < 64)) give_up(misc + 30, poison, tp.fault);
     }
 #pragma unroll
     for (int j = 0; j < PER; ++j)
@@ -755,7 +757,7 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
         while (!(w[j] & THR_TAG) && !misc[30]) {
           __builtin_amdgcn_s_sleep(1);
           w[j] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (wait_is_over(++spins, poison, tp)) give_up(misc + 30, poison, tp.fault);
+          if (wait_is_over(++spins, poison, tp, tid < 64)) give_up(misc + 30, poison, tp.fault);
         }
         cand[sc[k + sl] + i] = w[j] & ~THR_TAG;
       }

@@ -25,6 +25,12 @@ for DT in fp16 fp32; do
   rm -rf $O/kt_loop_$DT
   sed -n 5,9p $O/in_loop_trace_$DT.md
 done
+for DT in fp16 fp32; do   # the same behind the conv network (MIOpen kernels in front of the stage kernel)
+  timeout 420 rocprofv3 --kernel-trace --stats --output-format rocpd csv -d $O/kt_loopc_$DT -o kt -- python tools/in_loop.py --dtype $DT --kinds conv --trace-only > $O/kt_loopc_$DT.log 2>&1; echo "rocprof in-loop conv $DT rc=$?"
+  python tools/in_loop.py --summarise $O/kt_loopc_$DT --md $O/in_loop_trace_conv_$DT.md --title "stage kernel inside a torch network loop, conv network (rocprofv3 --kernel-trace)" > /dev/null 2>&1
+  rm -rf $O/kt_loopc_$DT
+  sed -n 5,9p $O/in_loop_trace_conv_$DT.md
+done
 timeout 900 python tools/stage_bench.py --md $O/stage_table.md > $O/stage_bench.log 2>&1; echo "stage_bench rc=$?"; tail -8 $O/stage_bench.log
 timeout 300 python tools/thr_routes.py > $O/thr_routes.txt 2>&1; echo "thr_routes rc=$?"
 # the unmodified reference, when it travelled here as git-ignored scratch (_refscratch/, removed after the call): its CPU timing
