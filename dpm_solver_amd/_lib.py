@@ -204,8 +204,8 @@ for _i, _t in enumerate((Stage, Buffers, PlanDesc, RunBuffers, AdaptiveDesc)):  
                           % (_t.__name__, C.sizeof(_t), lib.dpm_sizeof(_i)))
 
 
-if lib.dpm_version() < 102:
-    raise ImportError("dpm_solver_amd: libdpm_hip.so reports version %d, this binding needs >= 102 -- stale library, rebuild"
+if lib.dpm_version() < 103:
+    raise ImportError("dpm_solver_amd: libdpm_hip.so reports version %d, this binding needs >= 103 -- stale library, rebuild"
                       % lib.dpm_version())
 
 

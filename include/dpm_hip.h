@@ -34,12 +34,13 @@ extern "C" {
 #endif
 
 /* major*10000 + minor*100 + patch.  History: 100 rounds 1-2; 101 dpm_buffers / dpm_run_buffers gained the trailing
-   `thr_hint` pointer; 102 dpm_cluster_timeout_poll, DPM_TUNE_THR_SPIN_LIMIT / _DEBUG_FAULT, DPM_ERR_FAULT retired.
+   `thr_hint` pointer; 102 dpm_cluster_timeout_poll, DPM_TUNE_THR_SPIN_LIMIT / _DEBUG_FAULT, DPM_ERR_FAULT retired;
+   103 DPM_TUNE_BLOCK_THREADS, dpm_calib_launch kind 2 (no struct changed).
    The structs grow at their END only.  A host MUST zero-initialise every struct it passes (memset / = {0}: new trailing
    fields then read as "absent") and SHOULD check at load time that dpm_version() >= the version it was built against and
    that dpm_sizeof(DPM_SIZEOF_*) == its own sizeof() -- a host compiled against an older header passes shorter structs,
    and the library would read past their end (examples/native_host.c and dpm_solver_amd/_lib.py do both checks). */
-#define DPM_HIP_VERSION 102
+#define DPM_HIP_VERSION 103
 
 /* ---- status --------------------------------------------------------------------------- */
 enum {
