@@ -648,6 +648,24 @@ def test_abi_version_and_load_time_checks():
     assert L.cluster_timeout_poll() is False            # no clustered launch has run in this process
 
 
+def test_tuning_knobs_validate_their_values():
+    """the run-time tuning hooks are host state (no device needed): set / get round trip, bad values refused with a text"""
+    for knob, good, bad in [(L.TUNE_BLOCK_THREADS, (256, 512, 0), (1024, 100, -1)),
+                            (L.TUNE_THR_DEBUG_FAULT, (1, 2, 3, 0), (4, -1)),
+                            (L.TUNE_THR_SPIN_LIMIT, (0, 32, 4096), (-1,))]:
+        old = L.lib.dpm_tuning_get(knob)
+        try:
+            for v in good:
+                assert L.lib.dpm_tuning_set(knob, v) == 0 and L.lib.dpm_tuning_get(knob) == v
+            for v in bad:
+                assert L.lib.dpm_tuning_set(knob, v) != 0
+                assert L.lib.dpm_last_error().decode()
+                assert L.lib.dpm_tuning_get(knob) == good[-1]
+        finally:
+            L.lib.dpm_tuning_set(knob, old)
+    assert L.lib.dpm_tuning_set(999, 0) != 0 and L.lib.dpm_tuning_get(999) == -1
+
+
 def test_plan_and_adaptive_caches_are_bounded():
     ns = make_schedule("sd")
     dpm = D.DPM_Solver(D.model_wrapper(lambda xx, t: xx * 0.5, ns), ns)
