@@ -11,8 +11,8 @@
 //
 // Memory-bound (~0.5 flop/B): no MFMA.  What matters is (i) 16-byte coalesced accesses -- each lane moves
 // 8 consecutive elements per tensor per iteration, a wavefront 512 contiguous elements, (ii) all loads of
-// an iteration issued before the first use, (iii) >= 2048 workgroups of 256 threads so every CU holds 8
-// waves per SIMD, (iv) the per-stage scalars arrive as kernel arguments, i.e. in SGPRs via the scalar
+// an iteration issued before the first use, (iii) >= 2048 groups of 256 lanes (in workgroups of one or two) so every CU
+// holds 8 waves per SIMD, (iv) the per-stage scalars arrive as kernel arguments, i.e. in SGPRs via the scalar
 // cache, so the vector pipeline only ever sees the five streams.  The arithmetic keeps the reference's
 // association and is compiled with -ffp-contract=off: given equal coefficients the result is bit-identical
 // to the reference's chain of ATen kernels (no fused multiply-adds there either).
