@@ -87,6 +87,8 @@ CASES = {
     # the plain 2M kernel behind a conv network in the default layout and in channels_last
     # SD-style autocast at the north-star size: fp32 state, fp16 network (the split layout + lane exchange of the 2-byte streams)
     "autocast256": dict(shape=(256, 4, 64, 64), state="fp32", net="fp16", cfg=None, thr=False, kw=dict(steps=20, order=2), sched="sd", width=256),
+    # the plain 2M kernel at SD's batch (512 tiles: the smallest launch that takes 512-thread workgroups)
+    "plain64": dict(shape=(64, 4, 64, 64), state="fp16", net="fp16", cfg=None, thr=False, kw=dict(steps=20, order=2), sched="sd", width=256),
     "nchw": dict(shape=(256, 4, 64, 64), state="fp16", net="fp16", cfg=None, thr=False, kw=dict(steps=20, order=2), sched="sd", width=256),
     "nhwc": dict(shape=(256, 4, 64, 64), state="fp16", net="fp16", cfg=None, thr=False, kw=dict(steps=20, order=2), sched="sd", width=256,
                  channels_last=True),

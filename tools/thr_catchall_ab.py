@@ -14,7 +14,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import bench  # noqa: E402
 import dpm_solver_amd as D  # noqa: E402
 
 
