@@ -461,14 +461,15 @@ int launch_stream(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
     const Tuning tn = g_tuning;
     const bool big = ntiles >= 4 * (int64_t)n_cu;  // two tiles per iteration only when there is work for it
     // launch shape: one 256-lane group per U tiles, capped per CU; two groups per workgroup (stage_kernel) when that still
-    // leaves a workgroup for every CU: what larger workgroups save is dispatches ([256,4,64,64]: 2048 -> 1024), and a small
-    // launch needs every CU more than it needs that.  (At the boundary -- SD's [64,4,64,64] with CFG, 512 tiles -- 512
-    // threads measure 6.87-6.98 us against 7.00-7.02 inside the loop, profiles/r04_block_threads.md.)
+    // leaves two workgroups per CU: what larger workgroups save is dispatches ([256,4,64,64]: 2048 -> 1024), and a small
+    // launch needs every CU more than it needs that.  (One step below -- 512 tiles, SD's [64,4,64,64] -- 512 threads measure
+    // neutral inside the loop: CFG + duplicate store 6.87-6.98 us against 7.00-7.02, the plain fp16 kernel 4.81-4.86 against
+    // 4.66-4.84; profiles/r04_block_threads.md.)
     auto shape_for = [&](int u) {
       const int64_t iters = (ntiles + u - 1) / u;
       int bt = 256;
       if (tn.block_threads > 0) bt = tn.block_threads;
-      else if (iters >= 2 * (int64_t)n_cu) bt = STAGE_MAX_THREADS;
+      else if (iters >= 4 * (int64_t)n_cu) bt = STAGE_MAX_THREADS;
       const int64_t per = bt / 256;
       int64_t blocks = (iters + per - 1) / per;
       const int64_t cap = std::max<int64_t>(1, (int64_t)n_cu * tn.blocks_per_cu / per);

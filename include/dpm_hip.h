@@ -409,8 +409,8 @@ enum {
   DPM_TUNE_THR_SPIN_LIMIT = 10,     /* polls (a microsecond or two each) before a wait on a cluster peer gives up and
                                        the workgroup finishes its sample alone; default 4096                          */
   DPM_TUNE_BLOCK_THREADS = 12,      /* streaming stage kernel: threads per workgroup, 256 / 512 (every 256-lane group takes
-                                       tiles of its own); 0 (default): by size -- 512 when that leaves a workgroup for
-                                       every CU                                                                         */
+                                       tiles of its own); 0 (default): by size -- 512 when that leaves two workgroups
+                                       per CU                                                                          */
   DPM_TUNE_THR_DEBUG_FAULT = 11     /* testing.  1: every cluster wait gives up at its first unsuccessful poll;
                                        2 / 3: workgroup 1 of every cluster takes no part in its cluster from the start,
                                        with / without marking its samples (the peers see the mark / run out of polls).

@@ -460,7 +460,7 @@ def test_ragged_sizes_and_unaligned_views(shape):
 
 def test_workgroup_size_of_the_streaming_kernel_does_not_change_a_bit():
     """The streaming stage kernel runs with 256 or 512 threads per workgroup (every 256-lane group takes tiles of its own; by
-    default 512 when that leaves a workgroup for every CU -- [64,4,64,64] requests and larger).  The lanes do the same work on the
+    default 512 when that leaves two workgroups per CU -- [128,4,64,64] requests and larger).  The lanes do the same work on the
     same tiles: every workgroup size forced through DPM_TUNE_BLOCK_THREADS gives the bits of the 256-thread launch -- fp32 / fp16 / bf16 states, half outputs next to an fp32 state (split layout + lane exchange),
     ragged tiles, classifier-free guidance with the duplicate store, a mask blend, singlestep forms, a BASELINE-sized
     request where the default picks 512."""
