@@ -205,41 +205,31 @@ def cpu_baseline_port(ac, budget_s=8.0):
 
 
 def cpu_baseline(ac):
-    """`cpu_baseline` of the JSON line.  Where the reference checkout is present ($DPM_REFERENCE_DIR or /root/reference) it
-    is timed live (kind "reference", measured_in_this_run true).  On the GPU box it is not -- the reference is not part of
-    this repository -- so the top level carries THE REFERENCE'S OWN FIGURE measured on an MI355X box's host cores and
-    committed (profiles/cpu_baseline_reference_gpubox.json: tools/cpu_baseline.py through gpurun, the file travelled as
-    git-ignored scratch), marked measured_in_this_run false with its source; the numpy port timed live in this run rides
-    along as `port_live`.  `cores` = the threads actually used (the best of the swept counts), `host_cores` = the box."""
+    """`cpu_baseline` of the JSON line: ALWAYS what was timed in this run on this box's host cores.  Where the reference
+    checkout is present ($DPM_REFERENCE_DIR or /root/reference) that is the unmodified reference (kind "reference"); on the
+    GPU box it is not -- the reference is not part of this repository -- so the numpy oracle is timed (kind "port") and the
+    reference's own figure measured earlier on an MI355X box's host cores rides along under `reference_committed`
+    (profiles/cpu_baseline_reference_gpubox.json: tools/cpu_baseline.py through gpurun; not measured in this run).
+    `cores` = the threads actually used, `host_cores` = the box."""
     ref = reference_dir()
     if ref:
         out = cpu_baseline_reference(ref, ac)
         out["measured_in_this_run"] = True
         out["source"] = os.path.join(ref, "dpm_solver_pytorch.py") + ", timed in this run"
         return out
-    port = cpu_baseline_port(ac)
-    port["measured_in_this_run"] = True
-    committed = None
+    out = cpu_baseline_port(ac)
+    out["measured_in_this_run"] = True
+    out["host_cores"] = os.cpu_count() or 1
     p = os.path.join(ROOT, "profiles", "cpu_baseline_reference_gpubox.json")
-    if os.path.exists(p):
-        try:
-            committed = json.load(open(p))
-        except Exception:
-            committed = None
-    if not committed or committed.get("kind") != "reference":
-        return port
-    out = dict(committed)
-    out["measured_in_this_run"] = False
-    out["source"] = ("profiles/cpu_baseline_reference_gpubox.json: the unmodified reference timed on an MI355X box's host "
-                     "cores (tools/cpu_baseline.py through gpurun); committed, not re-measured in this run because the "
-                     "reference is not part of this repository")
-    out["port_live"] = port
-    p2 = os.path.join(ROOT, "profiles", "cpu_baseline_reference.json")
-    if os.path.exists(p2):
-        try:
-            out["reference_in_build_container"] = json.load(open(p2))
-        except Exception:
-            pass
+    try:
+        committed = json.load(open(p))
+    except Exception:
+        committed = None
+    if committed and committed.get("kind") == "reference":
+        committed["measured_in_this_run"] = False
+        committed["source"] = ("profiles/cpu_baseline_reference_gpubox.json: the unmodified reference timed on an MI355X box's "
+                               "host cores (tools/cpu_baseline.py through gpurun); committed, not re-measured in this run")
+        out["reference_committed"] = committed
     return out
 
 
@@ -290,111 +280,28 @@ class LoopNet(torch.nn.Module):
         return self.c3(h)
 
 
-def in_network_loop(D, L, ns, dev, dtype, kind="gemm", width=256, trajectories=6, prefetch=None, net_dtype=None):
-    """DPM_Solver.sample() (2M++, 20 steps) on one [256,4,64,64] request with LoopNet as the network.  Returns the
-    kernel-only duration of the steady-state stage kernel inside the loop (start/stop events attached to each launch,
-    no synchronisation between launches: dpm_stage_launch_traced) and the wall time the solver stages add to the network
-    calls.  prefetch = None | 0 | 1: pull the next stage's x and cached model value towards the memory-side cache from a
-    side stream while the network's last layer runs (dpm_prefetch_launch, default / streaming loads)."""
-    import dpm_solver_amd.solver as S
-    net_dtype = net_dtype or dtype                  # fp16 network under an fp32 state: SD under autocast
-    net = LoopNet(kind, width, net_dtype, dev)
-    g = torch.Generator(device="cpu").manual_seed(4321)
-    x_T = torch.randn((B,) + SHAPE, generator=g).to(dev, dtype)
-    model = net if net_dtype == dtype else (lambda x, t: net(x.to(net_dtype), t))
-    dpm = D.DPM_Solver(D.model_wrapper(model, ns), ns, algorithm_type="dpmsolver++", state_dtype=dtype)
-    with torch.no_grad():
-        out0 = dpm.sample(x_T, steps=STEPS_SOLVER, order=2)              # builds the launch records, warms the allocator
-        torch.cuda.synchronize(dev)
-        n_st = STEPS_SOLVER
-        trace = C.c_void_p()
-        L.check(L.lib.dpm_trace_create(n_st * trajectories, C.byref(trace)))
-        raw = S._stage_launch_raw
-        count = [0]
-        fr = next(iter(dpm._fast.values()))
-        side = torch.cuda.Stream(device=dev)
-        ev = torch.cuda.Event()
-
-        def traced(st, b, stream):
-            k = count[0]
-            count[0] += 1
-            return L.lib.dpm_stage_launch_traced(st, b, stream, trace, k)
-
-        def pull():                                                       # called by the network before its last layer
-            i = count[0] % n_st                                           # the stage this network call feeds
-            b = fr.bufs[i]
-            ptrs = [p for p in (b.x, b.h1, b.h2) if p]
-            if not ptrs:
-                return
-            ev.record()
-            side.wait_event(ev)
-            arr = (C.c_void_p * len(ptrs))(*ptrs)
-            nb = (C.c_int64 * len(ptrs))(*[x_T.numel() * x_T.element_size()] * len(ptrs))
-            L.check(L.lib.dpm_prefetch_launch(arr, nb, len(ptrs), int(prefetch), C.c_void_p(side.cuda_stream)))
-
-        net.before_last = pull if prefetch is not None else None
-        if prefetch is not None:          # x and the cached model value are expected in the memory-side cache then
-            for b in fr.bufs[1:]:
-                b.inputs_resident = 1
-        try:
-            S._stage_launch_raw = traced
-            for _ in range(trajectories):
-                out = dpm.sample(x_T, steps=STEPS_SOLVER, order=2)
-            ms = (C.c_float * (n_st * trajectories))()
-            L.check(L.lib.dpm_trace_read(trace, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), ms, n_st * trajectories))
-        finally:
-            S._stage_launch_raw = raw
-            L.lib.dpm_trace_destroy(trace)
-        assert torch.equal(out, out0), "traced / prefetching runs changed the result"
-        us = np.frombuffer(ms, dtype=np.float32).reshape(trajectories, n_st).astype(np.float64) * 1e3
-        steady = us[1:, 1:n_st - 1]                                       # first trajectory: warm-up
-        # wall: K trajectories with the solver vs the same network calls alone
-        tb = dpm._get_plan(method="multistep", order=2, steps=STEPS_SOLVER, skip_type="time_uniform", solver_type="dpmsolver",
-                           lower_order_final=True, denoise_to_zero=False, t_T=1.0, t_0=1.0 / ns.total_N).time_views(dev, B, False)
-        tin = tb["t_input_b"]
-
-        def timed(fn):
-            torch.cuda.synchronize(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            fn()
-            e1.record()
-            torch.cuda.synchronize(dev)
-            return e0.elapsed_time(e1) * 1e3                              # us
-
-        def net_only():
-            for i in range(n_st):
-                model(x_T, tin[i])
-        with_solver = lambda: dpm.sample(x_T, steps=STEPS_SOLVER, order=2)
-        with_solver()
-        net_only()
-        # alternate the two (A B A B ...) and take medians: the network's own time drifts by more than the 20 stage
-        # kernels cost, so back-to-back blocks of each would measure the drift
-        ts, tn = [], []
-        for _ in range(max(8, 2 * trajectories)):
-            ts.append(timed(with_solver))
-            tn.append(timed(net_only))
-        t_solver, t_net = float(np.median(ts)), float(np.median(tn))
-        net.before_last = None
-        for b in fr.bufs:
-            b.inputs_resident = 0
-    n_el = B * int(np.prod(SHAPE))
-    ssz = x_T.element_size()
-    alg = n_el * (4 * ssz + torch.empty((), dtype=net_dtype).element_size())
-    med = float(np.median(steady))
-    added = (t_solver - t_net) / n_st
-    return dict(network="LoopNet(%s, width %d): %.2f ms per call" % (kind, width, t_net / n_st / 1e3),
-                network_ms_per_call=round(t_net / n_st / 1e3, 4),
-                stage_kernel_us=round(med, 3), stage_kernel_mean_us=round(float(steady.mean()), 3),
-                stage_kernel_p10_p90_us=[round(float(np.percentile(steady, 10)), 3), round(float(np.percentile(steady, 90)), 3)],
-                frac=round(alg / med / 1e3 / HBM_PEAK_GBS, 4), achieved=round(alg / med / 1e3, 1),
-                first_stage_us=round(float(np.median(us[1:, 0])), 3), last_stage_us=round(float(np.median(us[1:, -1])), 3),
-                stage_added_wall_us=round(added, 3), frac_wall=round(alg / max(added, 1e-3) / 1e3 / HBM_PEAK_GBS, 4),
-                trajectory_ms=round(t_solver / 1e3, 4), prefetch=prefetch,
-                how="DPM_Solver.sample() on one [%d,4,64,64] %s request, 2M++ 20 steps, torch network as model_fn; "
-                    "stage_kernel_us = median start->stop event interval of the steady-state stage launches inside the "
-                    "loop (dpm_stage_launch_traced); stage_added_wall_us = (trajectory - 20 network calls alone) / 20"
-                    % (B, str(dtype).split(".")[-1]))
+def lab_secondary(dtype_name, eps_dtype_name, loop_net, requests, timeout=600):
+    """The secondary measurements that need what the product library does not export -- event pairs attached to single
+    launches inside a torch network loop (`in_network_loop`), the no-arithmetic kernels (`no_arithmetic_ceiling`,
+    `lone_launch_floor`) -- run in a SUBPROCESS on the lab build of the same sources (tools/lab_secondary.py,
+    DPM_SOLVER_AMD_LIB=tools/_variants/lab/libdpm_lab.so): this process, the one the headline is timed in, loads the product
+    library only.  Returns the subprocess's JSON dict, or {"error": ...}."""
+    import subprocess
+    lab = os.path.join(ROOT, "tools", "_variants", "lab", "libdpm_lab.so")
+    if not os.path.exists(lab):
+        return dict(error="no lab build (%s): run __graft_entry__.build()" % lab)
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "lab_secondary.py"), "--dtype", dtype_name, "--loop-net", loop_net,
+           "--requests", str(requests)]
+    if eps_dtype_name:
+        cmd += ["--eps-dtype", eps_dtype_name]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, DPM_SOLVER_AMD_LIB=lab), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=timeout)
+        if r.returncode != 0:
+            return dict(error="tools/lab_secondary.py exited %d: %s" % (r.returncode, r.stderr[-400:]))
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:                                           # a secondary must not cost the headline
+        return dict(error="%s: %s" % (type(e).__name__, e))
 
 
 def main():
@@ -475,8 +382,8 @@ def main():
 
     import dpm_solver_amd as D
     from dpm_solver_amd import _lib as L
-    if os.environ.get("DPM_BENCH_BLOCK_THREADS") and not STUB:      # experiments only (tools/gpu_r04_s.sh)
-        L.check(L.lib.dpm_tuning_set(L.TUNE_BLOCK_THREADS, int(os.environ["DPM_BENCH_BLOCK_THREADS"])))
+    assert STUB or not L.IS_LAB or os.environ.get("DPM_BENCH_ALLOW_LAB") == "1", \
+        "bench.py times the PRODUCT library (unset DPM_SOLVER_AMD_LIB)"
 
     ac = sd_alphas_cumprod()
     ns = D.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(ac))
@@ -602,12 +509,14 @@ def main():
                                        frac=round(alg_bytes * R / ko_us / 1e3 / HBM_PEAK_GBS, 4),
                                        how="steady-state fused launches, start->stop events of each launch")
         # (2) the same requests, one launch each (interleaved): what a single request's stage costs from HBM
-        L.lib.dpm_tuning_set(L.TUNE_MULTI_FUSE, 0)
+        no_fuse = L.LaunchOpts()                         # dpm_launch_opts.no_fuse: a per-call option, no process-wide switch
+        no_fuse.no_fuse = 1
+        rbs[0].opts = C.pointer(no_fuse)
         cold = []
         for _ in range(3):
             L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, R, sptr, msb, resm))
             cold.append(np.frombuffer(msb, dtype=np.float32).reshape(R, n_stages)[:, 1:n_stages - 1].copy())
-        L.lib.dpm_tuning_set(L.TUNE_MULTI_FUSE, 1)
+        rbs[0].opts = None
         cold = np.asarray(cold, dtype=np.float64) * 1e3
         cold_med = float(np.median(cold))
         stalled = cold > 50.0 * cold_med                 # see profiles/r02_stall.md
@@ -633,7 +542,7 @@ def main():
         buf = (C.c_float * n_stages)()
         ms1 = []
         for r in range(16):
-            L.check(L.lib.dpm_plan_run_timed(plan.handle, C.byref(sets[r % min(8, R)]["rb"]), sptr, buf, C.byref(res1)))
+            L.check(L.lib.dpm_plan_run_multi(plan.handle, C.byref(sets[r % min(8, R)]["rb"]), 1, sptr, buf, C.byref(res1)))
             ms1.append(np.frombuffer(buf, dtype=np.float32)[1:n_stages - 1].astype(np.float64).mean() * 1e3)
         k1_us = float(np.mean(ms1))
         roofline["cache_resident"] = dict(
@@ -643,36 +552,6 @@ def main():
             kernel_only_us=round(k1_us, 3), kernel_only_frac=round(alg_bytes / k1_us / 1e3 / HBM_PEAK_GBS, 4),
             how="ONE request, 20 launches back to back (dpm_plan_run, frozen outputs): x and m are re-read from the "
                 "256 MiB Infinity Cache -- not the situation of a real sampling loop")
-        # (4) what the memory system sustains for these streams with no arithmetic at all (3 read + 2 write streams)
-        if ssz == esz:
-            cal = {}
-            msv = C.c_float()
-            for mode in ("warm", "cold"):
-                ts = []
-                for it in range(24):
-                    s_ = sets[0] if mode == "warm" else sets[it % R]
-                    L.check(L.lib.dpm_calib_launch(1, 256, 8, 0 if mode == "warm" else 5,
-                                                   s_["x"][1].data_ptr(), s_["x"][2].data_ptr(), s_["x"][3].data_ptr(),
-                                                   s_["h"][0].data_ptr(), s_["h"][1].data_ptr(), n_el * ssz, sptr, C.byref(msv)))
-                    if it >= 8:
-                        ts.append(msv.value)
-                cal[mode] = float(np.mean(ts) * 1e3)
-            big = [torch.empty(R * n_el * ssz, dtype=torch.uint8, device=dev) for _ in range(5)]
-            ts = []
-            for it in range(6):
-                L.check(L.lib.dpm_calib_launch(1, 256, 4096, 1, big[0].data_ptr(), big[1].data_ptr(), big[2].data_ptr(),
-                                               big[3].data_ptr(), big[4].data_ptr(), R * n_el * ssz, sptr, C.byref(msv)))
-                if it >= 2:
-                    ts.append(msv.value)
-            del big
-            cal["fused"] = float(np.mean(ts) * 1e3)
-            roofline["no_arithmetic_ceiling"] = dict(
-                pattern="3 read + 2 write streams, same bytes, 256-thread workgroups",
-                one_request_warm_us=round(cal["warm"], 3), one_request_cold_us=round(cal["cold"], 3),
-                fused_size_us=round(cal["fused"], 3),
-                fused_size_frac_of_peak=round(alg_bytes * R / cal["fused"] / 1e3 / HBM_PEAK_GBS, 4),
-                stage_kernel_vs_ceiling=round(cal["fused"] / roofline["kernel_only"]["us"], 3))
-
         # (5) SURVEY 8(d): what a plain device-to-device copy of the same footprint achieves on this box
         half = R * n_el * ssz * 5 // 2 // 4096 * 4096          # read + write = the fused launch's bytes
         src_c = torch.empty(half, dtype=torch.uint8, device=dev)
@@ -746,38 +625,31 @@ def main():
             o = (rank + 1) % world
             assert not torch.equal(out[o * nb:(o + 1) * nb], final)
 
-    # ---- the stage kernel inside a real torch network loop (one request, the drop-in sample() call) ------------------
-    if not args.no_secondary and args.loop_net != "none" and world == 1:
-        for kind in ([args.loop_net, "gemm"] if args.loop_net != "gemm" else ["gemm"]):
-            try:
-                roofline["in_network_loop"] = in_network_loop(D, L, ns, dev, dtype, kind=kind, net_dtype=eps_dtype)
-                break
-            except Exception as e:                                      # a secondary must not cost the headline
-                roofline["in_network_loop"] = dict(error="%s: %s" % (type(e).__name__, e))
-        # ONE headline figure for the stage kernel inside the loop: the rocprofv3 kernel rows of the same loop (committed,
-        # profiles/in_loop.json -- bench.py cannot run under rocprofv3 inside itself); the event figure measured live in
-        # this run is kept next to it under its own name, labelled with the offset event pairs around a short kernel carry
-        inl = roofline["in_network_loop"]
+    # ---- secondaries on the LAB build, in a subprocess: the stage kernel inside a real torch network loop (one request,
+    # the drop-in sample() call), the no-arithmetic ceilings, the floor of the lone launch ------------------------------
+    if not args.no_secondary and world == 1:
+        torch.cuda.synchronize(dev)
+        lab = lab_secondary(args.dtype, args.eps_dtype, args.loop_net, R)
+        if "error" in lab:
+            roofline["in_network_loop"] = dict(error=lab["error"])
+        else:
+            for k in ("in_network_loop", "no_arithmetic_ceiling", "lone_launch_floor"):
+                if k in lab:
+                    roofline[k] = lab[k]
+            nac = roofline.get("no_arithmetic_ceiling")
+            if nac and "fused_size_us" in nac and "kernel_only" in roofline:
+                nac["stage_kernel_vs_ceiling"] = round(nac["fused_size_us"] / roofline["kernel_only"]["us"], 3)
+        inl = roofline.get("in_network_loop", {})
         if "error" not in inl:
-            live = {k: inl.pop(k) for k in ("stage_kernel_us", "stage_kernel_mean_us", "stage_kernel_p10_p90_us", "frac",
-                                            "achieved", "first_stage_us", "last_stage_us") if k in inl}
-            live["note"] = ("start/stop HIP events attached to each launch, measured in this run: 1.2-1.5 us above the kernel's "
-                            "own duration for a cold ~9 us launch (dispatch + event signalling, profiles/README.md) -- a check "
-                            "that the loop ran, not the headline")
-            inl["live_events_incl_dispatch_offset"] = live
+            # the rocprofv3 kernel rows of the same loop, committed (bench.py cannot run under rocprofv3 inside itself): a
+            # SEPARATE key -- `stage_kernel_us` / `frac` above are this run's own event measurement
             try:
                 rows = json.load(open(os.path.join(ROOT, "profiles", "in_loop.json"))).get(args.dtype)
             except Exception:
                 rows = None
             if rows:
-                inl["stage_kernel_us"] = rows.get("stage_kernel_us_median")
-                inl["frac"] = rows.get("frac")
-                inl["measured_in_this_run"] = False
-                inl["source"] = "profiles/in_loop.json: rocprofv3 --kernel-trace rows of the same loop (tools/in_loop.py), committed"
-                inl["rocprofv3_kernel_rows"] = rows
-            else:
-                inl["stage_kernel_us"] = None
-                inl["frac"] = None
+                inl["rocprofv3_rows_committed"] = dict(rows, measured_in_this_run=False,
+                                                       source="profiles/in_loop.json (tools/in_loop.py under rocprofv3 --kernel-trace)")
 
     if rank == 0:
         samples = world * steps * P * R * B

@@ -13,8 +13,11 @@ import os
 import torch  # noqa: F401  (import order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# DPM_SOLVER_AMD_LIB: an instrumented build of the same library (tools/thr_timeline.py); unset in normal use
+# DPM_SOLVER_AMD_LIB: another build of the same sources -- the LAB build (tools/_variants/lab/libdpm_lab.so: tuning knobs,
+# fault injection, event-bracketed launches, include/dpm_lab.h) that tools/ and the lab-marked tests run on, or the
+# escape-hatch build; unset in normal use
 LIB_PATH = os.environ.get("DPM_SOLVER_AMD_LIB") or os.path.join(_HERE, "libdpm_hip.so")
+LAB_LIB_PATH = os.path.join(os.path.dirname(_HERE), "tools", "_variants", "lab", "libdpm_lab.so")
 
 # ---- enumerations (mirror include/dpm_hip.h) --------------------------------------------------
 DPM_OK = 0
@@ -25,16 +28,18 @@ METHOD = {"multistep": 0, "singlestep": 1, "singlestep_fixed": 2}
 SKIP = {"time_uniform": 0, "logSNR": 1, "time_quadratic": 2}
 MODEL = {"noise": 0, "x_start": 1, "v": 2, "score": 3}
 GUIDE = {"uncond": 0, "classifier-free": 1, "classifier": 2}
-DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
+DTYPE_F32, DTYPE_F16, DTYPE_BF16, DTYPE_F64 = 0, 1, 2, 3
 EVAL_LOG_ALPHA, EVAL_ALPHA, EVAL_STD, EVAL_LAMBDA, EVAL_INV_LAMBDA = 0, 1, 2, 3, 4
 FORM_LIN1, FORM_TWO, FORM_MS3, FORM_SS3T, FORM_DENOISE = 0, 1, 2, 3, 4
 F_TO_X0, F_STORE_M, F_BASE_HIST, F_THRESH, F_USER_X0, F_BLEND = 1, 2, 4, 8, 16, 32
 SRC_STATE, SRC_TMP = 0, 1
+# knobs of the LAB build (include/dpm_lab.h: dpm_tuning_set / dpm_tuning_get; the product library has none)
 TUNE_UNROLL, TUNE_NONTEMPORAL, TUNE_BLOCKS_PER_CU, TUNE_ASSUME_RESIDENT = 0, 1, 2, 3
 TUNE_MULTI_FUSE, TUNE_MULTI_BLOCKS_PER_CU, TUNE_CLUSTER_IN_GRAPH, TUNE_CLUSTER_ONE_HOP = 4, 5, 6, 7
 TUNE_MULTI_XCD_REMAP = 8
 TUNE_THR_PREDICT = 9
 TUNE_THR_SPIN_LIMIT, TUNE_THR_DEBUG_FAULT, TUNE_BLOCK_THREADS = 10, 11, 12
+TUNE_FORCE_GENERIC, TUNE_THR_ELECT = 13, 14
 MULTI_MAX = 32
 THR_HINT_WORDS = 4
 
@@ -58,6 +63,12 @@ class Stage(C.Structure):
         return s
 
 
+class LaunchOpts(C.Structure):
+    """dpm_launch_opts: what a caller may choose per call (zero = defaults)"""
+    _fields_ = [("cluster_in_graph", C.c_int32), ("no_fuse", C.c_int32), ("thr_spin_limit", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
+
+
 class Buffers(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("xe", C.c_void_p), ("e0", C.c_void_p), ("e1", C.c_void_p), ("g", C.c_void_p),
@@ -67,6 +78,7 @@ class Buffers(C.Structure):
         ("x_out2", C.c_void_p), ("eps_stride", C.c_int64), ("mask", C.c_void_p), ("blend_a", C.c_void_p),
         ("blend_b", C.c_void_p), ("mask_period", C.c_int64),
         ("inputs_resident", C.c_int32), ("reserved", C.c_int32), ("thr_hint", C.c_void_p),
+        ("opts", C.POINTER(LaunchOpts)),
     ]
 
 
@@ -87,6 +99,7 @@ class RunBuffers(C.Structure):
         ("workspace", C.c_void_p), ("n", C.c_int64), ("batch", C.c_int64),
         ("state_dtype", C.c_int32), ("eps_dtype", C.c_int32),
         ("eps_stride", C.c_int64), ("dup_state", C.c_int32), ("reserved", C.c_int32), ("thr_hint", C.c_void_p),
+        ("opts", C.POINTER(LaunchOpts)),
     ]
 
 
@@ -154,34 +167,52 @@ _SIGNATURES = [
     ("dpm_adaptive_done_at", C.c_int, [C.c_void_p, C.c_int]),
     ("dpm_adaptive_poll", C.c_int, [C.c_void_p, _P(C.c_int), _P(C.c_int), _P(C.c_int), _P(C.c_int)]),
     ("dpm_plan_run", C.c_int, [C.c_void_p, _P(RunBuffers), C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int)]),
-    ("dpm_stage_launch_timed", C.c_int, [_P(Stage), _P(Buffers), C.c_void_p, _P(C.c_float)]),
-    ("dpm_trace_create", C.c_int, [C.c_int, _P(C.c_void_p)]),
-    ("dpm_stage_launch_traced", C.c_int, [_P(Stage), _P(Buffers), C.c_void_p, C.c_void_p, C.c_int]),
-    ("dpm_trace_read", C.c_int, [C.c_void_p, C.c_void_p, _P(C.c_float), C.c_int]),
-    ("dpm_trace_destroy", None, [C.c_void_p]),
-    ("dpm_prefetch_launch", C.c_int, [_P(C.c_void_p), _P(C.c_int64), C.c_int, C.c_int, C.c_void_p]),
-    ("dpm_plan_run_timed", C.c_int, [C.c_void_p, _P(RunBuffers), C.c_void_p, _P(C.c_float), _P(C.c_int)]),
     ("dpm_plan_run_multi", C.c_int, [C.c_void_p, _P(RunBuffers), C.c_int, C.c_void_p, _P(C.c_float), _P(C.c_int)]),
     ("dpm_graph_create", C.c_int, [C.c_void_p, _P(RunBuffers), C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
     ("dpm_graph_launch", C.c_int, [C.c_void_p, C.c_void_p]),
     ("dpm_graph_result", C.c_int, [C.c_void_p]),
     ("dpm_graph_num_nodes", C.c_int, [C.c_void_p]),
     ("dpm_graph_destroy", None, [C.c_void_p]),
-    ("dpm_tuning_set", C.c_int, [C.c_int, C.c_int]),
-    ("dpm_tuning_get", C.c_int, [C.c_int]),
-    ("dpm_calib_launch", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                   C.c_void_p, C.c_int64, C.c_void_p, _P(C.c_float)]),
     ("dpm_cluster_timeout_poll", C.c_int, []),
-    ("dpm_resident_create", C.c_int, [_P(Stage), _P(Buffers), C.c_int, C.c_int, C.c_int, _P(C.c_void_p)]),
-    ("dpm_resident_start", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    ("dpm_resident_signal", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
-    ("dpm_resident_destroy", None, [C.c_void_p]),
     ("dpm_version", C.c_int, []),
     ("dpm_sizeof", C.c_size_t, [C.c_int]),
     ("dpm_last_error", C.c_char_p, []),
     ("dpm_device_info", C.c_int, [_P(C.c_int), _P(C.c_int), C.c_char_p, C.c_int]),
 ]
 SYMBOLS = [s[0] for s in _SIGNATURES]
+
+
+class FloorDesc(C.Structure):
+    """dpm_floor_desc (include/dpm_lab.h)"""
+    _fields_ = [("load_path", C.c_int32), ("rows", C.c_int32), ("block", C.c_int32), ("blocks_per_cu", C.c_int32),
+                ("nt", C.c_int32), ("prio", C.c_int32), ("store", C.c_int32), ("reserved", C.c_int32)]
+
+
+# what include/dpm_lab.h declares: exported by the LAB build only (bound when the loaded library is one)
+_LAB_SIGNATURES = [
+    ("dpm_lab_build", C.c_int, []),
+    ("dpm_lab_device_context", C.c_void_p, [C.c_int]),
+    ("dpm_stage_launch_timed", C.c_int, [_P(Stage), _P(Buffers), C.c_void_p, _P(C.c_float)]),
+    ("dpm_trace_create", C.c_int, [C.c_int, _P(C.c_void_p)]),
+    ("dpm_stage_launch_traced", C.c_int, [_P(Stage), _P(Buffers), C.c_void_p, C.c_void_p, C.c_int]),
+    ("dpm_trace_read", C.c_int, [C.c_void_p, C.c_void_p, _P(C.c_float), C.c_int]),
+    ("dpm_trace_destroy", None, [C.c_void_p]),
+    ("dpm_prefetch_launch", C.c_int, [_P(C.c_void_p), _P(C.c_int64), C.c_int, C.c_int, C.c_void_p]),
+    ("dpm_tuning_set", C.c_int, [C.c_int, C.c_int]),
+    ("dpm_tuning_get", C.c_int, [C.c_int]),
+    ("dpm_calib_launch", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int64, C.c_void_p, _P(C.c_float)]),
+    ("dpm_resident_create", C.c_int, [_P(Stage), _P(Buffers), C.c_int, C.c_int, C.c_int, _P(C.c_void_p)]),
+    ("dpm_resident_start", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("dpm_resident_signal", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    ("dpm_resident_destroy", None, [C.c_void_p]),
+    ("dpm_floor_launch", C.c_int, [_P(FloorDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                   C.c_void_p, _P(C.c_float)]),
+    ("dpm_floor_launch_traced", C.c_int, [_P(FloorDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                          C.c_void_p, C.c_void_p, C.c_int]),
+    ("dpm_pagetouch_launch", C.c_int, [_P(C.c_void_p), _P(C.c_int64), C.c_int, C.c_int64, C.c_void_p]),
+]
+LAB_SYMBOLS = [s[0] for s in _LAB_SIGNATURES]
 
 
 def _load():
@@ -194,23 +225,37 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the library is stale
         fn.restype = res
         fn.argtypes = args
+    if hasattr(lib, "dpm_lab_build"):       # the lab build: everything above + include/dpm_lab.h
+        for name, res, args in _LAB_SIGNATURES:
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     return lib
 
 
 lib = _load()
-for _i, _t in enumerate((Stage, Buffers, PlanDesc, RunBuffers, AdaptiveDesc)):  # the ctypes mirrors must match the compiled structs
+IS_LAB = hasattr(lib, "dpm_lab_build")
+for _i, _t in enumerate((Stage, Buffers, PlanDesc, RunBuffers, AdaptiveDesc, LaunchOpts)):  # the ctypes mirrors must match the compiled structs
     if lib.dpm_sizeof(_i) != C.sizeof(_t):
         raise ImportError("dpm_solver_amd: %s is %d bytes in _lib.py but %d in libdpm_hip.so -- stale library, rebuild"
                           % (_t.__name__, C.sizeof(_t), lib.dpm_sizeof(_i)))
 
 
-if lib.dpm_version() < 103:
-    raise ImportError("dpm_solver_amd: libdpm_hip.so reports version %d, this binding needs >= 103 -- stale library, rebuild"
+if lib.dpm_version() < 200:
+    raise ImportError("dpm_solver_amd: libdpm_hip.so reports version %d, this binding needs >= 200 -- stale library, rebuild"
                       % lib.dpm_version())
 
 
 class DpmError(RuntimeError):
     pass
+
+
+def require_lab(what="this tool"):
+    """tools/ and the lab-marked tests: fail with the recipe when the loaded library is the product one"""
+    if not IS_LAB:
+        raise RuntimeError("%s needs the LAB build of the library (tuning knobs / fault injection / event-bracketed launches, "
+                           "include/dpm_lab.h): run with DPM_SOLVER_AMD_LIB=%s (built by __graft_entry__.build())"
+                           % (what, LAB_LIB_PATH))
 
 
 def cluster_timeout_poll():

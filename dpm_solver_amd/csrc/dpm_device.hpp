@@ -40,7 +40,14 @@
 
 int dpm_set_error(int code, const char* fmt, ...);  // dpm_host.cpp
 
+#ifndef DPM_LAB
+#define DPM_LAB 0   // 1: the lab build (include/dpm_lab.h): process-global tuning knobs, fault injection, experiments
+#endif
+
 namespace dpmk {
+// Launch-shape parameters.  In the PRODUCT build this is a constant: every launch starts from the defaults below (the
+// measured best) and takes what the caller may choose per call from dpm_launch_opts -- no process-global mutable state.
+// The LAB build keeps one mutable instance behind dpm_tuning_set / dpm_tuning_get for the tuning tools and the tests.
 struct Tuning {
   int unroll = 0;           // tiles per workgroup iteration: 1, 2;  0 = default
   int nontemporal = -1;     // nt mask; -1 = per-dtype default
@@ -55,21 +62,39 @@ struct Tuning {
   int thr_predict = 1;      // clustered thresholding: predict the select bound from the previous stages (thr_hint)
   int thr_spin_limit = 1 << 12;  // clustered thresholding: polls before a wait on a peer gives up (THR_SPIN_LIMIT)
   int block_threads = 0;    // streaming kernel: threads per workgroup (256 / 512); 0 = by size (launch_stream)
-  int thr_debug_fault = 0;  // testing: 1 = every cluster wait gives up at its first unsuccessful poll, 2 / 3 = workgroup 1 of
-                            // every cluster takes no part from the start, with / without marking the sample (its peers
-                            // see the mark / time out by their own polls, and recover)
+  int force_generic = 0;    // LAB: take the run-time-prologue kernels (SPEC_GENERIC / HOT 3) where a compile-time one exists (A/B)
+  int thr_elect = -1;       // clustered thresholding: one elected reducer per sample (1) / every workgroup reads every slot (0)
+  int thr_debug_fault = 0;  // LAB ONLY (fault injection; compiled out of the product kernels): 1 = every cluster wait gives
+                            // up at its first unsuccessful poll, 2 / 3 = workgroup 1 of every cluster takes no part from the
+                            // start, with / without marking the sample
 };
-extern Tuning g_tuning;     // defined in dpm_kernels.hip
-// device-wide chain of clustered thresholding launches (see launch_typed): one instance per device for the library
-struct ClusterChain {
+#if DPM_LAB
+extern Tuning g_lab_tuning;  // defined in csrc/lab/dpm_lab.hip
+inline Tuning base_tuning() { return g_lab_tuning; }
+#else
+inline Tuning base_tuning() { return Tuning{}; }
+#endif
+// the parameters of ONE call: the defaults (lab: the knobs) + the caller's dpm_launch_opts
+inline Tuning tuning_for(const dpm_launch_opts* o) {
+  Tuning t = base_tuning();
+  if (o) {
+    if (o->cluster_in_graph) t.cluster_in_graph = 1;
+    if (o->no_fuse) t.multi_fuse = 0;
+    if (o->thr_spin_limit > 0) t.thr_spin_limit = o->thr_spin_limit;
+  }
+  return t;
+}
+// Per-device context of the library -- the only state that outlives a call: the chain of clustered thresholding launches
+// of the device (see launch_thresh) and the host-mapped word a clustered kernel raises when one of its waits timed out
+// (and was recovered from: diagnostics only).  One instance per device ordinal, created on first use.
+struct DeviceContext {
   std::mutex mu;
-  hipEvent_t ev = nullptr;
+  hipEvent_t ev = nullptr;      // recorded behind the device's last eager clustered launch
   bool recorded = false;
+  uint32_t* fault = nullptr;    // host-mapped (portable) diagnostics word; nullptr until created
 };
-ClusterChain& cluster_chain(int dev);  // defined in dpm_kernels.hip
-// host-mapped word a clustered kernel raises when one of its waits timed out (and was recovered from: diagnostics only);
-// nullptr until created (create = false never allocates: stream capture)
-uint32_t* cluster_fault_word(bool create);
+DeviceContext& device_context(int dev);                   // defined in dpm_kernels.hip
+uint32_t* cluster_fault_word(int dev, bool create);       // create = false never allocates (stream capture)
 // bfloat16 storage (a named type with external linkage: it is a template argument of functions shared between
 // translation units, dpm_catchall_* below)
 struct bf16_t {
@@ -77,9 +102,9 @@ struct bf16_t {
 };
 }  // namespace dpmk
 using dpmk::Tuning;
-using dpmk::g_tuning;
-using dpmk::ClusterChain;
-using dpmk::cluster_chain;
+using dpmk::tuning_for;
+using dpmk::DeviceContext;
+using dpmk::device_context;
 using dpmk::cluster_fault_word;
 
 // The catch-all kernels of a dtype pair (run-time form / guidance: the one-element-per-lane stage kernel and the general

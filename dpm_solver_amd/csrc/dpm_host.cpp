@@ -43,6 +43,7 @@ extern "C" size_t dpm_sizeof(int which) {
     case DPM_SIZEOF_PLAN_DESC: return sizeof(dpm_plan_desc);
     case DPM_SIZEOF_RUN_BUFFERS: return sizeof(dpm_run_buffers);
     case DPM_SIZEOF_ADAPTIVE_DESC: return sizeof(dpm_adaptive_desc);
+    case DPM_SIZEOF_LAUNCH_OPTS: return sizeof(dpm_launch_opts);
   }
   return 0;
 }
@@ -619,6 +620,7 @@ static int plan_run_impl(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model
     b.m_out = st.m_slot >= 0 ? rb->hist[st.m_slot] : nullptr;
     b.workspace = rb->workspace;
     b.thr_hint = rb->thr_hint;
+    b.opts = rb->opts;
     b.n = rb->n;
     b.batch = rb->batch;
     b.state_dtype = rb->state_dtype;
@@ -645,18 +647,6 @@ static int plan_run_impl(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model
 extern "C" int dpm_plan_run(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model_cb model, void* user, void* stream,
                             int* result) {
   return plan_run_impl(p, rb, model, user, stream, result, nullptr, nullptr);
-}
-
-extern "C" int dpm_plan_run_timed(const dpm_plan* p, const dpm_run_buffers* rb, void* stream, float* ms_per_stage,
-                                  int* result) {
-  if (!p || !ms_per_stage) return dpm_set_error(DPM_ERR_ARG, "null pointer");
-  const int n = (int)p->stages.size();
-  void **starts = nullptr, **stops = nullptr;
-  int rc = dpm_timing_begin(n, &starts, &stops);
-  if (rc) return rc;
-  rc = plan_run_impl(p, rb, nullptr, nullptr, stream, result, starts, stops);
-  int rc2 = dpm_timing_end(n, starts, stops, stream, rc ? nullptr : ms_per_stage, nullptr);
-  return rc ? rc : rc2;
 }
 
 int dpm_stage_launch_multi_ev(const dpm_stage* st, const dpm_buffers* bs, int n_req, void* stream, void** ev_start,
@@ -697,6 +687,7 @@ extern "C" int dpm_plan_run_multi(const dpm_plan* p, const dpm_run_buffers* rbs,
       b.m_out = st.m_slot >= 0 ? rb.hist[st.m_slot] : nullptr;
       b.workspace = rb.workspace;
       b.thr_hint = rb.thr_hint;
+      b.opts = rbs[0].opts;
       b.n = rb.n;
       b.batch = rb.batch;
       b.state_dtype = rb.state_dtype;

@@ -6,23 +6,23 @@
 #include "dpm_coef.hpp"
 
 namespace dpmk {
-Tuning g_tuning;
-ClusterChain& cluster_chain(int dev) {
-  static ClusterChain chains[64];
-  return chains[(dev < 0 ? 0 : dev) % 64];
+// one context per device ordinal (dpm_device.hpp): the only state of the library that outlives a call
+DeviceContext& device_context(int dev) {
+  static DeviceContext ctx[64];
+  return ctx[(dev < 0 ? 0 : dev) % 64];
 }
-uint32_t* cluster_fault_word(bool create) {
-  static std::mutex mu;
-  static uint32_t* word = nullptr;
-  std::lock_guard<std::mutex> lk(mu);
-  if (!word && create) {
+uint32_t* cluster_fault_word(int dev, bool create) {
+  DeviceContext& c = device_context(dev);
+  std::lock_guard<std::mutex> lk(c.mu);
+  if (!c.fault && create) {
     void* p = nullptr;
-    if (hipHostMalloc(&p, 64, hipHostMallocMapped) == hipSuccess && p) {
-      word = static_cast<uint32_t*>(p);
-      *word = 0u;
+    // portable: a host of several devices (one thread per device) maps the word into every device's address space
+    if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && p) {
+      c.fault = static_cast<uint32_t*>(p);
+      *c.fault = 0u;
     }
   }
-  return word;
+  return c.fault;
 }
 }  // namespace dpmk
 
@@ -97,7 +97,7 @@ int dpm_stage_launch_multi_ev(const dpm_stage* st, const dpm_buffers* bs, int n_
                               void** ev_stop, int* fused_first) {
   if (!st || !bs || n_req < 1) return dpm_set_error(DPM_ERR_ARG, "stage_launch_multi: bad arguments");
   int done = 0;  // requests already advanced by fused launches
-  bool same = g_tuning.multi_fuse != 0 && n_req > 1;
+  bool same = n_req > 1 && tuning_for(bs[0].opts).multi_fuse != 0;
   for (int r = 1; r < n_req && same; ++r)
     same = bs[r].n == bs[0].n && bs[r].batch == bs[0].batch && bs[r].state_dtype == bs[0].state_dtype &&
            bs[r].eps_dtype == bs[0].eps_dtype;
@@ -175,118 +175,6 @@ int dpm_timing_end(int n, void** starts, void** stops, void* stream, float* ms, 
   for (int i = 0; i < 2 * n; ++i) (void)hipEventDestroy(static_cast<hipEvent_t>(starts[i]));
   delete[] starts;
   return ret;
-}
-
-extern "C" int dpm_stage_launch_timed(const dpm_stage* st, const dpm_buffers* b, void* stream, float* ms) {
-  if (!ms) return dpm_set_error(DPM_ERR_ARG, "null pointer");
-  void **starts = nullptr, **stops = nullptr;
-  int rc = dpm_timing_begin(1, &starts, &stops);
-  if (rc) return rc;
-  rc = dpm_stage_launch_ev(st, b, stream, starts[0], stops[0]);
-  int rc2 = dpm_timing_end(1, starts, stops, stream, rc ? nullptr : ms, nullptr);
-  return rc ? rc : rc2;
-}
-
-// ---- event-bracketed launches without a synchronisation per launch (include/dpm_hip.h: dpm_trace_*)
-struct dpm_trace {
-  int cap = 0;
-  void** starts = nullptr;  // 2 * cap events: starts, then stops (dpm_timing_begin's layout)
-  void** stops = nullptr;
-  std::vector<unsigned char> used;
-};
-
-extern "C" int dpm_trace_create(int capacity, dpm_trace** out) {
-  if (!out || capacity < 1 || capacity > (1 << 20)) return dpm_set_error(DPM_ERR_ARG, "trace_create: bad arguments");
-  dpm_trace* t = new (std::nothrow) dpm_trace;
-  if (!t) return dpm_set_error(DPM_ERR_NOMEM, "out of memory");
-  int rc = dpm_timing_begin(capacity, &t->starts, &t->stops);
-  if (rc) {
-    delete t;
-    return rc;
-  }
-  t->cap = capacity;
-  t->used.assign((size_t)capacity, 0);
-  *out = t;
-  return DPM_OK;
-}
-
-extern "C" int dpm_stage_launch_traced(const dpm_stage* st, const dpm_buffers* b, void* stream, dpm_trace* t, int slot) {
-  if (!t || slot < 0 || slot >= t->cap) return dpm_set_error(DPM_ERR_ARG, "stage_launch_traced: slot %d outside the trace", slot);
-  const int rc = dpm_stage_launch_ev(st, b, stream, t->starts[slot], t->stops[slot]);
-  if (!rc) t->used[(size_t)slot] = 1;
-  return rc;
-}
-
-extern "C" int dpm_trace_read(dpm_trace* t, void* stream, float* ms, int n) {
-  if (!t || !ms || n < 0) return dpm_set_error(DPM_ERR_ARG, "trace_read: bad arguments");
-  hipError_t rc = hipStreamSynchronize(static_cast<hipStream_t>(stream));
-  if (rc != hipSuccess) return dpm_set_error((int)rc, "hipStreamSynchronize: %s", hipGetErrorString(rc));
-  for (int i = 0; i < n; ++i) {
-    ms[i] = -1.f;
-    if (i < t->cap && t->used[(size_t)i]) {
-      rc = hipEventElapsedTime(&ms[i], static_cast<hipEvent_t>(t->starts[i]), static_cast<hipEvent_t>(t->stops[i]));
-      if (rc != hipSuccess) return dpm_set_error((int)rc, "hipEventElapsedTime(slot %d): %s", i, hipGetErrorString(rc));
-      t->used[(size_t)i] = 0;
-    }
-  }
-  return DPM_OK;
-}
-
-extern "C" void dpm_trace_destroy(dpm_trace* t) {
-  if (!t) return;
-  for (int i = 0; i < 2 * t->cap; ++i) (void)hipEventDestroy(static_cast<hipEvent_t>(t->starts[i]));
-  delete[] t->starts;
-  delete t;
-}
-
-// ---- prefetch: read buffers and drop the data (dpm_prefetch_launch)
-namespace {
-constexpr int PREFETCH_MAX = 8;
-struct PrefetchTab {
-  const u32x4* p[PREFETCH_MAX];
-  int64_t nvec[PREFETCH_MAX];
-};
-template <bool NT>
-__global__ __launch_bounds__(256) void prefetch_kernel(const PrefetchTab tab, int n_buf) {
-  for (int r = 0; r < n_buf; ++r) {
-    const u32x4* p = tab.p[r];
-    const int64_t nv = tab.nvec[r];
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
-      const u32x4 v = ld16<NT>(p + i);
-      asm volatile("" ::"v"(v));  // keeps the load; the data is not wanted
-    }
-  }
-}
-}  // namespace
-
-extern "C" int dpm_prefetch_launch(const void* const* bufs, const int64_t* bytes, int n_buf, int policy, void* stream) {
-  if (!bufs || !bytes || n_buf < 0 || n_buf > PREFETCH_MAX) return dpm_set_error(DPM_ERR_ARG, "prefetch: bad arguments (<= %d buffers)", PREFETCH_MAX);
-  PrefetchTab tab;
-  std::memset(&tab, 0, sizeof tab);
-  int64_t total = 0;
-  int k = 0;
-  for (int i = 0; i < n_buf; ++i) {
-    if (!bufs[i] || bytes[i] < 16) continue;
-    if (!aligned(bufs[i], 16)) return dpm_set_error(DPM_ERR_ALIGN, "prefetch: buffer %d is not 16-byte aligned", i);
-    tab.p[k] = static_cast<const u32x4*>(bufs[i]);
-    tab.nvec[k] = bytes[i] / 16;
-    total += tab.nvec[k];
-    ++k;
-  }
-  if (!k) return DPM_OK;
-  const DeviceInfo& di = device_info();
-  const int64_t cap = (int64_t)(di.n_cu > 0 ? di.n_cu : 256) * 4;
-  int64_t blocks = (total / k + 255) / 256;
-  if (blocks > cap) blocks = cap;
-  if (blocks < 1) blocks = 1;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (policy == 1)
-    hipLaunchKernelGGL(prefetch_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, tab, k);
-  else
-    hipLaunchKernelGGL(prefetch_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, tab, k);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return dpm_set_error((int)e, "prefetch launch failed: %s", hipGetErrorString(e));
-  return DPM_OK;
 }
 
 extern "C" size_t dpm_threshold_workspace_bytes(int64_t batch, int64_t per_sample) {
@@ -874,141 +762,10 @@ extern "C" void dpm_graph_destroy(dpm_graph* g) {
   delete g;
 }
 
-// ------------------------------------------------------------------------------------------------
-// calibration kernels: what the memory system sustains for this access pattern and size, with no arithmetic.
-// kind 0: copy (1 read + 1 write stream); kind 1: 3 read + 2 write streams (the 2M stage's pattern); kind 2: 4 read + 1 write
-// streams (the same bytes: what a 2M stage would move that re-derives the previous model value from the previous state and
-// network output instead of storing it -- `e` is read).
-// ------------------------------------------------------------------------------------------------
-namespace {
-template <int BLOCK, int KIND, int NT>
-__global__ __launch_bounds__(BLOCK) void calib_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b,
-                                                      const u32x4* __restrict__ c, u32x4* __restrict__ d,
-                                                      u32x4* __restrict__ e, int64_t nvec) {
-  const int64_t stride = (int64_t)gridDim.x * BLOCK;
-  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < nvec; i += stride) {
-    if (KIND == 0) {
-      st16<(NT & 2) != 0>(d + i, ld16<(NT & 1) != 0>(a + i));
-    } else if (KIND == 2) {
-      const u32x4 va = ld16<(NT & 1) != 0>(a + i), vb = ld16<(NT & 1) != 0>(b + i), vc = ld16<(NT & 1) != 0>(c + i);
-      const u32x4 ve = ld16<(NT & 1) != 0>(e + i);
-      st16<(NT & 2) != 0>(d + i, (va ^ vb) ^ (vc ^ ve));
-    } else {
-      const u32x4 va = ld16<(NT & 1) != 0>(a + i), vb = ld16<(NT & 1) != 0>(b + i), vc = ld16<(NT & 1) != 0>(c + i);
-      st16<(NT & 2) != 0>(d + i, va ^ vb);
-      st16<(NT & 4) != 0>(e + i, vb ^ vc);
-    }
-  }
-}
-
-template <int BLOCK, int KIND>
-void calib_nt(int nt, dim3 grid, const LaunchCtx& c, const u32x4* a, const u32x4* b, const u32x4* cc, u32x4* d, u32x4* e,
-              int64_t nvec) {
-  switch (nt) {
-    case 1: launch(calib_kernel<BLOCK, KIND, 1>, grid, dim3(BLOCK), 0, c, a, b, cc, d, e, nvec); break;
-    case 5: launch(calib_kernel<BLOCK, KIND, 5>, grid, dim3(BLOCK), 0, c, a, b, cc, d, e, nvec); break;
-    case 7: launch(calib_kernel<BLOCK, KIND, 7>, grid, dim3(BLOCK), 0, c, a, b, cc, d, e, nvec); break;
-    default: launch(calib_kernel<BLOCK, KIND, 0>, grid, dim3(BLOCK), 0, c, a, b, cc, d, e, nvec); break;
-  }
-}
-}  // namespace
-
-extern "C" int dpm_calib_launch(int kind, int block, int blocks_per_cu, int nt, const void* a, const void* b, const void* c,
-                                void* d, void* e, int64_t nbytes, void* stream, float* ms) {
-  if (!a || !d || nbytes < 16 || (kind >= 1 && (!b || !c || !e))) return dpm_set_error(DPM_ERR_ARG, "calib: bad arguments");
-  const int64_t nvec = nbytes / 16;
-  const DeviceInfo& di = device_info();
-  int64_t blocks = (nvec + block - 1) / block;
-  const int64_t cap = (int64_t)(di.n_cu > 0 ? di.n_cu : 256) * blocks_per_cu;
-  if (blocks > cap) blocks = cap;
-  void **starts = nullptr, **stops = nullptr;
-  if (ms) {
-    int rc = dpm_timing_begin(1, &starts, &stops);
-    if (rc) return rc;
-  }
-  const LaunchCtx ctx{static_cast<hipStream_t>(stream), ms ? static_cast<hipEvent_t>(starts[0]) : nullptr,
-                      ms ? static_cast<hipEvent_t>(stops[0]) : nullptr};
-  const u32x4 *pa = (const u32x4*)a, *pb = (const u32x4*)b, *pc = (const u32x4*)c;
-  u32x4 *pd = (u32x4*)d, *pe = (u32x4*)e;
-  const dim3 grid((unsigned)blocks);
-  int rc = DPM_OK;
-  if (kind == 0 && block == 256) calib_nt<256, 0>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
-  else if (kind == 0 && block == 512) calib_nt<512, 0>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
-  else if (kind == 0 && block == 1024) calib_nt<1024, 0>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
-  else if (kind == 1 && block == 256) calib_nt<256, 1>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
-  else if (kind == 1 && block == 512) calib_nt<512, 1>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
-  else if (kind == 1 && block == 1024) calib_nt<1024, 1>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
-  else if (kind == 2 && block == 256) calib_nt<256, 2>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
-  else if (kind == 2 && block == 512) calib_nt<512, 2>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
-  else if (kind == 2 && block == 1024) calib_nt<1024, 2>(nt, grid, ctx, pa, pb, pc, pd, pe, nvec);
-  else rc = dpm_set_error(DPM_ERR_ARG, "calib: kind %d / block %d not built", kind, block);
-  if (ms) {
-    int rc2 = dpm_timing_end(1, starts, stops, stream, rc ? nullptr : ms, nullptr);
-    if (!rc) rc = rc2;
-  }
-  return rc;
-}
-
-extern "C" int dpm_tuning_set(int knob, int value) {
-  switch (knob) {
-    case DPM_TUNE_UNROLL:
-      if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
-        return dpm_set_error(DPM_ERR_ARG, "unroll must be 0 (default), 1, 2, 4 or 8 (4 and 8: tuning builds only)");
-      g_tuning.unroll = value;
-      return DPM_OK;
-    case DPM_TUNE_NONTEMPORAL: g_tuning.nontemporal = value < 0 ? -1 : (value & 7); return DPM_OK;
-    case DPM_TUNE_BLOCKS_PER_CU:
-      if (value < 1 || value > 64) return dpm_set_error(DPM_ERR_ARG, "blocks_per_cu must be in 1..64");
-      g_tuning.blocks_per_cu = value;
-      return DPM_OK;
-    case DPM_TUNE_ASSUME_RESIDENT: g_tuning.assume_resident = value != 0; return DPM_OK;
-    case DPM_TUNE_MULTI_FUSE: g_tuning.multi_fuse = value != 0; return DPM_OK;
-    case DPM_TUNE_CLUSTER_IN_GRAPH: g_tuning.cluster_in_graph = value != 0; return DPM_OK;
-    case DPM_TUNE_MULTI_XCD_REMAP: g_tuning.multi_xcd_remap = value < 0 ? -1 : (value != 0); return DPM_OK;
-    case DPM_TUNE_CLUSTER_ONE_HOP: g_tuning.cluster_one_hop = value < 0 ? 0 : (value > 2 ? 2 : value); return DPM_OK;
-    case DPM_TUNE_THR_PREDICT: g_tuning.thr_predict = value != 0; return DPM_OK;
-    case DPM_TUNE_THR_SPIN_LIMIT:
-      if (value < 0) return dpm_set_error(DPM_ERR_ARG, "thr_spin_limit must be >= 0");
-      g_tuning.thr_spin_limit = value;
-      return DPM_OK;
-    case DPM_TUNE_THR_DEBUG_FAULT:
-      if (value < 0 || value > 3) return dpm_set_error(DPM_ERR_ARG, "thr_debug_fault must be 0 .. 3");
-      g_tuning.thr_debug_fault = value;
-      return DPM_OK;
-    case DPM_TUNE_BLOCK_THREADS:
-      if (value != 0 && value != 256 && value != 512)
-        return dpm_set_error(DPM_ERR_ARG, "block_threads must be 0 (by size), 256 or 512");
-      g_tuning.block_threads = value;
-      return DPM_OK;
-    case DPM_TUNE_MULTI_BLOCKS_PER_CU:
-      if (value < 0 || value > 4096) return dpm_set_error(DPM_ERR_ARG, "multi_blocks_per_cu must be in 0..4096");
-      g_tuning.multi_blocks_per_cu = value;
-      return DPM_OK;
-  }
-  return dpm_set_error(DPM_ERR_ARG, "unknown tuning knob %d", knob);
-}
-
-extern "C" int dpm_tuning_get(int knob) {
-  switch (knob) {
-    case DPM_TUNE_UNROLL: return g_tuning.unroll;
-    case DPM_TUNE_NONTEMPORAL: return g_tuning.nontemporal;
-    case DPM_TUNE_BLOCKS_PER_CU: return g_tuning.blocks_per_cu;
-    case DPM_TUNE_ASSUME_RESIDENT: return g_tuning.assume_resident;
-    case DPM_TUNE_MULTI_FUSE: return g_tuning.multi_fuse;
-    case DPM_TUNE_CLUSTER_IN_GRAPH: return g_tuning.cluster_in_graph;
-    case DPM_TUNE_MULTI_XCD_REMAP: return g_tuning.multi_xcd_remap;
-    case DPM_TUNE_CLUSTER_ONE_HOP: return g_tuning.cluster_one_hop;
-    case DPM_TUNE_MULTI_BLOCKS_PER_CU: return g_tuning.multi_blocks_per_cu;
-    case DPM_TUNE_THR_PREDICT: return g_tuning.thr_predict;
-    case DPM_TUNE_THR_SPIN_LIMIT: return g_tuning.thr_spin_limit;
-    case DPM_TUNE_THR_DEBUG_FAULT: return g_tuning.thr_debug_fault;
-    case DPM_TUNE_BLOCK_THREADS: return g_tuning.block_threads;
-  }
-  return -1;
-}
-
 extern "C" int dpm_cluster_timeout_poll(void) {
-  uint32_t* w = cluster_fault_word(false);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  uint32_t* w = cluster_fault_word(dev, false);
   if (!w || !*w) return 0;
   *w = 0u;
   return 1;

@@ -185,6 +185,7 @@ int launch_thresh(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
   TS *xo = op.xo, *mo = op.mo;
   const KExt& ext = op.ext;
   const int n_cu = op.n_cu;
+  const Tuning tn = tuning_for(b->opts);
   if (stream.dyn) return dpm_set_error(DPM_ERR_UNSUPPORTED, "dynamic thresholding with device-resident coefficients");
   const int64_t per_sample = b->n / b->batch;
   // several requests in one launch: one batch of n_multi * batch samples -- more samples per launch, smaller (or no)
@@ -201,8 +202,8 @@ int launch_thresh(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
   // the chip at the same time.  Eager launches of this process are chained device-wide (below); a captured graph is
   // replayed outside that chain, possibly next to another graph on another stream.  Under capture a sample that fits
   // one workgroup's LDS therefore takes the cluster-free shape (one workgroup per sample) unless the caller opts in
-  // (DPM_TUNE_CLUSTER_IN_GRAPH); larger samples have no such shape and keep their clusters, with bounded waits.
-  if (capturing && pl.k > 1 && per_sample <= THR_CHUNK_MAX && !g_tuning.cluster_in_graph) {
+  // (dpm_launch_opts.cluster_in_graph); larger samples have no such shape and keep their clusters, with bounded waits.
+  if (capturing && pl.k > 1 && per_sample <= THR_CHUNK_MAX && !tn.cluster_in_graph) {
     pl.k = 1;
     pl.chunk = (per_sample + 3) / 4 * 4;
   }
@@ -280,17 +281,18 @@ int launch_thresh(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
       while (((int64_t)1 << slot_shift) < quota * 3 / 2 && slot_shift < 8) ++slot_shift;
       while (slot_shift > 0 && ((int64_t)1 << slot_shift) > std::min<int64_t>(THR_SLOT_CAP, THR_CAP / pl.k)) --slot_shift;
       const int64_t slot_cap = (int64_t)1 << slot_shift;
-      if (quota * 3 / 2 <= slot_cap && g_tuning.cluster_one_hop) {
+      if (quota * 3 / 2 <= slot_cap && tn.cluster_one_hop) {
         tp.quota = (int32_t)quota;
         tp.kbig = (int32_t)K;
         tp.slot_cap = (int32_t)slot_cap;
         tp.slot_pub = (int32_t)std::min<int64_t>(slot_cap, quota + quota / 4 + 4);
         tp.slot_shift = slot_shift;
-        tp.debug_reject = g_tuning.cluster_one_hop == 2;
+        tp.debug_reject = tn.cluster_one_hop == 2;
       }
     }
   }
 #ifdef DPM_THR_TIMING
+  static_assert(DPM_LAB, "DPM_THR_TIMING instruments the lab build only");
   // debug build only: the DPM_THR_TIMING_LAUNCH-th thresholding launch of the process (default 40) is synchronised
   // and its stamps are written to $DPM_THR_TIMING_FILE, one line of 16 values per workgroup
   static uint64_t* t_dev = nullptr;
@@ -331,7 +333,7 @@ int launch_thresh(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
     // parameterisation with the usual near-1 quantile: the run-time prologue (HOT 3); the rest: the catch-all kernel
     bool chosen = false;
     if constexpr (HOT12_BUILT) {
-      if (hot && tp.fastdiv) {
+      if (hot && tp.fastdiv && !tn.force_generic) {
         kern = front ? stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 1>
                      : stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 2>;
         chosen = true;
@@ -344,17 +346,20 @@ int launch_thresh(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
   tp.groups = (int32_t)batch;
   if (pl.k > 1) {
     // clusters synchronise through spin barriers: every workgroup of the grid must be resident at once
+    // (cached per thread for the last (device, kernel, LDS size): kernels of different flavours may differ in occupancy)
     static thread_local int occ_dev = -1, occ = 0;
     static thread_local size_t occ_lds = 0;
+    static thread_local const void* occ_kern = nullptr;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev != occ_dev || lds_bytes != occ_lds) {
+    if (dev != occ_dev || lds_bytes != occ_lds || occ_kern != reinterpret_cast<const void*>(kern)) {
       int nb = 0;
       hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), THR_THREADS,
                                                                   lds_bytes);
       if (e != hipSuccess) return dpm_set_error((int)e, "hipOccupancyMaxActiveBlocksPerMultiprocessor: %s", hipGetErrorString(e));
       occ_dev = dev;
       occ_lds = lds_bytes;
+      occ_kern = reinterpret_cast<const void*>(kern);
       occ = nb;
     }
     const int64_t cap = (int64_t)n_cu * (occ < 1 ? 1 : (occ > 2 ? 2 : occ));
@@ -374,9 +379,12 @@ int launch_thresh(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
     // No clearing of the workspace here: the caller hands it over zero-filled once, the kernel leaves it zero-filled
     // (dpm_threshold_workspace_bytes).  A wait on a peer that times out is recovered from inside the kernel (solo_select:
     // same results, no error); the host-mapped word only records that it happened (dpm_cluster_timeout_poll).
-    tp.fault = cluster_fault_word(!capturing);
-    tp.spin_limit = g_tuning.thr_debug_fault == 1 ? 0u : (uint32_t)g_tuning.thr_spin_limit;
-    tp.debug_fault = g_tuning.thr_debug_fault;
+    tp.fault = cluster_fault_word(dev, !capturing);
+    tp.spin_limit = (uint32_t)tn.thr_spin_limit;
+#if DPM_LAB
+    if (tn.thr_debug_fault == 1) tp.spin_limit = 0u;
+    tp.debug_fault = tn.thr_debug_fault;
+#endif
     // the select bound predicted from the previous stages (dpm_buffers.thr_hint): single requests on the one-exchange route
     // -- where it pays: a small K (the wanted rank from the top), so that the predicted union (~1.3-1.9 K entries instead
     // of k * quota) is finished by rank counting.  Measured (tools/thr_routes.py): [32,3,64,64] (K = 63) 11.3 -> 10.7 us per
@@ -385,16 +393,14 @@ int launch_thresh(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
     if (!multi && tp.quota > 0 && b->thr_hint && tp.kbig <= 128) {
       tp.hint = b->thr_hint;
       tp.hint_reset = st->index <= 0;
-      tp.hint_predict = g_tuning.thr_predict;
+      tp.hint_predict = tn.thr_predict;
     }
     // Two clustered launches on different streams could each hold part of the CUs with spinning workgroups and
     // starve the other's missing peers.  Within this process they are therefore chained device-wide: wait for the
     // previous clustered launch (whatever its stream), record after this one.  (Not under stream capture, where an
     // event recorded outside the capture cannot be waited on; see above.)
     if (!capturing) {
-      int dev = 0;
-      (void)hipGetDevice(&dev);
-      ClusterChain& ch = cluster_chain(dev);
+      DeviceContext& ch = device_context(dev);
       std::lock_guard<std::mutex> lk(ch.mu);
       if (!ch.ev && hipEventCreateWithFlags(&ch.ev, hipEventDisableTiming) != hipSuccess) ch.ev = nullptr;
       if (ch.ev && ch.recorded) (void)hipStreamWaitEvent(stream.stream, ch.ev, 0);
@@ -454,11 +460,11 @@ int launch_stream(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
     launch(reinterpret_cast<ScalarKernel>(const_cast<void*>(k)), dim3((unsigned)blocks), dim3(256), 0, stream, x, xe ? xe : x,
            e0, e1, g, h1, h2, xo, mo, b->n, p, ext, stream.dyn, stream.skip);
   } else if constexpr (COMBO_BUILT) {
-    const bool noise = SPEC_BUILT && !stream.dyn && st->model_type == DPM_MODEL_NOISE &&
+    const Tuning tn = tuning_for(b->opts);
+    const bool noise = SPEC_BUILT && !stream.dyn && !tn.force_generic && st->model_type == DPM_MODEL_NOISE &&
                        (!(st->flags & DPM_F_TO_X0) || div_invariant_ok(st->alpha_e));
     const int spec = !noise ? SPEC_GENERIC : ((st->flags & DPM_F_TO_X0) ? SPEC_NOISE_X0 : SPEC_NOISE_EPS);
     const int64_t ntiles = ((b->n / EPT) + 255) / 256;
-    const Tuning tn = g_tuning;
     const bool big = ntiles >= 4 * (int64_t)n_cu;  // two tiles per iteration only when there is work for it
     // launch shape: one 256-lane group per U tiles, capped per CU; two groups per workgroup (stage_kernel) when that still
     // leaves two workgroups per CU: what larger workgroups save is dispatches ([256,4,64,64]: 2048 -> 1024), and a small
@@ -574,7 +580,7 @@ template <typename TS, typename TE, int FORM, int GUIDE, int SPEC>
 int launch_multi_spec(const dpm_stage* st, const dpm_buffers* bs, int n_req, const LaunchCtx& c) {
   const DeviceInfo& di = device_info();
   const int n_cu = di.n_cu > 0 ? di.n_cu : 256;
-  const Tuning tn = g_tuning;
+  const Tuning tn = tuning_for(bs[0].opts);
   MultiTab tab;
   std::memset(&tab, 0, sizeof tab);
   for (int r = 0; r < n_req; ++r) {
@@ -650,7 +656,8 @@ int launch_multi_typed(const dpm_stage* st, const dpm_buffers* bs, int n_req, co
   const bool x0 = (st->flags & DPM_F_TO_X0) != 0;
   const bool cfg = st->guidance == DPM_GUIDE_CFG;
   // x_start / v / score networks (and an alpha the division-by-invariant guard rejects) take the general prologue
-  const bool generic = st->model_type != DPM_MODEL_NOISE || (x0 && !div_invariant_ok(st->alpha_e));
+  const bool generic = st->model_type != DPM_MODEL_NOISE || (x0 && !div_invariant_ok(st->alpha_e)) ||
+                       tuning_for(bs[0].opts).force_generic != 0;
 #define DPM_MULTI(FORM_)                                                                                        \
   (generic ? (cfg ? launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_CFG, SPEC_GENERIC>(st, bs, n_req, c)             \
                   : launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_NONE, SPEC_GENERIC>(st, bs, n_req, c))           \

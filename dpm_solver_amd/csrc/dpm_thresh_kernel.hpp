@@ -97,12 +97,14 @@ struct ThrParams {
   uint32_t* fault; // host-mapped word: set when a cluster wait timed out and was recovered from (diagnostics only:
                    // dpm_cluster_timeout_poll; the launch's results are correct either way)
   uint32_t spin_limit;  // polls before a wait on a peer gives up (THR_SPIN_LIMIT)
-  int32_t debug_fault;  // testing (DPM_TUNE_THR_DEBUG_FAULT): 2 / 3 = workgroup 1 of every cluster takes no part in its cluster
+#if DPM_LAB
+  int32_t debug_fault;  // LAB build only (DPM_TUNE_THR_DEBUG_FAULT): 2 / 3 = workgroup 1 of every cluster takes no part in its cluster
+#endif
   float* hint;     // dpm_buffers.thr_hint (THR_HINT_W floats per sample) or null: the selected order statistic of the
                    // previous two stages -> predicted select bound of this one (cluster_select_once, `pbound`)
   int32_t hint_reset; // this is the first stage of a trajectory: the stored values are stale, overwrite without reading
   int32_t hint_predict; // 0: maintain the hint but do not use it (DPM_TUNE_THR_PREDICT)
-#ifdef DPM_THR_TIMING
+#ifdef DPM_THR_TIMING  // (lab build only)
   uint64_t* tdbg;  // 16 timestamps per workgroup (tools/thr_timeline.py)
 #endif
 };
@@ -897,9 +899,14 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
   const TS* ba = HOT != 0 ? nullptr : static_cast<const TS*>(ext.ba);
   const TS* bb = HOT != 0 ? nullptr : static_cast<const TS*>(ext.bb);
   TS* xo2 = static_cast<TS*>(ext.xo2);
-  // misc[30]: this workgroup gave up a wait on a peer and is out of the cluster protocol (give_up).  Testing
-  // (ThrParams.debug_fault 2 / 3): workgroup 1 of every cluster is out from the start, with / without the sample mark.
-  if (threadIdx.x == 0) misc[30] = (k > 1 && tp.debug_fault >= 2 && c == 1) ? 1u : 0u;
+  // misc[30]: this workgroup gave up a wait on a peer and is out of the cluster protocol (give_up).  Fault injection (LAB
+  // build only, ThrParams.debug_fault 2 / 3): workgroup 1 of every cluster is out from the start, with / without the mark.
+#if DPM_LAB
+  const int dbg_fault = tp.debug_fault;
+#else
+  constexpr int dbg_fault = 0;
+#endif
+  if (threadIdx.x == 0) misc[30] = (k > 1 && dbg_fault >= 2 && c == 1) ? 1u : 0u;
   for (int s_idx = grp; s_idx < tp.batch; s_idx += tp.groups) {
     // The thread index is re-materialised per sample: otherwise the compiler hoists every per-thread predicate of the
     // body (dozens of 64-bit lane masks) out of this loop, runs out of SGPRs and pays v_readlane pairs all over the select.
@@ -973,7 +980,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
       }
       misc[25] = pb;
       // a workgroup that gave up a wait on an earlier sample takes no part in this one either: tell the peers
-      if (k > 1 && misc[30] && tp.debug_fault != 3)
+      if (k > 1 && misc[30] && dbg_fault != 3)
         __hip_atomic_store(ws + THR_WS_POISON, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       misc[4] = 0u;   // candidate counter
       misc[3] = ABS;  // smallest value above the selected top digit (cluster exchange)
@@ -1509,7 +1516,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
         const int zshift = tp.slot_shift;
         const uint32_t zw = 1u << zshift, zwords = k << zshift;  // slot_cap is a power of two
         for (uint32_t area = 0; area < 2u; ++area) {
-          const bool used = area == 0u ? (searched || (any_dead && route1)) : pbound != 0u;
+          // (any_dead: a workgroup that gave up may have rewritten the hint words a late peer predicts from -- `pbound` and
+          // `searched` are then no longer cluster-uniform, and a peer may have published into an area this workgroup's own
+          // route never touched: clear both)
+          const bool used = (any_dead && route1) || (area == 0u ? searched : pbound != 0u);
           if (!used) continue;
           uint32_t* as = slots + (size_t)area * k * THR_SLOTW;
           for (uint32_t q = tid; q < zwords; q += T) as[(size_t)(q >> zshift) * THR_SLOTW + THR_SLOT_HDR + (q & (zw - 1u))] = 0u;

@@ -12,6 +12,7 @@
 // 20-step 2M trajectory of BASELINE configs[1] launches.  Nothing in DPM_Solver uses this; tools/in_loop.py --resident
 // measures it against the dispatched kernel (profiles/r04_resident.md has the verdict).
 #include "dpm_device.hpp"
+#include "dpm_lab.h"
 
 namespace {
 
@@ -28,7 +29,11 @@ struct ResStage {
 struct ResCtl {
   uint64_t go[RES_MAX_STAGES];      // 0, then the network output's address (hipStreamWriteValue64)
   uint32_t arrive[RES_MAX_STAGES];  // workgroups through with the stage
+  uint32_t abort;                   // a wait ran out (a signal never came): every workgroup leaves, the done words are raised
 };
+// polls before a resident workgroup gives up on a stage's signal (~2 us each at sleep = 1: about ten seconds) -- a missed
+// dpm_resident_signal must not hang the GPU
+constexpr uint32_t RES_SPIN_LIMIT = 5u << 20;
 
 template <typename TS, typename TE>
 __global__ __launch_bounds__(256) void resident_kernel(const ResStage* __restrict__ stages, ResCtl* ctl, uint32_t** done,
@@ -40,13 +45,24 @@ __global__ __launch_bounds__(256) void resident_kernel(const ResStage* __restric
   for (int s = 0; s < n_stages; ++s) {
     if (threadIdx.x == 0) {
       uint64_t v;
+      uint32_t spins = 0;
       // `sleep` x s_sleep 64 (64 x 64 clocks, ~2 us) between polls: pollers that sleep shorter take bandwidth from the
       // network that runs next to them (MI355X_MICROARCH.md prices busy pollers at up to -37 % of the chip's bandwidth)
-      while ((v = __hip_atomic_load(&ctl->go[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == 0ull)
+      while ((v = __hip_atomic_load(&ctl->go[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) == 0ull) {
         for (int r = 0; r < sleep; ++r) __builtin_amdgcn_s_sleep(64);
+        if (++spins > RES_SPIN_LIMIT || ((spins & 63u) == 0u && __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+      }
       eps_sh = v;
     }
     __syncthreads();
+    if (eps_sh == 0ull) {  // aborted: release every stream wait of the remaining stages and leave
+      if (threadIdx.x == 0 && blockIdx.x == 0)
+        for (int q = s; q < n_stages; ++q) __hip_atomic_store(done[q], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
     // the network's last kernel wrote eps (and this kernel may hold stale lines of the same address from an earlier stage)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     const TE* e0 = reinterpret_cast<const TE*>(eps_sh);
@@ -94,6 +110,19 @@ extern "C" int dpm_resident_create(const dpm_stage* stages, const dpm_buffers* b
     return dpm_set_error(DPM_ERR_ARG, "resident_create: bad arguments");
   Resident* r = new (std::nothrow) Resident();
   if (!r) return dpm_set_error(DPM_ERR_NOMEM, "resident_create: out of memory");
+  {
+    // every workgroup of the grid has to be resident at once (the last one to arrive raises done[s]): cap the grid at what
+    // the device holds -- and at 7 of its 8 wavefront slots per SIMD, so that the network's kernels can still be scheduled
+    // (2048 workgroups hung the loop in round 4)
+    int occ = 0;
+    const void* kf = bufs[0].state_dtype == DPM_DTYPE_F16 ? reinterpret_cast<const void*>(&resident_kernel<__half, __half>)
+                                                            : reinterpret_cast<const void*>(&resident_kernel<float, float>);
+    const DeviceInfo& di = device_info();
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kf, 256, 0) == hipSuccess && occ > 0 && di.n_cu > 0) {
+      const int cap = di.n_cu * std::max(1, std::min(occ, 8) - 1);
+      if (workgroups > cap) workgroups = cap;
+    }
+  }
   r->n_stages = n_stages;
   r->wgs = workgroups;
   r->sleep = sleep;
@@ -107,7 +136,7 @@ extern "C" int dpm_resident_create(const dpm_stage* stages, const dpm_buffers* b
                     (!b.xe || b.xe == b.x) && b.state_dtype == b.eps_dtype && b.n % (EPT * 256) == 0 && div_invariant_ok(st.alpha_e) &&
                     (b.state_dtype == DPM_DTYPE_F16 || b.state_dtype == DPM_DTYPE_F32);
     if (!ok) {
-      delete r;
+      delete r;  // (no device allocation yet)
       return dpm_set_error(DPM_ERR_UNSUPPORTED, "resident_create: stage %d is outside the experiment (unguided noise-prediction "
                            "2M++ stages, equal fp16 / fp32 dtypes, whole tiles)", s);
     }
@@ -125,7 +154,7 @@ extern "C" int dpm_resident_create(const dpm_stage* stages, const dpm_buffers* b
   if (e == hipSuccess) e = hipMemcpy(r->d_done, r->done, sizeof(uint32_t*) * RES_MAX_STAGES, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     const int rc = dpm_set_error((int)e, "resident_create: %s", hipGetErrorString(e));
-    delete r;
+    dpm_resident_destroy(r);  // frees whatever was allocated
     return rc;
   }
   *out = r;
@@ -169,7 +198,7 @@ extern "C" int dpm_resident_signal(void* h, int s, const void* eps, void* stream
 extern "C" void dpm_resident_destroy(void* h) {
   Resident* r = static_cast<Resident*>(h);
   if (!r) return;
-  for (int s = 0; s < r->n_stages; ++s)
+  for (int s = 0; s < RES_MAX_STAGES; ++s)
     if (r->done[s]) (void)hipFree(r->done[s]);
   if (r->d_stages) (void)hipFree(r->d_stages);
   if (r->d_ctl) (void)hipFree(r->d_ctl);

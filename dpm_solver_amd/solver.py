@@ -101,7 +101,7 @@ def _in_layout_of(t, ref):
     return t if mf is None else _conv(t, t.dtype, mf)
 
 
-def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=None):
+def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=None, opts=None):
     """One `dpm_stage_launch` on the current stream.  Allocates x_out (and m_out when the stage stores
     its model value) through torch's caching allocator; returns (x_out, m_out).
 
@@ -164,6 +164,8 @@ def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=No
     b.state_dtype = _DT[sd]
     b.eps_dtype = _DT[ed]
     b.eps_stride = eps_stride
+    if opts is not None:
+        b.opts = opts
     stream, idx = _raw_stream(dev)
     ws = None
     if st.flags & L.F_THRESH:
@@ -499,6 +501,8 @@ class _FastRun:
                 b.m_out = self.hist[st.m_slot].data_ptr()
             b.n, b.batch = n, max(B, 1)
             b.state_dtype = _DT[sd]
+            if solver._opts_ptr() is not None:
+                b.opts = solver._opts_ptr()
             if st.flags & L.F_THRESH:
                 nb = L.lib.dpm_threshold_workspace_bytes(b.batch, n // b.batch)
                 if nb:
@@ -523,6 +527,14 @@ class DPM_Solver:
     # network calls can be (lookahead + 1) * order larger than the reference's.
     adaptive_on_device = True
     adaptive_lookahead = 1
+    # per-call launch options of the C ABI (dpm_launch_opts), handed to every launch of this solver:
+    #   cluster_in_graph  dynamic thresholding keeps its workgroup clusters under hipGraph capture also for samples that fit
+    #                     one workgroup (default: one workgroup per sample there -- a replayed graph runs outside the
+    #                     library's per-device chain of clustered launches)
+    #   thr_spin_limit    polls before a wait between the workgroups of a thresholding cluster gives up and the workgroup
+    #                     finishes its sample alone (0 = the library's default, 4096: milliseconds)
+    cluster_in_graph = False
+    thr_spin_limit = 0
 
     def __init__(self, model_fn, noise_schedule, algorithm_type="dpmsolver++", correcting_x0_fn=None,
                  correcting_xt_fn=None, thresholding_max_val=1., dynamic_thresholding_ratio=0.995,
@@ -581,6 +593,18 @@ class DPM_Solver:
     @property
     def _algo(self):
         return L.ALGO[self.algorithm_type]
+
+    def _opts_ptr(self):
+        """ctypes pointer to this solver's dpm_launch_opts, or None when everything is at its default"""
+        key = (bool(self.cluster_in_graph), int(self.thr_spin_limit))
+        if key == (False, 0):
+            return None
+        hit = getattr(self, "_opts_cache", None)
+        if hit is None or hit[0] != key:
+            o = L.LaunchOpts()
+            o.cluster_in_graph, o.thr_spin_limit = int(key[0]), key[1]
+            hit = self._opts_cache = (key, o, C.pointer(o))
+        return hit[2]
 
     def _model_codes(self):
         if self._wrapped is not None:
@@ -662,10 +686,11 @@ class DPM_Solver:
             s1 = st.copy()
             s1.form = L.FORM_DENOISE
             s1.flags = L.F_TO_X0
-            x0, _ = _launch_stage(s1, None, xe if xe is not None else x, e0, e1, g, None, None, sd, want_m=False)
+            x0, _ = _launch_stage(s1, None, xe if xe is not None else x, e0, e1, g, None, None, sd, want_m=False,
+                                  opts=self._opts_ptr())
             x0 = self._call_x0(x0, t_eval_t)                                             # ref :440-441
             return self._run_given(st, x, x0, h1, h2, sd, want_m, ext=ext)
-        return _launch_stage(st, x, xe, e0, e1, g, h1, h2, sd, want_m=want_m, ext=ext)
+        return _launch_stage(st, x, xe, e0, e1, g, h1, h2, sd, want_m=want_m, ext=ext, opts=self._opts_ptr())
 
     def _run_given(self, st, x, m, h1, h2, sd, want_m=None, ext=None):
         """the update of `st` with the model value already known (no prologue)"""
@@ -674,7 +699,8 @@ class DPM_Solver:
         s2.model_type = L.MODEL["noise"]
         s2.guidance = L.GUIDE["uncond"]
         store = bool(st.flags & L.F_STORE_M) if want_m is None else want_m
-        x_out, _ = _launch_stage(s2, x if x is not None else m, None, m, None, None, h1, h2, sd, want_m=False, ext=ext)
+        x_out, _ = _launch_stage(s2, x if x is not None else m, None, m, None, None, h1, h2, sd, want_m=False, ext=ext,
+                                 opts=self._opts_ptr())
         return x_out, (m if store else None)
 
     # ------------------------------------------------------------------------------------------
@@ -691,7 +717,7 @@ class DPM_Solver:
         st.thr_max = float(self.thresholding_max_val)
         st.alpha_e, st.sigma_e, st.cfg_scale = 1.0, 0.0, 1.0
         sd = x0.dtype if x0.dtype in _DT else torch.float32
-        out, _ = _launch_stage(st, None, x0, x0, None, None, None, None, sd, want_m=False)
+        out, _ = _launch_stage(st, None, x0, x0, None, None, None, None, sd, want_m=False, opts=self._opts_ptr())
         return out
 
     def _eval_model(self, x, t, to_x0):
@@ -1183,7 +1209,7 @@ class DPM_Solver:
         first = [first0] + [net(x, 0) for x in xs[1:]]
         sd = self._promoted(sd, first[0][0])
         mf = _mf_of(first[0][0]) if first[0][0].shape == shape else None
-        key = (id(plan), tuple(shape), sd, idx, stream, cfg, R, mf)
+        key = (id(plan), tuple(shape), sd, idx, stream, cfg, R, mf, bool(self.cluster_in_graph), int(self.thr_spin_limit))
         grp = None if capturing else self._fast_groups.get(key)
         if grp is None:
             runs = [_FastRun(self, plan, shape, sd, device, cfg, mf) for _ in range(R)]
@@ -1271,7 +1297,7 @@ class DPM_Solver:
         # the network's layout is the run's (see _mf_of): an NHWC network gets NHWC states and its outputs are bound as
         # they are; x_T is brought there once and the result goes back to x_T's layout, like ATen would return it
         mf = _mf_of(first[0]) if first[0].shape == x.shape else None
-        key = (id(plan), tuple(x.shape), sd, idx, stream, cfg, mf)
+        key = (id(plan), tuple(x.shape), sd, idx, stream, cfg, mf, bool(self.cluster_in_graph), int(self.thr_spin_limit))
         fr = None if capturing else self._fast.get(key)      # a captured graph bakes its buffers in: give it its own
         if fr is None:
             fr = _FastRun(self, plan, x.shape, sd, device, cfg, mf)

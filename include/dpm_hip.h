@@ -35,19 +35,25 @@ extern "C" {
 
 /* major*10000 + minor*100 + patch.  History: 100 rounds 1-2; 101 dpm_buffers / dpm_run_buffers gained the trailing
    `thr_hint` pointer; 102 dpm_cluster_timeout_poll, DPM_TUNE_THR_SPIN_LIMIT / _DEBUG_FAULT, DPM_ERR_FAULT retired;
-   103 DPM_TUNE_BLOCK_THREADS, dpm_calib_launch kind 2 (no struct changed).
+   103 DPM_TUNE_BLOCK_THREADS, dpm_calib_launch kind 2 (no struct changed);
+   200 (round 5) the measurement / tuning / experiment entry points left this header and the product library: dpm_tuning_*,
+   dpm_calib_launch, dpm_prefetch_launch, dpm_resident_*, dpm_trace_*, dpm_stage_launch_timed and dpm_plan_run_timed are
+   declared in include/dpm_lab.h and exported by the lab build only (libdpm_lab.so, the same sources with -DDPM_LAB=1);
+   what a caller may legitimately choose per call travels in dpm_launch_opts (dpm_buffers.opts / dpm_run_buffers.opts);
+   DPM_DTYPE_F64 (double-precision state, NoiseScheduleVP(dtype=torch.float64) callers).  The product library has no
+   process-global mutable state: per-device contexts only (the chain of clustered launches, the diagnostics word).
    The structs grow at their END only.  A host MUST zero-initialise every struct it passes (memset / = {0}: new trailing
    fields then read as "absent") and SHOULD check at load time that dpm_version() >= the version it was built against and
    that dpm_sizeof(DPM_SIZEOF_*) == its own sizeof() -- a host compiled against an older header passes shorter structs,
    and the library would read past their end (examples/native_host.c and dpm_solver_amd/_lib.py do both checks). */
-#define DPM_HIP_VERSION 103
+#define DPM_HIP_VERSION 200
 
 /* ---- status --------------------------------------------------------------------------- */
 enum {
   DPM_OK = 0,
   DPM_ERR_ARG = -1,         /* bad argument value (ValueError at the Python layer)            */
   DPM_ERR_UNSUPPORTED = -2, /* valid in the reference, not (yet) built here -- never silent   */
-  DPM_ERR_ALIGN = -3,       /* a buffer is not aligned as the entry point requires (dpm_prefetch_launch)     */
+  DPM_ERR_ALIGN = -3,       /* a buffer is not aligned as the entry point requires (lab entry points only)   */
   DPM_ERR_NOMEM = -4,
   DPM_ERR_CALLBACK = -5,    /* the model callback of dpm_plan_run returned non-zero           */
   DPM_ERR_FAULT = -6        /* retired (version 102): a clustered thresholding launch whose wait on a peer
@@ -63,7 +69,9 @@ enum { DPM_METHOD_MULTISTEP = 0, DPM_METHOD_SINGLESTEP = 1, DPM_METHOD_SINGLESTE
 enum { DPM_SKIP_TIME_UNIFORM = 0, DPM_SKIP_LOGSNR = 1, DPM_SKIP_TIME_QUADRATIC = 2 };          /* ref :468-478    */
 enum { DPM_MODEL_NOISE = 0, DPM_MODEL_X_START = 1, DPM_MODEL_V = 2, DPM_MODEL_SCORE = 3 };     /* ref :288-298    */
 enum { DPM_GUIDE_NONE = 0, DPM_GUIDE_CFG = 1, DPM_GUIDE_CLASSIFIER = 2 };                      /* ref :313-330    */
-enum { DPM_DTYPE_F32 = 0, DPM_DTYPE_F16 = 1, DPM_DTYPE_BF16 = 2 };
+enum { DPM_DTYPE_F32 = 0, DPM_DTYPE_F16 = 1, DPM_DTYPE_BF16 = 2,
+       DPM_DTYPE_F64 = 3 /* state AND network output in double, double arithmetic: the reference run on x.double()
+                            (ref :14, :105-107); one run-time dispatched kernel, not a performance path */ };
 enum { DPM_EVAL_LOG_ALPHA = 0, DPM_EVAL_ALPHA = 1, DPM_EVAL_STD = 2, DPM_EVAL_LAMBDA = 3, DPM_EVAL_INV_LAMBDA = 4 };
 
 /* update forms.  `mn` = model value produced by this stage's prologue, h1/h2 = cached values.  */
@@ -119,6 +127,18 @@ typedef struct dpm_stage {
   float blend_sigma;   /* DPM_F_BLEND: sigma at that time                                        */
 } dpm_stage;
 
+/* ---- per-call options (optional; NULL or all-zero = the defaults) ------------------------ */
+typedef struct dpm_launch_opts {
+  int32_t cluster_in_graph; /* 1: dynamic thresholding keeps its workgroup clusters under stream capture also for samples
+                               that fit one workgroup (default 0: one workgroup per sample there -- a replayed graph runs
+                               outside the library's per-device chain of clustered launches)                          */
+  int32_t no_fuse;          /* 1: dpm_stage_launch_multi / dpm_plan_run_multi launch request by request (results are
+                               identical; what a single request's stage costs next to the fused launch)               */
+  int32_t thr_spin_limit;   /* > 0: polls (a microsecond or two each) before a wait on a cluster peer gives up and the
+                               workgroup finishes its sample alone; 0 = the default, 4096                             */
+  int32_t reserved[5];      /* zero                                                                                   */
+} dpm_launch_opts;
+
 /* ---- buffers of one launch ------------------------------------------------------------- */
 typedef struct dpm_buffers {
   const void* x;    /* state the update starts from                          [n] state dtype     */
@@ -158,6 +178,7 @@ typedef struct dpm_buffers {
                           wrong one is detected and costs one extra exchange, never exactness); [2]: route taken
                           (diagnostics: 1 predicted, 2 prediction rejected, 3 single exchange, 4 general); [3]: entries of
                           the last union gathered (diagnostics)                                                      */
+  const dpm_launch_opts* opts; /* per-call options, NULL = defaults (version 200; dpm_stage_launch_multi reads bs[0].opts) */
 } dpm_buffers;
 
 /* ---- noise schedule (NoiseScheduleVP, ref :6-167) --------------------------------------- */
@@ -255,7 +276,7 @@ int dpm_stage_launch_multi(const dpm_stage* st, const dpm_buffers* bs, int n_req
    Pass it as dpm_buffers.workspace.  Contract: the caller ZERO-FILLS the workspace once (hipMemset) before its first use;
    every launch leaves it zero-filled again (the last workgroup of a cluster cleans up), so no launch pays for a clear.
    Launches that share a workspace must be ordered (same stream).
-   Cluster waits are bounded (DPM_TUNE_THR_SPIN_LIMIT polls, milliseconds).  When the peers of a cluster are kept off the
+   Cluster waits are bounded (dpm_launch_opts.thr_spin_limit polls, milliseconds).  When the peers of a cluster are kept off the
    chip that long -- another process running clusters on the same GPU, two clustered graphs replayed concurrently -- the
    waiting workgroup gives up, computes the order statistics of its sample alone from global memory and carries on:
    the launch's results are the same bits, the workspace is left zero-filled as always, nothing is reported as an error. */
@@ -347,38 +368,18 @@ typedef struct dpm_run_buffers {
                           (xbuf[0] must already hold x_T twice)                                                  */
   int32_t reserved;
   float* thr_hint;     /* as dpm_buffers.thr_hint (DPM_THR_HINT_WORDS floats per sample, or NULL)                */
+  const dpm_launch_opts* opts; /* per-call options handed to every launch of the run, NULL = defaults (version 200;
+                                  dpm_plan_run_multi reads rbs[0].opts)                                            */
 } dpm_run_buffers;
 int dpm_plan_run(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model_cb model, void* user, void* stream,
                  int* result);
-/* profiling variants: every kernel is launched with hipExtLaunchKernelGGL start/stop events, so the reported
-   time is the kernel's own execution time (what rocprofv3 --kernel-trace reports), without launch gaps.
-   dpm_plan_run_timed runs the frozen-model trajectory, synchronises the stream once at the end and fills
-   ms_per_stage[num_stages]. */
-int dpm_stage_launch_timed(const dpm_stage* st, const dpm_buffers* b, void* stream, float* ms);
-int dpm_plan_run_timed(const dpm_plan* p, const dpm_run_buffers* rb, void* stream, float* ms_per_stage, int* result);
-
-/* kernel durations INSIDE a real loop, without synchronising between launches: a trace owns `capacity` start/stop event
-   pairs; dpm_stage_launch_traced is dpm_stage_launch with the pair of `slot` bracketing the kernel itself
-   (hipExtLaunchKernelGGL), dpm_trace_read synchronises the stream once and fills ms[0..n) (-1 for slots never used).
-   What bench.py's `in_network_loop` and tools/in_loop.py use between the kernels of a torch network. */
-typedef struct dpm_trace dpm_trace;
-int dpm_trace_create(int capacity, dpm_trace** out);
-int dpm_stage_launch_traced(const dpm_stage* st, const dpm_buffers* b, void* stream, dpm_trace* t, int slot);
-int dpm_trace_read(dpm_trace* t, void* stream, float* ms, int n);
-void dpm_trace_destroy(dpm_trace* t);
-
-/* read `n_buf` device buffers (bytes[i] each, 16-byte aligned) and discard the data: pulls a later stage's inputs (x, the
-   cached model values) towards the memory-side cache from a side stream while the network's last layers still run
-   (ref :1195-1213 leaves a network call between two updates, so they are HBM-cold otherwise).  policy 0: default loads
-   (allocate in L2 and the Infinity Cache), 1: streaming loads.  Asynchronous on `stream`. */
-int dpm_prefetch_launch(const void* const* bufs, const int64_t* bytes, int n_buf, int policy, void* stream);
-
 /* several independent sampling requests advanced stage by stage (all requests stage s, then all stage s+1, ...)
    through dpm_stage_launch_multi: what a server holding n requests in flight does, and -- with a frozen model -- the
    HBM-cold measurement mode of bench.py: between two stages of one request the other n-1 requests stream their buffers
    through the 256 MiB Infinity Cache.  All requests must share n, batch and dtypes.  ms (optional,
    [n_req * num_stages], request-major) receives kernel-only durations; a fused launch's duration is divided evenly
-   over the requests it advanced.  DPM_TUNE_MULTI_FUSE = 0 launches request by request instead. */
+   over the requests it advanced (with n_req = 1: the kernel-only durations of one frozen-model trajectory).
+   dpm_launch_opts.no_fuse launches request by request instead. */
 int dpm_plan_run_multi(const dpm_plan* p, const dpm_run_buffers* rbs, int n_req, void* stream, float* ms, int* results);
 
 /* ---- hipGraph capture of a whole trajectory ------------------------------------------------------------
@@ -394,53 +395,11 @@ int dpm_graph_result(const dpm_graph* g);    /* index of the xbuf that holds the
 int dpm_graph_num_nodes(const dpm_graph* g); /* kernel / memset nodes captured                           */
 void dpm_graph_destroy(dpm_graph* g);
 
-/* ---- launch-shape tuning hooks (autotuning / benchmarking; defaults are the measured best) --------- */
-enum {
-  DPM_TUNE_UNROLL = 0, DPM_TUNE_NONTEMPORAL = 1, DPM_TUNE_BLOCKS_PER_CU = 2, DPM_TUNE_ASSUME_RESIDENT = 3,
-  DPM_TUNE_MULTI_FUSE = 4,          /* 1 (default): dpm_stage_launch_multi fuses; 0: one launch per request          */
-  DPM_TUNE_MULTI_BLOCKS_PER_CU = 5, /* grid cap of the fused launch, workgroups per CU; 0 (default) = no cap      */
-  DPM_TUNE_CLUSTER_IN_GRAPH = 6,    /* 1: thresholding keeps workgroup clusters under stream capture for samples that
-                                       fit one workgroup too (default 0: one workgroup per sample there)           */
-  DPM_TUNE_CLUSTER_ONE_HOP = 7,     /* 0: clusters skip the single-exchange select (testing the general route)     */
-  DPM_TUNE_MULTI_XCD_REMAP = 8,     /* fused launch gives every XCD one contiguous eighth of the tiles: 1 on, 0 off,
-                                       -1 (default) on for 2-byte states only (measured +1.4 % fp16, -3 % fp32)    */
-  DPM_TUNE_THR_PREDICT = 9,         /* 1 (default): clustered thresholding launches predict the select bound from
-                                       dpm_buffers.thr_hint; 0: the hint is still maintained but never used          */
-  DPM_TUNE_THR_SPIN_LIMIT = 10,     /* polls (a microsecond or two each) before a wait on a cluster peer gives up and
-                                       the workgroup finishes its sample alone; default 4096                          */
-  DPM_TUNE_BLOCK_THREADS = 12,      /* streaming stage kernel: threads per workgroup, 256 / 512 (every 256-lane group takes
-                                       tiles of its own); 0 (default): by size -- 512 when that leaves two workgroups
-                                       per CU                                                                          */
-  DPM_TUNE_THR_DEBUG_FAULT = 11     /* testing.  1: every cluster wait gives up at its first unsuccessful poll;
-                                       2 / 3: workgroup 1 of every cluster takes no part in its cluster from the start,
-                                       with / without marking its samples (the peers see the mark / run out of polls).
-                                       Results must not change.  0 (default): off                                     */
-};
-int dpm_tuning_set(int knob, int value);
-int dpm_tuning_get(int knob);
-/* memory-system calibration with no arithmetic (kind 0: copy; kind 1: 3 read + 2 write streams, the 2M stage's
-   pattern; kind 2: 4 read + 1 write streams, `e` read) over nbytes per stream; block in {256,512,1024}; nt mask as DPM_TUNE_NONTEMPORAL; ms = kernel time. */
-int dpm_calib_launch(int kind, int block, int blocks_per_cu, int nt, const void* a, const void* b, const void* c,
-                     void* d, void* e, int64_t nbytes, void* stream, float* ms);
-
-/* ---- EXPERIMENT: a resident stage kernel woken by a stream-ordered write -----------------
-   Not used by any loop of the library or by DPM_Solver; kept for the measurement in profiles/r04_resident.md
-   (tools/in_loop.py --resident).  One launch per trajectory on a side stream keeps `workgroups` workgroups on the chip;
-   per stage the host enqueues dpm_resident_signal behind the network's last kernel: hipStreamWriteValue64 of the
-   output's address wakes the workgroups, hipStreamWaitValue32 holds the stream until the stage's last workgroup is
-   through.  Covers what the unguided 20-step DPM-Solver++(2M) trajectory launches: noise-prediction network, forms LIN1 /
-   TWO, equal fp16 or fp32 dtypes, n a multiple of 2048.  `stages` / `bufs`: the n_stages records a dpm_stage_launch loop
-   would use (static buffers; e0 is supplied per stage by dpm_resident_signal). */
-int dpm_resident_create(const dpm_stage* stages, const dpm_buffers* bufs, int n_stages, int workgroups, int sleep, void** out);
-int dpm_resident_start(void* handle, const void* x_first, void* x_last_out, void* side_stream);
-int dpm_resident_signal(void* handle, int stage, const void* eps, void* stream);
-void dpm_resident_destroy(void* handle);
-
 /* ---- misc ---------------------------------------------------------------------------------- */
 int dpm_version(void);
 /* sizeof() of the ABI structs as compiled, so a binding can verify its own layout at load time */
 enum { DPM_SIZEOF_STAGE = 0, DPM_SIZEOF_BUFFERS = 1, DPM_SIZEOF_PLAN_DESC = 2, DPM_SIZEOF_RUN_BUFFERS = 3,
-       DPM_SIZEOF_ADAPTIVE_DESC = 4 };
+       DPM_SIZEOF_ADAPTIVE_DESC = 4, DPM_SIZEOF_LAUNCH_OPTS = 5 };
 size_t dpm_sizeof(int which);
 const char* dpm_last_error(void); /* thread-local text of the last non-zero return */
 int dpm_device_info(int* n_cu, int* lds_bytes, char* arch, int arch_len);

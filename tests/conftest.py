@@ -12,6 +12,38 @@ for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "lab: needs the LAB build of the library (tuning knobs, fault injection, event-bracketed "
+                                       "launches: include/dpm_lab.h); skipped on the product library and run by "
+                                       "test_lab_suite_* in a subprocess with DPM_SOLVER_AMD_LIB=tools/_variants/lab/libdpm_lab.so")
+
+
+def pytest_collection_modifyitems(config, items):
+    from dpm_solver_amd import _lib as L
+    if L.IS_LAB:
+        return
+    skip = pytest.mark.skip(reason="needs the lab build (run by test_lab_suite_* on tools/_variants/lab/libdpm_lab.so)")
+    for item in items:
+        if "lab" in item.keywords:
+            item.add_marker(skip)
+
+
+def run_lab_suite(marker_expr, timeout=1500):
+    """the lab-marked tests in a subprocess on the lab library; returns the number that passed"""
+    import re
+    import subprocess
+    from dpm_solver_amd import _lib as L
+    if not os.path.exists(L.LAB_LIB_PATH):
+        pytest.skip("no lab build next to the library (__graft_entry__.build() makes it)")
+    assert os.path.getmtime(L.LAB_LIB_PATH) >= os.path.getmtime(os.path.join(ROOT, "dpm_solver_amd", "libdpm_hip.so")) - 3600, \
+        "the lab build is older than the library"
+    env = dict(os.environ, DPM_SOLVER_AMD_LIB=L.LAB_LIB_PATH)
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests", "-q", "-x", "-m", marker_expr, "-p", "no:cacheprovider"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=timeout)
+    tail = r.stdout[-3000:]
+    assert r.returncode == 0, tail
+    m = re.search(r"(\d+) passed", r.stdout.splitlines()[-1])
+    assert m and "failed" not in r.stdout.splitlines()[-1], tail
+    return int(m.group(1))
 
 
 class Golden:

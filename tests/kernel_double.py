@@ -79,7 +79,7 @@ def blend(st_alpha, st_sigma, v, mask, a, b):
     return (v * m + (F32(1.0) - m) * r).astype(F32)
 
 
-def launch_stage_double(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=None):
+def launch_stage_double(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=None, opts=None):
     ref_t = x if x is not None else xe
     xn, xen = _np(x), _np(xe)
     if xen is None:

@@ -507,18 +507,15 @@ def test_sharded_sampling_over_rccl_single_rank():
 def test_captured_sample_with_clustered_thresholding(shape, in_graph):
     """hipGraph capture of a trajectory with dynamic thresholding.  Eagerly a small batch runs as workgroup clusters; under
     capture a sample that fits one workgroup takes the cluster-free shape (a replayed graph is outside the library's
-    device-wide chain of clustered launches) unless DPM_TUNE_CLUSTER_IN_GRAPH opts in; larger samples keep their
+    device-wide chain of clustered launches) unless dpm_launch_opts.cluster_in_graph (DPM_Solver.cluster_in_graph) opts in; larger samples keep their
     clusters.  Replays must keep matching eager runs in every case."""
     case = dict(C.E2E_BY_NAME["cfg5_thresh"], shape=shape, steps=8)
     dpm = build_solver(case, DEV)
     x = tt(C.x_T_for(case), DEV)
     kw = sample_kwargs(case, False)
     want = dpm.sample(x, **kw)
-    L.lib.dpm_tuning_set(L.TUNE_CLUSTER_IN_GRAPH, in_graph)
-    try:
-        g = dpm.capture(x, **kw)
-    finally:
-        L.lib.dpm_tuning_set(L.TUNE_CLUSTER_IN_GRAPH, 0)
+    dpm.cluster_in_graph = bool(in_graph)          # a per-call option of the C ABI: no process-wide switch
+    g = dpm.capture(x, **kw)
     for _ in range(3):
         assert torch.equal(g(x), want)
     x2 = x * 0.75
@@ -566,6 +563,7 @@ def test_adaptive_sharded_with_an_empty_shard_on_the_gpu():
 # ------------------------------------------------------------------------------------------------
 # measurement entry points of the C ABI (round 3): event-bracketed launches without synchronisation, the prefetch kernel
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.lab
 def test_traced_launches_time_the_kernel_and_change_nothing():
     """dpm_stage_launch_traced = dpm_stage_launch with a start / stop event pair attached to the kernel itself; nothing
     synchronises until dpm_trace_read.  Same results as the plain launches, positive durations for the slots used, -1 for
@@ -602,6 +600,7 @@ def test_traced_launches_time_the_kernel_and_change_nothing():
     assert L.lib.dpm_trace_create(0, C_.byref(trace)) == L.ERR_ARG
 
 
+@pytest.mark.lab
 def test_prefetch_launch_reads_and_leaves_the_buffers_alone():
     """dpm_prefetch_launch (the rejected experiment of DESIGN.md 4.3 stays callable): reads up to 8 buffers with either load
     policy, writes nothing, rejects unaligned buffers and more than 8."""
@@ -767,6 +766,14 @@ def test_escape_hatch_build_without_write_through_stores():
                        env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
     assert " passed" in r.stdout and "failed" not in r.stdout.splitlines()[-1], r.stdout[-500:]
+
+
+def test_lab_suite_on_the_lab_build():
+    """The tests that need what the product library does not have -- forced cluster faults, the general / predicted route
+    switches, forced workgroup sizes, event-bracketed launches, the side-stream helpers -- run on the LAB build of the same
+    sources (tools/_variants/lab/libdpm_lab.so, -DDPM_LAB=1) in a subprocess."""
+    from conftest import run_lab_suite
+    assert run_lab_suite("lab and gpu") >= 40
 
 
 def test_quickstart_example_runs():

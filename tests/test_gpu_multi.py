@@ -280,15 +280,20 @@ def test_stage_launch_multi_direct_and_mismatched_requests():
 
 
 def test_fuse_switch_off_gives_identical_results():
+    """dpm_launch_opts.no_fuse (a per-call option: no process-wide switch) launches request by request"""
     ns = sd_schedule()
     _, plan = plan_for(ns, torch.float16, order=2, steps=6)
     reqs = make_requests(4, (8, 4, 32, 32), torch.float16, torch.float16, seed=2)
     fused, _ = run_both(plan, reqs)
-    L.lib.dpm_tuning_set(L.TUNE_MULTI_FUSE, 0)
+    opts = L.LaunchOpts()
+    opts.no_fuse = 1
+    for r in reqs:
+        r["rb"].opts = C_.pointer(opts)
     try:
         unfused, _ = run_both(plan, reqs)
     finally:
-        L.lib.dpm_tuning_set(L.TUNE_MULTI_FUSE, 1)
+        for r in reqs:
+            r["rb"].opts = None
     for a, b in zip(fused, unfused):
         assert torch.equal(a, b)
 

@@ -170,6 +170,7 @@ def test_dynamic_thresholding_topk_front_end():
         np.testing.assert_array_equal(y.cpu().numpy(), O.dynamic_threshold(x0, p, 1.0), err_msg=str((shape, p, top)))
 
 
+@pytest.mark.lab
 def test_cluster_single_exchange_route_and_its_fallback():
     """Clusters (k workgroups per sample) first try to settle a sample with one exchange of per-chunk candidates
     (cluster_select_once).  That is exact by construction or declared failed inside the kernel, in which case the
@@ -222,6 +223,10 @@ def test_thresholded_sampling_random_sweep():
     # the in-kernel recovery must reproduce the oracle's bits on every configuration
     fault = int(os.environ.get("DPM_THR_SWEEP_FAULT", "0"))
     one_hop = int(os.environ.get("DPM_THR_SWEEP_ONE_HOP", "1"))
+    if not fault and one_hop == 1:          # the product library's own behaviour: no knob touched
+        _thr_sweep(rng, total)
+        return
+    L.require_lab("a forced-fault / general-route sweep")
     if fault:
         L.check(L.lib.dpm_tuning_set(L.TUNE_THR_DEBUG_FAULT, fault))
         L.check(L.lib.dpm_tuning_set(L.TUNE_THR_SPIN_LIMIT, 32))
@@ -458,6 +463,7 @@ def test_ragged_sizes_and_unaligned_views(shape):
     np.testing.assert_array_equal(xf2.cpu().numpy(), xf.cpu().numpy())
 
 
+@pytest.mark.lab
 def test_workgroup_size_of_the_streaming_kernel_does_not_change_a_bit():
     """The streaming stage kernel runs with 256 or 512 threads per workgroup (every 256-lane group takes tiles of its own; by
     default 512 when that leaves two workgroups per CU -- [128,4,64,64] requests and larger).  The lanes do the same work on the
@@ -663,9 +669,9 @@ def test_plan_run_native_loop_matches_python_loop(method, order, steps, shape):
     torch.cuda.synchronize()
     assert torch.equal(xb[res.value], want)
     assert torch.equal(xb[0], x)                                   # the caller's x_T is never written
-    # profiling variant: same result, one kernel-only duration per stage
+    # with durations (dpm_plan_run_multi over ONE request): same result, one kernel-only duration per stage
     ms = (C_.c_float * len(plan.stages))()
-    L.check(L.lib.dpm_plan_run_timed(plan.handle, C_.byref(rb), C_.c_void_p(torch.cuda.current_stream().cuda_stream),
+    L.check(L.lib.dpm_plan_run_multi(plan.handle, C_.byref(rb), 1, C_.c_void_p(torch.cuda.current_stream().cuda_stream),
                                      ms, C_.byref(res)))
     assert torch.equal(xb[res.value], want)
     # one launch in several thousand shows a 50-85 ms start -> stop interval (profiles/r02_stall.md): judge the typical one
@@ -715,6 +721,7 @@ def _routes_per_stage(dpm, x, monkeypatch, **kw):
     return out, routes
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("shape", [(4, 3, 64, 64), (32, 3, 64, 64), (3, 3, 80, 80)])
 def test_threshold_bound_prediction_is_taken_and_exact(shape, monkeypatch):
     """A smooth trajectory: from the third thresholded stage on the clusters select with the PREDICTED bound (route 1);
@@ -745,6 +752,7 @@ def test_threshold_bound_prediction_is_taken_and_exact(shape, monkeypatch):
     assert torch.equal(again.sample(x, steps=12, order=2), want) and torch.equal(again.sample(x, steps=12, order=2), want)
 
 
+@pytest.mark.lab
 def test_threshold_bound_misprediction_is_detected():
     """A network whose output scale jumps from stage to stage: predictions that are too high (union smaller than K) or
     too low (slot overflow / oversized union) are rejected by every workgroup alike and the searched bound takes over --
@@ -795,6 +803,7 @@ def _thr_solver(ns, model=lambda xx, t: xx * 0.5, **kw):
     return D.DPM_Solver(D.model_wrapper(model, ns, **kw), ns, correcting_x0_fn="dynamic_thresholding")
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("shape", [(32, 3, 64, 64), (5, 3, 64, 64), (2, 3, 160, 160), (300, 1, 128, 128)])
 @pytest.mark.parametrize("mode,one_hop", [(1, 1), (2, 1), (3, 1), (1, 0), (2, 0), (3, 0)])
 def test_cluster_wait_timeout_is_recovered_inside_the_kernel(shape, mode, one_hop):
@@ -828,6 +837,7 @@ def test_cluster_wait_timeout_is_recovered_inside_the_kernel(shape, mode, one_ho
     assert not L.cluster_timeout_poll()
 
 
+@pytest.mark.lab
 @pytest.mark.parametrize("mode,one_hop,spin", [(1, 0, 0), (3, 0, 32), (2, 0, 32), (3, 1, 32), (3, 0, 512)])
 def test_staggered_timeouts_in_a_twelve_workgroup_cluster(mode, one_hop, spin):
     """The case the forced-fault sweep (DPM_THR_SWEEP_FAULT) caught in the first version of the recovery: [40, 3, 64, 128]
@@ -853,6 +863,7 @@ def test_staggered_timeouts_in_a_twelve_workgroup_cluster(mode, one_hop, spin):
     assert L.cluster_timeout_poll()
 
 
+@pytest.mark.lab
 def test_cluster_wait_timeout_with_cfg_half_state_and_requests_in_flight():
     """the recovery path recomputes x0 with the launch's own prologue: classifier-free guidance, fp16 state, fp32 state with
     fp16 outputs; and a fused multi-request launch of clustered shapes (a workspace per request)"""

@@ -640,14 +640,15 @@ def test_sampling_under_inference_mode():
 def test_abi_version_and_load_time_checks():
     """the structs grew (thr_hint) -- the version says so, and a binding can verify its layout at load time
     (dpm_sizeof); DPM_ERR_FAULT is retired: no hook machinery is left in the binding."""
-    assert L.lib.dpm_version() >= 102
+    assert L.lib.dpm_version() >= 200
     import ctypes
-    for i, t in enumerate((L.Stage, L.Buffers, L.PlanDesc, L.RunBuffers, L.AdaptiveDesc)):
+    for i, t in enumerate((L.Stage, L.Buffers, L.PlanDesc, L.RunBuffers, L.AdaptiveDesc, L.LaunchOpts)):
         assert L.lib.dpm_sizeof(i) == ctypes.sizeof(t)
     assert not hasattr(L, "fault_hooks")
     assert L.cluster_timeout_poll() is False            # no clustered launch has run in this process
 
 
+@pytest.mark.lab
 def test_tuning_knobs_validate_their_values():
     """the run-time tuning hooks are host state (no device needed): set / get round trip, bad values refused with a text"""
     for knob, good, bad in [(L.TUNE_BLOCK_THREADS, (256, 512, 0), (1024, 100, -1)),
@@ -664,6 +665,56 @@ def test_tuning_knobs_validate_their_values():
         finally:
             L.lib.dpm_tuning_set(knob, old)
     assert L.lib.dpm_tuning_set(999, 0) != 0 and L.lib.dpm_tuning_get(999) == -1
+
+
+@pytest.mark.lab
+def test_every_device_ordinal_has_a_context_of_its_own():
+    """8-GPU readiness that needs no GPU: one process per GPU, so 7 of 8 ranks launch on a device ordinal != 0.  The only
+    state of the library that outlives a call is its per-device context (chain of clustered thresholding launches,
+    diagnostics word): ordinals 0..7 must not share one, the same ordinal must get the same one from every thread."""
+    import threading
+    ctx = [L.lib.dpm_lab_device_context(d) for d in range(8)]
+    assert all(ctx) and len(set(ctx)) == 8
+    seen = []
+    th = [threading.Thread(target=lambda d=d: seen.append((d, L.lib.dpm_lab_device_context(d)))) for d in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert sorted(seen) == sorted(enumerate(ctx))
+    assert L.lib.dpm_lab_device_context(-1) == ctx[0]      # "no current device" falls back to ordinal 0
+
+
+def test_lab_suite_on_cpu():
+    """the lab-marked host tests (tuning knob validation, per-device contexts), on the lab build in a subprocess"""
+    from conftest import run_lab_suite
+    assert run_lab_suite("lab and not gpu", timeout=600) >= 2
+
+
+def test_launch_options_travel_per_call_not_per_process(monkeypatch):
+    """dpm_launch_opts (DPM_Solver.cluster_in_graph / thr_spin_limit): the prebuilt launch records of a solver carry a
+    pointer to ITS options; another solver in the same process keeps the defaults (a null pointer)."""
+    ns = make_schedule("ddpm")
+    install_cpu_double(monkeypatch, S, D)
+    seen = []
+    real = S._stage_launch_raw
+
+    def spy(st, b, stream):
+        bb = b._obj
+        seen.append((bool(bb.opts), bb.opts.contents.cluster_in_graph if bb.opts else 0,
+                     bb.opts.contents.thr_spin_limit if bb.opts else 0))
+        return real(st, b, stream)
+    monkeypatch.setattr(S, "_stage_launch_raw", spy)
+    x = torch.randn(2, 3, 8, 8)
+    a = D.DPM_Solver(D.model_wrapper(lambda xx, t: xx * 0.5, ns), ns, correcting_x0_fn="dynamic_thresholding")
+    b = D.DPM_Solver(D.model_wrapper(lambda xx, t: xx * 0.5, ns), ns, correcting_x0_fn="dynamic_thresholding")
+    a.cluster_in_graph, a.thr_spin_limit = True, 77
+    ya = a.sample(x, steps=4, order=2)
+    na = len(seen)
+    yb = b.sample(x, steps=4, order=2)
+    assert na == 4 and all(s == (True, 1, 77) for s in seen[:na])
+    assert all(s == (False, 0, 0) for s in seen[na:]) and len(seen) == 8
+    assert torch.equal(ya, yb)
 
 
 def test_plan_and_adaptive_caches_are_bounded():

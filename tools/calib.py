@@ -2,12 +2,15 @@
 """Memory-system ceilings for the 2M stage's access pattern on this GPU (no arithmetic), warm and cold."""
 import ctypes as C
 import json
+import os
 import sys
 
 import numpy as np
 import torch
 
 sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _lab  # noqa: E402,F401  (tools run on the LAB build of the library: include/dpm_lab.h)
 from dpm_solver_amd import _lib as L
 
 

@@ -11,6 +11,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _lab  # noqa: E402,F401  (tools run on the LAB build of the library: include/dpm_lab.h)
 import dpm_solver_amd as D  # noqa: E402
 from dpm_solver_amd import _lib as L  # noqa: E402
 

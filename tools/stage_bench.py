@@ -18,6 +18,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _lab  # noqa: E402,F401  (tools run on the LAB build of the library: include/dpm_lab.h)
 import dpm_solver_amd as D  # noqa: E402
 import dpm_solver_amd.solver as S  # noqa: E402
 from dpm_solver_amd import _lib as L  # noqa: E402
@@ -162,9 +164,14 @@ def main():
     ap.add_argument("--md", default=None)
     ap.add_argument("--only", default=None, help="substring filter on scenario names (skips the others and the loop timing)")
     ap.add_argument("--block-threads", type=int, default=-1, help="DPM_TUNE_BLOCK_THREADS for the run (default: by size)")
+    ap.add_argument("--force-generic", action="store_true",
+                    help="DPM_TUNE_FORCE_GENERIC: the run-time-prologue kernels everywhere (the A/B behind the kernel-count budget)")
     args = ap.parse_args()
+    L.require_lab("tools/stage_bench.py")
     if args.block_threads >= 0:
         L.check(L.lib.dpm_tuning_set(L.TUNE_BLOCK_THREADS, args.block_threads))
+    if args.force_generic:
+        L.check(L.lib.dpm_tuning_set(L.TUNE_FORCE_GENERIC, 1))
     torch.manual_seed(0)
     global ONLY
     ONLY = args.only

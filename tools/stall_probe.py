@@ -13,6 +13,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _lab  # noqa: E402,F401  (tools run on the LAB build of the library: include/dpm_lab.h)
 import dpm_solver_amd as D  # noqa: E402
 from dpm_solver_amd import _lib as L  # noqa: E402
 
@@ -45,7 +47,7 @@ def main():
         for r in range(runs):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            L.check(L.lib.dpm_plan_run_timed(plan.handle, C.byref(rb), sp, ms, C.byref(res)))
+            L.check(L.lib.dpm_plan_run_multi(plan.handle, C.byref(rb), 1, sp, ms, C.byref(res)))
             w = (time.perf_counter() - t0) * 1e3
             a = np.frombuffer(ms, dtype=np.float32)
             walls.append(w)

@@ -24,6 +24,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _lab  # noqa: E402,F401  (tools run on the LAB build of the library: include/dpm_lab.h)
 import bench  # noqa: E402
 import dpm_solver_amd as D  # noqa: E402
 from dpm_solver_amd import _lib as L  # noqa: E402
@@ -122,7 +124,7 @@ def sweep_single(args):
                 L.lib.dpm_tuning_set(L.TUNE_NONTEMPORAL, nt)
                 warm = []
                 for i in range(16):
-                    L.check(L.lib.dpm_plan_run_timed(plan.handle, C.byref(sets[i % 8]["rb"]), sptr, buf, C.byref(res)))
+                    L.check(L.lib.dpm_plan_run_multi(plan.handle, C.byref(sets[i % 8]["rb"]), 1, sptr, buf, C.byref(res)))
                     warm.append(np.frombuffer(buf, dtype=np.float32)[1:nst - 1].astype(np.float64).mean() * 1e3)
                 cold = []
                 for i in range(args.reps):
