@@ -39,7 +39,7 @@ TUNE_MULTI_FUSE, TUNE_MULTI_BLOCKS_PER_CU, TUNE_CLUSTER_IN_GRAPH, TUNE_CLUSTER_O
 TUNE_MULTI_XCD_REMAP = 8
 TUNE_THR_PREDICT = 9
 TUNE_THR_SPIN_LIMIT, TUNE_THR_DEBUG_FAULT, TUNE_BLOCK_THREADS = 10, 11, 12
-TUNE_FORCE_GENERIC, TUNE_THR_ELECT = 13, 14
+TUNE_FORCE_GENERIC, TUNE_THR_ELECT, TUNE_LDS_DMA = 13, 14, 15
 MULTI_MAX = 32
 THR_HINT_WORDS = 4
 
@@ -63,6 +63,14 @@ class Stage(C.Structure):
         return s
 
 
+class StageF64(C.Structure):
+    """dpm_stage_f64: the float fields of a stage in double (double-precision plans)"""
+    _fields_ = [(n, C.c_double) for n in ("t_eval", "t_input", "t_out", "alpha_e", "sigma_e", "cfg_scale", "cg_scale",
+                                          "cx", "c0", "c1", "c2")] + [("k", C.c_double * 5)] + \
+               [(n, C.c_double) for n in ("thr_ratio", "thr_max", "blend_alpha", "blend_sigma")] + \
+               [("time_f64", C.c_int32), ("reserved", C.c_int32)]
+
+
 class LaunchOpts(C.Structure):
     """dpm_launch_opts: what a caller may choose per call (zero = defaults)"""
     _fields_ = [("cluster_in_graph", C.c_int32), ("no_fuse", C.c_int32), ("thr_spin_limit", C.c_int32),
@@ -78,7 +86,7 @@ class Buffers(C.Structure):
         ("x_out2", C.c_void_p), ("eps_stride", C.c_int64), ("mask", C.c_void_p), ("blend_a", C.c_void_p),
         ("blend_b", C.c_void_p), ("mask_period", C.c_int64),
         ("inputs_resident", C.c_int32), ("reserved", C.c_int32), ("thr_hint", C.c_void_p),
-        ("opts", C.POINTER(LaunchOpts)),
+        ("opts", C.POINTER(LaunchOpts)), ("coef64", C.POINTER(StageF64)),
     ]
 
 
@@ -87,7 +95,7 @@ class PlanDesc(C.Structure):
         ("algorithm_type", C.c_int32), ("method", C.c_int32), ("order", C.c_int32), ("steps", C.c_int32),
         ("skip_type", C.c_int32), ("solver_type", C.c_int32), ("lower_order_final", C.c_int32),
         ("denoise_to_zero", C.c_int32), ("model_type", C.c_int32), ("guidance", C.c_int32),
-        ("thresholding", C.c_int32), ("reserved", C.c_int32),
+        ("thresholding", C.c_int32), ("precision", C.c_int32),
         ("t_start", C.c_double), ("t_end", C.c_double), ("guidance_scale", C.c_double),
         ("thr_ratio", C.c_double), ("thr_max", C.c_double),
     ]
@@ -126,6 +134,9 @@ _SIGNATURES = [
     ("dpm_numerical_clip_len_f64", C.c_int, [_P(C.c_double), C.c_int, C.c_double, _P(C.c_int)]),
     ("dpm_schedule_create_linear", C.c_int, [C.c_double, C.c_double, _P(C.c_void_p)]),
     ("dpm_schedule_create_cosine", C.c_int, [_P(C.c_void_p)]),
+    ("dpm_schedule_set_table_dtype", C.c_int, [C.c_void_p, C.c_int]),
+    ("dpm_schedule_tables_f64", C.c_int, [C.c_void_p, _P(_P(C.c_double)), _P(_P(C.c_double)), _P(C.c_int)]),
+    ("dpm_schedule_eval_f64", C.c_int, [C.c_void_p, C.c_int, _P(C.c_double), C.c_int, _P(C.c_double)]),
     ("dpm_schedule_destroy", None, [C.c_void_p]),
     ("dpm_schedule_is_discrete", C.c_int, [C.c_void_p]),
     ("dpm_schedule_total_N", C.c_int, [C.c_void_p]),
@@ -140,6 +151,7 @@ _SIGNATURES = [
     ("dpm_plan_num_stages", C.c_int, [C.c_void_p]),
     ("dpm_plan_num_slots", C.c_int, [C.c_void_p]),
     ("dpm_plan_stage", C.c_int, [C.c_void_p, C.c_int, _P(Stage)]),
+    ("dpm_plan_stage_f64", C.c_int, [C.c_void_p, C.c_int, _P(StageF64)]),
     ("dpm_plan_timesteps", C.c_int, [C.c_void_p, _P(C.c_float), C.c_int, _P(C.c_int)]),
     ("dpm_coef_first", C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, _P(Stage)]),
     ("dpm_coef_multistep", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_float), C.c_float, _P(Stage)]),
@@ -235,7 +247,7 @@ def _load():
 
 lib = _load()
 IS_LAB = hasattr(lib, "dpm_lab_build")
-for _i, _t in enumerate((Stage, Buffers, PlanDesc, RunBuffers, AdaptiveDesc, LaunchOpts)):  # the ctypes mirrors must match the compiled structs
+for _i, _t in enumerate((Stage, Buffers, PlanDesc, RunBuffers, AdaptiveDesc, LaunchOpts, StageF64)):  # the ctypes mirrors must match the compiled structs
     if lib.dpm_sizeof(_i) != C.sizeof(_t):
         raise ImportError("dpm_solver_amd: %s is %d bytes in _lib.py but %d in libdpm_hip.so -- stale library, rebuild"
                           % (_t.__name__, C.sizeof(_t), lib.dpm_sizeof(_i)))

@@ -23,7 +23,7 @@ import torch
 
 from . import _lib as L
 
-_DT = {torch.float32: L.DTYPE_F32, torch.float16: L.DTYPE_F16, torch.bfloat16: L.DTYPE_BF16}
+_DT = {torch.float32: L.DTYPE_F32, torch.float16: L.DTYPE_F16, torch.bfloat16: L.DTYPE_BF16, torch.float64: L.DTYPE_F64}
 
 
 class MaskBlend:

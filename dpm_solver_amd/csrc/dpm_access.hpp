@@ -70,6 +70,36 @@ __device__ __forceinline__ void st8(V2* p, V2 v) {
 }
 
 
+// LDS-DMA: 16 bytes per lane straight from global memory into LDS at (wave-uniform base, in M0) + lane * 16, no VGPR in
+// between (global_load_lds_dwordx4; aux 2 = nt).  `lds_row` = this WAVEFRONT's 1 KiB row: lane l's bytes land at row + 16 l,
+// so a lane reads back exactly what it would have loaded.  The issuing wavefront waits with `s_waitcnt vmcnt(0)` (lds_dma_wait)
+// before its ds_read -- rows are private to a wavefront, no barrier.  Measured on the lone [256,4,64,64] launch inside a network
+// loop (tools/floor.py, profiles/r05_lone_floor.md): the no-arithmetic kernel of the 2M stage's five streams takes 9.20 us by
+// events with its three read streams on this path against 9.62 through registers.
+template <bool NT>
+__device__ __forceinline__ void glds16(const u32x4* gsrc, u32x4* lds_row) {
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)lds_row, 16, 0, NT ? 2 : 0);
+}
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// the 8 elements of one 16-byte pack of a 2-byte type -> fp32
+__device__ __forceinline__ void unpack8(const u32x4& a, const __half*, float (&out)[8]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    out[2 * j] = __half2float(__ushort_as_half((unsigned short)(a[j] & 0xffffu)));
+    out[2 * j + 1] = __half2float(__ushort_as_half((unsigned short)(a[j] >> 16)));
+  }
+}
+__device__ __forceinline__ void unpack8(const u32x4& a, const bf16_t*, float (&out)[8]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    out[2 * j] = __uint_as_float(a[j] << 16);
+    out[2 * j + 1] = __uint_as_float(a[j] & 0xffff0000u);
+  }
+}
+
 // 8 consecutive elements of group `group` -> fp32.  Always global_load_dwordx4 (x2 for fp32).
 template <bool NT>
 __device__ __forceinline__ void load_pack(const float* __restrict__ p, int64_t group, float (&out)[EPT]) {
@@ -83,21 +113,11 @@ __device__ __forceinline__ void load_pack(const float* __restrict__ p, int64_t g
 }
 template <bool NT>
 __device__ __forceinline__ void load_pack(const __half* __restrict__ p, int64_t group, float (&out)[EPT]) {
-  const u32x4 a = ld16<NT>(reinterpret_cast<const u32x4*>(p) + group);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    out[2 * j] = __half2float(__ushort_as_half((unsigned short)(a[j] & 0xffffu)));
-    out[2 * j + 1] = __half2float(__ushort_as_half((unsigned short)(a[j] >> 16)));
-  }
+  unpack8(ld16<NT>(reinterpret_cast<const u32x4*>(p) + group), p, out);
 }
 template <bool NT>
 __device__ __forceinline__ void load_pack(const bf16_t* __restrict__ p, int64_t group, float (&out)[EPT]) {
-  const u32x4 a = ld16<NT>(reinterpret_cast<const u32x4*>(p) + group);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    out[2 * j] = __uint_as_float(a[j] << 16);
-    out[2 * j + 1] = __uint_as_float(a[j] & 0xffff0000u);
-  }
+  unpack8(ld16<NT>(reinterpret_cast<const u32x4*>(p) + group), p, out);
 }
 
 template <bool NT>

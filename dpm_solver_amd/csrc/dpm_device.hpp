@@ -62,6 +62,7 @@ struct Tuning {
   int thr_predict = 1;      // clustered thresholding: predict the select bound from the previous stages (thr_hint)
   int thr_spin_limit = 1 << 12;  // clustered thresholding: polls before a wait on a peer gives up (THR_SPIN_LIMIT)
   int block_threads = 0;    // streaming kernel: threads per workgroup (256 / 512); 0 = by size (launch_stream)
+  int lds_dma = -1;         // lone-launch north-star kernels: read streams by LDS-DMA (1) / through registers (0); -1 = default
   int force_generic = 0;    // LAB: take the run-time-prologue kernels (SPEC_GENERIC / HOT 3) where a compile-time one exists (A/B)
   int thr_elect = -1;       // clustered thresholding: one elected reducer per sample (1) / every workgroup reads every slot (0)
   int thr_debug_fault = 0;  // LAB ONLY (fault injection; compiled out of the product kernels): 1 = every cluster wait gives

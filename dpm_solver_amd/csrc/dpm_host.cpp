@@ -44,6 +44,7 @@ extern "C" size_t dpm_sizeof(int which) {
     case DPM_SIZEOF_RUN_BUFFERS: return sizeof(dpm_run_buffers);
     case DPM_SIZEOF_ADAPTIVE_DESC: return sizeof(dpm_adaptive_desc);
     case DPM_SIZEOF_LAUNCH_OPTS: return sizeof(dpm_launch_opts);
+    case DPM_SIZEOF_STAGE_F64: return sizeof(dpm_stage_f64);
   }
   return 0;
 }
@@ -72,10 +73,17 @@ void linspace32(float start, float end, int n, float* out) {
 // schedule
 // ------------------------------------------------------------------------------------------------
 struct dpm_schedule {
+  typedef float F;  // the scalar type of the evaluation methods below (the coefficient builders of dpm_coef.hpp read it)
   bool discrete = true;
   int total_N = 1000;
   std::vector<float> la, t;        // log_alpha_array, t_array (ref :105,:107)
   std::vector<float> la_rev, t_rev;  // flipped copies for inverse_lambda (ref :166)
+  // double-precision runs (a double state: torch's type promotion evaluates every scalar in double): the tables as the
+  // reference holds them -- the double values they were computed in when the schedule was declared dtype=float64
+  // (dpm_schedule_set_table_dtype, ref :105-107), else the fp32 tables above converted exactly
+  std::vector<double> la_src;      // log_alpha as computed (double for the *_f64 constructors, (double)fp32 otherwise)
+  std::vector<double> d_la, d_t, d_la_rev, d_t_rev;
+  bool table_f64 = false;
   double beta0 = 0.1, beta1 = 20.0;
   // 'cosine' continuous-time schedule of the older vendored revision (examples/score_sde_pytorch/dpm_solver.py
   // :114-124, :134-137, :171-175)
@@ -92,14 +100,31 @@ struct dpm_schedule {
   float std_(float tt) const { return view().std_(tt); }             // ref :146
   float lambda(float tt) const { return view().lambda(tt); }         // ref :152-154
   float inv_lambda(float lam) const { return view().inv_lambda(lam); }  // ref :156-167
+  float inv_lambda_of_f32(float lam) const { return view().inv_lambda(lam); }
+  dpmc::SchedView64 view64() const {
+    return dpmc::SchedView64{discrete ? 1 : 0, cosine ? 1 : 0, total_N, d_la.data(), d_t.data(), d_la_rev.data(),
+                             d_t_rev.data(), beta0, beta1, cos_s, cos_la0};
+  }
+  void build_double_tables() {
+    if (!discrete) return;
+    d_la.resize(total_N);
+    d_t.resize(total_N);
+    for (int i = 0; i < total_N; ++i) {
+      d_la[i] = table_f64 && (int)la_src.size() == total_N ? la_src[i] : (double)la[i];
+      d_t[i] = (double)t[i];  // linspace in fp32, then .to(dtype) (ref :107)
+    }
+    d_la_rev.assign(d_la.rbegin(), d_la.rend());
+    d_t_rev.assign(d_t.rbegin(), d_t.rend());
+  }
 };
 
 namespace {
-int finish_discrete(std::vector<float>&& la, dpm_schedule** out) {
+int finish_discrete(std::vector<float>&& la, dpm_schedule** out, const std::vector<double>* src = nullptr) {
   if (la.size() < 2) return dpm_set_error(DPM_ERR_ARG, "discrete schedule needs >= 2 entries after clipping, got %zu", la.size());
   dpm_schedule* s = new (std::nothrow) dpm_schedule;
   if (!s) return dpm_set_error(DPM_ERR_NOMEM, "out of memory");
   s->discrete = true;
+  if (src) s->la_src = *src;
   s->la = std::move(la);
   s->total_N = (int)s->la.size();
   std::vector<float> full(s->total_N + 1);
@@ -107,6 +132,7 @@ int finish_discrete(std::vector<float>&& la, dpm_schedule** out) {
   s->t.assign(full.begin() + 1, full.end());
   s->la_rev.assign(s->la.rbegin(), s->la.rend());
   s->t_rev.assign(s->t.rbegin(), s->t.rend());
+  s->build_double_tables();
   *out = s;
   return DPM_OK;
 }
@@ -167,7 +193,7 @@ extern "C" int dpm_schedule_create_betas_f64(const double* betas, int n, int cli
     la[i] = 0.5 * acc;
   }
   if (clip) la.resize(clip_len(la));
-  return finish_discrete(std::vector<float>(la.begin(), la.end()), out);  // .to(dtype=float32), ref :105
+  return finish_discrete(std::vector<float>(la.begin(), la.end()), out, &la);  // .to(dtype=float32), ref :105
 }
 
 extern "C" int dpm_schedule_create_alphas_cumprod_f32(const float* ac, int n, int clip, dpm_schedule** out) {
@@ -183,7 +209,7 @@ extern "C" int dpm_schedule_create_alphas_cumprod_f64(const double* ac, int n, i
   std::vector<double> la(n);
   for (int i = 0; i < n; ++i) la[i] = 0.5 * std::log(ac[i]);
   if (clip) la.resize(clip_len(la));
-  return finish_discrete(std::vector<float>(la.begin(), la.end()), out);
+  return finish_discrete(std::vector<float>(la.begin(), la.end()), out, &la);
 }
 
 extern "C" int dpm_schedule_create_log_alpha(const float* log_alpha, int n, dpm_schedule** out) {
@@ -213,6 +239,39 @@ extern "C" int dpm_schedule_create_cosine(dpm_schedule** out) {
   s->cos_s = 0.008;   // legacy :114
   s->cos_la0 = std::log(std::cos(s->cos_s / (1. + s->cos_s) * M_PI / 2.));  // legacy :117 (Python float arithmetic)
   *out = s;
+  return DPM_OK;
+}
+
+extern "C" int dpm_schedule_set_table_dtype(dpm_schedule* s, int dtype) {
+  if (!s || (dtype != DPM_DTYPE_F32 && dtype != DPM_DTYPE_F64)) return dpm_set_error(DPM_ERR_ARG, "table dtype must be DPM_DTYPE_F32 or DPM_DTYPE_F64");
+  s->table_f64 = dtype == DPM_DTYPE_F64;
+  s->build_double_tables();
+  return DPM_OK;
+}
+
+int dpm_schedule_table_is_f64(const dpm_schedule* s) { return s && s->table_f64; }
+
+extern "C" int dpm_schedule_tables_f64(const dpm_schedule* s, const double** log_alpha, const double** t_array, int* K) {
+  if (!s || !s->discrete) return dpm_set_error(DPM_ERR_ARG, "tables exist only for discrete schedules");
+  if (log_alpha) *log_alpha = s->d_la.data();
+  if (t_array) *t_array = s->d_t.data();
+  if (K) *K = s->total_N;
+  return DPM_OK;
+}
+
+extern "C" int dpm_schedule_eval_f64(const dpm_schedule* s, int what, const double* in, int n, double* out) {
+  if (!s || (n > 0 && (!in || !out))) return dpm_set_error(DPM_ERR_ARG, "schedule_eval: null pointer");
+  const dpmc::SchedView64 v = s->view64();
+  for (int i = 0; i < n; ++i) {
+    switch (what) {
+      case DPM_EVAL_LOG_ALPHA: out[i] = v.log_alpha(in[i]); break;
+      case DPM_EVAL_ALPHA: out[i] = v.alpha(in[i]); break;
+      case DPM_EVAL_STD: out[i] = v.std_(in[i]); break;
+      case DPM_EVAL_LAMBDA: out[i] = v.lambda(in[i]); break;
+      case DPM_EVAL_INV_LAMBDA: out[i] = v.inv_lambda(in[i]); break;
+      default: return dpm_set_error(DPM_ERR_ARG, "schedule_eval: unknown quantity %d", what);
+    }
+  }
   return DPM_OK;
 }
 
@@ -249,20 +308,28 @@ extern "C" int dpm_schedule_eval(const dpm_schedule* s, int what, const float* i
 // time grids
 // ------------------------------------------------------------------------------------------------
 namespace {
-int time_steps(const dpm_schedule* s, int skip, double t_T, double t_0, int N, float* out) {
+// S::F = float: the reference's fp32 grids.  S::F = double (a double-precision run): torch.linspace still builds its grid
+// in fp32 (the default dtype, ref :472-477) -- the values are fp32 numbers --, and only what is then evaluated on the
+// schedule's double tables (the logSNR grid's inverse_lambda) is a double.
+template <class S>
+int time_steps(const S* s, int skip, double t_T, double t_0, int N, typename S::F* out) {
+  typedef typename S::F F;
+  std::vector<float> g((size_t)N + 1);
   switch (skip) {
     case DPM_SKIP_TIME_UNIFORM:  // ref :474
-      linspace32((float)t_T, (float)t_0, N + 1, out);
+      linspace32((float)t_T, (float)t_0, N + 1, g.data());
+      for (int i = 0; i <= N; ++i) out[i] = (F)g[i];
       return DPM_OK;
     case DPM_SKIP_LOGSNR: {  // ref :469-472
-      float lT = s->lambda((float)t_T), l0 = s->lambda((float)t_0);
-      linspace32(lT, l0, N + 1, out);
-      for (int i = 0; i <= N; ++i) out[i] = s->inv_lambda(out[i]);
+      // lambda(t_T).cpu().item(): a Python float; linspace rounds its end points to fp32
+      const F lT = s->lambda((F)(float)t_T), l0 = s->lambda((F)(float)t_0);
+      linspace32((float)lT, (float)l0, N + 1, g.data());
+      for (int i = 0; i <= N; ++i) out[i] = s->inv_lambda_of_f32(g[i]);
       return DPM_OK;
     }
     case DPM_SKIP_TIME_QUADRATIC:  // ref :476-478
-      linspace32((float)std::pow(t_T, 0.5), (float)std::pow(t_0, 0.5), N + 1, out);
-      for (int i = 0; i <= N; ++i) out[i] = out[i] * out[i];
+      linspace32((float)std::pow(t_T, 0.5), (float)std::pow(t_0, 0.5), N + 1, g.data());
+      for (int i = 0; i <= N; ++i) out[i] = (F)(g[i] * g[i]);
       return DPM_OK;
   }
   return dpm_set_error(DPM_ERR_ARG, "Unsupported skip_type %d, need to be 'logSNR' or 'time_uniform' or 'time_quadratic'", skip);
@@ -301,8 +368,9 @@ int singlestep_orders(int steps, int order, std::vector<int>& orders, int& K) { 
   return DPM_OK;
 }
 
-int singlestep_grid(const dpm_schedule* s, int steps, int order, int skip, double t_T, double t_0,
-                    std::vector<float>& outer, std::vector<int>& orders) {
+template <class S>
+int singlestep_grid(const S* s, int steps, int order, int skip, double t_T, double t_0,
+                    std::vector<typename S::F>& outer, std::vector<int>& orders) {
   int K = 0;
   int rc = singlestep_orders(steps, order, orders, K);
   if (rc) return rc;
@@ -310,7 +378,7 @@ int singlestep_grid(const dpm_schedule* s, int steps, int order, int skip, doubl
     outer.resize(K + 1);
     return time_steps(s, skip, t_T, t_0, K, outer.data());
   }
-  std::vector<float> full(steps + 1);  // ref :538
+  std::vector<typename S::F> full(steps + 1);  // ref :538
   rc = time_steps(s, skip, t_T, t_0, steps, full.data());
   if (rc) return rc;
   outer.clear();
@@ -414,9 +482,162 @@ extern "C" int dpm_coef_singlestep(const dpm_schedule* s, int algo, int solver_t
 // ------------------------------------------------------------------------------------------------
 struct dpm_plan {
   std::vector<dpm_stage> stages;
+  std::vector<dpm_stage_f64> stages64;  // double-precision plans (dpm_plan_desc.precision): the doubles behind `stages`
   std::vector<float> grid;
+  std::vector<double> grid64;
   int slots = 0;
 };
+
+namespace {
+// DPM_Solver.sample() unrolled into stages (ref :1047-1245), in the scalar type of the schedule view S (float: the
+// reference's default; double: a double-precision run) with stage records ST (dpm_stage / dpmc::Stage64)
+template <class S, class ST>
+int plan_build(const S* s, const dpm_plan_desc* d, std::vector<ST>& stages, std::vector<typename S::F>& grid, int& slots_out) {
+  typedef typename S::F F;
+  const bool pp = d->algorithm_type == DPM_ALGO_DPMSOLVERPP;
+  const double t_T = d->t_start, t_0 = d->t_end;
+  int rc = DPM_OK;
+  int last_step = 0;
+
+  // the dtype of the reference's time tensors (double-precision runs; see set_prologue): bit 0 t_eval, bit 1 t_out
+  std::vector<int> time_f64;
+  const bool grid_f64 = d->skip_type == DPM_SKIP_LOGSNR;  // the whole grid comes out of inverse_lambda
+  auto finish_stage = [&](ST& st, F t_eval, int tf64) {
+    st.index = (int)stages.size();
+    if (pp) st.flags |= DPM_F_TO_X0;
+    if (pp && d->thresholding) st.flags |= DPM_F_THRESH;
+    st.thr_ratio = (decltype(st.thr_ratio))d->thr_ratio;
+    st.thr_max = (decltype(st.thr_max))d->thr_max;
+    set_prologue(s, t_eval, d->model_type, d->guidance, d->guidance_scale, &st, !(tf64 & 1));
+    stages.push_back(st);
+    time_f64.push_back(tf64);
+  };
+
+  if (d->method == DPM_METHOD_MULTISTEP) {
+    const int S_ = d->steps, P = d->order;
+    if (P < 1 || P > 3) rc = dpm_set_error(DPM_ERR_ARG, "Solver order must be 1 or 2 or 3, got %d", P);
+    if (!rc && S_ < P) rc = dpm_set_error(DPM_ERR_ARG, "multistep needs steps >= order (steps=%d, order=%d)", S_, P);
+    if (!rc) {
+      grid.resize(S_ + 1);
+      rc = time_steps(s, d->skip_type, t_T, t_0, S_, grid.data());  // ref :1173
+    }
+    if (!rc) {
+      const F* ts = grid.data();
+      std::vector<int> ord(S_);
+      for (int i = 0; i < S_; ++i) {
+        int step = i + 1;  // the reference's loop variable: this stage produces x at ts[step]
+        if (step < P)
+          ord[i] = step;  // warm-up, ref :1185-1187
+        else
+          ord[i] = (d->lower_order_final && S_ < 10) ? std::min(P, S_ + 1 - step) : P;  // ref :1198-1201
+      }
+      for (int i = 0; i < S_; ++i) {
+        ST st;
+        stage_init(&st);
+        if (ord[i] == 1)
+          coef_first(s, pp, ts[i], ts[i + 1], &st);
+        else if (ord[i] == 2)
+          coef_ms2(s, pp, d->solver_type, ts[i - 1], ts[i], ts[i + 1], &st);
+        else
+          coef_ms3(s, pp, ts[i - 2], ts[i - 1], ts[i], ts[i + 1], &st);
+        st.outer_step = i + 1;
+        if (P >= 2) {
+          if (ord[i] >= 2) st.h1_slot = (i - 1) % P;
+          if (ord[i] >= 3) st.h2_slot = (i - 2) % P;
+          bool needed = false;  // does a later stage read this stage's model value?
+          for (int j = i + 1; j < S_ && j <= i + 2; ++j)
+            if (ord[j] > j - i) needed = true;
+          if (needed) {
+            st.flags |= DPM_F_STORE_M;
+            st.m_slot = i % P;
+          }
+        }
+        finish_stage(st, ts[i], grid_f64 ? 3 : 0);
+      }
+      slots_out = P >= 2 ? P : 0;
+      last_step = S_;
+    }
+  } else {
+    std::vector<F> outer;
+    std::vector<int> orders;
+    if (d->order < 1 || d->order > 3) rc = dpm_set_error(DPM_ERR_ARG, "'order' must be '1' or '2' or '3'.");
+    if (!rc) {
+      if (d->method == DPM_METHOD_SINGLESTEP) {
+        rc = singlestep_grid(s, d->steps, d->order, d->skip_type, t_T, t_0, outer, orders);  // ref :1216
+      } else {
+        const int K = d->steps / d->order;  // ref :1218-1220; K = 0 (steps < order) is a no-op in the reference too
+        orders.assign(K, d->order);
+        outer.resize(K + 1);
+        rc = time_steps(s, d->skip_type, t_T, t_0, K, outer.data());
+      }
+    }
+    if (!rc) {
+      grid = outer;
+      int slots = 0;
+      for (size_t j = 0; j < orders.size() && !rc; ++j) {
+        const int o = orders[j];
+        const F ts_ = outer[j], tt_ = outer[j + 1];
+        F inner[4], lam[4];
+        rc = time_steps(s, d->skip_type, (double)ts_, (double)tt_, o, inner);  // ref :1223 (s.item(), t.item(): Python floats)
+        if (rc) break;
+        for (int i = 0; i <= o; ++i) lam[i] = s->lambda(inner[i]);
+        F hh = lam[o] - lam[0];
+        double r1 = o >= 2 ? (double)((lam[1] - lam[0]) / hh) : 0.;  // ref :1226-1227 (tensors of the run's scalar type)
+        double r2 = o >= 3 ? (double)((lam[2] - lam[0]) / hh) : 0.;
+        ST st[3];
+        if (o >= 2 && (d->solver_type < 0 || d->solver_type > 1))
+          rc = dpm_set_error(DPM_ERR_ARG, "'solver_type' must be either 'dpmsolver' or 'taylor', got %d", d->solver_type);
+        if (rc) break;
+        singlestep_fill(s, d->algorithm_type, d->solver_type, o, ts_, tt_, r1, r2, 1, st);
+        for (int i = 0; i < o; ++i) {
+          st[i].outer_step = (int)j;
+          F te = (F)st[i].t_eval;
+          if (st[i].m_slot >= 0) slots = std::max(slots, st[i].m_slot + 1);
+          // inner nodes s1, s2 come out of inverse_lambda (ref :621, :706-707); an intermediate state's "t_out" is one too
+          finish_stage(st[i], te, ((i > 0 || grid_f64) ? 1 : 0) | ((i < o - 1 || grid_f64) ? 2 : 0));
+        }
+      }
+      slots_out = slots;
+      last_step = (int)orders.size() - 1;
+    }
+  }
+  if (!rc && d->denoise_to_zero) {  // ref :1235-1241, :541-545
+    ST st;
+    stage_init(&st);
+    st.form = DPM_FORM_DENOISE;
+    st.outer_step = last_step + 1;
+    st.t_out = (F)(float)t_0;       // torch.ones((1,)).to(device) * t_0: an fp32 tensor
+    finish_stage(st, (F)(float)t_0, 0);
+    ST& b = stages.back();
+    b.flags |= DPM_F_TO_X0;  // data_prediction_fn also under algorithm_type='dpmsolver'
+    if (d->thresholding) b.flags |= DPM_F_THRESH;
+  }
+  if constexpr (sizeof(F) == 8)
+    for (size_t i = 0; i < stages.size(); ++i) stages[i].time_f64 = time_f64[i];
+  return rc;
+}
+
+// the doubles of a double-precision stage and its fp32 twin (integer fields + the doubles rounded: what inspection, the
+// model time vectors and a host that ignores dpm_stage_f64 see)
+void split_stage64(const dpmc::Stage64& q, dpm_stage* st, dpm_stage_f64* d64) {
+  *st = dpm_stage{};
+  st->index = q.index; st->form = q.form; st->flags = q.flags; st->model_type = q.model_type; st->guidance = q.guidance;
+  st->outer_step = q.outer_step; st->emits_state = q.emits_state; st->x_src = q.x_src; st->xe_src = q.xe_src;
+  st->h1_slot = q.h1_slot; st->h2_slot = q.h2_slot; st->m_slot = q.m_slot;
+  st->t_eval = (float)q.t_eval; st->t_input = (float)q.t_input; st->t_out = (float)q.t_out;
+  st->alpha_e = (float)q.alpha_e; st->sigma_e = (float)q.sigma_e; st->cfg_scale = (float)q.cfg_scale;
+  st->cg_scale = (float)q.cg_scale; st->cx = (float)q.cx; st->c0 = (float)q.c0; st->c1 = (float)q.c1; st->c2 = (float)q.c2;
+  for (int i = 0; i < 5; ++i) st->k[i] = (float)q.k[i];
+  st->thr_ratio = (float)q.thr_ratio; st->thr_max = (float)q.thr_max;
+  st->blend_alpha = (float)q.blend_alpha; st->blend_sigma = (float)q.blend_sigma;
+  *d64 = dpm_stage_f64{};
+  d64->t_eval = q.t_eval; d64->t_input = q.t_input; d64->t_out = q.t_out; d64->alpha_e = q.alpha_e; d64->sigma_e = q.sigma_e;
+  d64->cfg_scale = q.cfg_scale; d64->cg_scale = q.cg_scale; d64->cx = q.cx; d64->c0 = q.c0; d64->c1 = q.c1; d64->c2 = q.c2;
+  for (int i = 0; i < 5; ++i) d64->k[i] = q.k[i];
+  d64->thr_ratio = q.thr_ratio; d64->thr_max = q.thr_max; d64->blend_alpha = q.blend_alpha; d64->blend_sigma = q.blend_sigma;
+  d64->time_f64 = q.time_f64;
+}
+}  // namespace
 
 extern "C" int dpm_plan_create(const dpm_schedule* s, const dpm_plan_desc* d, dpm_plan** out) {
   if (!s || !d || !out) return dpm_set_error(DPM_ERR_ARG, "null pointer");
@@ -431,118 +652,21 @@ extern "C" int dpm_plan_create(const dpm_schedule* s, const dpm_plan_desc* d, dp
   if (!(d->t_end > 0) || !(d->t_start > 0))
     return dpm_set_error(DPM_ERR_ARG, "Time range needs to be greater than 0. For discrete-time DPMs, it needs to be in [1 / N, 1], where N is the length of betas array");
   if (d->steps < 1) return dpm_set_error(DPM_ERR_ARG, "steps must be >= 1, got %d", d->steps);
-  const bool pp = d->algorithm_type == DPM_ALGO_DPMSOLVERPP;
-  const double t_T = d->t_start, t_0 = d->t_end;
+  if (d->precision != 0 && d->precision != 1) return dpm_set_error(DPM_ERR_ARG, "precision must be 0 (fp32) or 1 (double)");
   dpm_plan* p = new (std::nothrow) dpm_plan;
   if (!p) return dpm_set_error(DPM_ERR_NOMEM, "out of memory");
-  int rc = DPM_OK;
-  int last_step = 0;
-
-  auto finish_stage = [&](dpm_stage& st, float t_eval) {
-    st.index = (int)p->stages.size();
-    if (pp) st.flags |= DPM_F_TO_X0;
-    if (pp && d->thresholding) st.flags |= DPM_F_THRESH;
-    st.thr_ratio = (float)d->thr_ratio;
-    st.thr_max = (float)d->thr_max;
-    set_prologue(s, t_eval, d->model_type, d->guidance, d->guidance_scale, &st);
-    p->stages.push_back(st);
-  };
-
-  if (d->method == DPM_METHOD_MULTISTEP) {
-    const int S = d->steps, P = d->order;
-    if (P < 1 || P > 3) rc = dpm_set_error(DPM_ERR_ARG, "Solver order must be 1 or 2 or 3, got %d", P);
-    if (!rc && S < P) rc = dpm_set_error(DPM_ERR_ARG, "multistep needs steps >= order (steps=%d, order=%d)", S, P);
-    if (!rc) {
-      p->grid.resize(S + 1);
-      rc = time_steps(s, d->skip_type, t_T, t_0, S, p->grid.data());  // ref :1173
-    }
-    if (!rc) {
-      const float* ts = p->grid.data();
-      std::vector<int> ord(S);
-      for (int i = 0; i < S; ++i) {
-        int step = i + 1;  // the reference's loop variable: this stage produces x at ts[step]
-        if (step < P)
-          ord[i] = step;  // warm-up, ref :1185-1187
-        else
-          ord[i] = (d->lower_order_final && S < 10) ? std::min(P, S + 1 - step) : P;  // ref :1198-1201
-      }
-      for (int i = 0; i < S; ++i) {
-        dpm_stage st;
-        stage_init(&st);
-        if (ord[i] == 1)
-          coef_first(s, pp, ts[i], ts[i + 1], &st);
-        else if (ord[i] == 2)
-          coef_ms2(s, pp, d->solver_type, ts[i - 1], ts[i], ts[i + 1], &st);
-        else
-          coef_ms3(s, pp, ts[i - 2], ts[i - 1], ts[i], ts[i + 1], &st);
-        st.outer_step = i + 1;
-        if (P >= 2) {
-          if (ord[i] >= 2) st.h1_slot = (i - 1) % P;
-          if (ord[i] >= 3) st.h2_slot = (i - 2) % P;
-          bool needed = false;  // does a later stage read this stage's model value?
-          for (int j = i + 1; j < S && j <= i + 2; ++j)
-            if (ord[j] > j - i) needed = true;
-          if (needed) {
-            st.flags |= DPM_F_STORE_M;
-            st.m_slot = i % P;
-          }
-        }
-        finish_stage(st, ts[i]);
-      }
-      p->slots = P >= 2 ? P : 0;
-      last_step = S;
-    }
+  int rc;
+  if (d->precision == 0) {
+    rc = plan_build(s, d, p->stages, p->grid, p->slots);
+    p->grid64.assign(p->grid.begin(), p->grid.end());
   } else {
-    std::vector<float> outer;
-    std::vector<int> orders;
-    if (d->order < 1 || d->order > 3) rc = dpm_set_error(DPM_ERR_ARG, "'order' must be '1' or '2' or '3'.");
-    if (!rc) {
-      if (d->method == DPM_METHOD_SINGLESTEP) {
-        rc = singlestep_grid(s, d->steps, d->order, d->skip_type, t_T, t_0, outer, orders);  // ref :1216
-      } else {
-        const int K = d->steps / d->order;  // ref :1218-1220; K = 0 (steps < order) is a no-op in the reference too
-        orders.assign(K, d->order);
-        outer.resize(K + 1);
-        rc = time_steps(s, d->skip_type, t_T, t_0, K, outer.data());
-      }
-    }
-    if (!rc) {
-      p->grid = outer;
-      int slots = 0;
-      for (size_t j = 0; j < orders.size() && !rc; ++j) {
-        const int o = orders[j];
-        const float ts_ = outer[j], tt_ = outer[j + 1];
-        float inner[4], lam[4];
-        rc = time_steps(s, d->skip_type, (double)ts_, (double)tt_, o, inner);  // ref :1223
-        if (rc) break;
-        for (int i = 0; i <= o; ++i) lam[i] = s->lambda(inner[i]);
-        float hh = lam[o] - lam[0];
-        double r1 = o >= 2 ? (double)((lam[1] - lam[0]) / hh) : 0.;  // ref :1226-1227 (fp32 tensors)
-        double r2 = o >= 3 ? (double)((lam[2] - lam[0]) / hh) : 0.;
-        dpm_stage st[3];
-        rc = dpm_coef_singlestep(s, d->algorithm_type, d->solver_type, o, ts_, tt_, r1, r2, 1, st);
-        if (rc) break;
-        for (int i = 0; i < o; ++i) {
-          st[i].outer_step = (int)j;
-          float te = st[i].t_eval;
-          if (st[i].m_slot >= 0) slots = std::max(slots, st[i].m_slot + 1);
-          finish_stage(st[i], te);
-        }
-      }
-      p->slots = slots;
-      last_step = (int)orders.size() - 1;
-    }
-  }
-  if (!rc && d->denoise_to_zero) {  // ref :1235-1241, :541-545
-    dpm_stage st;
-    stage_init(&st);
-    st.form = DPM_FORM_DENOISE;
-    st.outer_step = last_step + 1;
-    st.t_out = (float)t_0;
-    finish_stage(st, (float)t_0);
-    dpm_stage& b = p->stages.back();
-    b.flags |= DPM_F_TO_X0;  // data_prediction_fn also under algorithm_type='dpmsolver'
-    if (d->thresholding) b.flags |= DPM_F_THRESH;
+    const dpmc::SchedView64 v = s->view64();
+    std::vector<dpmc::Stage64> st64;
+    rc = plan_build(&v, d, st64, p->grid64, p->slots);
+    p->grid.assign(p->grid64.begin(), p->grid64.end());
+    p->stages.resize(st64.size());
+    p->stages64.resize(st64.size());
+    for (size_t i = 0; i < st64.size(); ++i) split_stage64(st64[i], &p->stages[i], &p->stages64[i]);
   }
   if (rc) {
     delete p;
@@ -559,6 +683,13 @@ extern "C" int dpm_plan_num_slots(const dpm_plan* p) { return p ? p->slots : 0; 
 extern "C" int dpm_plan_stage(const dpm_plan* p, int i, dpm_stage* out) {
   if (!p || !out || i < 0 || i >= (int)p->stages.size()) return dpm_set_error(DPM_ERR_ARG, "plan_stage: bad index %d", i);
   *out = p->stages[i];
+  return DPM_OK;
+}
+
+extern "C" int dpm_plan_stage_f64(const dpm_plan* p, int i, dpm_stage_f64* out) {
+  if (!p || !out || i < 0 || i >= (int)p->stages.size()) return dpm_set_error(DPM_ERR_ARG, "plan_stage_f64: bad index %d", i);
+  if (p->stages64.empty()) return dpm_set_error(DPM_ERR_ARG, "plan_stage_f64: not a double-precision plan (dpm_plan_desc.precision)");
+  *out = p->stages64[i];
   return DPM_OK;
 }
 
@@ -621,6 +752,7 @@ static int plan_run_impl(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model
     b.workspace = rb->workspace;
     b.thr_hint = rb->thr_hint;
     b.opts = rb->opts;
+    b.coef64 = p->stages64.empty() ? nullptr : &p->stages64[(size_t)st.index];
     b.n = rb->n;
     b.batch = rb->batch;
     b.state_dtype = rb->state_dtype;
@@ -688,6 +820,7 @@ extern "C" int dpm_plan_run_multi(const dpm_plan* p, const dpm_run_buffers* rbs,
       b.workspace = rb.workspace;
       b.thr_hint = rb.thr_hint;
       b.opts = rbs[0].opts;
+      b.coef64 = p->stages64.empty() ? nullptr : &p->stages64[(size_t)st.index];
       b.n = rb.n;
       b.batch = rb.batch;
       b.state_dtype = rb.state_dtype;

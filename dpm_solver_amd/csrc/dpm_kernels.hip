@@ -32,6 +32,10 @@ int dpm_launch_f32_f16(const dpm_stage*, const dpm_buffers*, void*, void*, void*
 int dpm_launch_f32_bf16(const dpm_stage*, const dpm_buffers*, void*, void*, void*, const dpm_stage*, const int32_t*);
 int dpm_launch_f16_f16(const dpm_stage*, const dpm_buffers*, void*, void*, void*, const dpm_stage*, const int32_t*);
 int dpm_launch_bf16_bf16(const dpm_stage*, const dpm_buffers*, void*, void*, void*, const dpm_stage*, const int32_t*);
+int dpm_launch_f64(const dpm_stage*, const dpm_buffers*, void*, void*, void*);                     // dpm_f64.hip
+int dpm_add_noise_f64(double, double, const void*, const void*, void*, int64_t, void*);
+int dpm_blend_f64(const void*, const void*, const void*, const void*, double, double, void*, int64_t, int64_t, void*);
+int dpm_schedule_table_is_f64(const dpm_schedule* s);                                              // dpm_host.cpp
 int dpm_launch_multi_f32_f32(const dpm_stage*, const dpm_buffers*, int, void*, void*, void*);
 int dpm_launch_multi_f32_f16(const dpm_stage*, const dpm_buffers*, int, void*, void*, void*);
 int dpm_launch_multi_f32_bf16(const dpm_stage*, const dpm_buffers*, int, void*, void*, void*);
@@ -74,6 +78,11 @@ int dpm_stage_launch_dyn(const dpm_stage* st, const dpm_buffers* b, void* stream
   dpm_buffers bb = *b;
   if (!bb.x) bb.x = bb.xe;  // DENOISE form: only the evaluation state exists
   const int sd = bb.state_dtype, ed = bb.eps_dtype;
+  if (sd == DPM_DTYPE_F64 || ed == DPM_DTYPE_F64) {  // double-precision state: one run-time dispatched kernel (dpm_f64.hip)
+    if (sd != ed) return dpm_set_error(DPM_ERR_UNSUPPORTED, "stage_launch: a double state needs double network outputs (state=%d eps=%d)", sd, ed);
+    if (dyn) return dpm_set_error(DPM_ERR_UNSUPPORTED, "stage_launch: device-resident coefficients with a double state");
+    return dpm_launch_f64(st, &bb, stream, ev_start, ev_stop);
+  }
   if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_F32) return dpm_launch_f32_f32(st, &bb, stream, ev_start, ev_stop, dyn, skip);
   if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_F16) return dpm_launch_f32_f16(st, &bb, stream, ev_start, ev_stop, dyn, skip);
   if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_BF16) return dpm_launch_f32_bf16(st, &bb, stream, ev_start, ev_stop, dyn, skip);
@@ -190,6 +199,26 @@ extern "C" int dpm_add_noise_launch(const dpm_schedule* s, const float* t_host, 
   if (!s || !t_host || !x || !noise || !out || nt < 1 || n < 0) return dpm_set_error(DPM_ERR_ARG, "add_noise: bad arguments");
   if (n == 0) return DPM_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == DPM_DTYPE_F64) {  // double state: alpha / sigma in double on a dtype=float64 schedule, else fp32 values promoted
+    for (int j = 0; j < nt; ++j) {
+      double a64 = 0., s64 = 0.;
+      if (dpm_schedule_table_is_f64(s)) {
+        const double tj = (double)t_host[j];
+        dpm_schedule_eval_f64(s, DPM_EVAL_ALPHA, &tj, 1, &a64);
+        dpm_schedule_eval_f64(s, DPM_EVAL_STD, &tj, 1, &s64);
+      } else {
+        float a = 0.f, sg = 0.f;
+        dpm_schedule_eval(s, DPM_EVAL_ALPHA, &t_host[j], 1, &a);
+        dpm_schedule_eval(s, DPM_EVAL_STD, &t_host[j], 1, &sg);
+        a64 = a;
+        s64 = sg;
+      }
+      const int rc = dpm_add_noise_f64(a64, s64, x, static_cast<const double*>(noise) + (int64_t)j * n,
+                                       static_cast<double*>(out) + (int64_t)j * n, n, stream);
+      if (rc) return rc;
+    }
+    return DPM_OK;
+  }
   const DeviceInfo& di = device_info();
   int64_t blocks = (n + 255) / 256;
   const int64_t cap = (int64_t)(di.n_cu > 0 ? di.n_cu : 256) * 16;
@@ -231,6 +260,7 @@ extern "C" int dpm_blend_launch(const void* x, const void* mask, const void* a, 
                                 void* out, int64_t n, int64_t mask_period, int dtype, void* stream) {
   if (!x || !mask || !a || !out || n < 0 || mask_period < 1) return dpm_set_error(DPM_ERR_ARG, "blend: bad arguments");
   if (n == 0) return DPM_OK;
+  if (dtype == DPM_DTYPE_F64) return dpm_blend_f64(x, mask, a, b, (double)alpha, (double)sigma, out, n, mask_period, stream);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const DeviceInfo& di = device_info();
   int64_t blocks = (n + 255) / 256;

@@ -102,6 +102,10 @@ inline int64_t thr_ws_bytes(int64_t batch, int64_t per_sample, int n_cu) {
 //     workgroup iteration when there is work for it -- fp16 5.5 vs 7.4-7.6 us, fp32 12.35 vs 12.9 us.  Variants exist for
 //     the 2M / first-order kernels (HotCombo).
 constexpr int DEF_U = 1;
+// the lone-launch north-star kernels (2-byte state, 2M / first-order, inputs from HBM) read through LDS-DMA by default
+#ifndef DPM_LDS_DMA_DEFAULT
+#define DPM_LDS_DMA_DEFAULT 1
+#endif
 template <typename TS>
 struct DefNT {
   static constexpr int value = 5;
@@ -436,20 +440,28 @@ int launch_stream(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
     vec = vec && aligned(ext.xo2, as) && aligned(ext.mask, as) && aligned(ext.ba, as) && aligned(ext.bb, as) &&
           b->n % EPT == 0 && ext.mask_period % EPT == 0 &&
           (!ext.eps_stride || (ext.per_sample % EPT == 0 && ext.eps_stride % EPT == 0));
-  // what the streaming family instantiates (binary size: one kernel per combination and dtype pair):
+  // what the streaming family instantiates (binary size, build time and first-call cost: one kernel per combination and
+  // dtype pair).  Round 5 measured what a compile-time prologue is worth against the run-time one (SPEC_GENERIC: the mode is
+  // chosen once per workgroup iteration, the same straight-line code) -- 0-7 % per launch, profiles/r05_kernel_budget.md --
+  // and keeps it where samplers spend their time:
   //   * a separate evaluation state (xe != x) occurs in the singlestep mid / final stages -- forms TWO and SS3T -- and
   //     in the FIRST stage of a multistep run with a corrector on x_t (mask blend, any correcting_xt_fn): the network saw
   //     the raw x_T, the update starts from the corrected state (ref :1179-1183) -- form LIN1, unguided or CFG;
   //   * the compile-time prologues (noise-prediction network) for the forms samplers spend their time in -- LIN1, TWO,
-  //     MS3; SS3T and DENOISE run the general prologue (true division: the same bits);
+  //     MS3 -- unguided and under classifier-free guidance; classifier guidance (an autograd pass through the classifier
+  //     per step dwarfs 3 % of a stage kernel) and that one first stage take SPEC_GENERIC; SS3T and DENOISE run the general
+  //     prologue anyway (true division: the same bits);
   //   everything else goes through the one-element-per-lane kernel.
-  constexpr bool COMBO_BUILT = !XE || FORM == DPM_FORM_TWO || FORM == DPM_FORM_SS3T ||
-                               (FORM == DPM_FORM_LIN1 && GUIDE != DPM_GUIDE_CLASSIFIER);
-  constexpr bool SPEC_BUILT = FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3;
+  constexpr bool COMBO_BUILT = (!XE && !(FORM == DPM_FORM_DENOISE && GUIDE == DPM_GUIDE_CLASSIFIER)) || FORM == DPM_FORM_TWO ||
+                               FORM == DPM_FORM_SS3T || (FORM == DPM_FORM_LIN1 && GUIDE != DPM_GUIDE_CLASSIFIER);
+  constexpr bool SPEC_BUILT = (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3) &&
+                              GUIDE != DPM_GUIDE_CLASSIFIER && !(XE && FORM == DPM_FORM_LIN1);
   // device-resident coefficients (adaptive solver): DYN kernels exist for the forms it launches -- first-order,
-  // second-order and the singlestep-3 'taylor' combination -- without the KExt extensions; anything else takes the
+  // second-order and the singlestep-3 'taylor' combination -- with a 4-byte state (the reference's adaptive solver keeps
+  // fp32 with a discrete schedule), unguided or CFG, without the KExt extensions; anything else takes the
   // one-element-per-lane kernel
-  constexpr bool DYN_BUILT = COMBO_BUILT && (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_SS3T);
+  constexpr bool DYN_BUILT = COMBO_BUILT && sizeof(TS) == 4 && GUIDE != DPM_GUIDE_CLASSIFIER &&
+                             (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_SS3T);
   const bool dyn_vec = stream.dyn && DYN_BUILT && !use_ext;
   if (!vec || !COMBO_BUILT || (stream.dyn && !dyn_vec)) {
     int64_t blocks = (b->n + 255) / 256;
@@ -542,7 +554,18 @@ int launch_stream(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
           // interleaved-requests emulation (15.4 vs 15.6 us); INSIDE a torch network loop (profiles/r03_in_loop.md,
           // rocprofv3 rows, 342 launches each) one tile is 15.0 us against 16.3, and four / eight tiles -- fewer, fatter
           // wavefronts with every load issued up front, the emulation's favourite at 14.4 us -- are 15.2 / 23.8 us.
-          DPM_LAUNCH(SPEC_NOISE_X0, 1, CNT, false);
+          // 2-byte state and network output, no ragged tail: the read streams by LDS-DMA (stage_kernel_dma, round 5)
+          bool dma = false;
+          if constexpr (sizeof(TS) == 2 && sizeof(TE) == 2) dma = (tn.lds_dma < 0 ? DPM_LDS_DMA_DEFAULT : tn.lds_dma) != 0 && b->n % EPT == 0;
+          if (dma) {
+            if constexpr (sizeof(TS) == 2 && sizeof(TE) == 2) {
+              const auto sh = shape_for(1);
+              launch(stage_kernel_dma<TS, TE, FORM, CNT>, sh.first, sh.second, (size_t)(sh.second.x / 64) * 3072, stream, x, e0, h1, xo, mo,
+                     b->n, p);
+            }
+          } else {
+            DPM_LAUNCH(SPEC_NOISE_X0, 1, CNT, false);
+          }
         }
       } else {
         DPM_LAUNCH(SPEC_NOISE_X0, DEF_U, DefNT<TS>::value, false);

@@ -270,13 +270,21 @@ __device__ __forceinline__ void tile_models(const float (&vx)[U][EPT], const flo
 // takes those) and use the split layout only when no per-sample / per-period index is involved.
 // One workgroup iteration: the U tiles that start at tile t0 of ONE tensor set (shared by the single-request kernel and
 // the fused multi-request kernel below).  Everything outside the two unrolled loops is wave-uniform scalar work.
-template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int SPEC, int U, int NT, bool EXT>
+// DMA = the read streams travel by LDS-DMA (glds16: global memory -> this wavefront's LDS rows -> ds_read_b128) instead of
+// through global_load_dwordx4 into registers: the lone-launch variant of the north-star kernels (2-byte state and network
+// output, unguided noise-prediction network, dpmsolver++: x, eps and -- second order -- the cached model value).  Same
+// elements per lane, same arithmetic, same bits; `dma_rows` = the workgroup's dynamic LDS (3 KiB per wavefront).
+template <typename TS, typename TE, int FORM, int GUIDE, bool XE, int SPEC, int U, int NT, bool EXT, bool DMA = false>
 __device__ __forceinline__ void stage_tiles(const TS* __restrict__ x, const TS* __restrict__ xe,
                                             const TE* __restrict__ e0, const TE* __restrict__ e1,
                                             const TE* __restrict__ g, const TS* __restrict__ h1,
                                             const TS* __restrict__ h2, TS* __restrict__ xo, TS* __restrict__ mo,
-                                            const int64_t ngroups, const int64_t t0, const KParams& p, const KExt& ext) {
+                                            const int64_t ngroups, const int64_t t0, const KParams& p, const KExt& ext,
+                                            u32x4* dma_rows = nullptr) {
   using FT = FormTraits<FORM>;
+  static_assert(!DMA || (sizeof(TS) == 2 && sizeof(TE) == 2 && !EXT && !XE && GUIDE == DPM_GUIDE_NONE && SPEC == SPEC_NOISE_X0 &&
+                         U == 1 && (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO)),
+                "the LDS-DMA variant exists for the lone-launch north-star kernels only");
   constexpr bool SPLIT = sizeof(TS) == 4;  // see load_tile
   const bool need_xe = spec_need_xe<SPEC>(p);
   const bool store_m = p.flags & DPM_F_STORE_M;
@@ -296,8 +304,21 @@ __device__ __forceinline__ void stage_tiles(const TS* __restrict__ x, const TS* 
   float vm[EXT ? U : 1][EPT], va[EXT ? U : 1][EPT], vb[EXT ? U : 1][EPT];
   // Lanes past the end of the last tile load a clamped (valid) group and only skip the store: loads and arithmetic
   // stay in straight-line code, so the loaded registers are consumed where they land (no copies at a join).
+  if constexpr (DMA) {
+    // three (two: first order) 16-byte LDS-DMA loads per lane, one wait, three ds_read_b128 of the lane's own bytes
+    const int64_t gr = t0 * 256 + tile_lane();
+    const int64_t gi = gr < ngroups ? gr : ngroups - 1;
+    const uint32_t lane = threadIdx.x & 63u;
+    glds16<(NT & 1) != 0>(reinterpret_cast<const u32x4*>(x) + gi, dma_rows);
+    glds16<(NT & 1) != 0>(reinterpret_cast<const u32x4*>(e0) + gi, dma_rows + 64);
+    if (FT::needs_h1) glds16<(NT & 1) != 0>(reinterpret_cast<const u32x4*>(h1) + gi, dma_rows + 128);
+    lds_dma_wait();
+    unpack8(dma_rows[lane], x, vx[0]);
+    unpack8(dma_rows[64 + lane], e0, v0[0]);
+    if (FT::needs_h1) unpack8(dma_rows[128 + lane], h1, vh1[0]);
+  }
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
+  for (int u = 0; u < (DMA ? 0 : U); ++u) {
     const int64_t gr = (t0 + u) * 256 + tile_lane();
     const int64_t gi = gr < ngroups ? gr : ngroups - 1;
     const bool split = can_split && (t0 + u) * 256 + 256 <= ngroups;
@@ -426,6 +447,27 @@ __global__ __launch_bounds__(STAGE_MAX_THREADS) void stage_kernel(const TS* __re
       if (store_m) mo[i] = from_f32<TS>(mn);
     }
   }
+}
+
+// The lone-launch variant of the north-star kernels with its read streams on the LDS-DMA path (stage_tiles<..., DMA = true>).
+// One tile per 256-lane group and iteration like stage_kernel; dynamic LDS = 3 KiB per wavefront.  The rows of a wavefront
+// are reused by its next tile: the ds_reads of the previous tile are complete before the stores it waited on are issued
+// (their results are the stores' operands), so the next tile's LDS-DMA cannot overtake them.
+template <typename TS, typename TE, int FORM, int NT>
+__global__ __launch_bounds__(STAGE_MAX_THREADS) void stage_kernel_dma(const TS* __restrict__ x, const TE* __restrict__ e0,
+                                                                      const TS* __restrict__ h1, TS* __restrict__ xo,
+                                                                      TS* __restrict__ mo, int64_t n, const KParams p) {
+  extern __shared__ __align__(16) unsigned char dma_lds[];
+  const int64_t ngroups = n / EPT;
+  const int64_t ntiles = (ngroups + 255) / 256;
+  const uint32_t per = blockDim.x >> 8;
+  const uint32_t sub = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  u32x4* rows = reinterpret_cast<u32x4*>(dma_lds) + (size_t)wave * 192;
+  const KExt ext = {};
+  for (int64_t t0 = (int64_t)blockIdx.x * per + sub; t0 < ntiles; t0 += (int64_t)gridDim.x * per)
+    stage_tiles<TS, TE, FORM, DPM_GUIDE_NONE, false, SPEC_NOISE_X0, 1, NT, false, true>(x, nullptr, e0, nullptr, nullptr, h1, nullptr,
+                                                                                      xo, mo, ngroups, t0, p, ext, rows);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -24,7 +24,9 @@ class NoiseScheduleVP:
                 schedule, " or ".join("'%s'" % v for v in self._SCHEDULES)))
         self.schedule = schedule
         self.T = 1.
+        self.dtype = dtype
         self._h = C.c_void_p()
+        self._dev_tables = {}
         if schedule == 'discrete':
             src = betas if betas is not None else alphas_cumprod
             assert src is not None
@@ -37,8 +39,16 @@ class NoiseScheduleVP:
                                                   "f64" if f64 else "f32")
             ptr = arr.ctypes.data_as(C.POINTER(C.c_double if f64 else C.c_float))
             L.check(getattr(L.lib, name)(ptr, int(arr.shape[0]), 1 if self._clip else 0, C.byref(self._h)))
-            la, ta, K = C.POINTER(C.c_float)(), C.POINTER(C.c_float)(), C.c_int()
-            L.check(L.lib.dpm_schedule_tables(self._h, C.byref(la), C.byref(ta), C.byref(K)))
+            K = C.c_int()
+            if dtype == torch.float64:
+                # ref :105-107: the tables keep the values they were computed in (double for double inputs, the fp32 values
+                # converted otherwise); double-precision runs (a double state) evaluate every scalar on them in double
+                L.check(L.lib.dpm_schedule_set_table_dtype(self._h, L.DTYPE_F64))
+                la, ta = C.POINTER(C.c_double)(), C.POINTER(C.c_double)()
+                L.check(L.lib.dpm_schedule_tables_f64(self._h, C.byref(la), C.byref(ta), C.byref(K)))
+            else:
+                la, ta = C.POINTER(C.c_float)(), C.POINTER(C.c_float)()
+                L.check(L.lib.dpm_schedule_tables(self._h, C.byref(la), C.byref(ta), C.byref(K)))
             self.total_N = K.value
             self.log_alpha_array = torch.from_numpy(np.ctypeslib.as_array(la, (K.value,)).copy()).reshape((1, -1)).to(dtype=dtype)
             self.t_array = torch.from_numpy(np.ctypeslib.as_array(ta, (K.value,)).copy()).reshape((1, -1)).to(dtype=dtype)
@@ -92,14 +102,56 @@ class NoiseScheduleVP:
                                         out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
+    def _eval_np64(self, what, v):
+        v = np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(-1))
+        out = np.empty_like(v)
+        L.check(L.lib.dpm_schedule_eval_f64(self._h, what, v.ctypes.data_as(C.POINTER(C.c_double)), int(v.shape[0]),
+                                            out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def _double_scalars(self, t):
+        """the reference's type promotion: a double time, or double tables ('discrete', dtype=float64), make the scalar a
+        double (ref :127-134: interpolate_fn concatenates t with the tables)"""
+        return t.dtype == torch.float64 or (self.schedule == 'discrete' and self.dtype == torch.float64)
+
     def _eval(self, what, t):
         if not torch.is_tensor(t):
             t = torch.as_tensor(t, dtype=torch.float32)
-        out = torch.from_numpy(self._eval_np(what, t.detach().to(device="cpu", dtype=torch.float32).numpy()))
+        if self._double_scalars(t):
+            out = torch.from_numpy(self._eval_np64(what, t.detach().to(device="cpu", dtype=torch.float64).numpy()))
+        else:
+            out = torch.from_numpy(self._eval_np(what, t.detach().to(device="cpu", dtype=torch.float32).numpy()))
         # the reference flattens for 'discrete' (reshape((-1))) and keeps the shape for 'linear'
         if self.schedule != 'discrete':
             out = out.reshape(t.shape)
         return out.to(device=t.device)
+
+    def device_alpha_sigma(self, t):
+        """(alpha_t, sigma_t) of a DEVICE tensor of times, per element, computed on the device with torch operations and no
+        host synchronisation: ref :127-146 -- piecewise-linear interpolation of log alpha on the tables (the segment found by
+        torch.searchsorted instead of the reference's sort, same interpolation formula), exp, sqrt(1 - exp(2 log alpha)).  For
+        callers of model_fn(x, t) with per-sample times (model_wrapper's callable, ref :282-330); the solver itself never
+        needs it: every scalar of a sampling run is precomputed by the C planner."""
+        tt = t.reshape(-1)
+        if self.schedule == 'discrete':
+            key = (str(t.device),)
+            tab = self._dev_tables.get(key)
+            if tab is None:
+                tab = self._dev_tables[key] = (self.t_array.reshape(-1).to(t.device), self.log_alpha_array.reshape(-1).to(t.device))
+            xp, yp = tab
+            dt = torch.promote_types(tt.dtype, xp.dtype)
+            x = tt.to(dt)
+            xp, yp = xp.to(dt), yp.to(dt)
+            K = xp.shape[0]
+            idx = torch.searchsorted(xp, x.contiguous(), right=False)          # #{xp < x}
+            i0 = torch.where(idx == 0, torch.zeros_like(idx), torch.where(idx == K, torch.full_like(idx, K - 2), idx - 1))
+            i1 = i0 + 1
+            la = yp[i0] + (x - xp[i0]) * (yp[i1] - yp[i0]) / (xp[i1] - xp[i0])
+        elif self.schedule == 'linear':
+            la = -0.25 * tt ** 2 * (self.beta_1 - self.beta_0) - 0.5 * tt * self.beta_0
+        else:
+            raise NotImplementedError("device_alpha_sigma: schedule %r" % self.schedule)
+        return torch.exp(la), torch.sqrt(1. - torch.exp(2. * la))
 
     def marginal_log_mean_coeff(self, t):
         """log(alpha_t) of a continuous-time label t in [0, T]  (ref :127-134)."""
@@ -121,7 +173,10 @@ class NoiseScheduleVP:
         """t of a given half-logSNR lambda_t  (ref :156-167)."""
         if not torch.is_tensor(lamb):
             lamb = torch.as_tensor(lamb, dtype=torch.float32)
-        out = torch.from_numpy(self._eval_np(L.EVAL_INV_LAMBDA, lamb.detach().to(device="cpu", dtype=torch.float32).numpy()))
+        if self._double_scalars(lamb):
+            out = torch.from_numpy(self._eval_np64(L.EVAL_INV_LAMBDA, lamb.detach().to(device="cpu", dtype=torch.float64).numpy()))
+        else:
+            out = torch.from_numpy(self._eval_np(L.EVAL_INV_LAMBDA, lamb.detach().to(device="cpu", dtype=torch.float32).numpy()))
         if self.schedule != 'discrete':
             out = out.reshape(lamb.shape)
         return out.to(device=lamb.device)

@@ -21,7 +21,7 @@ from . import _lib as L
 from .correctors import MaskBlend
 from .wrapper import WrappedModel
 
-_DT = {torch.float32: L.DTYPE_F32, torch.float16: L.DTYPE_F16, torch.bfloat16: L.DTYPE_BF16}
+_DT = {torch.float32: L.DTYPE_F32, torch.float16: L.DTYPE_F16, torch.bfloat16: L.DTYPE_BF16, torch.float64: L.DTYPE_F64}
 _F32 = np.float32
 
 
@@ -101,7 +101,7 @@ def _in_layout_of(t, ref):
     return t if mf is None else _conv(t, t.dtype, mf)
 
 
-def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=None, opts=None):
+def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=None, opts=None, coef64=None):
     """One `dpm_stage_launch` on the current stream.  Allocates x_out (and m_out when the stage stores
     its model value) through torch's caching allocator; returns (x_out, m_out).
 
@@ -117,8 +117,8 @@ def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=No
     mf = _mf_of(e0) if (e0.shape == ref_t.shape and not (ext is not None and ext.get("blend") is not None)) else None
     x, xe, h1, h2 = _conv(x, sd, mf), _conv(xe, sd, mf), _conv(h1, sd, mf), _conv(h2, sd, mf)
     ed = e0.dtype
-    if ed not in _DT or (sd != torch.float32 and ed != sd):
-        ed = sd  # only (fp32 state, any eps) and equal low-precision pairs have kernels
+    if ed not in _DT or (sd != torch.float32 and ed != sd) or ed is torch.float64:
+        ed = sd  # only (fp32 state, any eps), equal low-precision pairs and (double, double) have kernels
     eps_stride = 0
     if mf is None and e0.dtype == ed and not e0.is_contiguous() and _sample_strided(e0) and e0.shape == ref_t.shape and (
             e1 is None or (e1.dtype == ed and _sample_strided(e1) and e1.stride(0) == e0.stride(0))):
@@ -166,6 +166,8 @@ def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=No
     b.eps_stride = eps_stride
     if opts is not None:
         b.opts = opts
+    if coef64 is not None and sd is torch.float64:
+        b.coef64 = C.pointer(coef64)           # the stage's scalars in double (a double-precision plan)
     stream, idx = _raw_stream(dev)
     ws = None
     if st.flags & L.F_THRESH:
@@ -224,6 +226,11 @@ def _adaptive_error(x_lower, x_higher, x_prev, atol, rtol):
     B = x_lower.shape[0]
     if B == 0:          # an empty shard of a batch-sharded run: contributes nothing to the batch maximum
         return torch.zeros((), dtype=torch.float32, device=x_lower.device)
+    if x_lower.dtype is torch.float64:
+        # double state (not a performance path): the reference's own tensor expression (ref :997-1001), on the device
+        delta = torch.max(torch.ones_like(x_lower) * atol, rtol * torch.max(torch.abs(x_lower), torch.abs(x_prev.to(x_lower.dtype))))
+        v = ((x_higher - x_lower) / delta).reshape((B, -1))
+        return torch.sqrt(torch.square(v).mean(dim=-1)).max()
     per_sample = x_lower.numel() // max(B, 1)
     e_dev = torch.empty((B + 1,), dtype=torch.float32, device=x_lower.device)
     xp = x_prev if x_prev.dtype == x_lower.dtype else x_prev.to(x_lower.dtype)
@@ -253,10 +260,17 @@ class _Plan:
         n = L.lib.dpm_plan_num_stages(self.handle)
         self.slots = L.lib.dpm_plan_num_slots(self.handle)
         self.stages = []
+        self.stages64 = None                 # double-precision plans: the dpm_stage_f64 twin of every stage
         for i in range(n):
             st = L.Stage()
             L.check(L.lib.dpm_plan_stage(self.handle, i, C.byref(st)))
             self.stages.append(st)
+        if desc.precision:
+            self.stages64 = []
+            for i in range(n):
+                s64 = L.StageF64()
+                L.check(L.lib.dpm_plan_stage_f64(self.handle, i, C.byref(s64)))
+                self.stages64.append(s64)
         self._dev = {}
         self._views = {}
         self.times_written = False
@@ -281,6 +295,15 @@ class _Plan:
         if key not in self._dev:
             arr = np.array([[s.t_eval for s in self.stages], [s.t_input for s in self.stages],
                             [s.t_out for s in self.stages]], dtype=np.float32)
+            self._dev[key] = torch.from_numpy(arr).to(device)
+        return self._dev[key]
+
+    def times64(self, device):
+        """double-precision plans: the same three rows in double"""
+        key = ("f64", str(device))
+        if key not in self._dev:
+            arr = np.array([[s.t_eval for s in self.stages64], [s.t_input for s in self.stages64],
+                            [s.t_out for s in self.stages64]], dtype=np.float64)
             self._dev[key] = torch.from_numpy(arr).to(device)
         return self._dev[key]
 
@@ -315,6 +338,23 @@ class _Plan:
                        t_input_b=[ti[i, :batch] for i in range(n)],
                        t_input_2b=[ti[i] for i in range(n)] if cfg else None,
                        base=(T, te, ti))
+            if self.stages64 is not None:
+                # A double-precision run hands the network the time in the dtype the reference's tensor has there: the
+                # grids torch.linspace builds are fp32 tensors also then (ref :472-477), whereas the singlestep solvers'
+                # inner nodes and the logSNR grid come out of inverse_lambda on double tables (ref :156-167) as doubles
+                # (dpm_stage_f64.time_f64, set by the planner).
+                T64 = self.times64(device)
+                te64 = T64[0].reshape(n, 1).repeat(1, batch)
+                ti64 = T64[1].reshape(n, 1).repeat(1, 2 * batch if cfg else batch)
+                for i, s64 in enumerate(self.stages64):
+                    if s64.time_f64 & 1:
+                        hit["t_eval"][i], hit["t_eval_b"][i] = T64[0, i], te64[i]
+                        hit["t_input_b"][i] = ti64[i, :batch]
+                        if cfg:
+                            hit["t_input_2b"][i] = ti64[i]
+                    if s64.time_f64 & 2:
+                        hit["t_out"][i] = T64[2, i]
+                hit["base"] = (T, te, ti, T64, te64, ti64)
             hit["ver"] = _versions(hit["base"])
             self._views[key] = hit
         return hit
@@ -503,6 +543,10 @@ class _FastRun:
             b.state_dtype = _DT[sd]
             if solver._opts_ptr() is not None:
                 b.opts = solver._opts_ptr()
+            if sd is torch.float64:
+                self.coef64 = getattr(self, "coef64", [])
+                self.coef64.append(solver._stage64(st, plan.stages64[i] if plan.stages64 is not None else None))
+                b.coef64 = C.pointer(self.coef64[-1])
             if st.flags & L.F_THRESH:
                 nb = L.lib.dpm_threshold_workspace_bytes(b.batch, n // b.batch)
                 if nb:
@@ -616,10 +660,21 @@ class DPM_Solver:
         if self._state_dtype is not None:
             return self._state_dtype
         if x.dtype not in _DT:
-            raise NotImplementedError("dpm_solver_amd: state dtype %s is not supported (fp32 / fp16 / bf16)" % x.dtype)
+            raise NotImplementedError("dpm_solver_amd: state dtype %s is not supported (fp64 / fp32 / fp16 / bf16)" % x.dtype)
+        # torch's type promotion between x and the reference's (1,)-shaped coefficient tensors (ref :573-576), which have the
+        # dtype of the schedule's tables for 'discrete' and of the time tensor (fp32) otherwise
+        if x.dtype is torch.float64:
+            return torch.float64
         if self.noise_schedule.schedule == 'discrete':
-            return torch.float32
+            return torch.float64 if getattr(self.noise_schedule, "dtype", torch.float32) == torch.float64 else torch.float32
         return x.dtype
+
+    def _precision(self, sd):
+        """1: the scalars of the run are doubles -- a double state on a 'discrete' schedule declared dtype=float64 (every
+        coefficient of the reference is then a double tensor); 0: fp32 scalars (meeting a double state they are converted
+        exactly, like the reference's fp32 coefficient tensors are by type promotion)"""
+        ns = self.noise_schedule
+        return int(sd is torch.float64 and ns.schedule == 'discrete' and getattr(ns, "dtype", torch.float32) == torch.float64)
 
     @staticmethod
     def _tf(t):
@@ -665,9 +720,29 @@ class DPM_Solver:
         eps next to an fp16 x on a 'linear' schedule, or fp16 next to bf16) continues in fp32 from the first update on
         (ref :573-576 are plain tensor expressions).  An explicit `state_dtype` keeps the state there and the output
         is converted to it."""
-        if self._state_dtype is None and sd is not torch.float32 and e0.dtype is not sd and e0.dtype in _DT:
+        if self._state_dtype is None and e0.dtype is torch.float64:
+            return torch.float64                    # a double network output promotes every state
+        if self._state_dtype is None and sd not in (torch.float32, torch.float64) and e0.dtype is not sd and e0.dtype in _DT:
             return torch.float32
         return sd
+
+    def _stage64(self, st, s64=None):
+        """the dpm_stage_f64 of a launch on a double state: the double-precision plan's record, or -- fp32 scalars (an fp32
+        schedule) -- the stage's floats converted exactly, as torch's type promotion converts the reference's fp32
+        coefficient tensors; either way with the thresholding parameters as the doubles torch.quantile / torch.maximum make
+        of the Python floats (ref :422-423)"""
+        out = L.StageF64()
+        if s64 is not None:
+            C.memmove(C.byref(out), C.byref(s64), C.sizeof(L.StageF64))
+        else:
+            for f in ("t_eval", "t_input", "t_out", "alpha_e", "sigma_e", "cfg_scale", "cg_scale", "cx", "c0", "c1", "c2",
+                      "blend_alpha", "blend_sigma"):
+                setattr(out, f, float(getattr(st, f)))
+            for j in range(5):
+                out.k[j] = float(st.k[j])
+        out.thr_ratio = float(self.dynamic_thresholding_ratio)
+        out.thr_max = float(self.thresholding_max_val)
+        return out
 
     def _prep_stage(self, st):
         """stage flags that depend on this solver's correctors"""
@@ -678,7 +753,7 @@ class DPM_Solver:
                 st.thr_max = float(self.thresholding_max_val)
         return st
 
-    def _run_stage(self, st, x, xe, outs, h1, h2, sd, t_eval_t, want_m=None, ext=None):
+    def _run_stage(self, st, x, xe, outs, h1, h2, sd, t_eval_t, want_m=None, ext=None, coef64=None):
         """outs = (e0, e1, g) fresh network outputs.  Handles a *callable* correcting_x0_fn by splitting the
         stage: prologue kernel -> user function (opaque torch) -> combination kernel."""
         e0, e1, g = outs
@@ -687,12 +762,12 @@ class DPM_Solver:
             s1.form = L.FORM_DENOISE
             s1.flags = L.F_TO_X0
             x0, _ = _launch_stage(s1, None, xe if xe is not None else x, e0, e1, g, None, None, sd, want_m=False,
-                                  opts=self._opts_ptr())
+                                  opts=self._opts_ptr(), coef64=coef64)
             x0 = self._call_x0(x0, t_eval_t)                                             # ref :440-441
-            return self._run_given(st, x, x0, h1, h2, sd, want_m, ext=ext)
-        return _launch_stage(st, x, xe, e0, e1, g, h1, h2, sd, want_m=want_m, ext=ext, opts=self._opts_ptr())
+            return self._run_given(st, x, x0, h1, h2, sd, want_m, ext=ext, coef64=coef64)
+        return _launch_stage(st, x, xe, e0, e1, g, h1, h2, sd, want_m=want_m, ext=ext, opts=self._opts_ptr(), coef64=coef64)
 
-    def _run_given(self, st, x, m, h1, h2, sd, want_m=None, ext=None):
+    def _run_given(self, st, x, m, h1, h2, sd, want_m=None, ext=None, coef64=None):
         """the update of `st` with the model value already known (no prologue)"""
         s2 = st.copy()
         s2.flags = st.flags & L.F_BASE_HIST
@@ -700,7 +775,7 @@ class DPM_Solver:
         s2.guidance = L.GUIDE["uncond"]
         store = bool(st.flags & L.F_STORE_M) if want_m is None else want_m
         x_out, _ = _launch_stage(s2, x if x is not None else m, None, m, None, None, h1, h2, sd, want_m=False, ext=ext,
-                                 opts=self._opts_ptr())
+                                 opts=self._opts_ptr(), coef64=coef64)
         return x_out, (m if store else None)
 
     # ------------------------------------------------------------------------------------------
@@ -717,7 +792,8 @@ class DPM_Solver:
         st.thr_max = float(self.thresholding_max_val)
         st.alpha_e, st.sigma_e, st.cfg_scale = 1.0, 0.0, 1.0
         sd = x0.dtype if x0.dtype in _DT else torch.float32
-        out, _ = _launch_stage(st, None, x0, x0, None, None, None, None, sd, want_m=False, opts=self._opts_ptr())
+        out, _ = _launch_stage(st, None, x0, x0, None, None, None, None, sd, want_m=False, opts=self._opts_ptr(),
+                               coef64=self._stage64(st) if sd is torch.float64 else None)
         return out
 
     def _eval_model(self, x, t, to_x0):
@@ -1024,7 +1100,7 @@ class DPM_Solver:
         # the device path too when sharded -- it runs the controller and the collectives, no stage launches.
         nonempty = x.numel() > 0 or (self.error_reduce is not None and x.dim() > 0)
         if (self.adaptive_on_device and x.is_cuda and x.dim() > 0 and nonempty and not self._thresholding
-                and self._user_x0 is None and not half_unknown):
+                and self._user_x0 is None and not half_unknown and self._sdtype(x) is not torch.float64):
             return self._adaptive_device(x, order, t_T, t_0, h_init, atol, rtol, theta, t_err, solver_type)
         ns = self.noise_schedule
         lam = lambda v: _F32(ns._eval_np(L.EVAL_LAMBDA, [v])[0])
@@ -1091,10 +1167,10 @@ class DPM_Solver:
                            method=method, lower_order_final=lower_order_final, denoise_to_zero=denoise_to_zero,
                            solver_type=solver_type, atol=atol, rtol=rtol, return_intermediate=return_intermediate)
 
-    def _get_plan(self, **kw):
+    def _get_plan(self, precision=0, **kw):
         mt, gd, sc = self._model_codes()
         key = (tuple(sorted(kw.items())), mt, gd, sc, self._thresholding, float(self.dynamic_thresholding_ratio),
-               float(self.thresholding_max_val), self.algorithm_type)
+               float(self.thresholding_max_val), self.algorithm_type, int(precision))
         plan = self._plans.get(key)
         if plan is None:
             d = L.PlanDesc()
@@ -1108,6 +1184,7 @@ class DPM_Solver:
             d.denoise_to_zero = int(bool(kw["denoise_to_zero"]))
             d.model_type, d.guidance, d.guidance_scale = mt, gd, sc
             d.thresholding = int(self._thresholding)
+            d.precision = int(precision)
             d.t_start, d.t_end = float(kw["t_T"]), float(kw["t_0"])
             d.thr_ratio = float(self.dynamic_thresholding_ratio)
             d.thr_max = float(self.thresholding_max_val)
@@ -1147,7 +1224,8 @@ class DPM_Solver:
                         raise ValueError("Solver order must be 1 or 2 or 3, got {}".format(order))
                 elif order not in (1, 2, 3):
                     raise ValueError("'order' must be '1' or '2' or '3'.")
-                plan = self._get_plan(method=method, order=order, steps=steps, skip_type=skip_type, solver_type=solver_type,
+                plan = self._get_plan(precision=self._precision(self._sdtype(x)), method=method, order=order, steps=steps,
+                                      skip_type=skip_type, solver_type=solver_type,
                                       lower_order_final=lower_order_final, denoise_to_zero=denoise_to_zero,
                                       t_T=float(t_T), t_0=float(t_0))
                 x = self._run_plan(plan, x, method, cxt, return_intermediate, intermediates)
@@ -1383,7 +1461,10 @@ class DPM_Solver:
                 ext["dup"] = True
             if blend is not None and st.emits_state:
                 ext["blend"] = blend.operands(x.shape, sd, device, ps.t_out, st.outer_step)
-            x_out, m_out = self._run_stage(st, state, xe, outs, h1, h2, sd, V["t_eval"][i], ext=ext or None)
+            c64 = None
+            if sd is torch.float64:
+                c64 = self._stage64(st, plan.stages64[i] if plan.stages64 is not None else None)
+            x_out, m_out = self._run_stage(st, state, xe, outs, h1, h2, sd, V["t_eval"][i], ext=ext or None, coef64=c64)
             if st.m_slot >= 0:
                 hist[st.m_slot] = m_out
             if st.emits_state:

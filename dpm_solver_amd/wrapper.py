@@ -7,11 +7,7 @@ blend (ref :326-330) and the classifier-guidance term (ref :315-321) into the pr
 kernel instead of running them as separate elementwise passes.  The network itself (and the autograd
 call through the classifier) stays an opaque PyTorch-ROCm call on the current stream.
 """
-import ctypes as C
-
 import torch
-
-from . import _lib as L
 
 
 class WrappedModel:
@@ -80,25 +76,34 @@ class WrappedModel:
 
     # ---- reference-compatible call: noise prediction ------------------------------------------
     def __call__(self, x, t_continuous):
-        """The reference's model_fn(x, t_continuous) -> noise (ref :309-330), for callers other than
-        DPM_Solver.  Runs the raw network(s) and one prologue-only stage kernel."""
-        from .solver import _launch_stage, _require_gpu
+        """The reference's model_fn(x, t_continuous) -> noise (ref :282-330) for callers OTHER than DPM_Solver (which fuses
+        these conversions into its stage kernels and never comes here): the raw network call(s), then the reference's own
+        tensor expressions in torch on x's device -- per-sample times (`t_continuous` of shape (B,) with distinct entries)
+        included, no host synchronisation (the schedule is evaluated on the device, NoiseScheduleVP.device_alpha_sigma)."""
+        from .utils import expand_dims
+        from .solver import _require_gpu
         _require_gpu(x)
-        tc = t_continuous.reshape(-1)
-        t0 = float(tc[0])
-        if tc.numel() > 1 and not bool((tc == tc[0]).all()):
-            raise NotImplementedError("dpm_solver_amd: per-sample time labels are not supported (the reference "
-                                      "solver always passes one time for the whole batch)")
         e0, e1, g = self.raw_outputs(x, t_continuous)
-        st = L.Stage()
-        st.h1_slot = st.h2_slot = st.m_slot = -1
-        L.check(L.lib.dpm_coef_prologue(self.noise_schedule._h, t0, L.MODEL[self.model_type],
-                                        L.GUIDE[self.effective_guidance], float(self.guidance_scale), C.byref(st)))
-        st.form = L.FORM_DENOISE
-        st.flags = 0
-        sd = x.dtype if x.dtype in (torch.float32, torch.float16, torch.bfloat16) else torch.float32
-        out, _ = _launch_stage(st, x=None, xe=x, e0=e0, e1=e1, g=g, h1=None, h2=None, state_dtype=sd, want_m=False)
-        return out
+        mt = self.model_type
+        dims = x.dim()
+
+        def to_noise(out):                                        # noise_pred_fn, ref :288-298
+            if mt == "noise":
+                return out
+            alpha_t, sigma_t = self.noise_schedule.device_alpha_sigma(t_continuous)
+            if mt == "x_start":
+                return (x - expand_dims(alpha_t, dims) * out) / expand_dims(sigma_t, dims)
+            if mt == "v":
+                return expand_dims(alpha_t, dims) * out + expand_dims(sigma_t, dims) * x
+            return -expand_dims(sigma_t, dims) * out              # "score"
+        eff = self.effective_guidance
+        if eff == "classifier":                                   # ref :315-321
+            _, sigma_t = self.noise_schedule.device_alpha_sigma(t_continuous)
+            return to_noise(e0) - self.guidance_scale * expand_dims(sigma_t, dims) * g
+        if eff == "classifier-free":                              # ref :326-330
+            nu, nc = to_noise(e1), to_noise(e0)
+            return nu + self.guidance_scale * (nc - nu)
+        return to_noise(e0)
 
 
 def model_wrapper(model, noise_schedule, model_type="noise", model_kwargs={}, guidance_type="uncond",

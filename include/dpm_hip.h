@@ -127,6 +127,22 @@ typedef struct dpm_stage {
   float blend_sigma;   /* DPM_F_BLEND: sigma at that time                                        */
 } dpm_stage;
 
+/* The float fields of dpm_stage in double: a double-precision run (state DPM_DTYPE_F64; dpm_plan_desc.precision = 1).
+   The reference computes in whatever dtype torch's type promotion yields (ref :14, :105-107, :573-576): with a double state
+   and NoiseScheduleVP(dtype=torch.float64) every scalar of a step is a double.  dpm_plan_stage_f64 returns these next to
+   the dpm_stage of the same index (whose float fields are the doubles rounded); a launch finds them through
+   dpm_buffers.coef64 (NULL: the launch converts the dpm_stage's floats exactly -- a double state on an fp32 schedule, where
+   the reference's scalars ARE fp32 tensors). */
+typedef struct dpm_stage_f64 {
+  double t_eval, t_input, t_out, alpha_e, sigma_e, cfg_scale, cg_scale, cx, c0, c1, c2, k[5], thr_ratio, thr_max, blend_alpha,
+      blend_sigma;
+  int32_t time_f64;  /* dtype of the reference's time TENSORS in this run: bit 0 set = the tensor the network is called with
+                        at t_eval is a double (singlestep inner nodes, logSNR grids: they come out of inverse_lambda on double
+                        tables), clear = an fp32 tensor (torch.linspace grids, ref :472-477) and t_input was computed in fp32
+                        (ref :278); bit 1: the same for t_out (the time handed to correcting_xt_fn)                       */
+  int32_t reserved;
+} dpm_stage_f64;
+
 /* ---- per-call options (optional; NULL or all-zero = the defaults) ------------------------ */
 typedef struct dpm_launch_opts {
   int32_t cluster_in_graph; /* 1: dynamic thresholding keeps its workgroup clusters under stream capture also for samples
@@ -179,6 +195,7 @@ typedef struct dpm_buffers {
                           (diagnostics: 1 predicted, 2 prediction rejected, 3 single exchange, 4 general); [3]: entries of
                           the last union gathered (diagnostics)                                                      */
   const dpm_launch_opts* opts; /* per-call options, NULL = defaults (version 200; dpm_stage_launch_multi reads bs[0].opts) */
+  const dpm_stage_f64* coef64; /* DPM_DTYPE_F64 launches: the stage's scalars in double (NULL: the dpm_stage's floats, exactly) */
 } dpm_buffers;
 
 /* ---- noise schedule (NoiseScheduleVP, ref :6-167) --------------------------------------- */
@@ -198,6 +215,11 @@ int dpm_schedule_create_linear(double beta_0, double beta_1, dpm_schedule** out)
 /* the continuous-time 'cosine' schedule of the older vendored revision (examples/score_sde_pytorch/dpm_solver.py
    :114-124,:134-137,:171-175): s = 0.008, T = 0.9946 (the caller's default end time) */
 int dpm_schedule_create_cosine(dpm_schedule** out);
+/* NoiseScheduleVP(dtype=torch.float64) (ref :14, :105-107): the tables keep the double values they were computed in (the
+   *_f64 constructors) instead of their fp32 roundings -- what double-precision plans and dpm_schedule_eval_f64 read.  Part of
+   construction: call it right after dpm_schedule_create_*, before the handle is shared. */
+int dpm_schedule_set_table_dtype(dpm_schedule* s, int dtype /* DPM_DTYPE_F32 | DPM_DTYPE_F64 */);
+int dpm_schedule_tables_f64(const dpm_schedule* s, const double** log_alpha, const double** t_array, int* K);
 void dpm_schedule_destroy(dpm_schedule* s);
 int dpm_schedule_is_discrete(const dpm_schedule* s);
 int dpm_schedule_total_N(const dpm_schedule* s);                                                       /* ref :106,:110 */
@@ -205,6 +227,7 @@ int dpm_schedule_total_N(const dpm_schedule* s);                                
 int dpm_schedule_tables(const dpm_schedule* s, const float** log_alpha, const float** t_array, int* K);
 /* marginal_log_mean_coeff / marginal_alpha / marginal_std / marginal_lambda / inverse_lambda (ref :127-167) */
 int dpm_schedule_eval(const dpm_schedule* s, int what, const float* in, int n, float* out);
+int dpm_schedule_eval_f64(const dpm_schedule* s, int what, const double* in, int n, double* out);  /* double times / tables */
 
 /* ---- time grids (ref :453-539) ---------------------------------------------------------- */
 int dpm_time_steps(const dpm_schedule* s, int skip_type, double t_T, double t_0, int N, float* out /* N+1 */);
@@ -225,7 +248,9 @@ typedef struct dpm_plan_desc {
   int32_t model_type;        /* DPM_MODEL_*                       */
   int32_t guidance;          /* DPM_GUIDE_*                       */
   int32_t thresholding;      /* bool: correcting_x0_fn == "dynamic_thresholding" */
-  int32_t reserved;
+  int32_t precision;         /* 0: scalars in fp32, the reference's default (fp32 schedule tables and times); 1: in double --
+                                a double state on a schedule declared dtype=float64 (dpm_schedule_set_table_dtype), or whose
+                                times are doubles: dpm_plan_stage_f64 then returns the doubles (version 200; was `reserved`) */
   double t_start;            /* t_T                               */
   double t_end;              /* t_0                               */
   double guidance_scale;
@@ -239,6 +264,7 @@ void dpm_plan_destroy(dpm_plan* p);
 int dpm_plan_num_stages(const dpm_plan* p);
 int dpm_plan_num_slots(const dpm_plan* p);                 /* history buffers the loop needs      */
 int dpm_plan_stage(const dpm_plan* p, int i, dpm_stage* out);
+int dpm_plan_stage_f64(const dpm_plan* p, int i, dpm_stage_f64* out);   /* double-precision plans only */
 int dpm_plan_timesteps(const dpm_plan* p, float* out, int cap, int* n); /* solver grid t_0..t_K    */
 
 /* ---- coefficient builders for the reference's public per-update methods -------------------- */
@@ -399,7 +425,7 @@ void dpm_graph_destroy(dpm_graph* g);
 int dpm_version(void);
 /* sizeof() of the ABI structs as compiled, so a binding can verify its own layout at load time */
 enum { DPM_SIZEOF_STAGE = 0, DPM_SIZEOF_BUFFERS = 1, DPM_SIZEOF_PLAN_DESC = 2, DPM_SIZEOF_RUN_BUFFERS = 3,
-       DPM_SIZEOF_ADAPTIVE_DESC = 4, DPM_SIZEOF_LAUNCH_OPTS = 5 };
+       DPM_SIZEOF_ADAPTIVE_DESC = 4, DPM_SIZEOF_LAUNCH_OPTS = 5, DPM_SIZEOF_STAGE_F64 = 6 };
 size_t dpm_sizeof(int which);
 const char* dpm_last_error(void); /* thread-local text of the last non-zero return */
 int dpm_device_info(int* n_cu, int* lds_bytes, char* arch, int arch_len);

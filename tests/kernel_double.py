@@ -16,12 +16,37 @@ from oracle import dpm_oracle as O
 F32 = np.float32
 
 
+F64 = np.float64
+
+
 def _np(t):
-    return None if t is None else t.detach().cpu().float().numpy()
+    if t is None:
+        return None
+    t = t.detach().cpu()
+    return t.numpy() if t.dtype == torch.float64 else t.float().numpy()
+
+
+class _Coef:
+    """the scalars of a stage in the arithmetic type FT of the launch: np.float32 (the stage record's floats), or -- a
+    double-precision state, dpm_f64.hip -- np.float64 from the dpm_stage_f64 record (coef64) when the plan is a
+    double-precision one, else the record's floats converted exactly (torch's type promotion of fp32 scalars)"""
+
+    def __init__(self, st, FT=F32, c64=None):
+        src = c64 if (FT is F64 and c64 is not None) else st
+        for f in ("alpha_e", "sigma_e", "cfg_scale", "cg_scale", "cx", "c0", "c1", "c2", "thr_ratio", "thr_max"):
+            setattr(self, f, FT(getattr(src, f)))
+        self.k = [FT(v) for v in src.k]
+        self.model_type, self.guidance, self.flags, self.form = st.model_type, st.guidance, st.flags, st.form
+        self.FT = FT
+
+
+def _as_coef(st):
+    return st if isinstance(st, _Coef) else _Coef(st)
 
 
 def to_noise(o, xe, st):
-    a, s = F32(st.alpha_e), F32(st.sigma_e)
+    st = _as_coef(st)
+    a, s = st.alpha_e, st.sigma_e
     if st.model_type == L.MODEL["x_start"]:
         return (xe - a * o) / s
     if st.model_type == L.MODEL["v"]:
@@ -32,21 +57,25 @@ def to_noise(o, xe, st):
 
 
 def prologue(st, xe, e0, e1, g):
+    st = _as_coef(st)
+    FT = st.FT
     if st.guidance == L.GUIDE["classifier-free"]:
         nu, nc = to_noise(e1, xe, st), to_noise(e0, xe, st)
-        eps = nu + F32(st.cfg_scale) * (nc - nu)
+        eps = nu + st.cfg_scale * (nc - nu)
     elif st.guidance == L.GUIDE["classifier"]:
-        eps = to_noise(e0, xe, st) - F32(st.cg_scale) * g
+        eps = to_noise(e0, xe, st) - st.cg_scale * g
     else:
         eps = to_noise(e0, xe, st)
     if st.flags & L.F_TO_X0:
-        return ((xe - F32(st.sigma_e) * eps) / F32(st.alpha_e)).astype(F32)
-    return eps.astype(F32)
+        return ((xe - st.sigma_e * eps) / st.alpha_e).astype(FT)
+    return eps.astype(FT)
 
 
 def combine(st, x, mn, h1, h2):
-    cx, c0, c1, c2 = F32(st.cx), F32(st.c0), F32(st.c1), F32(st.c2)
-    k = [F32(v) for v in st.k]
+    st = _as_coef(st)
+    F32 = st.FT                                  # (the literals below in the launch's arithmetic type)
+    cx, c0, c1, c2 = st.cx, st.c0, st.c1, st.c2
+    k = st.k
     if st.form == L.FORM_LIN1:
         return cx * x - c0 * mn
     if st.form == L.FORM_TWO:
@@ -79,22 +108,46 @@ def blend(st_alpha, st_sigma, v, mask, a, b):
     return (v * m + (F32(1.0) - m) * r).astype(F32)
 
 
-def launch_stage_double(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=None, opts=None):
+def threshold64(x0, ratio, max_val):
+    """dynamic thresholding in double (stage_thresh_kernel_f64; ref :416-425 with torch.quantile's semantics: ascending
+    rank q (n - 1) in double, ATen's lerp)"""
+    rows = x0.reshape(x0.shape[0], -1)
+    srt = np.sort(np.abs(rows), axis=1)
+    n = rows.shape[1]
+    rank = F64(ratio) * F64(n - 1)
+    lo, hi = int(np.floor(rank)), int(np.ceil(rank))
+    w = rank - F64(lo)
+    a, b = srt[:, lo], srt[:, hi]
+    q = a + w * (b - a) if w < 0.5 else b - (b - a) * (F64(1.0) - w)
+    s = np.maximum(q, F64(max_val)).reshape((-1,) + (1,) * (x0.ndim - 1))
+    return np.clip(x0, -s, s) / s
+
+
+def launch_stage_double(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=None, opts=None, coef64=None):
     ref_t = x if x is not None else xe
-    xn, xen = _np(x), _np(xe)
+    FT = F64 if state_dtype == torch.float64 else F32
+    c = _Coef(st, FT, coef64.contents if coef64 is not None and hasattr(coef64, "contents") else coef64)
+    cast = (lambda a: None if a is None else a.astype(FT)) if FT is F64 else (lambda a: a)
+    xn, xen = cast(_np(x)), cast(_np(xe))
     if xen is None:
         xen = xn
     if xn is None:
         xn = xen
-    mn = prologue(st, xen, _np(e0), _np(e1), _np(g))
+    mn = prologue(c, xen, cast(_np(e0)), cast(_np(e1)), cast(_np(g)))
     if st.flags & L.F_THRESH:
-        mn = O.dynamic_threshold(mn, F32(st.thr_ratio), F32(st.thr_max))
-    out = combine(st, xn, mn, _np(h1), _np(h2)).astype(F32)
+        mn = threshold64(mn, c.thr_ratio, c.thr_max) if FT is F64 else O.dynamic_threshold(mn, F32(st.thr_ratio), F32(st.thr_max))
+    out = combine(c, xn, mn, cast(_np(h1)), cast(_np(h2))).astype(FT)
     store = bool(st.flags & L.F_STORE_M) if want_m is None else want_m
     conv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(state_dtype).reshape(ref_t.shape)
     if ext is not None and ext.get("blend") is not None:
         mask, period, ba, bb, alpha, sigma = ext["blend"]
-        out = blend(alpha, sigma, conv(out).float().numpy(), _np(mask), _np(ba), _np(bb))
+        if FT is F64:
+            m_, a_, b_ = _np(mask).astype(F64), _np(ba).astype(F64), (None if bb is None else _np(bb).astype(F64))
+            mm = np.broadcast_to(m_.reshape((1,) * (out.ndim - m_.ndim) + m_.shape), out.shape) if m_.size != out.size else m_.reshape(out.shape)
+            r = a_ if b_ is None else F64(alpha) * a_ + F64(sigma) * b_
+            out = out * mm + (F64(1.0) - mm) * r
+        else:
+            out = blend(alpha, sigma, conv(out).float().numpy(), _np(mask), _np(ba), _np(bb))
     x_out = conv(out)
     if ext is not None and ext.get("dup"):
         ext["x2"] = torch.cat([x_out, x_out])
@@ -148,13 +201,15 @@ def _eval1(h, what, t):
 # ------------------------------------------------------------------------------------------------
 import ctypes as _C
 
-_SIZES = {L.DTYPE_F32: 4, L.DTYPE_F16: 2, L.DTYPE_BF16: 2}
+_SIZES = {L.DTYPE_F32: 4, L.DTYPE_F16: 2, L.DTYPE_BF16: 2, L.DTYPE_F64: 8}
 
 
 def _rd(ptr, n, code):
     if not ptr:
         return None
     raw = np.frombuffer((_C.c_char * (n * _SIZES[code])).from_address(ptr), dtype=np.uint8)
+    if code == L.DTYPE_F64:
+        return raw.view(np.float64).copy()
     if code == L.DTYPE_F32:
         return raw.view(np.float32).copy()
     if code == L.DTYPE_F16:
@@ -163,10 +218,12 @@ def _rd(ptr, n, code):
 
 
 def _wr(ptr, arr, code):
-    a = np.ascontiguousarray(arr, dtype=F32).reshape(-1)
+    a = np.ascontiguousarray(arr, dtype=F64 if code == L.DTYPE_F64 else F32).reshape(-1)
     n = a.size
     dst = np.frombuffer((_C.c_char * (n * _SIZES[code])).from_address(ptr), dtype=np.uint8)
-    if code == L.DTYPE_F32:
+    if code == L.DTYPE_F64:
+        dst.view(np.float64)[:] = a
+    elif code == L.DTYPE_F32:
         dst.view(np.float32)[:] = a
     elif code == L.DTYPE_F16:
         dst.view(np.float16)[:] = a.astype(np.float16)
@@ -193,11 +250,17 @@ def launch_raw_double(st_ref, b_ref, stream):
         xe = x
     if x is None:
         x = xe
-    mn = prologue(st, xe, eps(b.e0), eps(b.e1), _rd(b.g, n, ed))
+    FT = F64 if sd == L.DTYPE_F64 else F32
+    assert FT is F32 or ed == L.DTYPE_F64, "a double state needs double network outputs"
+    c = _Coef(st, FT, b.coef64.contents if b.coef64 else None)
+    mn = prologue(c, xe, eps(b.e0), eps(b.e1), _rd(b.g, n, ed))
     if st.flags & L.F_THRESH:
-        mn = O.dynamic_threshold(mn.reshape(B, per), F32(st.thr_ratio), F32(st.thr_max)).reshape(-1)
+        if FT is F64:
+            mn = threshold64(mn.reshape(B, per), c.thr_ratio, c.thr_max).reshape(-1)
+        else:
+            mn = O.dynamic_threshold(mn.reshape(B, per), F32(st.thr_ratio), F32(st.thr_max)).reshape(-1)
     assert not (st.flags & L.F_BLEND), "the fast path never carries a blend"
-    out = combine(st, x, mn, _rd(b.h1, n, sd), _rd(b.h2, n, sd)).astype(F32)
+    out = combine(c, x, mn, _rd(b.h1, n, sd), _rd(b.h2, n, sd)).astype(FT)
     _wr(b.x_out, out, sd)
     if b.x_out2:
         _wr(b.x_out2, out, sd)

@@ -21,10 +21,11 @@ dpm_adaptive_error_launch dpm_adaptive_poll dpm_adaptive_reset dpm_adaptive_stag
 dpm_add_noise_launch dpm_blend_launch dpm_cluster_timeout_poll dpm_coef_first dpm_coef_multistep dpm_coef_prologue
 dpm_coef_singlestep dpm_device_info dpm_graph_create dpm_graph_destroy dpm_graph_launch dpm_graph_num_nodes
 dpm_graph_result dpm_last_error dpm_numerical_clip_len_f32 dpm_numerical_clip_len_f64 dpm_plan_create dpm_plan_destroy
-dpm_plan_num_slots dpm_plan_num_stages dpm_plan_run dpm_plan_run_multi dpm_plan_stage dpm_plan_timesteps
+dpm_plan_num_slots dpm_plan_num_stages dpm_plan_run dpm_plan_run_multi dpm_plan_stage dpm_plan_stage_f64 dpm_plan_timesteps
 dpm_schedule_create_alphas_cumprod_f32 dpm_schedule_create_alphas_cumprod_f64 dpm_schedule_create_betas_f32
 dpm_schedule_create_betas_f64 dpm_schedule_create_cosine dpm_schedule_create_linear dpm_schedule_create_log_alpha
-dpm_schedule_destroy dpm_schedule_eval dpm_schedule_is_discrete dpm_schedule_tables dpm_schedule_total_N
+dpm_schedule_destroy dpm_schedule_eval dpm_schedule_eval_f64 dpm_schedule_is_discrete dpm_schedule_set_table_dtype
+dpm_schedule_tables dpm_schedule_tables_f64 dpm_schedule_total_N
 dpm_singlestep_grid dpm_singlestep_orders dpm_sizeof dpm_stage_launch dpm_stage_launch_multi
 dpm_threshold_workspace_bytes dpm_time_steps dpm_version
 """.split()
@@ -75,10 +76,11 @@ def test_lab_library_exports_both_headers():
 
 def test_struct_layouts_match_header():
     # sizes are part of the ABI: the ctypes mirrors against sizeof() as compiled, and against the header by count
-    for i, t in enumerate((L.Stage, L.Buffers, L.PlanDesc, L.RunBuffers, L.AdaptiveDesc, L.LaunchOpts)):
+    for i, t in enumerate((L.Stage, L.Buffers, L.PlanDesc, L.RunBuffers, L.AdaptiveDesc, L.LaunchOpts, L.StageF64)):
         assert L.lib.dpm_sizeof(i) == ctypes.sizeof(t), t.__name__
     assert ctypes.sizeof(L.Stage) == 12 * 4 + 20 * 4                       # 12 int32 + 20 float
-    assert ctypes.sizeof(L.Buffers) == 16 * 8 + 4 * 8 + 4 * 4              # 16 pointers (+ opts), 4 int64, 4 int32
+    assert ctypes.sizeof(L.Buffers) == 17 * 8 + 4 * 8 + 4 * 4              # 17 pointers (+ opts, coef64), 4 int64, 4 int32
+    assert ctypes.sizeof(L.StageF64) == 20 * 8 + 2 * 4
     assert ctypes.sizeof(L.PlanDesc) == 12 * 4 + 5 * 8
     assert ctypes.sizeof(L.RunBuffers) == 10 * 8 + 2 * 8 + 2 * 4 + 8 + 2 * 4 + 8 + 8  # + thr_hint, opts
     assert ctypes.sizeof(L.LaunchOpts) == 8 * 4

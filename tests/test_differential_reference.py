@@ -220,3 +220,109 @@ def test_dtype_promotion_of_a_half_state_follows_the_reference(R, xdt, edt):
     got2, inter = D.DPM_Solver(D.model_wrapper(net, ns), ns, algorithm_type="dpmsolver").sample(
         x, steps=6, order=2, return_intermediate=True)
     assert got2.dtype == want.dtype and torch.equal(got2, got)
+
+
+# ------------------------------------------------------------------------------------------------
+# round 5: a double-precision state (ref :14, :105-107) and per-sample times through model_fn(x, t) (ref :282-330)
+# ------------------------------------------------------------------------------------------------
+def _f64_schedules(R, name, dtype):
+    si = C.schedule_inputs(name)
+    key = "betas" if "betas" in si else "alphas_cumprod"
+    arr = torch.from_numpy(np.asarray(si[key], dtype=np.float64))
+    return R.NoiseScheduleVP("discrete", dtype=dtype, **{key: arr}), D.NoiseScheduleVP("discrete", dtype=dtype, **{key: arr})
+
+
+@pytest.mark.parametrize("ns_dtype,tol", [(torch.float64, 1e-12), (torch.float32, 1e-6)])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_double_precision_state_against_the_reference(R, ns_dtype, tol, seed):
+    """`sample(x.double())`: the reference computes in whatever dtype torch's type promotion yields.  On a schedule declared
+    dtype=float64 every scalar is a double (the planner's double-precision plans, dpm_plan_desc.precision): 1e-12 -- and
+    the time tensors handed to the network have the reference's dtypes (fp32 for linspace grids, double for the nodes that
+    come out of inverse_lambda).  On an fp32 schedule the reference's coefficients are fp32 tensors that meet double
+    states: the engine's fp32 coefficients converted exactly; 1e-6 (one ulp of an fp32 coefficient where torch's libm
+    rounds an elementary function differently -- most runs are bit-identical).  One fp32 step survives in a double run:
+    the logSNR grid's logaddexp runs on an fp32 tensor in the reference (ref :165 on the torch.linspace of ref :472), so a
+    grid time can differ by one fp32 ulp between torch's vectorised libm and a correctly rounded one: the states AT that time
+    then differ by 6e-8 of the time times dx/dt -- 1e-7 there."""
+    rng = np.random.default_rng(4000 + seed)
+    n = 0
+    seen_dtypes = set()
+    for _ in range(14):
+        cfg = random_case(rng)
+        cfg["cxt"] = cfg["cx0"] = False
+        if cfg["schedule"] == "vp_linear":
+            cfg["schedule"] = "ddpm"                   # dtype= only matters to 'discrete' schedules
+        if cfg["thresholding"] and cfg["algorithm_type"] == "dpmsolver":
+            cfg["thresholding"] = False
+        if cfg["call"] == "inverse":
+            cfg["denoise_to_zero"] = False
+            if cfg["model_type"] == "x_start":
+                cfg["model_type"] = "v"
+        g = np.random.default_rng(cfg["seed"])
+        x = torch.from_numpy(g.standard_normal((2, 3, 6, 6)))
+        assert x.dtype == torch.float64
+        mask = torch.from_numpy(g.random((6, 6)))
+        rns, ens = _f64_schedules(R, cfg["schedule"], ns_dtype)
+        assert ens.log_alpha_array.dtype == rns.log_alpha_array.dtype == ns_dtype
+        # (equal up to the last bit of a double log / cumsum: torch's vectorised libm against glibc's)
+        assert torch.allclose(ens.log_alpha_array, rns.log_alpha_array, rtol=1e-14, atol=0) and torch.equal(ens.t_array, rns.t_array)
+        want, wi = run(R, rns, cfg, x, mask)
+        if not bool(torch.isfinite(want).all()):
+            continue
+        got, gi = run(D, ens, cfg, x, mask)
+        assert got.dtype == want.dtype == torch.float64, cfg
+        peak = max(float(b.abs().max()) for b in wi + [want])
+        tl = max(tol, 1e-7) if cfg["skip_type"] == "logSNR" else tol
+        assert float((got - want).abs().max()) <= tl * peak, (cfg, float((got - want).abs().max()) / peak)
+        assert len(gi) == len(wi)
+        for a, b in zip(gi, wi):
+            assert a.dtype == b.dtype and float((a - b).abs().max()) <= tl * peak, cfg
+        n += 1
+    assert n >= 8
+
+
+def test_double_precision_time_tensors_have_the_reference_dtypes(R):
+    """the network of a double-precision run is called with fp32 time tensors where the reference's grid comes from
+    torch.linspace and with double tensors at the singlestep solvers' inner nodes / on a logSNR grid (values equal to the
+    last bit either way)"""
+    rns, ens = _f64_schedules(R, "ddpm", torch.float64)
+    x = torch.from_numpy(np.random.default_rng(5).standard_normal((2, 3, 4, 4)))
+    for kw in (dict(steps=6, order=3, method="singlestep"), dict(steps=7, order=2, skip_type="logSNR"),
+               dict(steps=5, order=2, denoise_to_zero=True)):
+        seen = {"r": [], "e": []}
+
+        def net(tag):
+            def f(xx, t):
+                seen[tag].append((t.dtype, tuple(t.shape), float(t[0])))
+                return xx * 0.5
+            return f
+        R.DPM_Solver(R.model_wrapper(net("r"), rns), rns).sample(x, **kw)
+        D.DPM_Solver(D.model_wrapper(net("e"), ens), ens).sample(x, **kw)
+        assert seen["r"] == seen["e"], kw
+        D.DPM_Solver(D.model_wrapper(net("e"), ens), ens).sample(x, return_intermediate=True, **kw)   # the general loop
+        assert seen["e"][len(seen["r"]):] == seen["r"], kw
+
+
+@pytest.mark.parametrize("model_type", ["noise", "x_start", "v", "score"])
+@pytest.mark.parametrize("guidance", ["uncond", "classifier-free", "classifier"])
+def test_model_fn_with_per_sample_times_against_the_reference(R, model_type, guidance):
+    """model_wrapper's callable for callers OTHER than the solver: `model_fn(x, t_continuous)` with a different time per
+    sample (ref :282-330 broadcasts a (B,) time through every conversion)."""
+    for sched in ("ddpm", "vp_linear"):
+        rns, ens = ref_schedule(R, sched), make_schedule(sched)
+        g = np.random.default_rng(77)
+        x = torch.from_numpy(g.standard_normal((5, 3, 6, 6)).astype(F32))
+        t = torch.tensor([0.9, 0.11, 0.5, 0.0312, 0.77], dtype=torch.float32)
+        cfg = dict(model_type=model_type, guidance=guidance, scale=3.5, algorithm_type="dpmsolver++", thresholding=False,
+                   cx0=False, cxt=False)
+        # the wrapped functions themselves (the reference keeps its one inside DPM_Solver.model's closure, ref :404)
+        rwrapped = build(R, rns, cfg, x, None)
+        efn = build(D, ens, cfg, x, None)._model_fn
+        rcell = [c.cell_contents for c in rwrapped.model.__closure__ if callable(c.cell_contents)][0]
+        want = rcell(x, t)
+        got = efn(x, t)
+        assert got.shape == want.shape and got.dtype == want.dtype
+        assert rel_err(got.numpy(), want.numpy()) < TOL, (sched, model_type, guidance)
+        # and a uniform vector equals the 0-dim path of the solver's own evaluation
+        t1 = torch.full((5,), 0.37)
+        assert rel_err(efn(x, t1).numpy(), rcell(x, t1).numpy()) < TOL

@@ -773,7 +773,7 @@ def test_lab_suite_on_the_lab_build():
     switches, forced workgroup sizes, event-bracketed launches, the side-stream helpers -- run on the LAB build of the same
     sources (tools/_variants/lab/libdpm_lab.so, -DDPM_LAB=1) in a subprocess."""
     from conftest import run_lab_suite
-    assert run_lab_suite("lab and gpu") >= 40
+    assert run_lab_suite("lab and gpu") >= 30
 
 
 def test_quickstart_example_runs():

@@ -907,3 +907,84 @@ def test_two_processes_run_clustered_thresholding_on_one_gpu():
     for r in res:
         assert r["ok"], r
         assert r["trajectories"] >= 20 and r["overlapped"], r
+
+
+# ------------------------------------------------------------------------------------------------
+# round 5: a double-precision state through the C ABI (dpm_f64.hip) and the LDS-DMA variant of the lone-launch kernels
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ns_dtype", [torch.float64, torch.float32])
+def test_double_precision_state_on_the_gpu(ns_dtype, monkeypatch):
+    """sample(x.double()) (ref :14, :105-107): DPM_DTYPE_F64 launches -- multistep, singlestep (double inner-node times),
+    logSNR, classifier-free guidance with the duplicate store, v-prediction, dynamic thresholding (63-bit radix select),
+    denoise_to_zero, the general loop with intermediates -- against the numpy double of the same stage arithmetic driven by
+    the same plan: the GPU computes IEEE double without contraction, so the states agree to the last bits (1e-14 of the
+    scale); tests/test_differential_reference.py pins that double to the reference (1e-12 / 1e-6)."""
+    betas = torch.linspace(1e-4, 0.02, 1000, dtype=torch.float64)
+    rng = np.random.default_rng(64)
+    xc = torch.from_numpy(rng.standard_normal((6, 3, 16, 16)))
+    cond = torch.arange(1, 7, dtype=torch.float64) * 0.5
+    net = lambda xx, t: xx * 0.5 * torch.cos(t.to(xx.dtype) * 1e-3).reshape(-1, 1, 1, 1) + 0.1
+    netc = lambda xx, t, c: net(xx, t) * (1.0 + 0.1 * c.to(xx.dtype).reshape(-1, 1, 1, 1))
+
+    def solver(dev, kind):
+        ns = D.NoiseScheduleVP("discrete", betas=betas, dtype=ns_dtype)
+        if kind == "cfg":
+            fn = D.model_wrapper(netc, ns, guidance_type="classifier-free", condition=cond.to(dev),
+                                 unconditional_condition=torch.zeros(6, dtype=torch.float64, device=dev), guidance_scale=3.0)
+            return D.DPM_Solver(fn, ns)
+        if kind == "v":
+            return D.DPM_Solver(D.model_wrapper(net, ns, model_type="v"), ns, algorithm_type="dpmsolver")
+        if kind == "thr":
+            return D.DPM_Solver(D.model_wrapper(net, ns), ns, correcting_x0_fn="dynamic_thresholding", dynamic_thresholding_ratio=0.93)
+        return D.DPM_Solver(D.model_wrapper(net, ns), ns)
+    cases = [("plain", dict(steps=12, order=2)), ("plain", dict(steps=9, order=3, method="singlestep")),
+             ("plain", dict(steps=8, order=3, skip_type="logSNR", denoise_to_zero=True)), ("cfg", dict(steps=10, order=2)),
+             ("v", dict(steps=9, order=3, method="singlestep", solver_type="taylor")), ("thr", dict(steps=10, order=2)),
+             ("thr", dict(steps=7, order=2, method="singlestep", return_intermediate=True))]
+    for kind, kw in cases:
+        got = solver(DEV, kind).sample(xc.to(DEV), **kw)
+        want = _double_on_cpu(monkeypatch, lambda: solver("cpu", kind).sample(xc, **kw))
+        if kw.get("return_intermediate"):
+            assert len(got[1]) == len(want[1])
+            for a, b in zip(got[1], want[1]):
+                assert a.dtype == torch.float64 and float((a.cpu() - b).abs().max()) <= 1e-14 * float(b.abs().max())
+            got, want = got[0], want[0]
+        assert got.dtype == torch.float64 and got.is_cuda
+        assert float((got.cpu() - want).abs().max()) <= 1e-14 * float(want.abs().max()), (kind, kw)
+    # add_noise and the stand-alone thresholding call in double
+    dpm = solver(DEV, "thr")
+    x0 = (xc * 2.0).to(DEV)
+    y = dpm.dynamic_thresholding_fn(x0, None)
+    rows = x0.abs().reshape(6, -1)
+    s = torch.maximum(torch.quantile(rows, 0.93, dim=1), torch.ones(6, dtype=torch.float64, device=DEV)).reshape(-1, 1, 1, 1)
+    assert torch.equal(y, torch.clamp(x0, -s, s) / s)                       # torch.quantile's own double semantics, bit for bit
+    tt_ = torch.tensor([0.3, 0.9])
+    noise = torch.from_numpy(rng.standard_normal((2, 6, 3, 16, 16))).to(DEV)
+    an = dpm.add_noise(x0, tt_, noise=noise)
+    ns = dpm.noise_schedule
+    a, sg = ns.marginal_alpha(tt_).double().to(DEV), ns.marginal_std(tt_).double().to(DEV)
+    want_an = a.reshape(2, 1, 1, 1, 1) * x0 + sg.reshape(2, 1, 1, 1, 1) * noise
+    assert an.dtype == torch.float64 and float((an - want_an).abs().max()) <= 1e-15 * float(want_an.abs().max())
+
+
+@pytest.mark.lab
+def test_lds_dma_variant_of_the_lone_launch_kernels_is_bit_identical():
+    """The lone-launch north-star kernels (2-byte state and network output, unguided noise prediction, dpmsolver++ first /
+    second order, inputs from HBM) read their three streams by LDS-DMA (stage_kernel_dma, round 5) -- the same elements per
+    lane, the same arithmetic: forcing the register path (DPM_TUNE_LDS_DMA = 0) must give the same bits, for whole and
+    ragged tile counts, both workgroup sizes, a grid that loops (capped) and one that does not."""
+    ns = make_schedule("sd")
+    for sdt in (torch.float16, torch.bfloat16):
+        for shape in ((256, 4, 64, 64), (8, 4, 64, 64), (3, 4, 40, 40), (1, 1, 8, 8), (700, 4, 64, 64)):
+            g = torch.Generator().manual_seed(sum(shape))
+            x = torch.randn(shape, generator=g).to(DEV, sdt)
+            eps = torch.randn(shape, generator=g).to(DEV, sdt)
+            mk = lambda: D.DPM_Solver(D.model_wrapper(lambda xx, t: eps, ns), ns, state_dtype=sdt)
+            outs = {}
+            for dma in (1, 0):
+                for bt in (0, 256, 512):
+                    with _Tuned(lds_dma=dma, block_threads=bt):
+                        outs[(dma, bt)] = mk().sample(x, steps=7, order=2)
+            ref = outs[(0, 256)]
+            for k, v in outs.items():
+                assert torch.equal(v.view(torch.int16), ref.view(torch.int16)), (sdt, shape, k)

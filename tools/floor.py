@@ -247,19 +247,26 @@ def sweep(args):
 
 
 def trace_only(args):
-    """for rocprofv3 --kernel-trace: the stage kernel, then every configuration of --configs, `trajectories` each, in the slot;
-    the order goes to --seq so that --summarise can attribute the floor-kernel rows (runtime parameters do not show in the
-    kernel name)"""
+    """for rocprofv3 --kernel-trace: passes of `trajectories` trajectories each -- the stage kernel as the library launches it
+    (read streams by LDS-DMA), the stage kernel forced onto the register path (DPM_TUNE_LDS_DMA = 0), every floor
+    configuration of --configs in the slot (followed by the real stage kernel), then the two stage-kernel passes again.  The
+    order goes to --seq so that --summarise can attribute the rows (run-time parameters do not show in a kernel's name)."""
     lp = Loop(args.dtype)
     L = lp.L
     ids = [s for s in args.configs.split(",") if s]
     seq = []
     T = args.trajectories
 
-    def stage_fn(k, st, b, stream):
+    def nothing(k, st, b, stream):
         return 0          # the real launch behind the slot IS the stage kernel: nothing extra in the slot
-    lp.run(stage_fn, T)
-    seq.append(dict(id="stage_kernel", trajectories=T))
+
+    def stage_pass(dma):
+        L.check(L.lib.dpm_tuning_set(L.TUNE_LDS_DMA, dma))
+        lp.run(nothing, T)
+        L.check(L.lib.dpm_tuning_set(L.TUNE_LDS_DMA, -1))
+        seq.append(dict(id="stage_kernel" if dma != 0 else "stage_kernel_register_path", trajectories=T, floor=False))
+    stage_pass(-1)
+    stage_pass(0)
     for s in ids:
         f = desc(L, parse_id(s))
 
@@ -270,9 +277,9 @@ def trace_only(args):
             return L.lib.dpm_floor_launch(C.byref(f), bb.x, bb.e0, bb.h1, lp.scratch[0].data_ptr(), lp.scratch[1].data_ptr(),
                                           lp.nbytes, stream, None)
         lp.run(fn, T)
-        seq.append(dict(id=s, trajectories=T))
-    lp.run(stage_fn, T)
-    seq.append(dict(id="stage_kernel", trajectories=T))
+        seq.append(dict(id=s, trajectories=T, floor=True))
+    stage_pass(-1)
+    stage_pass(0)
     lp.torch.cuda.synchronize()
     json.dump(seq, open(args.seq, "w"))
     print("traced %d configurations" % len(ids))
@@ -282,35 +289,43 @@ def summarise(args):
     f = glob.glob(os.path.join(args.summarise, "**", "*_results.db"), recursive=True)
     assert f, "no *_results.db under %s" % args.summarise
     cur = sqlite3.connect(f[0]).cursor()
-    rows = cur.execute("select name, start, duration from kernels order by start").fetchall()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')").fetchall()]
+    kt = "kernels" if "kernels" in tabs else [t for t in tabs if "kernel" in t.lower()][0]
+    rows = cur.execute("select name, start, duration from %s order by start" % kt).fetchall()
     seq = json.load(open(args.seq))
     names = [r[0] for r in rows]
     du = np.array([r[2] for r in rows], dtype=np.float64) / 1e3
     floor_rows = [i for i, n in enumerate(names) if "floor_kernel" in n]
     stage_rows = [i for i, n in enumerate(names) if "stage_kernel" in n]
     per = STEPS - 2
-    out = {}
-    pos = 0
     alg = 5 * B * int(np.prod(SHAPE)) * (2 if args.dtype != "fp32" else 4)
+    # the Loop's constructor ran one trajectory (STEPS stage rows) before the first pass; every pass launches T x STEPS stage
+    # kernels (in the floor passes: behind the floor kernel, inputs warm -- not reported)
+    out, stage = {}, {}
+    fpos, spos = 0, STEPS
     for s in seq:
-        if s["id"] == "stage_kernel":
-            continue
-        n = s["trajectories"] * per
-        v = du[floor_rows[pos:pos + n]][per:]                   # first trajectory of the configuration: warm-up
-        pos += n
-        out[s["id"]] = dict(median_us=round(float(np.median(v)), 3), mean_us=round(float(v.mean()), 3), rows=int(v.size),
-                            frac_of_peak=round(alg / float(np.median(v)) / 1e3 / PEAK, 4))
-    assert pos == len(floor_rows), (pos, len(floor_rows))
-    # the stage kernel's own rows: launches directly behind the network in the two stage-only passes (first and last), the 2M
-    # steady-state kernel only (its name carries FORM = 1 and the store of m)
-    T0 = seq[0]["trajectories"]
-    two = [i for i in stage_rows if "Li1E" in names[i]]
-    first, last = two[:T0 * per][per:], two[-seq[-1]["trajectories"] * per:][per:]
-    sk = du[first + last]
-    res = dict(stage_kernel=dict(median_us=round(float(np.median(sk)), 3), mean_us=round(float(sk.mean()), 3), rows=int(sk.size),
-                                 frac_of_peak=round(alg / float(np.median(sk)) / 1e3 / PEAK, 4)),
-               floor=out, algorithmic_bytes=alg,
-               what="rocprofv3 --kernel-trace rows: kernel durations in the slot right behind the network's last kernel")
+        T = s["trajectories"]
+        srows = stage_rows[spos:spos + T * STEPS]
+        spos += T * STEPS
+        if s["floor"]:
+            n = T * per
+            v = du[floor_rows[fpos:fpos + n]][per:]               # first trajectory of the configuration: warm-up
+            fpos += n
+            out[s["id"]] = dict(median_us=round(float(np.median(v)), 3), mean_us=round(float(v.mean()), 3), rows=int(v.size),
+                                frac_of_peak=round(alg / float(np.median(v)) / 1e3 / PEAK, 4))
+        else:
+            keep = [srows[t * STEPS + k] for t in range(1, T) for k in range(1, STEPS - 1)]
+            stage.setdefault(s["id"], []).extend(du[keep].tolist())
+            stage.setdefault(s["id"] + "|name", names[keep[0]][:160])
+    assert fpos == len(floor_rows) and spos == len(stage_rows), (fpos, len(floor_rows), spos, len(stage_rows))
+    res = dict(algorithmic_bytes=alg, floor=out,
+               what="rocprofv3 --kernel-trace rows: kernel durations in the slot right behind the network's last kernel "
+                    "(conv network, one [%d,4,64,64] %s request, DPM_Solver.sample 2M++ 20 steps)" % (B, args.dtype))
+    for k in ("stage_kernel", "stage_kernel_register_path"):
+        if k in stage:
+            v = np.array(stage[k])
+            res[k] = dict(median_us=round(float(np.median(v)), 3), mean_us=round(float(v.mean()), 3), rows=int(v.size),
+                          frac_of_peak=round(alg / float(np.median(v)) / 1e3 / PEAK, 4), kernel=stage[k + "|name"])
     best = min(out.items(), key=lambda kv: kv[1]["median_us"]) if out else None
     if best:
         res["best_floor"] = dict(id=best[0], **best[1])

@@ -303,6 +303,8 @@ def main():
                     "workgroups:sleep, e.g. 512:1,1024:1,2048:1,1024:4")
     ap.add_argument("--unroll", type=int, default=0, help="tuning build only: tiles per workgroup of the 2M stage kernel")
     ap.add_argument("--nt", type=int, default=-1, help="tuning build only: nt mask")
+    ap.add_argument("--lds-dma", type=int, default=-1, help="DPM_TUNE_LDS_DMA: 1 / 0 = the lone 2-byte 2M launch reads by LDS-DMA / "
+                    "through registers (default: the library's choice)")
     args = ap.parse_args()
     if args.summarise:
         return summarise(args.summarise, args.md, args.title, args.pattern)
@@ -319,8 +321,11 @@ def main():
         return
     import torch
     import bench
+    import lab_secondary as LS
     import dpm_solver_amd as D
     from dpm_solver_amd import _lib as L
+    if args.lds_dma >= 0:
+        L.check(L.lib.dpm_tuning_set(L.TUNE_LDS_DMA, args.lds_dma))
     dev = torch.device("cuda", 0)
     dtype = bench._DT[args.dtype]
     ns = D.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(bench.sd_alphas_cumprod()))
@@ -364,7 +369,7 @@ def main():
                 for nt in (0, 1, 5):
                     L.check(L.lib.dpm_tuning_set(L.TUNE_UNROLL, u))
                     L.check(L.lib.dpm_tuning_set(L.TUNE_NONTEMPORAL, nt))
-                    r = bench.in_network_loop(D, L, ns, dev, bench._DT[sname], kind=args.kinds.split(",")[0], width=args.width,
+                    r = LS.in_network_loop(D, L, ns, dev, bench._DT[sname], kind=args.kinds.split(",")[0], width=args.width,
                                               trajectories=args.trajectories, net_dtype=bench._DT[ename])
                     print("%s state / %s network  U=%d nt=%d   stage kernel in the loop %7.3f us (events; %.3f of peak)   "
                           "added wall per stage %7.3f us" % (sname, ename, u, nt, r["stage_kernel_us"], r["frac"],
@@ -377,12 +382,12 @@ def main():
     for kind in args.kinds.split(","):
         if args.trace_only:
             pf = None if args.prefetch in (None, "None", "none") else int(args.prefetch)
-            r = bench.in_network_loop(D, L, ns, dev, dtype, kind=kind, width=args.width, trajectories=args.trajectories, prefetch=pf)
+            r = LS.in_network_loop(D, L, ns, dev, dtype, kind=kind, width=args.width, trajectories=args.trajectories, prefetch=pf)
             r["variant"] = "%s prefetch=%s (under the profiler)" % (kind, pf)
             res.append(r)
             continue
         for pf in (None, 0, 1):
-            r = bench.in_network_loop(D, L, ns, dev, dtype, kind=kind, width=args.width, trajectories=args.trajectories, prefetch=pf)
+            r = LS.in_network_loop(D, L, ns, dev, dtype, kind=kind, width=args.width, trajectories=args.trajectories, prefetch=pf)
             r["variant"] = "%s prefetch=%s" % (kind, pf)
             res.append(r)
             print(json.dumps(r), flush=True)
