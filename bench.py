@@ -679,10 +679,15 @@ def main():
             "roofline": roofline,
             "gather_ms": None if gather_ms is None else round(gather_ms, 4),
             "per_rank_wall_s": {"min": round(wall_min, 4), "max": round(wall, 4)},   # value uses the max
+            # weak scaling: every GPU runs the N = 1 workload, so `value` / N is what one GPU of this run achieved -- the
+            # number to hold against the N = 1 line of the same box (BENCH vs SCALE[N=1]; the fastest rank's own rate next to it)
+            "value_per_gpu": round(samples / wall / 1e6 / world, 4),
+            "fastest_rank_value_per_gpu": round(samples / world / wall_min / 1e6, 4),
+            "launcher": "torch.distributed.run" if "RANK" in os.environ else "python",
         }
         if STUB:
             line["stub"] = True
-            line["value"] = line["roofline"] = None       # nothing was measured
+            line["value"] = line["roofline"] = line["value_per_gpu"] = line["fastest_rank_value_per_gpu"] = None   # nothing was measured
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ac)
         try:     # the unmodified reference on the same kind of GPU through PyTorch-ROCm eager (tools/gpu_reference.py; committed)

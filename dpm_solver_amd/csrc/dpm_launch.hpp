@@ -102,9 +102,12 @@ inline int64_t thr_ws_bytes(int64_t batch, int64_t per_sample, int n_cu) {
 //     workgroup iteration when there is work for it -- fp16 5.5 vs 7.4-7.6 us, fp32 12.35 vs 12.9 us.  Variants exist for
 //     the 2M / first-order kernels (HotCombo).
 constexpr int DEF_U = 1;
-// the lone-launch north-star kernels (2-byte state, 2M / first-order, inputs from HBM) read through LDS-DMA by default
+// LAB build only: the lone-launch north-star kernels (2-byte state, 2M / first-order, inputs from HBM) with their read streams
+// on the LDS-DMA path (stage_kernel_dma, DPM_TUNE_LDS_DMA).  Measured by rocprofv3 rows inside a network loop
+// (profiles/r05_lone_floor.md): 8.32 us against 8.28 us through registers -- the no-arithmetic floor kernel gains 3-4 % from
+// that path, the stage kernel nothing -- so the product keeps the register path and does not carry the variant.
 #ifndef DPM_LDS_DMA_DEFAULT
-#define DPM_LDS_DMA_DEFAULT 1
+#define DPM_LDS_DMA_DEFAULT 0
 #endif
 template <typename TS>
 struct DefNT {
@@ -554,8 +557,8 @@ int launch_stream(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
           // interleaved-requests emulation (15.4 vs 15.6 us); INSIDE a torch network loop (profiles/r03_in_loop.md,
           // rocprofv3 rows, 342 launches each) one tile is 15.0 us against 16.3, and four / eight tiles -- fewer, fatter
           // wavefronts with every load issued up front, the emulation's favourite at 14.4 us -- are 15.2 / 23.8 us.
-          // 2-byte state and network output, no ragged tail: the read streams by LDS-DMA (stage_kernel_dma, round 5)
           bool dma = false;
+#if DPM_LAB  // the LDS-DMA variant (2-byte state and network output, no ragged tail): an experiment of the lab build
           if constexpr (sizeof(TS) == 2 && sizeof(TE) == 2) dma = (tn.lds_dma < 0 ? DPM_LDS_DMA_DEFAULT : tn.lds_dma) != 0 && b->n % EPT == 0;
           if (dma) {
             if constexpr (sizeof(TS) == 2 && sizeof(TE) == 2) {
@@ -563,9 +566,9 @@ int launch_stream(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
               launch(stage_kernel_dma<TS, TE, FORM, CNT>, sh.first, sh.second, (size_t)(sh.second.x / 64) * 3072, stream, x, e0, h1, xo, mo,
                      b->n, p);
             }
-          } else {
-            DPM_LAUNCH(SPEC_NOISE_X0, 1, CNT, false);
           }
+#endif
+          if (!dma) DPM_LAUNCH(SPEC_NOISE_X0, 1, CNT, false);
         }
       } else {
         DPM_LAUNCH(SPEC_NOISE_X0, DEF_U, DefNT<TS>::value, false);

@@ -449,7 +449,8 @@ __global__ __launch_bounds__(STAGE_MAX_THREADS) void stage_kernel(const TS* __re
   }
 }
 
-// The lone-launch variant of the north-star kernels with its read streams on the LDS-DMA path (stage_tiles<..., DMA = true>).
+// LAB build (launch_stream): the lone-launch variant of the north-star kernels with its read streams on the LDS-DMA path
+// (stage_tiles<..., DMA = true>) -- measured equal to the register path (profiles/r05_lone_floor.md), not in the product.
 // One tile per 256-lane group and iteration like stage_kernel; dynamic LDS = 3 KiB per wavefront.  The rows of a wavefront
 // are reused by its next tile: the ds_reads of the previous tile are complete before the stores it waited on are issued
 // (their results are the stores' operands), so the next tile's LDS-DMA cannot overtake them.

@@ -579,6 +579,14 @@ class DPM_Solver:
     #                     finishes its sample alone (0 = the library's default, 4096: milliseconds)
     cluster_in_graph = False
     thr_spin_limit = 0
+    # auto_capture = N > 0 (opt-in): after N sample() calls with the same arguments, shape, dtype and stream, the call is
+    # hipGraph-captured (DPM_Solver.capture) and later calls replay the graph -- one launch per trajectory instead of one per
+    # kernel, which is what a launch-bound loop needs ([8,4,64,64]: 98 -> 52 us per trajectory with a frozen network).  Not
+    # the default: a replay does not re-run the PYTHON side of the network (counters, hooks, host-side control flow,
+    # conditioning tensors swapped for new objects), which the reference's eager loop does at every call -- the caller has
+    # to know its network is a pure function of (x, t) on fixed tensors, as for torch.cuda.graph.  Calls with Python callbacks
+    # (correcting_xt_fn, a callable correcting_x0_fn), return_intermediate or a host-side adaptive loop are never captured.
+    auto_capture = 0
 
     def __init__(self, model_fn, noise_schedule, algorithm_type="dpmsolver++", correcting_x0_fn=None,
                  correcting_xt_fn=None, thresholding_max_val=1., dynamic_thresholding_ratio=0.995,
@@ -619,6 +627,7 @@ class DPM_Solver:
         # (_Plan.time_views).
         self.fresh_time_tensors = False
         self._plans = {}
+        self._auto = {}                      # auto_capture: (arguments, shape, ...) -> [calls seen, GraphedSample]
         self._fast = {}
         self._fast_groups = {}
         self._group = None                   # sample_requests: the requests advanced together by this call
@@ -1208,6 +1217,13 @@ class DPM_Solver:
         device = x.device
         intermediates = []
         cxt = self.correcting_xt_fn
+        if self.auto_capture and self._group is None and not torch.cuda.is_current_stream_capturing():
+            hit = self._auto_captured(x, dict(steps=steps, t_start=t_start, t_end=t_end, order=order, skip_type=skip_type,
+                                              method=method, lower_order_final=lower_order_final,
+                                              denoise_to_zero=denoise_to_zero, solver_type=solver_type, atol=atol, rtol=rtol),
+                                      return_intermediate)
+            if hit is not None:
+                return hit
         with torch.no_grad():
             if method == 'adaptive':
                 x = self.dpm_solver_adaptive(x, order=order, t_T=t_T, t_0=t_0, atol=atol, rtol=rtol, solver_type=solver_type)
@@ -1334,6 +1350,31 @@ class DPM_Solver:
             if rc:
                 L.check(rc)
         return [_in_layout_of(o, x) for o, x in zip(outs, xs)]
+
+    def _auto_captured(self, x, kw, return_intermediate):
+        """auto_capture: the replayed result of this call, or None when the call is not (yet) served by a graph"""
+        if (return_intermediate or self.correcting_xt_fn is not None or self._user_x0 is not None or not x.is_cuda or x.dim() == 0
+                or x.numel() == 0 or (kw["method"] == "adaptive" and not self.adaptive_on_device)):
+            return None
+        dev = x.device
+        key = (tuple(sorted((k, (float(v) if isinstance(v, (int, float)) and not isinstance(v, bool) else v)) for k, v in kw.items())),
+               tuple(x.shape), x.dtype, x.stride(), dev.index, torch.cuda.current_stream(dev).cuda_stream,
+               bool(self.cluster_in_graph), int(self.thr_spin_limit))
+        ent = self._auto.get(key)
+        if ent is None:
+            if len(self._auto) >= 4:
+                self._auto.pop(next(iter(self._auto)))
+            ent = self._auto[key] = [0, None]
+        if ent[1] is None:
+            ent[0] += 1
+            if ent[0] <= int(self.auto_capture):
+                return None                       # eager until the call has been seen auto_capture times
+            saved, self.auto_capture = self.auto_capture, 0      # the capture's own warm-up runs go through sample()
+            try:
+                ent[1] = self.capture(x, **kw)
+            finally:
+                self.auto_capture = saved
+        return ent[1](x).clone()                  # a graph's output buffer is overwritten by the next replay: hand out a copy
 
     def capture(self, x, warmup=2, **sample_kwargs):
         """hipGraph-capture `sample(x, **sample_kwargs)` for a fixed shape (extension).
@@ -1492,7 +1533,10 @@ class GraphedSample:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                     # plans, time tensors, allocator pools: all warm before capture
-            for _ in range(max(int(warmup), 1)):
+            # at least TWO runs: a network that writes into its time argument is detected at the second call (version
+            # counters, _Plan.time_views), and the rebuild of the shared time vectors it triggers -- a pageable host-to-device
+            # copy and an allocation -- must not land inside the capture
+            for _ in range(max(int(warmup), 2)):
                 solver.sample(self.static_x, **self.kwargs)
         torch.cuda.current_stream(dev).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()

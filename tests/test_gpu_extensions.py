@@ -307,6 +307,35 @@ def test_captured_sample_equals_eager(name):
     assert rel_err(g(x).cpu().numpy(), xo) < TOL
 
 
+@pytest.mark.parametrize("name", ["cfg1_small", "cfg_ms2", "cfg5_thresh_small"])
+def test_auto_capture_replays_after_n_identical_calls(name):
+    """DPM_Solver.auto_capture = N (opt-in): N eager calls, then the call is captured and later calls replay the graph --
+    same bits as the eager loop, a fresh tensor per call, other shapes / arguments keep running eagerly; Python callbacks
+    and return_intermediate are never captured."""
+    case = C.E2E_BY_NAME[name]
+    dpm = build_solver(case, DEV)
+    x = tt(C.x_T_for(case), DEV)
+    kw = sample_kwargs(case, False)
+    want = dpm.sample(x, **kw)
+    x2 = x * 0.5 + 0.25
+    want2 = dpm.sample(x2, **kw)
+    dpm.auto_capture = 2
+    outs = [dpm.sample(x, **kw) for _ in range(2)]
+    assert all(e[1] is None for e in dpm._auto.values()) and len(dpm._auto) == 1       # still eager
+    outs += [dpm.sample(x, **kw) for _ in range(3)]                                     # captured at the third call
+    assert [e[1] is not None for e in dpm._auto.values()] == [True]
+    assert all(torch.equal(o, want) for o in outs)
+    assert len({o.data_ptr() for o in outs}) == len(outs)                               # never the graph's static buffer
+    assert torch.equal(dpm.sample(x2, **kw), want2)                                     # replay on new values
+    kw3 = dict(kw, steps=kw.get("steps", 20) - 1)
+    eager3 = dpm.sample(x, **kw3)                                                       # other arguments: a new, eager entry
+    assert len(dpm._auto) == 2 and torch.isfinite(eager3).all()
+    got_i, inter = dpm.sample(x, return_intermediate=True, **kw)                        # never captured
+    assert torch.equal(got_i, want) and len(inter) > 1
+    dpm.auto_capture = 0
+    assert torch.equal(dpm.sample(x, **kw), want)
+
+
 def test_capture_rejects_the_host_side_adaptive_loop():
     """only the host-side control loop (adaptive_on_device = False: one synchronisation per iteration) cannot be
     captured; the device-side controller can (tests/test_gpu_parity.py::test_adaptive_captured_into_a_graph)"""

@@ -112,13 +112,20 @@ def in_network_loop(D, L, ns, dev, dtype, kind="gemm", width=256, trajectories=6
         with_solver = lambda: dpm.sample(x_T, steps=STEPS_SOLVER, order=2)
         with_solver()
         net_only()
-        # alternate the two (A B A B ...) and take medians: the network's own time drifts by more than the 20 stage
-        # kernels cost, so back-to-back blocks of each would measure the drift
+        # alternate the two (A B A B ...) and take the median of the PAIRED differences: the network's own time drifts by more
+        # than the 20 stage kernels cost (40 ms +- 0.5 % is +- 10 us per stage), so medians of the two series taken
+        # separately measure the drift -- round 4's 4.5 ... 37.6 us spread over boxes was that, not host overhead: by
+        # rocprofv3 rows the stage kernel starts 0.00 us behind the network's last kernel and the next network kernel 0.12 us
+        # behind it (profiles/r03_in_loop.md).  Adjacent runs share the drift; their difference does not carry it.
         ts, tn = [], []
-        for _ in range(max(8, 2 * trajectories)):
+        for _ in range(max(24, 3 * trajectories)):
             ts.append(timed(with_solver))
             tn.append(timed(net_only))
-        t_solver, t_net = float(np.median(ts)), float(np.median(tn))
+        ts, tn = np.array(ts), np.array(tn)
+        pair = np.concatenate([ts - tn, ts[1:] - tn[:-1]])               # each solver run against both of its neighbours
+        t_net = float(np.median(tn))
+        t_solver = t_net + float(np.median(pair))
+        added_iqr = [float(np.percentile(pair, 25)) / n_st, float(np.percentile(pair, 75)) / n_st]
         net.before_last = None
         for b in fr.bufs:
             b.inputs_resident = 0
@@ -133,11 +140,13 @@ def in_network_loop(D, L, ns, dev, dtype, kind="gemm", width=256, trajectories=6
                 stage_kernel_p10_p90_us=[round(float(np.percentile(steady, 10)), 3), round(float(np.percentile(steady, 90)), 3)],
                 frac=round(alg / med / 1e3 / HBM_PEAK_GBS, 4), achieved=round(alg / med / 1e3, 1),
                 first_stage_us=round(float(np.median(us[1:, 0])), 3), last_stage_us=round(float(np.median(us[1:, -1])), 3),
-                stage_added_wall_us=round(added, 3), frac_wall=round(alg / max(added, 1e-3) / 1e3 / HBM_PEAK_GBS, 4),
+                stage_added_wall_us=round(added, 3), stage_added_wall_iqr_us=[round(v, 3) for v in added_iqr],
+                frac_wall=round(alg / max(added, 1e-3) / 1e3 / HBM_PEAK_GBS, 4),
                 trajectory_ms=round(t_solver / 1e3, 4), prefetch=prefetch,
                 how="DPM_Solver.sample() on one [%d,4,64,64] %s request, 2M++ 20 steps, torch network as model_fn; "
                     "stage_kernel_us = median start->stop event interval of the steady-state stage launches inside the "
-                    "loop (dpm_stage_launch_traced); stage_added_wall_us = (trajectory - 20 network calls alone) / 20"
+                    "loop (dpm_stage_launch_traced); stage_added_wall_us = median paired difference (trajectory - the same 20 network "
+                    "calls alone, alternating runs) / 20"
                     % (B, str(dtype).split(".")[-1]))
 
 
