@@ -258,6 +258,14 @@ if lib.dpm_version() < 200:
                       % lib.dpm_version())
 
 
+if IS_LAB and os.environ.get("DPM_LAB_TUNE"):
+    # lab build only: knobs for a whole tool run, e.g. DPM_LAB_TUNE="thr_elect=1,thr_predict=0" (A/B runs under rocprofv3)
+    for _kv in os.environ["DPM_LAB_TUNE"].split(","):
+        _k, _v = _kv.split("=")
+        if lib.dpm_tuning_set(globals()["TUNE_" + _k.strip().upper()], int(_v)) != 0:
+            raise ImportError("DPM_LAB_TUNE: %s refused: %s" % (_kv, lib.dpm_last_error().decode()))
+
+
 class DpmError(RuntimeError):
     pass
 

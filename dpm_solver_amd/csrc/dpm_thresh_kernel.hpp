@@ -67,6 +67,9 @@ constexpr int THR_HINT_W = DPM_THR_HINT_WORDS;
 // its extrapolation the union stays ~1.3 K entries (K = the wanted rank from the top) and holds the K-th largest
 constexpr float THR_HINT_MARGIN = 0.94f;
 constexpr int THR_WS_POISON = THR_WS_CNT + 16; // a workgroup of the cluster is out of the protocol on this sample (see give_up)
+// LAB build, elected reducer (ThrParams.elect): the verdict workgroup 0 of a cluster publishes for its peers -- per slot area
+// (searched: + 0, predicted: + 4) [0] tag | a, [1] tag | b, [2] tag | valid
+constexpr int THR_WS_RESULT = THR_WS_CNT + 24;
 // polls (a microsecond or two each: a dependent sc1 load + s_sleep) before a wait on a peer gives up -- milliseconds.
 // Giving up is safe (the workgroup then computes the sample's order statistics alone, solo_select), so the limit only
 // trades a stall against redundant work when the peers are off the chip (ThrParams.spin_limit, DPM_TUNE_THR_SPIN_LIMIT)
@@ -99,6 +102,9 @@ struct ThrParams {
   uint32_t spin_limit;  // polls before a wait on a peer gives up (THR_SPIN_LIMIT)
 #if DPM_LAB
   int32_t debug_fault;  // LAB build only (DPM_TUNE_THR_DEBUG_FAULT): 2 / 3 = workgroup 1 of every cluster takes no part in its cluster
+  int32_t elect;        // LAB build only (DPM_TUNE_THR_ELECT): workgroup 0 of a cluster reads the k slots, selects on the union
+                        // and publishes the verdict; its peers make one wait and read three words -- k slot reads per sample
+                        // instead of k^2 (profiles/r05_thresholding.md)
 #endif
   float* hint;     // dpm_buffers.thr_hint (THR_HINT_W floats per sample) or null: the selected order statistic of the
                    // previous two stages -> predicted select bound of this one (cluster_select_once, `pbound`)
@@ -665,6 +671,45 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
     __hip_atomic_store(&mine_slot[0], (over ? THR_OVERFLOW : ncl) | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   DPM_R1STAMP(9)
+#if DPM_LAB
+  // Elected reducer (experiment): workgroup 0 of the cluster goes on alone -- it polls the slots, gathers the union, selects
+  // and publishes (a, b, valid); everybody else waits for that verdict: one wait, three words.  Workgroup 0 is elected
+  // statically: a ticket ("the last to arrive reduces") would put a drain + a returning atomic in front of the first poll.
+  const bool elect = tp.elect != 0 && k <= 64u;
+  uint32_t* verdict = poison - THR_WS_POISON + THR_WS_RESULT + (pbound ? 4 : 0);
+  if (elect && c != 0) {
+    if (tid == 0) {
+      uint32_t r0 = 0u, r1 = 0u, r2 = 0u, spins = 0u;
+      for (;;) {
+        if (!(r0 & THR_TAG)) r0 = __hip_atomic_load(&verdict[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(r1 & THR_TAG)) r1 = __hip_atomic_load(&verdict[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(r2 & THR_TAG)) r2 = __hip_atomic_load(&verdict[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (((r0 & r1 & r2) & THR_TAG) || misc[30]) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (wait_is_over(++spins, poison, tp)) give_up(misc + 30, poison, tp.fault);
+      }
+      misc[26] = r0;
+      misc[27] = r1;
+      misc[29] = r2;
+    }
+    __syncthreads();
+    const bool got = !misc[30] && ((misc[26] & misc[27] & misc[29]) & THR_TAG);
+    const bool ok_v = got && (misc[29] & 1u);
+    if (ok_v) {
+      a_out = misc[26] & ~THR_TAG;
+      b_out = misc[27] & ~THR_TAG;
+    } else {  // the next attempt / the general route expect their LDS state (hist is still all zero here)
+      if (tid == 0) {
+        misc[4] = 0u;
+        misc[9] = 0u;
+        misc[10] = 0u;
+        misc[12] = 0u;
+      }
+      __syncthreads();
+    }
+    return ok_v;
+  }
+#endif
   // 5. the other workgroups' slots.  Word p of the slot area (slot p >> shift, entry p & (W - 1)) belongs to thread
   // p mod T whatever the counts turn out to be, and the first `pub` entries of every slot get written whatever the count:
   // headers and values are polled TOGETHER, every round's loads issued back to back -- one round trip after the last
@@ -789,6 +834,13 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
     // an unpublished element of some chunk could be among the K largest when the K-th of the union is below a bound
     valid = a >= bound_max && !tp.debug_reject;
   }
+#if DPM_LAB
+  if (elect && tid == 0 && !misc[30]) {  // the reducer's verdict for its peers (a workgroup that gave up publishes nothing)
+    __hip_atomic_store(&verdict[0], a_out | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&verdict[1], b_out | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&verdict[2], (valid ? 1u : 0u) | THR_TAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#endif
   if (!valid) {  // the next attempt / the general route expect their LDS state: hist all zero, no candidates
     if (leftovers) {
       hist[tid] = 0u;
@@ -1531,6 +1583,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
         } else if (tid == 0) {
           ws[THR_WS_DONE] = 0u;
           ws[THR_WS_POISON] = 0u;
+#if DPM_LAB
+          if (tp.elect)
+            for (int q = 0; q < 8; ++q) ws[THR_WS_RESULT + q] = 0u;
+#endif
         }
       }
     }

@@ -988,3 +988,33 @@ def test_lds_dma_variant_of_the_lone_launch_kernels_is_bit_identical():
             ref = outs[(0, 256)]
             for k, v in outs.items():
                 assert torch.equal(v.view(torch.int16), ref.view(torch.int16)), (sdt, shape, k)
+
+
+@pytest.mark.lab
+@pytest.mark.parametrize("shape", [(32, 3, 64, 64), (5, 3, 64, 64), (2, 3, 160, 160), (300, 1, 128, 128), (40, 3, 64, 128)])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_elected_reducer_experiment_keeps_the_bits(shape, mode):
+    """DPM_TUNE_THR_ELECT (lab build): workgroup 0 of a cluster reads the k slots, selects on the
+    union and publishes the verdict, its peers wait for three words -- k slot reads per sample instead of k^2.  Same bits
+    as the default protocol on the predicted and the searched route, with and without forced faults (a reducer that is
+    out of the protocol publishes nothing: its peers time out and select alone), workspace left zero-filled."""
+    ns = make_schedule("ddpm")
+    x = torch.from_numpy(np.random.default_rng(43).standard_normal(shape).astype(F32)).to(DEV)
+    want, wi = _thr_solver(ns).sample(x, steps=8, order=2, return_intermediate=True)
+    for predict in (1, 0):
+        dpm = _thr_solver(ns)
+        knobs = dict(thr_elect=1, thr_predict=predict)
+        if mode:
+            knobs.update(thr_debug_fault=mode, thr_spin_limit=48)
+        with _Tuned(**knobs):
+            got = dpm.sample(x, steps=8, order=2)
+            got2, gi = dpm.sample(x, steps=8, order=2, return_intermediate=True)
+            torch.cuda.synchronize()
+        assert torch.equal(got, want) and torch.equal(got2, want), (shape, mode, predict)
+        assert all(torch.equal(a, b) for a, b in zip(gi, wi))
+        for fr in dpm._fast.values():
+            if getattr(fr, "ws", None) is not None:
+                assert not bool(fr.ws.any()), "the workspace must be all zero between launches"
+        for ws in S._WS_CACHE.values():
+            assert not bool(ws.any()), "the workspace must be all zero between launches"
+    L.cluster_timeout_poll()
