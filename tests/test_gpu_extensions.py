@@ -330,7 +330,7 @@ def test_auto_capture_replays_after_n_identical_calls(name):
     kw3 = dict(kw, steps=kw.get("steps", 20) - 1)
     eager3 = dpm.sample(x, **kw3)                                                       # other arguments: a new, eager entry
     assert len(dpm._auto) == 2 and torch.isfinite(eager3).all()
-    got_i, inter = dpm.sample(x, return_intermediate=True, **kw)                        # never captured
+    got_i, inter = dpm.sample(x, **dict(kw, return_intermediate=True))                  # never captured
     assert torch.equal(got_i, want) and len(inter) > 1
     dpm.auto_capture = 0
     assert torch.equal(dpm.sample(x, **kw), want)
