@@ -158,6 +158,11 @@ _SIGNATURES = [
     ("dpm_coef_singlestep", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_double,
                                       C.c_double, C.c_int, _P(Stage)]),
     ("dpm_coef_prologue", C.c_int, [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_double, _P(Stage)]),
+    ("dpm_coef_multistep_f64", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _P(C.c_double), C.c_double, C.c_int, _P(Stage),
+                                         _P(StageF64)]),
+    ("dpm_coef_singlestep_f64", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_double,
+                                          C.c_double, C.c_int, _P(Stage), _P(StageF64)]),
+    ("dpm_coef_prologue_f64", C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, _P(Stage), _P(StageF64)]),
     ("dpm_stage_launch", C.c_int, [_P(Stage), _P(Buffers), C.c_void_p]),
     ("dpm_stage_launch_multi", C.c_int, [_P(Stage), _P(Buffers), C.c_int, C.c_void_p]),
     ("dpm_threshold_workspace_bytes", C.c_size_t, [C.c_int64, C.c_int64]),

@@ -477,6 +477,73 @@ extern "C" int dpm_coef_singlestep(const dpm_schedule* s, int algo, int solver_t
   return DPM_OK;
 }
 
+// ---- the same builders for a double-precision evaluation (double time tensors, or a schedule declared dtype=float64): the
+// stage records come back as dpm_stage (integers + the doubles rounded) and dpm_stage_f64 (the doubles).  time_f64: the
+// caller's time tensors are doubles (else fp32 tensors whose values arrive here converted exactly): decides the dtype
+// get_model_input_time computes in (ref :278), see set_prologue.
+namespace {
+void split_stage64(const dpmc::Stage64& q, dpm_stage* st, dpm_stage_f64* d64);
+}
+
+extern "C" int dpm_coef_prologue_f64(const dpm_schedule* s, double t_eval, int time_f64, int model_type, int guidance,
+                                     double guidance_scale, dpm_stage* st, dpm_stage_f64* st64) {
+  if (!s || !st || !st64) return dpm_set_error(DPM_ERR_ARG, "null pointer");
+  if (check_enum(model_type, 0, 3, "model_type") || check_enum(guidance, 0, 2, "guidance")) return DPM_ERR_ARG;
+  const dpmc::SchedView64 v = s->view64();
+  dpmc::Stage64 q{};
+  set_prologue(&v, t_eval, model_type, guidance, guidance_scale, &q, !time_f64);
+  st->t_eval = (float)q.t_eval; st->t_input = (float)q.t_input; st->alpha_e = (float)q.alpha_e; st->sigma_e = (float)q.sigma_e;
+  st->model_type = model_type; st->guidance = guidance; st->cfg_scale = (float)q.cfg_scale; st->cg_scale = (float)q.cg_scale;
+  st64->t_eval = q.t_eval; st64->t_input = q.t_input; st64->alpha_e = q.alpha_e; st64->sigma_e = q.sigma_e;
+  st64->cfg_scale = q.cfg_scale; st64->cg_scale = q.cg_scale;
+  st64->time_f64 = (st64->time_f64 & ~1) | (time_f64 ? 1 : 0);
+  return DPM_OK;
+}
+
+extern "C" int dpm_coef_multistep_f64(const dpm_schedule* s, int algo, int solver_type, int order, const double* t_prev,
+                                      double t_t, int time_f64, dpm_stage* out, dpm_stage_f64* out64) {
+  if (!s || !out || !out64 || !t_prev) return dpm_set_error(DPM_ERR_ARG, "null pointer");
+  if (check_enum(algo, 0, 1, "algorithm_type")) return DPM_ERR_ARG;
+  if (order < 1 || order > 3) return dpm_set_error(DPM_ERR_ARG, "Solver order must be 1 or 2 or 3, got %d", order);
+  if (order == 2 && (solver_type < 0 || solver_type > 1))
+    return dpm_set_error(DPM_ERR_ARG, "'solver_type' must be either 'dpmsolver' or 'taylor', got %d", solver_type);
+  const bool pp = algo == DPM_ALGO_DPMSOLVERPP;
+  const dpmc::SchedView64 v = s->view64();
+  dpmc::Stage64 q;
+  stage_init(&q);
+  if (order == 1)
+    coef_first(&v, pp, t_prev[0], t_t, &q);
+  else if (order == 2)
+    coef_ms2(&v, pp, solver_type, t_prev[0], t_prev[1], t_t, &q);
+  else
+    coef_ms3(&v, pp, t_prev[0], t_prev[1], t_prev[2], t_t, &q);
+  if (pp) q.flags |= DPM_F_TO_X0;
+  set_prologue(&v, t_prev[order - 1], DPM_MODEL_NOISE, DPM_GUIDE_NONE, 1., &q, !time_f64);
+  q.time_f64 = time_f64 ? 3 : 0;
+  split_stage64(q, out, out64);
+  return DPM_OK;
+}
+
+extern "C" int dpm_coef_singlestep_f64(const dpm_schedule* s, int algo, int solver_type, int order, double t_s, double t_t,
+                                       int time_f64, double r1, double r2, int r_mode, dpm_stage* out, dpm_stage_f64* out64) {
+  if (!s || !out || !out64) return dpm_set_error(DPM_ERR_ARG, "null pointer");
+  if (check_enum(algo, 0, 1, "algorithm_type")) return DPM_ERR_ARG;
+  if (order < 1 || order > 3) return dpm_set_error(DPM_ERR_ARG, "Solver order must be 1 or 2 or 3, got %d", order);
+  if (order >= 2 && (solver_type < 0 || solver_type > 1))
+    return dpm_set_error(DPM_ERR_ARG, "'solver_type' must be either 'dpmsolver' or 'taylor', got %d", solver_type);
+  const dpmc::SchedView64 v = s->view64();
+  dpmc::Stage64 q[3];
+  singlestep_fill(&v, algo, solver_type, order, t_s, t_t, r1, r2, r_mode, q);
+  for (int i = 0; i < order; ++i) {
+    // stage 0 is evaluated at the caller's time tensor; the inner nodes come out of inverse_lambda as doubles (ref :621)
+    const int tf = (i == 0 ? (time_f64 ? 1 : 0) : 1) | ((i < order - 1 || time_f64) ? 2 : 0);
+    set_prologue(&v, q[i].t_eval, DPM_MODEL_NOISE, DPM_GUIDE_NONE, 1., &q[i], !(tf & 1));
+    q[i].time_f64 = tf;
+    split_stage64(q[i], &out[i], &out64[i]);
+  }
+  return DPM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // plan
 // ------------------------------------------------------------------------------------------------

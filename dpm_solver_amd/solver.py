@@ -692,9 +692,23 @@ class DPM_Solver:
             return float(t.detach().reshape(-1)[0].float().item())
         return float(_F32(t))
 
-    def _tt(self, value, device, shape1=False):
-        t = torch.full((1,) if shape1 else (), float(value), dtype=torch.float32, device=device)
+    def _tt(self, value, device, shape1=False, dtype=torch.float32):
+        t = torch.full((1,) if shape1 else (), float(value), dtype=dtype, device=device)
         return t
+
+    @staticmethod
+    def _td(t):
+        """time argument -> host double (exact for fp32 / fp64 tensors and Python floats)"""
+        if torch.is_tensor(t):
+            return float(t.detach().reshape(-1)[0].double().item())
+        return float(t)
+
+    def _double_call(self, x, *times):
+        """(scalars are doubles, the time tensors are doubles) for a public per-update call: torch's type promotion makes
+        every scalar of the reference a double when a time tensor is one or the schedule's tables are (ref :127-134)"""
+        tf64 = any(torch.is_tensor(t) and t.dtype is torch.float64 for t in times)
+        ns = self.noise_schedule
+        return bool(tf64 or (ns.schedule == 'discrete' and getattr(ns, "dtype", torch.float32) == torch.float64)), tf64
 
     def _time_views(self, plan, device, batch, cfg):
         """plan.time_views; a network that was caught writing into the shared time vectors gets clones from now on"""
@@ -807,18 +821,29 @@ class DPM_Solver:
 
     def _eval_model(self, x, t, to_x0):
         _require_gpu(x)
-        tf = self._tf(t)
         mt, gd, sc = self._model_codes()
         st = L.Stage()
         st.h1_slot = st.h2_slot = st.m_slot = -1
-        L.check(L.lib.dpm_coef_prologue(self._h, tf, mt, gd, sc, C.byref(st)))
+        dbl, tf64 = self._double_call(x, t)
+        c64 = None
+        dev = x.device
+        if dbl:
+            c64 = L.StageF64()
+            L.check(L.lib.dpm_coef_prologue_f64(self._h, self._td(t), int(tf64), mt, gd, sc, C.byref(st), C.byref(c64)))
+            tdt = torch.float64 if tf64 else torch.float32
+            te_t, ti_t = self._tt(c64.t_eval, dev, dtype=tdt), self._tt(c64.t_input, dev, dtype=tdt)
+            tf = c64.t_eval
+        else:
+            tf = self._tf(t)
+            L.check(L.lib.dpm_coef_prologue(self._h, tf, mt, gd, sc, C.byref(st)))
+            te_t, ti_t = self._tt(st.t_eval, dev), self._tt(st.t_input, dev)
         st.form = L.FORM_DENOISE
         st.flags = L.F_TO_X0 if to_x0 else 0
         self._prep_stage(st)
-        dev = x.device
-        outs = self._network(x, self._tt(st.t_eval, dev), self._tt(st.t_input, dev))
-        sd = self._sdtype(x)
-        out, _ = self._run_stage(st, None, x, outs, None, None, sd, t if torch.is_tensor(t) else self._tt(tf, dev), want_m=False)
+        outs = self._network(x, te_t, ti_t)
+        sd = torch.float64 if dbl else self._sdtype(x)
+        out, _ = self._run_stage(st, None, x, outs, None, None, sd, t if torch.is_tensor(t) else self._tt(tf, dev), want_m=False,
+                                 coef64=self._stage64(st, c64) if sd is torch.float64 else None)
         return out
 
     def noise_prediction_fn(self, x, t):
@@ -863,13 +888,15 @@ class DPM_Solver:
     # ------------------------------------------------------------------------------------------
     # public per-update methods (ref :547-954)
     # ------------------------------------------------------------------------------------------
-    def _exec_single(self, stages, x, given, want):
+    def _exec_single(self, stages, x, given, want, c64s=None, tf64=False):
         """Run 1-3 singlestep stages starting from state x.  `given[i]` = model value already known for
-        stage i; `want` = return the model values.  Returns (x_t, [m_0, m_1, m_2])."""
+        stage i; `want` = return the model values.  Returns (x_t, [m_0, m_1, m_2]).  c64s: the stages' doubles
+        (dpm_coef_singlestep_f64) when the call's scalars are doubles; tf64: the caller's time tensors are doubles."""
         _require_gpu(x)
         dev = x.device
-        sd = self._sdtype(x)
+        sd = torch.float64 if c64s is not None else self._sdtype(x)
         mt, gd, sc = self._model_codes()
+        k64 = lambda i, st_: (self._stage64(st_, c64s[i] if c64s is not None else None) if sd is torch.float64 else None)
         n = len(stages)
         ms = [given.get(i) for i in range(n)]
         tmp = None
@@ -881,15 +908,21 @@ class DPM_Solver:
             h1 = ms[0] if st.h1_slot >= 0 else None
             h2 = ms[1] if st.h2_slot >= 0 else None
             if ms[i] is not None:
-                out, _ = self._run_given(st, x, ms[i], h1, h2, sd, want_m=False)
+                out, _ = self._run_given(st, x, ms[i], h1, h2, sd, want_m=False, coef64=k64(i, st))
             else:
                 xe = x if i == 0 else tmp
-                L.check(L.lib.dpm_coef_prologue(self._h, st.t_eval, mt, gd, sc, C.byref(st)))
+                if c64s is not None:
+                    t64 = bool(c64s[i].time_f64 & 1)
+                    L.check(L.lib.dpm_coef_prologue_f64(self._h, c64s[i].t_eval, int(t64), mt, gd, sc, C.byref(st), C.byref(c64s[i])))
+                    tdt = torch.float64 if t64 else torch.float32
+                    te_t, ti_t = self._tt(c64s[i].t_eval, dev, dtype=tdt), self._tt(c64s[i].t_input, dev, dtype=tdt)
+                else:
+                    L.check(L.lib.dpm_coef_prologue(self._h, st.t_eval, mt, gd, sc, C.byref(st)))
+                    te_t, ti_t = self._tt(st.t_eval, dev), self._tt(st.t_input, dev)
                 self._prep_stage(st)
-                outs = self._network(xe, self._tt(st.t_eval, dev), self._tt(st.t_input, dev))
+                outs = self._network(xe, te_t, ti_t)
                 need_m = want or (i == 0 and n > 1) or (i == 1 and n == 3 and stages[2].h2_slot >= 0)
-                out, m = self._run_stage(st, x, None if i == 0 else xe, outs, h1, h2, sd, self._tt(st.t_eval, dev),
-                                         want_m=need_m)
+                out, m = self._run_stage(st, x, None if i == 0 else xe, outs, h1, h2, sd, te_t, want_m=need_m, coef64=k64(i, st))
                 ms[i] = m
             if last:
                 x_t = out
@@ -897,11 +930,23 @@ class DPM_Solver:
                 tmp = out
         return x_t, ms
 
+    def _singlestep_stages(self, x, order, solver_code, s, t, r1, r2, mode):
+        """(stages, their doubles or None, the time tensors are doubles) of a singlestep update s -> t"""
+        dbl, tf64 = self._double_call(x, s, t, r1, r2)
+        st = (L.Stage * order)()
+        if not dbl:
+            L.check(L.lib.dpm_coef_singlestep(self._h, self._algo, solver_code, order, self._tf(s), self._tf(t), r1 if not mode else
+                                              self._tf(r1), r2 if not mode else self._tf(r2), mode, st))
+            return [st[i] for i in range(order)], None, False
+        c64 = (L.StageF64 * order)()
+        L.check(L.lib.dpm_coef_singlestep_f64(self._h, self._algo, solver_code, order, self._td(s), self._td(t), int(tf64),
+                                              self._td(r1), self._td(r2), mode, st, c64))
+        return [st[i] for i in range(order)], [c64[i] for i in range(order)], tf64
+
     def dpm_solver_first_update(self, x, s, t, model_s=None, return_intermediate=False):
         """DPM-Solver-1 (equivalent to DDIM) from time `s` to time `t` (ref :547-592)."""
-        st = (L.Stage * 1)()
-        L.check(L.lib.dpm_coef_singlestep(self._h, self._algo, 0, 1, self._tf(s), self._tf(t), 0., 0., 0, st))
-        x_t, ms = self._exec_single([st[0]], x, {0: model_s} if model_s is not None else {}, return_intermediate)
+        stages, c64s, tf64 = self._singlestep_stages(x, 1, 0, s, t, 0., 0., 0)
+        x_t, ms = self._exec_single(stages, x, {0: model_s} if model_s is not None else {}, return_intermediate, c64s, tf64)
         return (x_t, {'model_s': ms[0]}) if return_intermediate else x_t
 
     def singlestep_dpm_solver_second_update(self, x, s, t, r1=0.5, model_s=None, return_intermediate=False,
@@ -912,10 +957,8 @@ class DPM_Solver:
         if r1 is None:
             r1 = 0.5
         mode = 1 if torch.is_tensor(r1) else 0
-        st = (L.Stage * 2)()
-        L.check(L.lib.dpm_coef_singlestep(self._h, self._algo, L.SOLVER[solver_type], 2, self._tf(s), self._tf(t),
-                                          self._tf(r1) if mode else float(r1), 0., mode, st))
-        x_t, ms = self._exec_single([st[0], st[1]], x, {0: model_s} if model_s is not None else {}, return_intermediate)
+        stages, c64s, tf64 = self._singlestep_stages(x, 2, L.SOLVER[solver_type], s, t, r1 if mode else float(r1), 0., mode)
+        x_t, ms = self._exec_single(stages, x, {0: model_s} if model_s is not None else {}, return_intermediate, c64s, tf64)
         return (x_t, {'model_s': ms[0], 'model_s1': ms[1]}) if return_intermediate else x_t
 
     def singlestep_dpm_solver_third_update(self, x, s, t, r1=1. / 3., r2=2. / 3., model_s=None, model_s1=None,
@@ -928,31 +971,38 @@ class DPM_Solver:
         if r2 is None:
             r2 = 2. / 3.
         mode = 1 if (torch.is_tensor(r1) or torch.is_tensor(r2)) else 0
-        st = (L.Stage * 3)()
-        L.check(L.lib.dpm_coef_singlestep(self._h, self._algo, L.SOLVER[solver_type], 3, self._tf(s), self._tf(t),
-                                          self._tf(r1) if mode else float(r1), self._tf(r2) if mode else float(r2),
-                                          mode, st))
+        stages, c64s, tf64 = self._singlestep_stages(x, 3, L.SOLVER[solver_type], s, t, r1 if mode else float(r1),
+                                                     r2 if mode else float(r2), mode)
         given = {}
         if model_s is not None:
             given[0] = model_s
         if model_s1 is not None:
             given[1] = model_s1
-        stages = [st[0], st[1], st[2]]
         if 1 in given and 0 not in given:
             # reference: model_s is evaluated at (x, s) even when model_s1 is supplied (ref :720-721)
             given[0] = self.model_fn(x, s)
         # the taylor combination reads model_s1 (h2): keep it even when not asked for
-        x_t, ms = self._exec_single(stages, x, given, return_intermediate or solver_type == 'taylor')
+        x_t, ms = self._exec_single(stages, x, given, return_intermediate or solver_type == 'taylor', c64s, tf64)
         return (x_t, {'model_s': ms[0], 'model_s1': ms[1], 'model_s2': ms[2]}) if return_intermediate else x_t
 
     def _multistep(self, x, model_prev_list, t_prev_list, t, order, solver_type):
         _require_gpu(x)
-        tp = (C.c_float * order)(*[self._tf(v) for v in t_prev_list[-order:]])
         st = L.Stage()
-        L.check(L.lib.dpm_coef_multistep(self._h, self._algo, L.SOLVER[solver_type], order, tp, self._tf(t), C.byref(st)))
+        dbl, tf64 = self._double_call(x, t, *t_prev_list[-order:])
+        c64 = None
+        if dbl:
+            tp = (C.c_double * order)(*[self._td(v) for v in t_prev_list[-order:]])
+            c64 = L.StageF64()
+            L.check(L.lib.dpm_coef_multistep_f64(self._h, self._algo, L.SOLVER[solver_type], order, tp, self._td(t), int(tf64),
+                                                 C.byref(st), C.byref(c64)))
+        else:
+            tp = (C.c_float * order)(*[self._tf(v) for v in t_prev_list[-order:]])
+            L.check(L.lib.dpm_coef_multistep(self._h, self._algo, L.SOLVER[solver_type], order, tp, self._tf(t), C.byref(st)))
         h1 = model_prev_list[-2] if order >= 2 else None
         h2 = model_prev_list[-3] if order >= 3 else None
-        x_t, _ = self._run_given(st, x, model_prev_list[-1], h1, h2, self._sdtype(x), want_m=False)
+        sd = torch.float64 if dbl else self._sdtype(x)
+        x_t, _ = self._run_given(st, x, model_prev_list[-1], h1, h2, sd, want_m=False,
+                                 coef64=self._stage64(st, c64) if sd is torch.float64 else None)
         return x_t
 
     def multistep_dpm_solver_second_update(self, x, model_prev_list, t_prev_list, t, solver_type="dpmsolver"):
@@ -1112,11 +1162,17 @@ class DPM_Solver:
                 and self._user_x0 is None and not half_unknown and self._sdtype(x) is not torch.float64):
             return self._adaptive_device(x, order, t_T, t_0, h_init, atol, rtol, theta, t_err, solver_type)
         ns = self.noise_schedule
-        lam = lambda v: _F32(ns._eval_np(L.EVAL_LAMBDA, [v])[0])
-        s = _F32(t_T)
+        # the reference's loop variables are tensors of x's dtype (`t_T * torch.ones((1,)).to(x)`, ref :958): with a double
+        # state every scalar of the loop -- and of the updates it calls -- is a double, whatever the schedule's dtype
+        dbl = self._sdtype(x) is torch.float64
+        FT = np.float64 if dbl else _F32
+        ev = ns._eval_np64 if dbl else ns._eval_np
+        lam = lambda v: FT(ev(L.EVAL_LAMBDA, [v])[0])
+        tm = (lambda v: torch.tensor(float(v), dtype=torch.float64)) if dbl else float     # the time argument of the updates
+        s = FT(t_T)
         lambda_s = lam(s)
-        lambda_0 = lam(_F32(t_0))
-        h = _F32(h_init)
+        lambda_0 = lam(FT(t_0))
+        h = FT(h_init)
         x_prev = x
         nfe = 0
         if order == 2:
@@ -1132,20 +1188,21 @@ class DPM_Solver:
                 x, s, t, r1=r1, r2=r2, solver_type=solver_type, **kw)
         else:
             raise ValueError("For adaptive step size solver, order must be 2 or 3, got {}".format(order))
-        while abs(_F32(s - _F32(t_0))) > t_err:
-            t = _F32(ns._eval_np(L.EVAL_INV_LAMBDA, [_F32(lambda_s + h)])[0])
-            x_lower, lower_noise_kwargs = lower_update(x, float(s), float(t))
-            x_higher = higher_update(x, float(s), float(t), **lower_noise_kwargs)
+        while abs(FT(s - FT(t_0))) > t_err:
+            t = FT(ev(L.EVAL_INV_LAMBDA, [FT(lambda_s + h)])[0])
+            x_lower, lower_noise_kwargs = lower_update(x, tm(s), tm(t))
+            x_higher = higher_update(x, tm(s), tm(t), **lower_noise_kwargs)
             E_dev = _adaptive_error(x_lower, x_higher, x_prev, atol, rtol)
             if self.error_reduce is not None:
                 E_dev = self.error_reduce(E_dev)     # batch-sharded runs: MAX all-reduce over the ranks
-            E = _F32(E_dev.item())                   # the one host sync per iteration, as in the reference (ref :1002)
+            E = FT(E_dev.item())                     # the one host sync per iteration, as in the reference (ref :1002)
             if E <= 1.:
                 x = x_higher
                 s = t
                 x_prev = x_lower
                 lambda_s = lam(s)
-            h = min(_F32(_F32(theta) * h * _F32(np.float64(E) ** (-1. / order))), _F32(lambda_0 - lambda_s))
+            # torch.float_power(E, -1 / order).float(): the power is an fp32 number also in a double-precision run (ref :1007)
+            h = min(FT(FT(theta) * h * FT(_F32(np.float64(E) ** (-1. / order)))), FT(lambda_0 - lambda_s))
             nfe += order
         print('adaptive solver nfe', nfe)
         return x

@@ -281,6 +281,17 @@ int dpm_coef_singlestep(const dpm_schedule* s, int algo, int solver_type, int or
 int dpm_coef_prologue(const dpm_schedule* s, float t_eval, int model_type, int guidance, double guidance_scale,
                       dpm_stage* inout);
 
+/* the same in double (a double-precision evaluation: double time tensors, or a schedule declared dtype=float64): out = the
+   integer fields + the doubles rounded, out64 = the doubles.  time_f64: the caller's time tensors are doubles (else fp32
+   tensors whose values arrive converted exactly) -- decides the dtype the model time label is computed in (ref :278).
+   dpm_coef_first is dpm_coef_multistep_f64 with order 1. */
+int dpm_coef_multistep_f64(const dpm_schedule* s, int algo, int solver_type, int order, const double* t_prev, double t_t,
+                           int time_f64, dpm_stage* out, dpm_stage_f64* out64);
+int dpm_coef_singlestep_f64(const dpm_schedule* s, int algo, int solver_type, int order, double t_s, double t_t, int time_f64,
+                            double r1, double r2, int r_mode, dpm_stage* out /* [order] */, dpm_stage_f64* out64 /* [order] */);
+int dpm_coef_prologue_f64(const dpm_schedule* s, double t_eval, int time_f64, int model_type, int guidance, double guidance_scale,
+                          dpm_stage* inout, dpm_stage_f64* inout64);
+
 /* ---- device side --------------------------------------------------------------------------- */
 /* one fused stage kernel, asynchronous on `stream` */
 int dpm_stage_launch(const dpm_stage* st, const dpm_buffers* b, void* stream);

@@ -18,8 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PRODUCT_ABI = """
 dpm_adaptive_begin dpm_adaptive_create dpm_adaptive_destroy dpm_adaptive_done_at dpm_adaptive_error
 dpm_adaptive_error_launch dpm_adaptive_poll dpm_adaptive_reset dpm_adaptive_stage_launch dpm_adaptive_stage_template
-dpm_add_noise_launch dpm_blend_launch dpm_cluster_timeout_poll dpm_coef_first dpm_coef_multistep dpm_coef_prologue
-dpm_coef_singlestep dpm_device_info dpm_graph_create dpm_graph_destroy dpm_graph_launch dpm_graph_num_nodes
+dpm_add_noise_launch dpm_blend_launch dpm_cluster_timeout_poll dpm_coef_first dpm_coef_multistep dpm_coef_multistep_f64
+dpm_coef_prologue dpm_coef_prologue_f64 dpm_coef_singlestep dpm_coef_singlestep_f64 dpm_device_info dpm_graph_create dpm_graph_destroy dpm_graph_launch dpm_graph_num_nodes
 dpm_graph_result dpm_last_error dpm_numerical_clip_len_f32 dpm_numerical_clip_len_f64 dpm_plan_create dpm_plan_destroy
 dpm_plan_num_slots dpm_plan_num_stages dpm_plan_run dpm_plan_run_multi dpm_plan_stage dpm_plan_stage_f64 dpm_plan_timesteps
 dpm_schedule_create_alphas_cumprod_f32 dpm_schedule_create_alphas_cumprod_f64 dpm_schedule_create_betas_f32

@@ -326,3 +326,44 @@ def test_model_fn_with_per_sample_times_against_the_reference(R, model_type, gui
         # and a uniform vector equals the 0-dim path of the solver's own evaluation
         t1 = torch.full((5,), 0.37)
         assert rel_err(efn(x, t1).numpy(), rcell(x, t1).numpy()) < TOL
+
+
+@pytest.mark.parametrize("ns_dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("t_dtype", [torch.float64, torch.float32])
+def test_public_update_methods_and_adaptive_in_double(R, ns_dtype, t_dtype, capsys):
+    """The public per-update methods and the adaptive solver on a double state: every scalar is a double as soon as a time
+    tensor or the schedule's tables are (torch's type promotion; dpm_coef_*_f64), and the adaptive loop's own variables have
+    x's dtype (ref :958).  1e-12 wherever a scalar is a double; an fp32 schedule with fp32 times keeps fp32 scalars: 1e-6."""
+    rns, ens = _f64_schedules(R, "ddpm", ns_dtype)
+    x = torch.from_numpy(np.random.default_rng(9).standard_normal((3, 3, 8, 8)))
+    net = lambda xx, t: xx * 0.5 * torch.cos(t.to(xx.dtype) * 1e-3).reshape(-1, 1, 1, 1) + 0.1
+    tol = 1e-6 if (ns_dtype, t_dtype) == (torch.float32, torch.float32) else 1e-12
+    for algo in ("dpmsolver++", "dpmsolver"):
+        r = R.DPM_Solver(R.model_wrapper(net, rns), rns, algorithm_type=algo)
+        e = D.DPM_Solver(D.model_wrapper(net, ens), ens, algorithm_type=algo)
+        s_, t_ = torch.tensor([0.8], dtype=t_dtype), torch.tensor([0.6], dtype=t_dtype)
+        tl = [torch.tensor([0.95], dtype=t_dtype), torch.tensor([0.9], dtype=t_dtype), s_]
+        ml = [r.model_fn(x, tt_) for tt_ in tl]
+        pairs = [(e.dpm_solver_first_update(x, s_, t_), r.dpm_solver_first_update(x, s_, t_)),
+                 (e.singlestep_dpm_solver_second_update(x, s_, t_, solver_type="taylor"),
+                  r.singlestep_dpm_solver_second_update(x, s_, t_, solver_type="taylor")),
+                 (e.singlestep_dpm_solver_third_update(x, s_, t_), r.singlestep_dpm_solver_third_update(x, s_, t_)),
+                 (e.singlestep_dpm_solver_third_update(x, s_, t_, solver_type="taylor"),
+                  r.singlestep_dpm_solver_third_update(x, s_, t_, solver_type="taylor")),
+                 (e.model_fn(x, s_), r.model_fn(x, s_)), (e.data_prediction_fn(x, t_), r.data_prediction_fn(x, t_)),
+                 (e.multistep_dpm_solver_update(x, ml, tl, t_, 2), r.multistep_dpm_solver_update(x, ml, tl, t_, 2)),
+                 (e.multistep_dpm_solver_update(x, ml, tl, t_, 3, solver_type="taylor"),
+                  r.multistep_dpm_solver_update(x, ml, tl, t_, 3, solver_type="taylor"))]
+        for i, (a, b) in enumerate(pairs):
+            assert a.dtype == b.dtype == torch.float64, (algo, i)
+            assert rel_err(a.numpy(), b.numpy()) <= tol, (algo, i, rel_err(a.numpy(), b.numpy()))
+    if t_dtype is torch.float64:
+        r = R.DPM_Solver(R.model_wrapper(net, rns), rns)
+        e = D.DPM_Solver(D.model_wrapper(net, ens), ens)
+        for order in (2, 3):
+            want = r.sample(x, method="adaptive", order=order, t_end=1e-3)
+            nfe_r = capsys.readouterr().out
+            got = e.sample(x, method="adaptive", order=order, t_end=1e-3)
+            nfe_e = capsys.readouterr().out
+            assert nfe_r == nfe_e and "nfe" in nfe_e
+            assert got.dtype == want.dtype == torch.float64 and rel_err(got.numpy(), want.numpy()) <= 1e-12
