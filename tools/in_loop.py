@@ -373,7 +373,7 @@ def main():
                                               trajectories=args.trajectories, net_dtype=bench._DT[ename])
                     print("%s state / %s network  U=%d nt=%d   stage kernel in the loop %7.3f us (events; %.3f of peak)   "
                           "added wall per stage %7.3f us" % (sname, ename, u, nt, r["stage_kernel_us"], r["frac"],
-                                                            r["stage_added_wall_us"]), flush=True)
+                                                            r["trajectory_minus_network_alone_us_per_stage"]), flush=True)
         return
     if args.unroll:
         L.check(L.lib.dpm_tuning_set(L.TUNE_UNROLL, args.unroll))

@@ -140,13 +140,18 @@ def in_network_loop(D, L, ns, dev, dtype, kind="gemm", width=256, trajectories=6
                 stage_kernel_p10_p90_us=[round(float(np.percentile(steady, 10)), 3), round(float(np.percentile(steady, 90)), 3)],
                 frac=round(alg / med / 1e3 / HBM_PEAK_GBS, 4), achieved=round(alg / med / 1e3, 1),
                 first_stage_us=round(float(np.median(us[1:, 0])), 3), last_stage_us=round(float(np.median(us[1:, -1])), 3),
-                stage_added_wall_us=round(added, 3), stage_added_wall_iqr_us=[round(v, 3) for v in added_iqr],
-                frac_wall=round(alg / max(added, 1e-3) / 1e3 / HBM_PEAK_GBS, 4),
+                # (trajectory - the same 20 network calls alone) / 20, median of paired alternating runs -- NOT the solver's
+                # cost: the two runs feed the network different data (evolving states vs the constant x_T) and a 40 ms
+                # network-dominated pair differs by +-0.5 ms for that reason alone.  By rocprofv3 rows the stage kernel starts
+                # 0.00 us behind the network's last kernel and the network's next kernel 0.00 us behind it
+                # (profiles/r05_in_loop_trace_conv_fp16.md): on the GPU's timeline a stage adds its kernel, nothing else.
+                trajectory_minus_network_alone_us_per_stage=round(added, 3),
+                trajectory_minus_network_alone_iqr_us_per_stage=[round(v, 3) for v in added_iqr],
+                solver_share_of_trajectory=round(n_st * med / t_solver, 5),
                 trajectory_ms=round(t_solver / 1e3, 4), prefetch=prefetch,
                 how="DPM_Solver.sample() on one [%d,4,64,64] %s request, 2M++ 20 steps, torch network as model_fn; "
                     "stage_kernel_us = median start->stop event interval of the steady-state stage launches inside the "
-                    "loop (dpm_stage_launch_traced); stage_added_wall_us = median paired difference (trajectory - the same 20 network "
-                    "calls alone, alternating runs) / 20"
+                    "loop (dpm_stage_launch_traced)"
                     % (B, str(dtype).split(".")[-1]))
 
 
