@@ -263,6 +263,12 @@ def _thr_sweep(rng, total):
         sol = O.Solver(O.wrap_model(lambda xx, t: (xx * scale).astype(F32), osch), osch,
                        correcting_x0_fn="dynamic_thresholding", thresholding_max_val=mv, dynamic_thresholding_ratio=p)
         np.testing.assert_array_equal(got, sol.sample(x, steps=steps, order=order), err_msg=str((B, Cc, H, W, p, mv, sname, steps, order)))
+        #  the workspace of a clustered shape is left all zero by every launch -- also under the forced
+        # faults of DPM_THR_SWEEP_FAULT with the predicted route (thr_hint) active, where a workgroup that gave up may have
+        # rewritten the hint words a late peer predicts from
+        for fr in dpm._fast.values():
+            if getattr(fr, "ws", None) is not None:
+                assert not bool(fr.ws.any()), ("workspace not left zero-filled", B, Cc, H, W, p, mv, sname, steps, order)
         done += 1
 
 

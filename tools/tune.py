@@ -2,8 +2,8 @@
 """Launch-shape sweeps of the stage kernels on the GPU (run via gpurun).  One tool, two sweeps; both need a library
 built with every (tiles per iteration, nt mask) variant:
 
-    python -c "import __graft_entry__ as g; g.build_variant('tune', ['-DDPM_TUNING_VARIANTS'])"
-    export DPM_SOLVER_AMD_LIB=tools/_variants/tune/libdpm_hip.so
+    python -c "import __graft_entry__ as g; g.build_variant('tune', ['-DDPM_TUNING_VARIANTS'], lab=True)"   # a LAB variant: the knobs
+    export DPM_SOLVER_AMD_LIB=tools/_variants/tune/libdpm_lab.so
     python tools/tune.py multi  [--requests 32]      > profiles/rNN_tune_multi.txt     # fused multi-request launches
     python tools/tune.py single [--dtypes fp16,fp32] > profiles/rNN_tune_single.txt    # one request per launch
 
