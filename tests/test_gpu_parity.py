@@ -269,6 +269,8 @@ def _thr_sweep(rng, total):
         for fr in dpm._fast.values():
             if getattr(fr, "ws", None) is not None:
                 assert not bool(fr.ws.any()), ("workspace not left zero-filled", B, Cc, H, W, p, mv, sname, steps, order)
+        for ws in S._WS_CACHE.values():
+            assert not bool(ws.any()), ("shared workspace not left zero-filled", B, Cc, H, W, p, mv, sname, steps, order)
         done += 1
 
 
