@@ -65,6 +65,7 @@ struct Tuning {
   int lds_dma = -1;         // lone-launch north-star kernels: read streams by LDS-DMA (1) / through registers (0); -1 = default
   int force_generic = 0;    // LAB: take the run-time-prologue kernels (SPEC_GENERIC / HOT 3) where a compile-time one exists (A/B)
   int thr_elect = -1;       // clustered thresholding: one elected reducer per sample (1) / every workgroup reads every slot (0)
+  int thr_stagger = 0;      // LAB: start offset between thresholding clusters (ThrParams.stagger)
   int thr_debug_fault = 0;  // LAB ONLY (fault injection; compiled out of the product kernels): 1 = every cluster wait gives
                             // up at its first unsuccessful poll, 2 / 3 = workgroup 1 of every cluster takes no part from the
                             // start, with / without marking the sample

@@ -392,6 +392,7 @@ int launch_thresh(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
     if (tn.thr_debug_fault == 1) tp.spin_limit = 0u;
     tp.debug_fault = tn.thr_debug_fault;
     tp.elect = tn.thr_elect > 0 && tp.quota > 0;
+    tp.stagger = tn.thr_stagger;
 #endif
     // the select bound predicted from the previous stages (dpm_buffers.thr_hint): single requests on the one-exchange route
     // -- where it pays: a small K (the wanted rank from the top), so that the predicted union (~1.3-1.9 K entries instead

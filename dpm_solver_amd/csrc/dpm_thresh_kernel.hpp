@@ -105,6 +105,9 @@ struct ThrParams {
   int32_t elect;        // LAB build only (DPM_TUNE_THR_ELECT): workgroup 0 of a cluster reads the k slots, selects on the union
                         // and publishes the verdict; its peers make one wait and read three words -- k slot reads per sample
                         // instead of k^2 (profiles/r05_thresholding.md)
+  int32_t stagger;      // LAB build only (DPM_TUNE_THR_STAGGER): cluster g starts (g % groups) * ticks of 0.1 us late -- low 16
+                        // bits = ticks, high bits = groups (0 = 2): clusters that walk several large samples stay out of
+                        // phase, so that one group streams while another selects (profiles/r05_thresholding.md)
 #endif
   float* hint;     // dpm_buffers.thr_hint (THR_HINT_W floats per sample) or null: the selected order statistic of the
                    // previous two stages -> predicted select bound of this one (cluster_select_once, `pbound`)
@@ -959,6 +962,14 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
   constexpr int dbg_fault = 0;
 #endif
   if (threadIdx.x == 0) misc[30] = (k > 1 && dbg_fault >= 2 && c == 1) ? 1u : 0u;
+#if DPM_LAB
+  if (tp.stagger) {  // experiment: phase offset between clusters (all workgroups of a cluster wait alike)
+    const uint32_t ng = (uint32_t)tp.stagger >> 16 ? (uint32_t)tp.stagger >> 16 : 2u;
+    const uint64_t ticks = (uint64_t)(((uint32_t)grp % ng) * ((uint32_t)tp.stagger & 0xffffu)) * 10u;  // wall clock: 100 MHz
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
   for (int s_idx = grp; s_idx < tp.batch; s_idx += tp.groups) {
     // The thread index is re-materialised per sample: otherwise the compiler hoists every per-thread predicate of the
     // body (dozens of 64-bit lane masks) out of this loop, runs out of SGPRs and pays v_readlane pairs all over the select.

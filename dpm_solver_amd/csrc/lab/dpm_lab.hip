@@ -239,6 +239,7 @@ extern "C" int dpm_tuning_set(int knob, int value) {
       return DPM_OK;
     case DPM_TUNE_THR_ELECT: g_lab_tuning.thr_elect = value < 0 ? -1 : (value != 0); return DPM_OK;
     case DPM_TUNE_FORCE_GENERIC: g_lab_tuning.force_generic = value != 0; return DPM_OK;
+    case DPM_TUNE_THR_STAGGER: g_lab_tuning.thr_stagger = value < 0 ? 0 : value; return DPM_OK;
     case DPM_TUNE_LDS_DMA: g_lab_tuning.lds_dma = value < 0 ? -1 : (value != 0); return DPM_OK;
     case DPM_TUNE_BLOCK_THREADS:
       if (value != 0 && value != 256 && value != 512)
@@ -270,6 +271,7 @@ extern "C" int dpm_tuning_get(int knob) {
     case DPM_TUNE_BLOCK_THREADS: return g_lab_tuning.block_threads;
     case DPM_TUNE_THR_ELECT: return g_lab_tuning.thr_elect;
     case DPM_TUNE_FORCE_GENERIC: return g_lab_tuning.force_generic;
+    case DPM_TUNE_THR_STAGGER: return g_lab_tuning.thr_stagger;
     case DPM_TUNE_LDS_DMA: return g_lab_tuning.lds_dma;
   }
   return -1;

@@ -45,6 +45,8 @@ enum {
                                        compile-time specialisation exists: the A/B behind the kernel-count budget        */
   DPM_TUNE_LDS_DMA = 15,            /* lone 2-byte 2M / first-order launch: read streams by LDS-DMA (1) or through registers (0);
                                        -1 (default): through registers, like the product (measured equal: r05_lone_floor.md) */
+  DPM_TUNE_THR_STAGGER = 16,        /* clustered thresholding: cluster g starts (g % groups) * ticks x 0.1 us late; value = groups << 16
+                                       | ticks (groups 0 = 2); 0 (default): off (profiles/r05_thresholding.md)         */
   DPM_TUNE_THR_ELECT = 14           /* clustered thresholding: 1 = one elected reducer per sample selects on the union and
                                        publishes the result (k slot reads per sample), 0 = every workgroup reads every slot
                                        (k^2); -1 (default): the library's choice                                        */
