@@ -88,62 +88,107 @@ struct Ptrs64 {
   int64_t mask_period, per_sample, eps_stride;
 };
 
-__device__ __forceinline__ double model_value64(const Ptrs64& q, const KParams64& p, int64_t i, int64_t ie) {
+// the operands of one element, loaded before anything is computed or stored: U elements per lane in flight (the kernels below
+// unroll by hand -- the pointers of Ptrs64 may alias as far as the compiler knows, so it would not hoist loads over stores)
+struct In64 {
+  double xe, o0, o1, gg;      // prologue
+  double x, h1, h2, mk, ba, bb;  // combine + blend
+};
+__device__ __forceinline__ void load_prologue64(const Ptrs64& q, const KParams64& p, int64_t i, int64_t ie, In64& v) {
   const bool need_xe = (p.flags & DPM_F_TO_X0) || p.model_type == DPM_MODEL_X_START || p.model_type == DPM_MODEL_V;
-  return prologue64(need_xe ? q.xe[i] : 0., q.e0[ie], p.guidance == DPM_GUIDE_CFG ? q.e1[ie] : 0.,
-                    p.guidance == DPM_GUIDE_CLASSIFIER ? q.g[i] : 0., p);
+  v.xe = need_xe ? q.xe[i] : 0.;
+  v.o0 = q.e0[ie];
+  v.o1 = p.guidance == DPM_GUIDE_CFG ? q.e1[ie] : 0.;
+  v.gg = p.guidance == DPM_GUIDE_CLASSIFIER ? q.g[i] : 0.;
 }
-__device__ __forceinline__ void finish64(const Ptrs64& q, const KParams64& p, int64_t i, double mn) {
+__device__ __forceinline__ void load_rest64(const Ptrs64& q, const KParams64& p, int64_t i, In64& v) {
   const int f = p.form;
-  const double xv = f != DPM_FORM_DENOISE ? q.x[i] : 0.;
-  const double h1 = (f == DPM_FORM_TWO || f == DPM_FORM_MS3 || f == DPM_FORM_SS3T) ? q.h1[i] : 0.;
-  const double h2 = (f == DPM_FORM_MS3 || f == DPM_FORM_SS3T) ? q.h2[i] : 0.;
-  double o = combine64(xv, mn, h1, h2, p);
+  v.x = f != DPM_FORM_DENOISE ? q.x[i] : 0.;
+  v.h1 = (f == DPM_FORM_TWO || f == DPM_FORM_MS3 || f == DPM_FORM_SS3T) ? q.h1[i] : 0.;
+  v.h2 = (f == DPM_FORM_MS3 || f == DPM_FORM_SS3T) ? q.h2[i] : 0.;
+  if (q.mask) {
+    v.mk = q.mask[i % q.mask_period];
+    v.ba = q.ba[i];
+    v.bb = q.bb ? q.bb[i] : 0.;
+  }
+}
+__device__ __forceinline__ double model_value64(const In64& v, const KParams64& p) { return prologue64(v.xe, v.o0, v.o1, v.gg, p); }
+__device__ __forceinline__ void finish64(const Ptrs64& q, const KParams64& p, int64_t i, const In64& v, double mn) {
+  double o = combine64(v.x, mn, v.h1, v.h2, p);
   if (q.mask) {  // x * mask + (1 - mask) * (alpha * a + sigma * b): the DPM_F_BLEND epilogue
-    const double m = q.mask[i % q.mask_period];
-    const double r = q.bb ? p.blend_alpha * q.ba[i] + p.blend_sigma * q.bb[i] : q.ba[i];
-    o = o * m + (1. - m) * r;
+    const double r = q.bb ? p.blend_alpha * v.ba + p.blend_sigma * v.bb : v.ba;
+    o = o * v.mk + (1. - v.mk) * r;
   }
   q.xo[i] = o;
   if (q.xo2) q.xo2[i] = o;
   if (p.flags & DPM_F_STORE_M) q.mo[i] = mn;
 }
 
+constexpr int U64 = 2;  // elements per lane in flight: workgroup b owns the U64 consecutive 256-element rows from b * U64 on
 __global__ __launch_bounds__(256) void stage_kernel_f64(const Ptrs64 q, const KParams64 p, int64_t n) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  const int64_t i0 = (int64_t)blockIdx.x * (U64 * 256) + threadIdx.x;
+  In64 v[U64];
+#pragma unroll
+  for (int u = 0; u < U64; ++u) {
+    const int64_t i = i0 + u * 256 < n ? i0 + u * 256 : (i0 < n ? i0 : 0);  // clamped: the loads are unconditional
     const int64_t ie = q.eps_stride ? (i / q.per_sample) * q.eps_stride + i % q.per_sample : i;
-    finish64(q, p, i, model_value64(q, p, i, ie));
+    load_prologue64(q, p, i, ie, v[u]);
+    load_rest64(q, p, i, v[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < U64; ++u) {
+    const int64_t i = i0 + u * 256;
+    if (i < n) finish64(q, p, i, v[u], model_value64(v[u], p));
   }
 }
 
 // ---- dynamic thresholding in double (ref :416-425): one workgroup per sample.  The two order statistics torch.quantile
 // interpolates between -- ascending ranks lo and lo + 1 of |x0| -- by a radix select over the 63-bit patterns (non-negative
-// doubles order like their bit patterns): six passes of 11 / 11 / 11 / 11 / 11 / 8 bits, x0 recomputed from the inputs in
-// every pass (same arithmetic, same bits), then clamp, divide, combine.
+// doubles order like their bit patterns): histogram passes of 11 / 11 / 11 / 11 / 11 / 8 bits over the sample, x0 recomputed
+// from the inputs in every pass (same arithmetic, same bits; a sample's inputs stay in L2 between the passes), until the
+// selected bin holds few enough values to finish among them in LDS (normally after two passes: the binade, then 11 mantissa
+// bits): one more pass collects the bin's members -- and the smallest value above the bin -- and the ranks are counted there.
+// Then clamp, divide, combine.
 constexpr int T64 = 1024, NB64 = 2048;
+constexpr int CAP64 = NB64 / 2;  // the candidate list (64-bit patterns) reuses the histogram's LDS
+constexpr int UT64 = 4;          // elements per lane in flight in the select passes (four operands each) ...
+constexpr int UF64 = 2;          // ... and in the store phase (ten): 128 registers per lane at 1024 threads
 __global__ __launch_bounds__(T64) void stage_thresh_kernel_f64(const Ptrs64 q, const KParams64 p, int64_t per_sample, int64_t lo,
                                                                int hi_differs, double w) {
-  __shared__ uint32_t hist[NB64];
-  __shared__ uint64_t sh_prefix, sh_min;
+  __shared__ __align__(8) uint32_t hist[NB64];
+  __shared__ uint64_t sh_prefix, sh_min, sh_a, sh_b;
   __shared__ int64_t sh_rank, sh_cnt;
+  __shared__ uint32_t sh_n;
+  constexpr uint64_t TOP = 0x7fffffffffffffffull;
   const int tid = threadIdx.x;
   const int64_t b = blockIdx.x, base = b * per_sample, ebase = b * (q.eps_stride ? q.eps_stride : per_sample);
-  auto bits_at = [&](int64_t j) -> uint64_t {
-    return (uint64_t)__double_as_longlong(model_value64(q, p, base + j, ebase + j)) & 0x7fffffffffffffffull;
+  // the patterns of elements j, j + T64, .. (UT64 of them, loads issued together); beyond the sample: TOP + 1 (matches no prefix)
+  auto bitsU = [&](int64_t j, uint64_t (&u)[UT64]) {
+    In64 v[UT64];
+#pragma unroll
+    for (int r = 0; r < UT64; ++r) {
+      const int64_t jj = j + (int64_t)r * T64 < per_sample ? j + (int64_t)r * T64 : j;
+      load_prologue64(q, p, base + jj, ebase + jj, v[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < UT64; ++r)
+      u[r] = j + (int64_t)r * T64 < per_sample ? ((uint64_t)__double_as_longlong(model_value64(v[r], p)) & TOP) : ~0ull;
   };
   uint64_t prefix = 0ull, known = 0ull;
-  int64_t rank = lo;
+  int64_t rank = lo, cnt = per_sample;
   const int shifts[6] = {52, 41, 30, 19, 8, 0};
   const int widths[6] = {11, 11, 11, 11, 11, 8};
-  for (int pass = 0; pass < 6; ++pass) {
+  for (int pass = 0; pass < 6 && cnt > CAP64; ++pass) {
     for (int j = tid; j < NB64; j += T64) hist[j] = 0u;
     __syncthreads();
     const int sh = shifts[pass];
     const uint64_t dm = (1ull << widths[pass]) - 1ull;
-    for (int64_t j = tid; j < per_sample; j += T64) {
-      const uint64_t u = bits_at(j);
-      if ((u & known) == prefix) atomicAdd(&hist[(u >> sh) & dm], 1u);
+    for (int64_t j = tid; j < per_sample; j += (int64_t)UT64 * T64) {
+      uint64_t u[UT64];
+      bitsU(j, u);
+#pragma unroll
+      for (int r = 0; r < UT64; ++r)
+        if (u[r] != ~0ull && (u[r] & known) == prefix) atomicAdd(&hist[(u[r] >> sh) & dm], 1u);
     }
     __syncthreads();
     if (tid == 0) {
@@ -164,29 +209,90 @@ __global__ __launch_bounds__(T64) void stage_thresh_kernel_f64(const Ptrs64 q, c
     prefix = sh_prefix;
     known |= dm << sh;
     rank = sh_rank;
+    cnt = sh_cnt;
     __syncthreads();
   }
-  const uint64_t a_bits = prefix;
-  uint64_t b_bits = a_bits;
-  if (hi_differs && rank + 1 >= sh_cnt) {  // the next order statistic is the smallest value above a (if any)
-    if (tid == 0) sh_min = 0x7fffffffffffffffull;
-    __syncthreads();
-    uint64_t m = 0x7fffffffffffffffull;
-    for (int64_t j = tid; j < per_sample; j += T64) {
-      const uint64_t u = bits_at(j);
-      if (u > a_bits && u < m) m = u;
+  uint64_t a_bits, b_bits;
+  if (known != TOP) {
+    // few members left in the selected bin (all of the sample when it is that small): collect them and the smallest value
+    // above the bin, finish by rank counting -- member v is the wanted one when #{smaller} <= rank < #{smaller} + #{equal}
+    uint64_t* list = reinterpret_cast<uint64_t*>(hist);
+    if (tid == 0) {
+      sh_n = 0u;
+      sh_min = TOP;
+      sh_a = sh_b = 0ull;
     }
-    atomicMin(reinterpret_cast<unsigned long long*>(&sh_min), (unsigned long long)m);
     __syncthreads();
-    if (sh_min != 0x7fffffffffffffffull) b_bits = sh_min;
+    uint64_t m = TOP;
+    for (int64_t j = tid; j < per_sample; j += (int64_t)UT64 * T64) {
+      uint64_t u[UT64];
+      bitsU(j, u);
+#pragma unroll
+      for (int r = 0; r < UT64; ++r) {
+        if (u[r] == ~0ull) continue;
+        if ((u[r] & known) == prefix)
+          list[atomicAdd(&sh_n, 1u)] = u[r];
+        else if ((u[r] & known) > prefix && u[r] < m)
+          m = u[r];
+      }
+    }
+    if (m != TOP) atomicMin(reinterpret_cast<unsigned long long*>(&sh_min), (unsigned long long)m);
+    __syncthreads();
+    const uint32_t nl = sh_n;  // == cnt
+    if ((uint32_t)tid < nl) {
+      const uint64_t v = list[tid];
+      int64_t less = 0, eq = 0;
+      for (uint32_t jj = 0; jj < nl; ++jj) {
+        const uint64_t o = list[jj];
+        less += o < v;
+        eq += o == v;
+      }
+      if (less <= rank && rank < less + eq) sh_a = v;          // every thread holding this value writes the same bits
+      if (less <= rank + 1 && rank + 1 < less + eq) sh_b = v;
+    }
+    __syncthreads();
+    a_bits = sh_a;
+    // the next order statistic: inside the bin when rank + 1 is, otherwise the smallest value above it (if there is none,
+    // lo is the sample's last rank and torch reads the same element twice)
+    b_bits = (rank + 1 < (int64_t)nl) ? sh_b : (sh_min != TOP ? sh_min : a_bits);
+    if (!hi_differs) b_bits = a_bits;
+  } else {
+    // every bit settled by histograms (more than CAP64 copies of one value all the way down)
+    a_bits = prefix;
+    b_bits = a_bits;
+    if (hi_differs && rank + 1 >= cnt) {  // the next order statistic is the smallest value above a (if any)
+      if (tid == 0) sh_min = TOP;
+      __syncthreads();
+      uint64_t m = TOP;
+      for (int64_t j = tid; j < per_sample; j += (int64_t)UT64 * T64) {
+        uint64_t u[UT64];
+        bitsU(j, u);
+#pragma unroll
+        for (int r = 0; r < UT64; ++r)
+          if (u[r] != ~0ull && u[r] > a_bits && u[r] < m) m = u[r];
+      }
+      atomicMin(reinterpret_cast<unsigned long long*>(&sh_min), (unsigned long long)m);
+      __syncthreads();
+      if (sh_min != TOP) b_bits = sh_min;
+    }
   }
   const double a = __longlong_as_double((long long)a_bits), bb = __longlong_as_double((long long)b_bits);
   const double diff = bb - a;
   const double qv = w < 0.5 ? a + w * diff : bb - diff * (1. - w);  // ATen lerp
   const double s = fmax(qv, p.thr_max);                               // ref :423
-  for (int64_t j = tid; j < per_sample; j += T64) {
-    const double x0 = model_value64(q, p, base + j, ebase + j);
-    finish64(q, p, base + j, fmin(fmax(x0, -s), s) / s);              // ref :424
+  for (int64_t j = tid; j < per_sample; j += (int64_t)UF64 * T64) {
+    In64 v[UF64];
+#pragma unroll
+    for (int r = 0; r < UF64; ++r) {
+      const int64_t jj = j + (int64_t)r * T64 < per_sample ? j + (int64_t)r * T64 : j;
+      load_prologue64(q, p, base + jj, ebase + jj, v[r]);
+      load_rest64(q, p, base + jj, v[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < UF64; ++r) {
+      const int64_t jj = j + (int64_t)r * T64;
+      if (jj < per_sample) finish64(q, p, base + jj, v[r], fmin(fmax(model_value64(v[r], p), -s), s) / s);  // ref :424
+    }
   }
 }
 
@@ -241,10 +347,8 @@ int dpm_launch_f64(const dpm_stage* st, const dpm_buffers* b, void* stream, void
     launch(stage_thresh_kernel_f64, dim3((unsigned)b->batch), dim3(T64), 0, ctx, q, p, q.per_sample, (int64_t)lo, hi != lo ? 1 : 0,
            rank - lo);
   } else {
-    const DeviceInfo& di = device_info();
-    int64_t blocks = (b->n + 255) / 256;
-    const int64_t cap = (int64_t)(di.n_cu > 0 ? di.n_cu : 256) * 16;
-    if (blocks > cap) blocks = cap;
+    const int64_t blocks = (b->n + U64 * 256 - 1) / (U64 * 256);  // one tile per workgroup, no grid-stride loop
+    if (blocks > 0x7fffffff) return dpm_set_error(DPM_ERR_UNSUPPORTED, "stage_launch: double state of %lld elements", (long long)b->n);
     launch(stage_kernel_f64, dim3((unsigned)blocks), dim3(256), 0, ctx, q, p, b->n);
   }
   hipError_t e = hipGetLastError();

@@ -959,6 +959,11 @@ def test_double_precision_state_on_the_gpu(ns_dtype, monkeypatch):
             got, want = got[0], want[0]
         assert got.dtype == torch.float64 and got.is_cuda
         assert float((got.cpu() - want).abs().max()) <= 1e-14 * float(want.abs().max()), (kind, kw)
+    # more elements than one pass of the grid covers (several elements per lane in flight, the last group ragged)
+    xb = torch.from_numpy(rng.standard_normal((83, 4, 63, 65)))
+    got = solver(DEV, "plain").sample(xb.to(DEV), steps=4, order=3)
+    want = _double_on_cpu(monkeypatch, lambda: solver("cpu", "plain").sample(xb, steps=4, order=3))
+    assert float((got.cpu() - want).abs().max()) <= 1e-14 * float(want.abs().max())
     # add_noise and the stand-alone thresholding call in double
     dpm = solver(DEV, "thr")
     x0 = (xc * 2.0).to(DEV)
@@ -973,6 +978,30 @@ def test_double_precision_state_on_the_gpu(ns_dtype, monkeypatch):
     a, sg = ns.marginal_alpha(tt_).double().to(DEV), ns.marginal_std(tt_).double().to(DEV)
     want_an = a.reshape(2, 1, 1, 1, 1) * x0 + sg.reshape(2, 1, 1, 1, 1) * noise
     assert an.dtype == torch.float64 and float((an - want_an).abs().max()) <= 1e-15 * float(want_an.abs().max())
+
+
+@pytest.mark.parametrize("shape", [(5, 1, 7, 9), (3, 1, 32, 32), (4, 3, 64, 64), (2, 3, 100, 101)])
+def test_double_thresholding_select_against_torch_quantile(shape):
+    """the double-precision thresholding kernel's select (csrc/dpm_f64.hip: histogram passes over the 63-bit patterns until
+    the selected bin fits an LDS list, rank counting there) against torch.quantile in double, bit for bit: samples smaller
+    than the list (no histogram pass at all), odd sizes, heavy ties (more copies of one value than the list holds: every bit
+    settled by histograms), constant samples, ratios whose rank is integral / fractional / the last element"""
+    ns = D.NoiseScheduleVP("discrete", betas=torch.linspace(1e-4, 0.02, 1000, dtype=torch.float64), dtype=torch.float64)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    base = torch.randn(shape, dtype=torch.float64, device=DEV, generator=g) * 1.7
+    B = shape[0]
+    variants = {"random": base, "ties": torch.round(base * 2.0) / 2.0, "constant": torch.full_like(base, 1.25),
+                "two_values": torch.where(base > 0.3, torch.full_like(base, 3.0), torch.full_like(base, 0.5)),
+                "tiny": base * 1e-200, "with_zeros": torch.where(base.abs() < 1.0, torch.zeros_like(base), base)}
+    for name, x0 in variants.items():
+        for ratio in (0.5, 0.93, 0.995, 1.0, 0.0, 1.0 / 3.0):
+            for mv in (1.0, 1e-250):
+                dpm = D.DPM_Solver(D.model_wrapper(lambda xx, t: xx, ns), ns, correcting_x0_fn="dynamic_thresholding",
+                                   dynamic_thresholding_ratio=ratio, thresholding_max_val=mv)
+                y = dpm.dynamic_thresholding_fn(x0, None)
+                s = torch.maximum(torch.quantile(x0.abs().reshape(B, -1), ratio, dim=1),
+                                  mv * torch.ones(B, dtype=torch.float64, device=DEV)).reshape(-1, 1, 1, 1)
+                assert torch.equal(y, torch.clamp(x0, -s, s) / s), (name, ratio, mv, shape)
 
 
 @pytest.mark.lab
