@@ -964,6 +964,12 @@ def test_double_precision_state_on_the_gpu(ns_dtype, monkeypatch):
     got = solver(DEV, "plain").sample(xb.to(DEV), steps=4, order=3)
     want = _double_on_cpu(monkeypatch, lambda: solver("cpu", "plain").sample(xb, steps=4, order=3))
     assert float((got.cpu() - want).abs().max()) <= 1e-14 * float(want.abs().max())
+    # several double requests in flight: no fused double kernel, dpm_stage_launch_multi launches them one by one -- same results
+    for kind in ("plain", "thr"):
+        reqs = [torch.from_numpy(rng.standard_normal((6, 3, 16, 16))).to(DEV) for _ in range(3)]
+        outs = solver(DEV, kind).sample_requests(reqs, steps=6, order=2)
+        for xr, o in zip(reqs, outs):
+            assert o.dtype == torch.float64 and torch.equal(o, solver(DEV, kind).sample(xr, steps=6, order=2))
     # add_noise and the stand-alone thresholding call in double
     dpm = solver(DEV, "thr")
     x0 = (xc * 2.0).to(DEV)
