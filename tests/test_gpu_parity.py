@@ -1034,6 +1034,27 @@ def test_lds_dma_variant_of_the_lone_launch_kernels_is_bit_identical():
 
 
 @pytest.mark.lab
+@pytest.mark.parametrize("shape", [(32, 3, 64, 64), (300, 1, 128, 128), (8, 3, 256, 256), (1024, 3, 16, 16)])
+def test_staggered_cluster_start_experiment_keeps_the_bits(shape):
+    """DPM_TUNE_THR_STAGGER (lab build, profiles/r05_thresholding.md): clusters started out of phase -- an offset that stays
+    far below the wait limit changes nothing; one near it (a late cluster's peers are equally late, clusters never wait for
+    each other) does not either; workspace left zero-filled"""
+    ns = make_schedule("ddpm")
+    x = torch.from_numpy(np.random.default_rng(44).standard_normal(shape).astype(F32)).to(DEV)
+    want = _thr_solver(ns).sample(x, steps=6, order=2)
+    for value in ((2 << 16) | 20, (3 << 16) | 70, (4 << 16) | 400):
+        dpm = _thr_solver(ns)
+        with _Tuned(thr_stagger=value):
+            got = dpm.sample(x, steps=6, order=2)
+            torch.cuda.synchronize()
+        assert torch.equal(got, want), (shape, value)
+        for fr in dpm._fast.values():
+            if getattr(fr, "ws", None) is not None:
+                assert not bool(fr.ws.any()), "the workspace must be all zero between launches"
+    assert not L.cluster_timeout_poll()
+
+
+@pytest.mark.lab
 @pytest.mark.parametrize("shape", [(32, 3, 64, 64), (5, 3, 64, 64), (2, 3, 160, 160), (300, 1, 128, 128), (40, 3, 64, 128)])
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_elected_reducer_experiment_keeps_the_bits(shape, mode):
