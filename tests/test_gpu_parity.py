@@ -1042,6 +1042,8 @@ def test_staggered_cluster_start_experiment_keeps_the_bits(shape):
     ns = make_schedule("ddpm")
     x = torch.from_numpy(np.random.default_rng(44).standard_normal(shape).astype(F32)).to(DEV)
     want = _thr_solver(ns).sample(x, steps=6, order=2)
+    torch.cuda.synchronize()
+    L.cluster_timeout_poll()                     # clear what earlier (fault-injecting) tests may have left
     for value in ((2 << 16) | 20, (3 << 16) | 70, (4 << 16) | 400):
         dpm = _thr_solver(ns)
         with _Tuned(thr_stagger=value):
