@@ -280,6 +280,32 @@ class LoopNet(torch.nn.Module):
         return self.c3(h)
 
 
+def cold_start(timeout=300):
+    """`cold_start_ms` of the bench line: `import dpm_solver_amd` + the first `sample()` of a FRESH
+    process -- tools/cold_start.py, one subprocess per scenario, the product library -- at `[8,4,64,64]` and with dynamic
+    thresholding at `[32,3,64,64]`; the process's own torch import and HIP context are the caller's and listed apart."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "cold.json")
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "cold_start.py"), "--repeat", "1", "--scenarios", "plain,thresholding",
+               "--out", out]
+        env = {k: v for k, v in os.environ.items() if k not in ("DPM_SOLVER_AMD_LIB", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+        try:
+            r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+            if r.returncode != 0:
+                return dict(error="tools/cold_start.py exited %d: %s" % (r.returncode, r.stderr[-400:]))
+            rows = {q["scenario"]: q for q in json.load(open(out))["rows"]}
+        except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as e:
+            return dict(error="%s: %s" % (type(e).__name__, e))
+    p_, t_ = rows["plain"], rows["thresholding"]
+    return dict(plain_8x4x64x64=p_["cold_start_ms"], thresholding_32x3x64x64=t_["cold_start_ms"],
+                import_dpm_solver_amd_ms=p_["import_dpm_solver_amd_ms"], first_sample_ms=p_["first_sample_ms"],
+                second_sample_ms=p_["second_sample_ms"], import_torch_and_context_ms=p_["import_torch_and_context_ms"],
+                library_bytes=p_["library_bytes"], measured_in_this_run=True,
+                how="fresh process per scenario (tools/cold_start.py): import dpm_solver_amd + first sample(), 2M++ 20 steps "
+                    "(thresholding: 25 steps); torch import + HIP context apart")
+
+
 def lab_secondary(dtype_name, eps_dtype_name, loop_net, requests, timeout=600):
     """The secondary measurements that need what the product library does not export -- event pairs attached to single
     launches inside a torch network loop (`in_network_loop`), the no-arithmetic kernels (`no_arithmetic_ceiling`,
@@ -690,6 +716,8 @@ def main():
             line["value"] = line["roofline"] = line["value_per_gpu"] = line["fastest_rank_value_per_gpu"] = None   # nothing was measured
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ac)
+        if world == 1 and not args.no_secondary and not STUB:
+            line["cold_start_ms"] = cold_start()
         try:     # the unmodified reference on the same kind of GPU through PyTorch-ROCm eager (tools/gpu_reference.py; committed)
             gr = json.load(open(os.path.join(ROOT, "profiles", "gpu_reference.json")))
             line["reference_on_mi355x"] = dict(

@@ -68,9 +68,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "cold_start.json"))
+    ap.add_argument("--scenarios", default="plain,thresholding,cfg")
     args = ap.parse_args()
     rows = []
-    for scenario in ("plain", "thresholding", "cfg"):
+    for scenario in args.scenarios.split(","):
         runs = []
         for _ in range(args.repeat):
             r = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT, scenario=scenario)], cwd=ROOT, stdout=subprocess.PIPE,

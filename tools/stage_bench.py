@@ -199,6 +199,18 @@ def main():
         e, = frozen(shape, torch.float16)
         s = D.DPM_Solver(D.model_wrapper(lambda x, t: e, sd, model_type=mt), sd, state_dtype=torch.float16)
         rows += run("cfg2-size 2M++ float16 %s-prediction" % mt, s, torch.randn(shape, device=DEV).half(), steps=20, order=2)
+    # eps-form (algorithm_type="dpmsolver": no eps -> x0 conversion): multistep at cfg2 size, and the unconditional singlestep-3
+    # sampler the reference recommends for pixel-space models without guidance
+    for dt in (torch.float16, torch.float32):
+        shape = (256, 4, 64, 64)
+        e, = frozen(shape, dt)
+        s = D.DPM_Solver(D.model_wrapper(lambda x, t: e, sd), sd, algorithm_type="dpmsolver", state_dtype=dt)
+        rows += run("cfg2-size 2M dpmsolver (eps form) %s" % str(dt)[6:], s, torch.randn(shape, device=DEV).to(dt), steps=20, order=2)
+    shape = (64, 3, 256, 256)
+    e, = frozen(shape, torch.float32)
+    s = D.DPM_Solver(D.model_wrapper(lambda x, t: e, dd), dd, algorithm_type="dpmsolver")
+    rows += run("uncond 3S dpmsolver (eps form) [64,3,256,256]", s, torch.randn(shape, device=DEV), reps=3, steps=15, order=3, method="singlestep")
+    del e
     # 3M++
     shape = (256, 4, 64, 64)
     e, = frozen(shape, torch.float16)
