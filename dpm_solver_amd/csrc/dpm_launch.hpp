@@ -340,9 +340,10 @@ int launch_thresh(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
     // parameterisation with the usual near-1 quantile: the run-time prologue (HOT 3); the rest: the catch-all kernel
     bool chosen = false;
     if constexpr (HOT12_BUILT) {
-      if (hot && tp.fastdiv && !tn.force_generic) {
-        kern = front ? stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 1>
-                     : stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 2>;
+      // (HOT 2 -- the same without the front end, for quantiles far from 1 -- was instantiated until round 5: no BASELINE
+      // configuration and no reference example samples with such a ratio; those launches take the catch-all kernel)
+      if (hot && front && tp.fastdiv && !tn.force_generic) {
+        kern = stage_thresh_kernel<TS, TE, FORM, GUIDE, XE, THR_THREADS, 1>;
         chosen = true;
       }
     }
@@ -457,8 +458,11 @@ int launch_stream(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
   //     per step dwarfs 3 % of a stage kernel) and that one first stage take SPEC_GENERIC; SS3T and DENOISE run the general
   //     prologue anyway (true division: the same bits);
   //   everything else goes through the one-element-per-lane kernel.
-  constexpr bool COMBO_BUILT = (!XE && !(FORM == DPM_FORM_DENOISE && GUIDE == DPM_GUIDE_CLASSIFIER)) || FORM == DPM_FORM_TWO ||
-                               FORM == DPM_FORM_SS3T || (FORM == DPM_FORM_LIN1 && GUIDE != DPM_GUIDE_CLASSIFIER);
+  constexpr bool COMBO_BUILT = ((!XE && !(FORM == DPM_FORM_DENOISE && GUIDE == DPM_GUIDE_CLASSIFIER)) || FORM == DPM_FORM_TWO ||
+                                FORM == DPM_FORM_SS3T || (FORM == DPM_FORM_LIN1 && GUIDE != DPM_GUIDE_CLASSIFIER)) &&
+                               !(FORM == DPM_FORM_SS3T && GUIDE == DPM_GUIDE_CLASSIFIER);  // singlestep-3 'taylor' under classifier guidance: scalar kernel
+  // the one denoise_to_zero launch of a trajectory with a KExt extension (mask blend, strided network output): scalar kernel
+  constexpr bool EXT_BUILT = FORM != DPM_FORM_DENOISE;
   constexpr bool SPEC_BUILT = (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3) &&
                               GUIDE != DPM_GUIDE_CLASSIFIER && !(XE && FORM == DPM_FORM_LIN1);
   // device-resident coefficients (adaptive solver): DYN kernels exist for the forms it launches -- first-order,
@@ -468,7 +472,7 @@ int launch_stream(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
   constexpr bool DYN_BUILT = COMBO_BUILT && sizeof(TS) == 4 && GUIDE != DPM_GUIDE_CLASSIFIER &&
                              (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_SS3T);
   const bool dyn_vec = stream.dyn && DYN_BUILT && !use_ext;
-  if (!vec || !COMBO_BUILT || (stream.dyn && !dyn_vec)) {
+  if (!vec || !COMBO_BUILT || (stream.dyn && !dyn_vec) || (use_ext && !EXT_BUILT)) {
     int64_t blocks = (b->n + 255) / 256;
     const int64_t cap = (int64_t)n_cu * 16;
     if (blocks > cap) blocks = cap;
@@ -478,9 +482,13 @@ int launch_stream(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
            e0, e1, g, h1, h2, xo, mo, b->n, p, ext, stream.dyn, stream.skip);
   } else if constexpr (COMBO_BUILT) {
     const Tuning tn = tuning_for(b->opts);
+    // the compile-time prologue exists for the data-prediction form of a noise network (dpmsolver++: eps -> x0 by the
+    // invariant alpha) only.  The eps form (algorithm_type "dpmsolver") had one too until round 5: with inputs from HBM the
+    // run-time prologue measures equal or faster on every eps-form launch (2M at cfg2 size fp16 / fp32, the unconditional
+    // and the CFG singlestep-3 sampler at [64,3,256,256]; profiles/r05_kernel_budget.md), so it takes SPEC_GENERIC now
     const bool noise = SPEC_BUILT && !stream.dyn && !tn.force_generic && st->model_type == DPM_MODEL_NOISE &&
-                       (!(st->flags & DPM_F_TO_X0) || div_invariant_ok(st->alpha_e));
-    const int spec = !noise ? SPEC_GENERIC : ((st->flags & DPM_F_TO_X0) ? SPEC_NOISE_X0 : SPEC_NOISE_EPS);
+                       (st->flags & DPM_F_TO_X0) && div_invariant_ok(st->alpha_e);
+    const int spec = noise ? SPEC_NOISE_X0 : SPEC_GENERIC;
     const int64_t ntiles = ((b->n / EPT) + 255) / 256;
     const bool big = ntiles >= 4 * (int64_t)n_cu;  // two tiles per iteration only when there is work for it
     // launch shape: one 256-lane group per U tiles, capped per CU; two groups per workgroup (stage_kernel) when that still
@@ -516,17 +524,17 @@ int launch_stream(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
       // [256,4,64,64] 18.1 / 20.3 us back-to-back / evicted against 17.3 / 19.3 with one, tools/stage_bench.py); nt mask of
       // the inputs-from-HBM situation
       constexpr int ENT = sizeof(TS) == 2 ? 1 : (sizeof(TE) == 4 ? 5 : 1);
-      if (spec == SPEC_GENERIC) {
-        DPM_LAUNCH(SPEC_GENERIC, 1, ENT, true);
-      } else if constexpr (SPEC_BUILT) {
-        if (spec == SPEC_NOISE_X0) DPM_LAUNCH(SPEC_NOISE_X0, 1, ENT, true); else DPM_LAUNCH(SPEC_NOISE_EPS, 1, ENT, true);
+      if constexpr (EXT_BUILT) {
+        if (spec == SPEC_GENERIC) {
+          DPM_LAUNCH(SPEC_GENERIC, 1, ENT, true);
+        } else if constexpr (SPEC_BUILT) {
+          DPM_LAUNCH(SPEC_NOISE_X0, 1, ENT, true);
+        }
       }
     } else if (spec == SPEC_GENERIC) {
       DPM_LAUNCH(SPEC_GENERIC, 1, DefNT<TS>::value, false);
     } else if constexpr (SPEC_BUILT) {
-      if (spec == SPEC_NOISE_EPS) {
-        DPM_LAUNCH(SPEC_NOISE_EPS, DEF_U, DefNT<TS>::value, false);
-      } else if constexpr (HotCombo<FORM, GUIDE, XE>::value) {
+      if constexpr (HotCombo<FORM, GUIDE, XE>::value) {
         // the north-star kernels (2M / 1st-order update, no guidance): (tiles per iteration, nt mask) by situation and
         // dtypes, from profiles/r01_tuning_v3.txt / r01_tuning_v4.txt:
         //   inputs cache-resident: default policy, two tiles per iteration when there is work for it
@@ -684,15 +692,14 @@ int launch_multi_typed(const dpm_stage* st, const dpm_buffers* bs, int n_req, co
   const bool x0 = (st->flags & DPM_F_TO_X0) != 0;
   const bool cfg = st->guidance == DPM_GUIDE_CFG;
   // x_start / v / score networks (and an alpha the division-by-invariant guard rejects) take the general prologue
-  const bool generic = st->model_type != DPM_MODEL_NOISE || (x0 && !div_invariant_ok(st->alpha_e)) ||
+  // ... and so does the eps form of a noise network (launch_stream: no compile-time prologue of its own since round 5)
+  const bool generic = st->model_type != DPM_MODEL_NOISE || !x0 || !div_invariant_ok(st->alpha_e) ||
                        tuning_for(bs[0].opts).force_generic != 0;
 #define DPM_MULTI(FORM_)                                                                                        \
   (generic ? (cfg ? launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_CFG, SPEC_GENERIC>(st, bs, n_req, c)             \
                   : launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_NONE, SPEC_GENERIC>(st, bs, n_req, c))           \
-   : cfg   ? (x0 ? launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_CFG, SPEC_NOISE_X0>(st, bs, n_req, c)             \
-                 : launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_CFG, SPEC_NOISE_EPS>(st, bs, n_req, c))           \
-           : (x0 ? launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_NONE, SPEC_NOISE_X0>(st, bs, n_req, c)            \
-                 : launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_NONE, SPEC_NOISE_EPS>(st, bs, n_req, c)))
+   : cfg   ? launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_CFG, SPEC_NOISE_X0>(st, bs, n_req, c)                   \
+           : launch_multi_spec<TS, TE, FORM_, DPM_GUIDE_NONE, SPEC_NOISE_X0>(st, bs, n_req, c))
   switch (st->form) {
     case DPM_FORM_LIN1: return DPM_MULTI(DPM_FORM_LIN1);
     case DPM_FORM_TWO: return DPM_MULTI(DPM_FORM_TWO);

@@ -95,6 +95,8 @@ __device__ __forceinline__ KParams params_from_dyn(const KParams& p, const dpm_s
 // record at run time (true divisions when a divisor fails the guard).  Kernels are instantiated for the two modes of a
 // noise-prediction network (SPEC_NOISE_EPS, SPEC_NOISE_X0: the common case) and as SPEC_GENERIC, which picks the mode
 // once per tile iteration (wave-uniform switch) and runs the same straight-line code for x_start / v / score networks.
+// (Since round 5 the launchers instantiate SPEC_NOISE_X0 and SPEC_GENERIC only: the eps form measured no faster with a
+// prologue of its own, profiles/r05_kernel_budget.md.)
 enum { PM_RT = -1, SPEC_NOISE_EPS = DPM_MODEL_NOISE * 2, SPEC_NOISE_X0 = DPM_MODEL_NOISE * 2 + 1, SPEC_GENERIC = 100 };
 
 template <int SPEC>

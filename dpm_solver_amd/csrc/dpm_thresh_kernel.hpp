@@ -914,7 +914,8 @@ __device__ __forceinline__ void solo_select(F&& bits_at, int n, uint32_t rank, b
 // known -- so that the load and store loops are straight-line code without the wave-uniform branches of the run-time form
 // and guidance and their operands (the kernel is as sensitive to its instruction count as to HBM):
 //   HOT = 1  noise-prediction network with the division by the invariant alpha, top-K front end of the select;
-//   HOT = 2  the same with the full level-0 histogram;
+//   HOT = 2  the same with the full level-0 histogram (quantiles far from 1; not instantiated since round 5: the catch-all
+//            kernel serves them);
 //   HOT = 3  like 1, the prologue chosen per sample at run time: x_start / v / score networks and divisors that fail the
 //            guard of the division by an invariant (round 4: those ran the catch-all kernel, 14-19 % slower).
 // Everything else runs the same source with HOT = 0 (run-time form, guidance, evaluation state, mask blend).
