@@ -48,6 +48,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import threading
 import time
@@ -312,7 +313,6 @@ def lab_secondary(dtype_name, eps_dtype_name, loop_net, requests, timeout=600):
     `lone_launch_floor`) -- run in a SUBPROCESS on the lab build of the same sources (tools/lab_secondary.py,
     DPM_SOLVER_AMD_LIB=tools/_variants/lab/libdpm_lab.so): this process, the one the headline is timed in, loads the product
     library only.  Returns the subprocess's JSON dict, or {"error": ...}."""
-    import subprocess
     lab = os.path.join(ROOT, "tools", "_variants", "lab", "libdpm_lab.so")
     if not os.path.exists(lab):
         return dict(error="no lab build (%s): run __graft_entry__.build()" % lab)
@@ -717,7 +717,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ac)
         if world == 1 and not args.no_secondary and not STUB:
-            line["cold_start_ms"] = cold_start()
+            try:
+                line["cold_start_ms"] = cold_start()
+            except Exception as e:                           # a secondary never takes the primary line down
+                line["cold_start_ms"] = dict(error="%s: %s" % (type(e).__name__, e))
         try:     # the unmodified reference on the same kind of GPU through PyTorch-ROCm eager (tools/gpu_reference.py; committed)
             gr = json.load(open(os.path.join(ROOT, "profiles", "gpu_reference.json")))
             line["reference_on_mi355x"] = dict(

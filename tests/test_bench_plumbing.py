@@ -79,3 +79,17 @@ def test_cpu_baseline_record_is_what_this_run_timed():
     assert ref["kind"] == "reference" and ref["measured_in_this_run"] is False
     assert ref["source"].startswith("profiles/cpu_baseline_reference_gpubox.json")
     assert ref["cores"] == ref["threads"] == ref["best"]["threads"] and ref["value"] == ref["best"]["value"]
+
+
+def test_secondaries_that_need_a_gpu_report_an_error_instead_of_raising():
+    """`cold_start_ms` and the lab secondaries of the bench line run in subprocesses; without a GPU (here) each comes back
+    as a dict with an `error` text -- a secondary never takes the primary line down"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("the error path: no GPU")
+    sys.path.insert(0, ROOT)
+    import bench
+    out = bench.cold_start(timeout=240)
+    assert isinstance(out, dict) and "error" in out and "cold_start.py" in out["error"]
+    lab = bench.lab_secondary("fp16", "fp16", "conv", 2, timeout=240)
+    assert isinstance(lab, dict) and "error" in lab
