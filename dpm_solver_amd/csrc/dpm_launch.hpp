@@ -460,7 +460,9 @@ int launch_stream(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
   //   everything else goes through the one-element-per-lane kernel.
   constexpr bool COMBO_BUILT = ((!XE && !(FORM == DPM_FORM_DENOISE && GUIDE == DPM_GUIDE_CLASSIFIER)) || FORM == DPM_FORM_TWO ||
                                 FORM == DPM_FORM_SS3T || (FORM == DPM_FORM_LIN1 && GUIDE != DPM_GUIDE_CLASSIFIER)) &&
-                               !(FORM == DPM_FORM_SS3T && GUIDE == DPM_GUIDE_CLASSIFIER);  // singlestep-3 'taylor' under classifier guidance: scalar kernel
+                               !(FORM == DPM_FORM_SS3T && GUIDE == DPM_GUIDE_CLASSIFIER) &&  // singlestep-3 'taylor' under classifier guidance: scalar kernel
+                               !(FORM == DPM_FORM_SS3T && !XE);  // the samplers always hand SS3T its evaluation state (the rocprofv3 name
+                                                                 // set of the suite, profiles/r05_kernels_launched_suite.md, has no launch without)
   // the one denoise_to_zero launch of a trajectory with a KExt extension (mask blend, strided network output): scalar kernel
   constexpr bool EXT_BUILT = FORM != DPM_FORM_DENOISE;
   constexpr bool SPEC_BUILT = (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_MS3) &&
@@ -470,7 +472,8 @@ int launch_stream(const dpm_stage* st, const dpm_buffers* b, const LaunchCtx& st
   // fp32 with a discrete schedule), unguided or CFG, without the KExt extensions; anything else takes the
   // one-element-per-lane kernel
   constexpr bool DYN_BUILT = COMBO_BUILT && sizeof(TS) == 4 && GUIDE != DPM_GUIDE_CLASSIFIER &&
-                             (FORM == DPM_FORM_LIN1 || FORM == DPM_FORM_TWO || FORM == DPM_FORM_SS3T);
+                             ((FORM == DPM_FORM_LIN1 && !XE) || (FORM == DPM_FORM_TWO && (XE || GUIDE == DPM_GUIDE_NONE)) ||
+                              (FORM == DPM_FORM_SS3T && XE));  // the launches of the adaptive solver's device-side controller
   const bool dyn_vec = stream.dyn && DYN_BUILT && !use_ext;
   if (!vec || !COMBO_BUILT || (stream.dyn && !dyn_vec) || (use_ext && !EXT_BUILT)) {
     int64_t blocks = (b->n + 255) / 256;

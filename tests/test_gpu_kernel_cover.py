@@ -116,3 +116,42 @@ def test_device_resident_coefficient_kernels_equal_the_scalar_kernel(algo, guida
         o = capsys.readouterr().out.strip().splitlines()
         assert o[0] == o[1], (algo, guidance, order, st, o)            # same NFE
         assert torch.equal(res[0], res[1]), (algo, guidance, order, st)
+
+
+@pytest.mark.parametrize("mt,algo", [("noise", "dpmsolver++"), ("noise", "dpmsolver"), ("v", "dpmsolver++")])
+def test_third_order_multistep_under_cfg_ends_without_the_duplicate_store(mt, algo):
+    """10 steps or more: `lower_order_final` does not apply, the last stage is a third-order one -- under classifier-free
+    guidance the only MS3 launch without the [2B] network input of a next stage (no KExt)"""
+    ns = make_schedule("sd")
+    x = torch.randn((4, 4, 16, 16), device=DEV, generator=torch.Generator(device=DEV).manual_seed(14))
+    res = [_solver(ns, algo, "cfg", mt, None, un, None, None, shape=(4, 4, 16, 16)).sample(x, steps=11, order=3) for un in (False, True)]
+    assert torch.equal(res[0], res[1])
+
+
+@pytest.mark.parametrize("guidance,mt", [("uncond", "v"), ("cfg", "noise"), ("cfg", "v"), ("uncond", "noise")])
+def test_third_order_requests_in_flight_equal_single_requests(guidance, mt):
+    """the fused multi-request kernels of the third-order form (compile-time and run-time prologue, unguided and CFG)"""
+    ns = make_schedule("sd")
+    g = torch.Generator(device=DEV).manual_seed(15)
+    for dt in (torch.float32, torch.float16):
+        xs = [torch.randn((4, 4, 16, 16), device=DEV, generator=g).to(dt) for _ in range(3)]
+        mk = lambda: _solver(ns, "dpmsolver++", guidance, mt, None, False, None, None, edt=dt, shape=(4, 4, 16, 16), state_dtype=dt)
+        outs = mk().sample_requests(xs, steps=12, order=3)
+        for x, o in zip(xs, outs):
+            assert torch.equal(o, mk().sample(x, steps=12, order=3)), (guidance, mt, dt)
+
+
+@pytest.mark.parametrize("guidance", ["cfg", "classifier"])
+def test_third_order_thresholded_stages_equal_the_catch_all_kernel(guidance):
+    """3M++ with dynamic thresholding under guidance (the reference's ImageNet examples sample with both): the specialised
+    thresholding kernels of form MS3 against the catch-all kernel"""
+    ns = make_schedule("ddpm")
+    g = torch.Generator(device=DEV).manual_seed(16)
+    for shape in ((32, 3, 64, 64), (600, 3, 16, 16)):
+        x = torch.randn(shape, device=DEV, generator=g) * 1.5
+        res = []
+        for un in (False, True):
+            dpm = _solver(ns, "dpmsolver++", guidance, "noise", None, un, None, None, shape=shape)
+            dpm = D.DPM_Solver(dpm._wrapped, ns, correcting_x0_fn="dynamic_thresholding")
+            res.append(dpm.sample(x, steps=12, order=3))
+        assert torch.equal(res[0], res[1]), (guidance, shape)
