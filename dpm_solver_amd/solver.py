@@ -1597,8 +1597,20 @@ class GraphedSample:
                 solver.sample(self.static_x, **self.kwargs)
         torch.cuda.current_stream(dev).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.static_out = solver.sample(self.static_x, **self.kwargs)
+        # No garbage collection while the stream is capturing: a finaliser that frees device resources inside the capture
+        # region -- a communicator of a destroyed process group, another graph, anything a cycle kept alive -- makes a call
+        # that is illegal there, and the error surfaces inside a C++ destructor (the process aborts).  torch.cuda.graph
+        # collects once before it begins; what becomes garbage during the capture waits until it is over.
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.static_out = solver.sample(self.static_x, **self.kwargs)
+        finally:
+            if gc_was_on:
+                gc.enable()
 
     def replay(self):
         self.graph.replay()
