@@ -367,3 +367,30 @@ def test_public_update_methods_and_adaptive_in_double(R, ns_dtype, t_dtype, caps
             nfe_e = capsys.readouterr().out
             assert nfe_r == nfe_e and "nfe" in nfe_e
             assert got.dtype == want.dtype == torch.float64 and rel_err(got.numpy(), want.numpy()) <= 1e-12
+
+
+@pytest.mark.parametrize("hdt", [torch.float16, torch.bfloat16])
+def test_half_state_is_as_close_to_the_fp32_reference_as_the_reference_with_half_storage(R, hdt):
+    """An INDEPENDENT yardstick for the half-precision states (the bit-for-bit statement of the GPU suite is against
+    tests/kernel_double.py, the builder's own restatement).  The reference has no half-state mode on a discrete schedule (it
+    promotes at the first update), but its own callbacks emulate half STORAGE around fp32 arithmetic: correcting_xt_fn rounds
+    the state after every update, correcting_x0_fn rounds every model value, the network answers in half.  The engine's
+    half state (fp32 arithmetic, every stored tensor rounded once; the fresh model value enters the running update
+    unrounded) must deviate from the unmodified fp32 run no more than that emulation does: rms within 1.3 x, maximum within
+    2 x, over first / second / third order."""
+    nsr, ns = ref_schedule(R, "sd"), make_schedule("sd")
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda t: t.to(hdt).float()
+    netf = lambda xx, t: C.model_tdep(xx.float(), t)
+    for order, steps in ((2, 20), (3, 20), (1, 10), (2, 8)):
+        x = torch.randn((8, 4, 16, 16), generator=g).to(hdt)
+        f32 = R.DPM_Solver(R.model_wrapper(netf, nsr), nsr, algorithm_type="dpmsolver++").sample(x.float(), steps=steps, order=order)
+        emu = R.DPM_Solver(R.model_wrapper(lambda xx, t: rnd(netf(xx, t)), nsr), nsr, algorithm_type="dpmsolver++",
+                           correcting_x0_fn=lambda x0, t: rnd(x0), correcting_xt_fn=lambda xx, t, step: rnd(xx)
+                           ).sample(x.float(), steps=steps, order=order)
+        ours = D.DPM_Solver(D.model_wrapper(lambda xx, t: netf(xx, t).to(hdt), ns), ns, state_dtype=hdt).sample(x, steps=steps, order=order)
+        assert ours.dtype == hdt
+        e_ours, e_emu = (ours.float() - f32).abs(), (emu - f32).abs()
+        rms = lambda e: float(e.pow(2).mean().sqrt())
+        assert rms(e_ours) <= 1.3 * rms(e_emu), (hdt, order, steps, rms(e_ours), rms(e_emu))
+        assert float(e_ours.max()) <= 2.0 * float(e_emu.max()), (hdt, order, steps)
