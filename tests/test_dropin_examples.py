@@ -1,7 +1,7 @@
 """The reference's own example call sites (source files unchanged) on the engine's host side -- CPU edition of
 tools/dropin_examples.py: tests/kernel_double.py stands behind the launch records, everything above it (shims, planner,
 wrapper batching, buffer choreography, callbacks, dtype policy) is the product.  The GPU edition is the tool itself
-(profiles/r04_dropin.json) and tests/test_gpu_extensions.py::test_dropin_examples_on_the_gpu when the tree travelled.
+(profiles/r05_dropin.json) and tests/test_gpu_extensions.py::test_dropin_examples_on_the_gpu when the tree travelled.
 
 Needs the reference checkout ($DPM_REFERENCE_DIR or /root/reference); skipped where it does not exist (the GPU box)."""
 import importlib.util

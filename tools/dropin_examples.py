@@ -21,7 +21,7 @@ Per call site the tool reports max |own - shim| / max |own| and whether the netw
 agree; the bar is 1e-5 (BASELINE.json).  The reference tree is read from $DPM_REFERENCE_DIR (default /root/reference):
 it is NOT part of this repository and nothing here is imported by the product.
 
-    python tools/dropin_examples.py --device cuda:0 --out profiles/r04_dropin.json
+    python tools/dropin_examples.py --device cuda:0 --out profiles/r05_dropin.json
     (tests/test_dropin_examples.py runs the same functions on CPU with tests/kernel_double.py behind the launch records)
 """
 import argparse
