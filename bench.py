@@ -300,6 +300,10 @@ def cold_start(timeout=300):
             return dict(error="%s: %s" % (type(e).__name__, e))
     p_, t_ = rows["plain"], rows["thresholding"]
     return dict(plain_8x4x64x64=p_["cold_start_ms"], thresholding_32x3x64x64=t_["cold_start_ms"],
+                network_warm=dict(plain_8x4x64x64=p_.get("cold_start_network_warm_ms"), thresholding_32x3x64x64=t_.get("cold_start_network_warm_ms"),
+                                  network_first_call_ms=p_.get("network_first_call_ms"),
+                                  what="the same in a second fresh process whose stand-in network ran once before the first sample(): "
+                                       "without torch loading the network's own kernels"),
                 import_dpm_solver_amd_ms=p_["import_dpm_solver_amd_ms"], first_sample_ms=p_["first_sample_ms"],
                 second_sample_ms=p_["second_sample_ms"], import_torch_and_context_ms=p_["import_torch_and_context_ms"],
                 library_bytes=p_["library_bytes"], measured_in_this_run=True,
