@@ -1202,7 +1202,9 @@ class DPM_Solver:
                 x_prev = x_lower
                 lambda_s = lam(s)
             # torch.float_power(E, -1 / order).float(): the power is an fp32 number also in a double-precision run (ref :1007)
-            h = min(FT(FT(theta) * h * FT(_F32(np.float64(E) ** (-1. / order)))), FT(lambda_0 - lambda_s))
+            # (E == 0 -- identical estimates -- gives inf like torch.float_power does: the step is then capped by the range)
+            with np.errstate(divide="ignore", over="ignore"):
+                h = min(FT(FT(theta) * h * FT(_F32(np.float64(E) ** (-1. / order)))), FT(lambda_0 - lambda_s))
             nfe += order
         print('adaptive solver nfe', nfe)
         return x
