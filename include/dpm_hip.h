@@ -29,6 +29,13 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The library is compiled with -fvisibility=hidden: DPM_API marks the entry points, which are then the ONLY symbols in its
+   dynamic table (tests/test_capi_symbols.py compares `nm -D --defined-only` with this header name by name) -- no mangled
+   internal can collide with a symbol of the host process or of a second library it links. */
+#ifndef DPM_API
+#define DPM_API __attribute__((visibility("default")))
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -202,37 +209,37 @@ typedef struct dpm_buffers {
 typedef struct dpm_schedule dpm_schedule;
 
 /* discrete-time schedules; `clip` != 0 applies numerical_clip_alpha at lambda = -5.1 (ref :114-125). */
-int dpm_schedule_create_betas_f32(const float* betas, int n, int clip, dpm_schedule** out);           /* ref :100 */
-int dpm_schedule_create_betas_f64(const double* betas, int n, int clip, dpm_schedule** out);
-int dpm_schedule_create_alphas_cumprod_f32(const float* ac, int n, int clip, dpm_schedule** out);      /* ref :103 */
-int dpm_schedule_create_alphas_cumprod_f64(const double* ac, int n, int clip, dpm_schedule** out);
-int dpm_schedule_create_log_alpha(const float* log_alpha, int n, dpm_schedule** out);                  /* ready table */
+DPM_API int dpm_schedule_create_betas_f32(const float* betas, int n, int clip, dpm_schedule** out);           /* ref :100 */
+DPM_API int dpm_schedule_create_betas_f64(const double* betas, int n, int clip, dpm_schedule** out);
+DPM_API int dpm_schedule_create_alphas_cumprod_f32(const float* ac, int n, int clip, dpm_schedule** out);      /* ref :103 */
+DPM_API int dpm_schedule_create_alphas_cumprod_f64(const double* ac, int n, int clip, dpm_schedule** out);
+DPM_API int dpm_schedule_create_log_alpha(const float* log_alpha, int n, dpm_schedule** out);                  /* ready table */
 /* numerical_clip_alpha on its own (ref :114-125): *out_len = number of leading entries of `log_alphas` whose
    half-logSNR is >= clipped_lambda (the reference returns log_alphas[:out_len]); arithmetic in the array's type */
-int dpm_numerical_clip_len_f32(const float* log_alphas, int n, double clipped_lambda, int* out_len);
-int dpm_numerical_clip_len_f64(const double* log_alphas, int n, double clipped_lambda, int* out_len);
-int dpm_schedule_create_linear(double beta_0, double beta_1, dpm_schedule** out);                      /* ref :109-112 */
+DPM_API int dpm_numerical_clip_len_f32(const float* log_alphas, int n, double clipped_lambda, int* out_len);
+DPM_API int dpm_numerical_clip_len_f64(const double* log_alphas, int n, double clipped_lambda, int* out_len);
+DPM_API int dpm_schedule_create_linear(double beta_0, double beta_1, dpm_schedule** out);                      /* ref :109-112 */
 /* the continuous-time 'cosine' schedule of the older vendored revision (examples/score_sde_pytorch/dpm_solver.py
    :114-124,:134-137,:171-175): s = 0.008, T = 0.9946 (the caller's default end time) */
-int dpm_schedule_create_cosine(dpm_schedule** out);
+DPM_API int dpm_schedule_create_cosine(dpm_schedule** out);
 /* NoiseScheduleVP(dtype=torch.float64) (ref :14, :105-107): the tables keep the double values they were computed in (the
    *_f64 constructors) instead of their fp32 roundings -- what double-precision plans and dpm_schedule_eval_f64 read.  Part of
    construction: call it right after dpm_schedule_create_*, before the handle is shared. */
-int dpm_schedule_set_table_dtype(dpm_schedule* s, int dtype /* DPM_DTYPE_F32 | DPM_DTYPE_F64 */);
-int dpm_schedule_tables_f64(const dpm_schedule* s, const double** log_alpha, const double** t_array, int* K);
-void dpm_schedule_destroy(dpm_schedule* s);
-int dpm_schedule_is_discrete(const dpm_schedule* s);
-int dpm_schedule_total_N(const dpm_schedule* s);                                                       /* ref :106,:110 */
+DPM_API int dpm_schedule_set_table_dtype(dpm_schedule* s, int dtype /* DPM_DTYPE_F32 | DPM_DTYPE_F64 */);
+DPM_API int dpm_schedule_tables_f64(const dpm_schedule* s, const double** log_alpha, const double** t_array, int* K);
+DPM_API void dpm_schedule_destroy(dpm_schedule* s);
+DPM_API int dpm_schedule_is_discrete(const dpm_schedule* s);
+DPM_API int dpm_schedule_total_N(const dpm_schedule* s);                                                       /* ref :106,:110 */
 /* borrowed pointers into the handle: log_alpha_array / t_array of ref :105,:107 (K floats each). */
-int dpm_schedule_tables(const dpm_schedule* s, const float** log_alpha, const float** t_array, int* K);
+DPM_API int dpm_schedule_tables(const dpm_schedule* s, const float** log_alpha, const float** t_array, int* K);
 /* marginal_log_mean_coeff / marginal_alpha / marginal_std / marginal_lambda / inverse_lambda (ref :127-167) */
-int dpm_schedule_eval(const dpm_schedule* s, int what, const float* in, int n, float* out);
-int dpm_schedule_eval_f64(const dpm_schedule* s, int what, const double* in, int n, double* out);  /* double times / tables */
+DPM_API int dpm_schedule_eval(const dpm_schedule* s, int what, const float* in, int n, float* out);
+DPM_API int dpm_schedule_eval_f64(const dpm_schedule* s, int what, const double* in, int n, double* out);  /* double times / tables */
 
 /* ---- time grids (ref :453-539) ---------------------------------------------------------- */
-int dpm_time_steps(const dpm_schedule* s, int skip_type, double t_T, double t_0, int N, float* out /* N+1 */);
-int dpm_singlestep_orders(int steps, int order, int* orders /* >= steps */, int* n_orders);
-int dpm_singlestep_grid(const dpm_schedule* s, int steps, int order, int skip_type, double t_T, double t_0,
+DPM_API int dpm_time_steps(const dpm_schedule* s, int skip_type, double t_T, double t_0, int N, float* out /* N+1 */);
+DPM_API int dpm_singlestep_orders(int steps, int order, int* orders /* >= steps */, int* n_orders);
+DPM_API int dpm_singlestep_grid(const dpm_schedule* s, int steps, int order, int skip_type, double t_T, double t_0,
                         float* outer /* >= steps+1 */, int* orders /* >= steps */, int* n_orders);
 
 /* ---- plan: DPM_Solver.sample() unrolled into stages (ref :1047-1245) ---------------------- */
@@ -259,42 +266,42 @@ typedef struct dpm_plan_desc {
 } dpm_plan_desc;
 
 typedef struct dpm_plan dpm_plan;
-int dpm_plan_create(const dpm_schedule* s, const dpm_plan_desc* d, dpm_plan** out);
-void dpm_plan_destroy(dpm_plan* p);
-int dpm_plan_num_stages(const dpm_plan* p);
-int dpm_plan_num_slots(const dpm_plan* p);                 /* history buffers the loop needs      */
-int dpm_plan_stage(const dpm_plan* p, int i, dpm_stage* out);
-int dpm_plan_stage_f64(const dpm_plan* p, int i, dpm_stage_f64* out);   /* double-precision plans only */
-int dpm_plan_timesteps(const dpm_plan* p, float* out, int cap, int* n); /* solver grid t_0..t_K    */
+DPM_API int dpm_plan_create(const dpm_schedule* s, const dpm_plan_desc* d, dpm_plan** out);
+DPM_API void dpm_plan_destroy(dpm_plan* p);
+DPM_API int dpm_plan_num_stages(const dpm_plan* p);
+DPM_API int dpm_plan_num_slots(const dpm_plan* p);                 /* history buffers the loop needs      */
+DPM_API int dpm_plan_stage(const dpm_plan* p, int i, dpm_stage* out);
+DPM_API int dpm_plan_stage_f64(const dpm_plan* p, int i, dpm_stage_f64* out);   /* double-precision plans only */
+DPM_API int dpm_plan_timesteps(const dpm_plan* p, float* out, int cap, int* n); /* solver grid t_0..t_K    */
 
 /* ---- coefficient builders for the reference's public per-update methods -------------------- */
 /* dpm_solver_first_update (ref :547-592) */
-int dpm_coef_first(const dpm_schedule* s, int algo, float t_s, float t_t, dpm_stage* out);
+DPM_API int dpm_coef_first(const dpm_schedule* s, int algo, float t_s, float t_t, dpm_stage* out);
 /* multistep_dpm_solver_update (ref :932-954): t_prev[0..order-1] oldest..newest */
-int dpm_coef_multistep(const dpm_schedule* s, int algo, int solver_type, int order, const float* t_prev, float t_t,
+DPM_API int dpm_coef_multistep(const dpm_schedule* s, int algo, int solver_type, int order, const float* t_prev, float t_t,
                        dpm_stage* out);
 /* singlestep_dpm_solver_update (ref :906-930): fills `order` stages.  r_mode 0: r1/r2 are the reference's
    Python-float defaults or user floats (double arithmetic then one fp32 rounding), 1: fp32 tensors. */
-int dpm_coef_singlestep(const dpm_schedule* s, int algo, int solver_type, int order, float t_s, float t_t,
+DPM_API int dpm_coef_singlestep(const dpm_schedule* s, int algo, int solver_type, int order, float t_s, float t_t,
                         double r1, double r2, int r_mode, dpm_stage* out /* [order] */);
 /* fill the prologue scalars (alpha_e, sigma_e, t_input, guidance) of a stage evaluated at t */
-int dpm_coef_prologue(const dpm_schedule* s, float t_eval, int model_type, int guidance, double guidance_scale,
+DPM_API int dpm_coef_prologue(const dpm_schedule* s, float t_eval, int model_type, int guidance, double guidance_scale,
                       dpm_stage* inout);
 
 /* the same in double (a double-precision evaluation: double time tensors, or a schedule declared dtype=float64): out = the
    integer fields + the doubles rounded, out64 = the doubles.  time_f64: the caller's time tensors are doubles (else fp32
    tensors whose values arrive converted exactly) -- decides the dtype the model time label is computed in (ref :278).
    dpm_coef_first is dpm_coef_multistep_f64 with order 1. */
-int dpm_coef_multistep_f64(const dpm_schedule* s, int algo, int solver_type, int order, const double* t_prev, double t_t,
+DPM_API int dpm_coef_multistep_f64(const dpm_schedule* s, int algo, int solver_type, int order, const double* t_prev, double t_t,
                            int time_f64, dpm_stage* out, dpm_stage_f64* out64);
-int dpm_coef_singlestep_f64(const dpm_schedule* s, int algo, int solver_type, int order, double t_s, double t_t, int time_f64,
+DPM_API int dpm_coef_singlestep_f64(const dpm_schedule* s, int algo, int solver_type, int order, double t_s, double t_t, int time_f64,
                             double r1, double r2, int r_mode, dpm_stage* out /* [order] */, dpm_stage_f64* out64 /* [order] */);
-int dpm_coef_prologue_f64(const dpm_schedule* s, double t_eval, int time_f64, int model_type, int guidance, double guidance_scale,
+DPM_API int dpm_coef_prologue_f64(const dpm_schedule* s, double t_eval, int time_f64, int model_type, int guidance, double guidance_scale,
                           dpm_stage* inout, dpm_stage_f64* inout64);
 
 /* ---- device side --------------------------------------------------------------------------- */
 /* one fused stage kernel, asynchronous on `stream` */
-int dpm_stage_launch(const dpm_stage* st, const dpm_buffers* b, void* stream);
+DPM_API int dpm_stage_launch(const dpm_stage* st, const dpm_buffers* b, void* stream);
 /* The same stage of n_req independent requests (same plan position: one dpm_stage; same n, batch and dtypes; each its
    own buffers) as ONE fused launch per group of DPM_MULTI_MAX requests: a server that keeps R sampling requests in
    flight pays a launch's ramp-up and drain once per R x (5 n s) bytes instead of once per 5 n s -- with inputs coming
@@ -306,7 +313,7 @@ int dpm_stage_launch(const dpm_stage* st, const dpm_buffers* b, void* stream);
    unaligned buffers, the singlestep mid-stages, thresholding with a shared workspace) are launched request by
    request; results are identical either way. */
 #define DPM_MULTI_MAX 32
-int dpm_stage_launch_multi(const dpm_stage* st, const dpm_buffers* bs, int n_req, void* stream);
+DPM_API int dpm_stage_launch_multi(const dpm_stage* st, const dpm_buffers* bs, int n_req, void* stream);
 /* scratch needed by stages with DPM_F_THRESH on the current device: 0 when one workgroup per sample is the plan (the
    sample lives in that workgroup's LDS), else ~45-80 KiB per sample of slots, histograms and counters through which the
    workgroup cluster of a sample exchanges its candidates (small batches, samples beyond 12288 elements).
@@ -317,22 +324,22 @@ int dpm_stage_launch_multi(const dpm_stage* st, const dpm_buffers* bs, int n_req
    chip that long -- another process running clusters on the same GPU, two clustered graphs replayed concurrently -- the
    waiting workgroup gives up, computes the order statistics of its sample alone from global memory and carries on:
    the launch's results are the same bits, the workspace is left zero-filled as always, nothing is reported as an error. */
-size_t dpm_threshold_workspace_bytes(int64_t batch, int64_t per_sample);
+DPM_API size_t dpm_threshold_workspace_bytes(int64_t batch, int64_t per_sample);
 /* diagnostics: 1 when a cluster wait of any clustered thresholding launch of this process timed out (and was recovered
    from) since the last call, else 0.  Reads and clears a host-mapped word; meaningful after the launches in question
    have completed (no synchronisation here). */
-int dpm_cluster_timeout_poll(void);
+DPM_API int dpm_cluster_timeout_poll(void);
 #define DPM_THR_HINT_WORDS 4   /* floats per sample of dpm_buffers.thr_hint / dpm_run_buffers.thr_hint */
 /* x_t = alpha_t*x + sigma_t*noise for nt times (add_noise, ref :1012-1030); out is [nt, n] */
-int dpm_add_noise_launch(const dpm_schedule* s, const float* t_host, int nt, const void* x, const void* noise,
+DPM_API int dpm_add_noise_launch(const dpm_schedule* s, const float* t_host, int nt, const void* x, const void* noise,
                          void* out, int64_t n, int dtype, void* stream);
 /* stand-alone mask blend  out = x*mask + (1-mask)*(alpha*a + sigma*b)  (b NULL: (1-mask)*a): the DPM_F_BLEND
    epilogue as its own launch, for callable use of the corrector and for x_T before the first update (ref :1180) */
-int dpm_blend_launch(const void* x, const void* mask, const void* a, const void* b, float alpha, float sigma, void* out,
+DPM_API int dpm_blend_launch(const void* x, const void* mask, const void* a, const void* b, float alpha, float sigma, void* out,
                      int64_t n, int64_t mask_period, int dtype, void* stream);
 /* error norm of the adaptive solver (ref :999-1001): E_b = sqrt(mean(((xh-xl)/delta)^2)) per sample in e_out[0..batch),
    and their maximum over the batch (the value the step-size controller reads) in e_out[batch] */
-int dpm_adaptive_error_launch(const void* x_lower, const void* x_higher, const void* x_prev, float atol, float rtol,
+DPM_API int dpm_adaptive_error_launch(const void* x_lower, const void* x_higher, const void* x_prev, float atol, float rtol,
                               float* e_out /* [batch + 1] device */, int64_t batch, int64_t per_sample, int dtype,
                               void* stream);
 
@@ -361,28 +368,28 @@ typedef struct dpm_adaptive_desc {
   double h_init, atol, rtol, theta, t_err; /* ref :956 defaults 0.05, 0.0078, 0.05, 0.9, 1e-5 */
 } dpm_adaptive_desc;
 typedef struct dpm_adaptive dpm_adaptive;
-int dpm_adaptive_create(const dpm_schedule* s, const dpm_adaptive_desc* d, dpm_adaptive** out);
-void dpm_adaptive_destroy(dpm_adaptive* a);
+DPM_API int dpm_adaptive_create(const dpm_schedule* s, const dpm_adaptive_desc* d, dpm_adaptive** out);
+DPM_API void dpm_adaptive_destroy(dpm_adaptive* a);
 /* static fields (form, flags, slots) of stage `which` (0..4); the float fields are placeholders */
-int dpm_adaptive_stage_template(const dpm_adaptive* a, int which, dpm_stage* out);
+DPM_API int dpm_adaptive_stage_template(const dpm_adaptive* a, int which, dpm_stage* out);
 /* start of a run: s = t_T, h = h_init, nfe = 0 */
-int dpm_adaptive_reset(dpm_adaptive* a, void* stream);
+DPM_API int dpm_adaptive_reset(dpm_adaptive* a, void* stream);
 /* decision on the previous iteration (E read from *e_dev, then cleared), commit of an accepted step
    (x <- x_higher, x_prev <- x_lower), plan of the next iteration, t_vectors[j][0 | 1][0..tv_len) <- t_eval | t_input of
    network evaluation j */
-int dpm_adaptive_begin(dpm_adaptive* a, void* x, void* x_prev, const void* x_lower, const void* x_higher, int64_t n,
+DPM_API int dpm_adaptive_begin(dpm_adaptive* a, void* x, void* x_prev, const void* x_lower, const void* x_higher, int64_t n,
                        int dtype, float* e_dev, float* t_vectors, int64_t tv_len, void* stream);
 /* stage `which` of the current iteration: `st` = the caller's copy of the template (it may edit flags / model_type /
    guidance, e.g. to feed a known model value), float coefficients come from the device */
-int dpm_adaptive_stage_launch(dpm_adaptive* a, int which, const dpm_stage* st, const dpm_buffers* b, void* stream);
+DPM_API int dpm_adaptive_stage_launch(dpm_adaptive* a, int which, const dpm_stage* st, const dpm_buffers* b, void* stream);
 /* *e_dev <- max(*e_dev, max_b E_b) (ref :999-1001); several workgroups per sample, fp32 / fp16 / bf16 */
-int dpm_adaptive_error(dpm_adaptive* a, const void* x_lower, const void* x_higher, const void* x_prev, int64_t batch,
+DPM_API int dpm_adaptive_error(dpm_adaptive* a, const void* x_lower, const void* x_higher, const void* x_prev, int64_t batch,
                        int64_t per_sample, int dtype, float* e_dev, void* stream);
 /* host-mapped status as of the last dpm_adaptive_begin the device has executed: no synchronisation */
-int dpm_adaptive_poll(const dpm_adaptive* a, int* done, int* nfe, int* iterations, int* accepted);
+DPM_API int dpm_adaptive_poll(const dpm_adaptive* a, int* done, int* nfe, int* iterations, int* accepted);
 /* `done` as recorded by the begin_index-th dpm_adaptive_begin since the last reset (a ring of the last 32): the value to
    look at after waiting for THAT launch -- identical on every rank of a batch-sharded run, whatever has run since */
-int dpm_adaptive_done_at(const dpm_adaptive* a, int begin_index);
+DPM_API int dpm_adaptive_done_at(const dpm_adaptive* a, int begin_index);
 
 /* native sample loop for non-Python hosts and for the solver-only benchmark.
    model(user, stage, x, t_input, t_eval, e0_out, e1_out): evaluate the network on x, write the raw output(s);
@@ -408,7 +415,7 @@ typedef struct dpm_run_buffers {
   const dpm_launch_opts* opts; /* per-call options handed to every launch of the run, NULL = defaults (version 200;
                                   dpm_plan_run_multi reads rbs[0].opts)                                            */
 } dpm_run_buffers;
-int dpm_plan_run(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model_cb model, void* user, void* stream,
+DPM_API int dpm_plan_run(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model_cb model, void* user, void* stream,
                  int* result);
 /* several independent sampling requests advanced stage by stage (all requests stage s, then all stage s+1, ...)
    through dpm_stage_launch_multi: what a server holding n requests in flight does, and -- with a frozen model -- the
@@ -417,7 +424,7 @@ int dpm_plan_run(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model_cb mode
    [n_req * num_stages], request-major) receives kernel-only durations; a fused launch's duration is divided evenly
    over the requests it advanced (with n_req = 1: the kernel-only durations of one frozen-model trajectory).
    dpm_launch_opts.no_fuse launches request by request instead. */
-int dpm_plan_run_multi(const dpm_plan* p, const dpm_run_buffers* rbs, int n_req, void* stream, float* ms, int* results);
+DPM_API int dpm_plan_run_multi(const dpm_plan* p, const dpm_run_buffers* rbs, int n_req, void* stream, float* ms, int* results);
 
 /* ---- hipGraph capture of a whole trajectory ------------------------------------------------------------
    The step loop is launch-bound between network calls (a stage kernel runs for microseconds): capture the plan's
@@ -425,21 +432,21 @@ int dpm_plan_run_multi(const dpm_plan* p, const dpm_run_buffers* rbs, int n_req,
    (non-null) stream; `model` as in dpm_plan_run -- everything it does must be capturable (enqueue-only on `stream`);
    NULL = frozen outputs already staged in e0/e1.  The buffers named by `rb` are baked into the graph. */
 typedef struct dpm_graph dpm_graph;
-int dpm_graph_create(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model_cb model, void* user, void* stream,
+DPM_API int dpm_graph_create(const dpm_plan* p, const dpm_run_buffers* rb, dpm_model_cb model, void* user, void* stream,
                      dpm_graph** out);
-int dpm_graph_launch(dpm_graph* g, void* stream);
-int dpm_graph_result(const dpm_graph* g);    /* index of the xbuf that holds the final sample            */
-int dpm_graph_num_nodes(const dpm_graph* g); /* kernel / memset nodes captured                           */
-void dpm_graph_destroy(dpm_graph* g);
+DPM_API int dpm_graph_launch(dpm_graph* g, void* stream);
+DPM_API int dpm_graph_result(const dpm_graph* g);    /* index of the xbuf that holds the final sample            */
+DPM_API int dpm_graph_num_nodes(const dpm_graph* g); /* kernel / memset nodes captured                           */
+DPM_API void dpm_graph_destroy(dpm_graph* g);
 
 /* ---- misc ---------------------------------------------------------------------------------- */
-int dpm_version(void);
+DPM_API int dpm_version(void);
 /* sizeof() of the ABI structs as compiled, so a binding can verify its own layout at load time */
 enum { DPM_SIZEOF_STAGE = 0, DPM_SIZEOF_BUFFERS = 1, DPM_SIZEOF_PLAN_DESC = 2, DPM_SIZEOF_RUN_BUFFERS = 3,
        DPM_SIZEOF_ADAPTIVE_DESC = 4, DPM_SIZEOF_LAUNCH_OPTS = 5, DPM_SIZEOF_STAGE_F64 = 6 };
-size_t dpm_sizeof(int which);
-const char* dpm_last_error(void); /* thread-local text of the last non-zero return */
-int dpm_device_info(int* n_cu, int* lds_bytes, char* arch, int arch_len);
+DPM_API size_t dpm_sizeof(int which);
+DPM_API const char* dpm_last_error(void); /* thread-local text of the last non-zero return */
+DPM_API int dpm_device_info(int* n_cu, int* lds_bytes, char* arch, int arch_len);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 /* 1: this library is the lab build */
-int dpm_lab_build(void);
+DPM_API int dpm_lab_build(void);
 
 /* ---- launch-shape knobs, PROCESS-GLOBAL and unsynchronised (lab only: a tool sets them around its own launches) ----- */
 enum {
@@ -51,25 +51,25 @@ enum {
                                        publishes the result (k slot reads per sample), 0 = every workgroup reads every slot
                                        (k^2); -1 (default): the library's choice                                        */
 };
-int dpm_tuning_set(int knob, int value);
-int dpm_tuning_get(int knob);
+DPM_API int dpm_tuning_set(int knob, int value);
+DPM_API int dpm_tuning_get(int knob);
 
 /* ---- event-bracketed launches: hipExtLaunchKernelGGL start / stop events around the kernel itself ---------------- */
-int dpm_stage_launch_timed(const dpm_stage* st, const dpm_buffers* b, void* stream, float* ms);
+DPM_API int dpm_stage_launch_timed(const dpm_stage* st, const dpm_buffers* b, void* stream, float* ms);
 /* kernel durations INSIDE a real loop, without synchronising between launches: a trace owns `capacity` start/stop event
    pairs; dpm_stage_launch_traced is dpm_stage_launch with the pair of `slot` bracketing the kernel itself,
    dpm_trace_read synchronises the stream once and fills ms[0..n) (-1 for slots never used). */
 typedef struct dpm_trace dpm_trace;
-int dpm_trace_create(int capacity, dpm_trace** out);
-int dpm_stage_launch_traced(const dpm_stage* st, const dpm_buffers* b, void* stream, dpm_trace* t, int slot);
-int dpm_trace_read(dpm_trace* t, void* stream, float* ms, int n);
-void dpm_trace_destroy(dpm_trace* t);
+DPM_API int dpm_trace_create(int capacity, dpm_trace** out);
+DPM_API int dpm_stage_launch_traced(const dpm_stage* st, const dpm_buffers* b, void* stream, dpm_trace* t, int slot);
+DPM_API int dpm_trace_read(dpm_trace* t, void* stream, float* ms, int n);
+DPM_API void dpm_trace_destroy(dpm_trace* t);
 
 /* ---- memory-system calibration with no arithmetic ------------------------------------------------------------------
    kind 0: copy; kind 1: 3 read + 2 write streams, the 2M stage's pattern; kind 2: 4 read + 1 write streams, `e` read;
    nbytes per stream; block in {256,512,1024}; nt mask: bit 0 nt loads, bits 1 / 2 nt store of d / e (plain builds only);
    ms (optional) = kernel time by events. */
-int dpm_calib_launch(int kind, int block, int blocks_per_cu, int nt, const void* a, const void* b, const void* c,
+DPM_API int dpm_calib_launch(int kind, int block, int blocks_per_cu, int nt, const void* a, const void* b, const void* c,
                      void* d, void* e, int64_t nbytes, void* stream, float* ms);
 
 /* The FLOOR of the lone 2M launch: 3 read + 2 write streams of nbytes each (a, b, c -> d = a ^ b, e = b ^ c), no
@@ -88,10 +88,10 @@ int dpm_calib_launch(int kind, int block, int blocks_per_cu, int nt, const void*
 typedef struct dpm_floor_desc {
   int32_t load_path, rows, block, blocks_per_cu, nt, prio, store, reserved;
 } dpm_floor_desc;
-int dpm_floor_launch(const dpm_floor_desc* f, const void* a, const void* b, const void* c, void* d, void* e, int64_t nbytes,
+DPM_API int dpm_floor_launch(const dpm_floor_desc* f, const void* a, const void* b, const void* c, void* d, void* e, int64_t nbytes,
                      void* stream, float* ms);
 /* the same launch bracketed by the event pair of trace slot `slot` (no synchronisation: inside a loop) */
-int dpm_floor_launch_traced(const dpm_floor_desc* f, const void* a, const void* b, const void* c, void* d, void* e,
+DPM_API int dpm_floor_launch_traced(const dpm_floor_desc* f, const void* a, const void* b, const void* c, void* d, void* e,
                             int64_t nbytes, void* stream, dpm_trace* t, int slot);
 
 /* ---- side-stream helpers measured against the lone launch's ramp-up (neither is used by any loop of the library) ----
@@ -99,22 +99,22 @@ int dpm_floor_launch_traced(const dpm_floor_desc* f, const void* a, const void* 
    default loads, 1: streaming loads): rejected in round 3 (profiles/r03_in_loop.md).
    dpm_pagetouch_launch: ONE 4-byte load per `stride` bytes (4096 = one per page) of each buffer -- kilobytes, not
    megabytes: warms the TLB and the first-byte path without moving the data (round 5, profiles/r05_lone_floor.md). */
-int dpm_prefetch_launch(const void* const* bufs, const int64_t* bytes, int n_buf, int policy, void* stream);
-int dpm_pagetouch_launch(const void* const* bufs, const int64_t* bytes, int n_buf, int64_t stride, void* stream);
+DPM_API int dpm_prefetch_launch(const void* const* bufs, const int64_t* bytes, int n_buf, int policy, void* stream);
+DPM_API int dpm_pagetouch_launch(const void* const* bufs, const int64_t* bytes, int n_buf, int64_t stride, void* stream);
 
 /* ---- EXPERIMENT (rejected, profiles/r04_resident.md): a resident stage kernel woken by a stream-ordered write --------
    One launch per trajectory on a side stream keeps `workgroups` workgroups on the chip (capped at what is co-resident);
    per stage the host enqueues dpm_resident_signal behind the network's last kernel.  Covers the unguided 20-step
    DPM-Solver++(2M) trajectory: noise-prediction network, forms LIN1 / TWO, equal fp16 or fp32 dtypes, n a multiple of
    2048.  Waits are bounded (spin limit + abort word). */
-int dpm_resident_create(const dpm_stage* stages, const dpm_buffers* bufs, int n_stages, int workgroups, int sleep, void** out);
-int dpm_resident_start(void* handle, const void* x_first, void* x_last_out, void* side_stream);
-int dpm_resident_signal(void* handle, int stage, const void* eps, void* stream);
-void dpm_resident_destroy(void* handle);
+DPM_API int dpm_resident_create(const dpm_stage* stages, const dpm_buffers* bufs, int n_stages, int workgroups, int sleep, void** out);
+DPM_API int dpm_resident_start(void* handle, const void* x_first, void* x_last_out, void* side_stream);
+DPM_API int dpm_resident_signal(void* handle, int stage, const void* eps, void* stream);
+DPM_API void dpm_resident_destroy(void* handle);
 
 /* ---- per-device context probe (tests): the address of the library's context of device `dev` (the chain of clustered
    launches, the diagnostics word), so that a host-only test can check devices do not share one */
-const void* dpm_lab_device_context(int dev);
+DPM_API const void* dpm_lab_device_context(int dev);
 
 #ifdef __cplusplus
 }

@@ -35,13 +35,17 @@ PRODUCT_LIB = os.path.join(ROOT, "dpm_solver_amd", "libdpm_hip.so")
 def declared_functions(header="dpm_hip.h"):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"^\s*(?:const\s+)?(?:int|void|size_t|char\s*\*|const char\s*\*|const void\s*\*)\s+\**(dpm_[A-Za-z0-9_]+)\s*\(", src, flags=re.M)
+    names = re.findall(r"^\s*(?:DPM_API\s+)?(?:const\s+)?(?:int|void|size_t|char\s*\*|const char\s*\*|const void\s*\*)\s+\**(dpm_[A-Za-z0-9_]+)\s*\(", src, flags=re.M)
     return sorted(set(names))
 
 
 def exported(lib):
+    """the library's WHOLE dynamic table (defined symbols): with -fvisibility=hidden + DPM_API + csrc/dpm_exports.map that is
+    the C ABI name by name -- a mangled internal (`_Z...`), a libstdc++ instantiation or a data symbol fails the comparison"""
     out = subprocess.run(["nm", "-D", "--defined-only", lib], check=True, stdout=subprocess.PIPE, text=True).stdout
-    return sorted(l.split()[-1] for l in out.splitlines() if " T dpm_" in l)
+    rows = [l.split() for l in out.splitlines() if l.strip()]
+    assert all(r[-2] == "T" for r in rows), [r for r in rows if r[-2] != "T"][:5]
+    return sorted(r[-1] for r in rows)
 
 
 def test_header_functions_are_exported_and_bound():
@@ -58,6 +62,7 @@ def test_product_library_exports_the_pinned_abi_and_nothing_else():
     """no tuning knob, no fault-injection switch, no calibration kernel, no experiment in the shipped library"""
     got = exported(PRODUCT_LIB)
     assert got == sorted(PRODUCT_ABI), (set(got) ^ set(PRODUCT_ABI))
+    assert len(got) == 61 and not [n for n in got if n.startswith("_Z")]
     lab_only = declared_functions("dpm_lab.h")
     assert lab_only and not (set(got) & set(lab_only))
     # ... and no process-global tuning state either: the lab build's knobs live in a variable the product does not have
