@@ -231,6 +231,16 @@ def cpu_baseline(ac):
         committed["source"] = ("profiles/cpu_baseline_reference_gpubox.json: the unmodified reference timed on an MI355X box's "
                                "host cores (tools/cpu_baseline.py through gpurun); committed, not re-measured in this run")
         out["reference_committed"] = committed
+        ratio = committed.get("port_over_reference")
+        if isinstance(ratio, dict) and ratio.get("best"):
+            # scalars (the driver's record keeps those): the committed same-box ratio port / reference, and this run's port
+            # figure scaled by it -- an ESTIMATE of the reference's rate on this box, labelled as such
+            out["port_over_reference"] = ratio["best"]
+            out["port_over_reference_single_thread"] = ratio.get("single_thread")
+            out["port_over_reference_source"] = ("profiles/cpu_baseline_reference_gpubox.json: port and reference timed on the same "
+                                                 "MI355X box's host cores in one run (tools/cpu_baseline.py); committed")
+            out["reference_estimate"] = round(out["value"] / ratio["best"], 6)
+            out["reference_estimate_unit"] = "Msamples/s (this run's port figure / the committed ratio; not a measurement)"
     return out
 
 
@@ -334,6 +344,101 @@ def lab_secondary(dtype_name, eps_dtype_name, loop_net, requests, timeout=600):
         return dict(error="%s: %s" % (type(e).__name__, e))
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# preflight: every rank proves its OWN device ordinal before anything is timed
+# ---------------------------------------------------------------------------------------------------------------
+def _torch_2m_double(ac, x, eps, steps):
+    """DPM-Solver++(2M), time_uniform grid, 'discrete' schedule, frozen eps -- the textbook recurrence (ref :553-576,
+    :805-852, :1171-1213) as a dozen torch-double lines on x's device.  The preflight's in-run checker: independent of the
+    library, of its planner and of oracle/ (which only tests, smoke() and the cpu_baseline leg may touch)."""
+    N = ac.shape[0]
+    la_tab = 0.5 * torch.log(torch.from_numpy(ac.astype(np.float64)))
+    t_tab = torch.linspace(0.0, 1.0, N + 1, dtype=torch.float64)[1:]
+
+    def la(t):                                                    # piecewise-linear log(alpha_t) (ref :127-134)
+        i = int(torch.searchsorted(t_tab, torch.tensor(t, dtype=torch.float64)).clamp(1, N - 1))
+        w = (t - float(t_tab[i - 1])) / float(t_tab[i] - t_tab[i - 1])
+        return float(la_tab[i - 1]) + w * float(la_tab[i] - la_tab[i - 1])
+    alpha = lambda t: float(np.exp(la(t)))
+    sigma = lambda t: float(np.sqrt(1.0 - np.exp(2.0 * la(t))))
+    lam = lambda t: la(t) - np.log(sigma(t))
+    ts = [float(np.float32(v)) for v in torch.linspace(1.0, 1.0 / N, steps + 1, dtype=torch.float32)]
+    xd, ed = x.double(), eps.double()
+    x0 = lambda xx, t: (xx - sigma(t) * ed) / alpha(t)            # eps -> x0 (ref :439)
+    ms, tp = [x0(xd, ts[0])], [ts[0]]
+    for k in range(1, steps + 1):
+        t = ts[k]
+        h = lam(t) - lam(tp[-1])
+        xn = sigma(t) / sigma(tp[-1]) * xd - alpha(t) * np.expm1(-h) * ms[-1]
+        if k > 1:                                                 # second-order term (ref :827-831)
+            r0 = (lam(tp[-1]) - lam(tp[-2])) / h
+            xn = xn - 0.5 * alpha(t) * np.expm1(-h) * ((ms[-1] - ms[-2]) / r0)
+        xd = xn
+        if k < steps:
+            ms.append(x0(xd, t))
+            tp.append(t)
+    return xd
+
+
+def preflight(D, L, dev, rank, world, dist, stub=False):
+    """Three checks on THIS rank's device, before the timed region; returns a dict (and never raises: a failed check is
+    reported per rank and fails the run after every rank has printed its line):
+      smoke         one DPM-Solver++(2M) 20-step trajectory [4,4,64,64] fp32 through DPM_Solver.sample() against a torch-double
+                    restatement computed on the same device (<= 1e-5 of the result's magnitude)
+      thresholding  one CLUSTERED dynamic-thresholding launch (k > 1 workgroups per sample: [4,3,64,64]) -- the per-device
+                    context (`device_context(dev)`) and the host-mapped fault word of an ordinal != 0 -- bit-exact against
+                    torch.quantile / clamp on the same device
+      collective    an all-gather of 512 KiB over the run's process group (RCCL on GPUs), contents checked"""
+    t0 = time.perf_counter()
+    res = dict(rank=rank, device=str(dev), ordinal=(None if stub else torch.cuda.current_device()))
+    try:
+        if stub:
+            res["smoke"] = res["thresholding"] = "stubbed"
+        else:
+            ac = sd_alphas_cumprod()
+            g = torch.Generator(device="cpu").manual_seed(77 + rank)
+            x = torch.randn((4, 4, 64, 64), generator=g).to(dev)
+            eps = torch.randn((4, 4, 64, 64), generator=g).to(dev)
+            ns = D.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(ac))
+            dpm = D.DPM_Solver(D.model_wrapper(lambda xx, t: eps, ns), ns, algorithm_type="dpmsolver++")
+            got = dpm.sample(x, steps=20, order=2)
+            want = _torch_2m_double(ac, x, eps, 20)
+            err = float((got.double() - want).abs().max() / want.abs().max())
+            assert got.device == x.device and err < 1e-5, "smoke rel-err %.3g on %s" % (err, dev)
+            res["smoke"] = dict(ok=True, rel_err=err)
+            x0 = torch.randn((4, 3, 64, 64), generator=g).to(dev) * 2.0
+            assert L.lib.dpm_threshold_workspace_bytes(4, 3 * 64 * 64) > 0, "not a clustered launch"
+            dthr = D.DPM_Solver(D.model_wrapper(lambda xx, t: xx, ns), ns, correcting_x0_fn="dynamic_thresholding")
+            gt = dthr.dynamic_thresholding_fn(x0)
+            s_ = torch.quantile(torch.abs(x0).reshape(4, -1), 0.995, dim=1)
+            s_ = torch.maximum(s_, torch.ones_like(s_)).reshape(4, 1, 1, 1)
+            wt = torch.clamp(x0, -s_, s_) / s_
+            torch.cuda.synchronize(dev)
+            assert torch.equal(gt, wt), "clustered thresholding differs from torch.quantile on %s (max %.3g)" % (
+                dev, float((gt - wt).abs().max()))
+            res["thresholding"] = dict(ok=True, clustered=True, timeouts=int(L.lib.dpm_cluster_timeout_poll()))
+        if dist is not None:
+            nb = 512 * 1024 // 4
+            mine = torch.full((nb,), float(rank + 1), dtype=torch.float32, device=dev)
+            allv = torch.empty((world * nb,), dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(allv, mine)
+            if not stub:
+                torch.cuda.synchronize(dev)
+            want_g = torch.arange(1, world + 1, dtype=torch.float32, device=dev).repeat_interleave(nb)
+            assert torch.equal(allv, want_g), "all-gather contents"
+            res["collective"] = dict(ok=True, bytes_per_rank=nb * 4, backend=dist.get_backend(), ranks=dist.get_world_size())
+        else:
+            res["collective"] = "no process group (plain python launch)"
+        res["ok"] = True
+    except Exception as e:                                       # reported per rank; the caller fails the run
+        res["ok"] = False
+        res["error"] = "%s: %s" % (type(e).__name__, e)
+    res["seconds"] = round(time.perf_counter() - t0, 3)
+    print("[preflight] rank %d of %d on %s: %s (%.2f s)%s" % (rank, world, dev, "PASS" if res["ok"] else "FAIL", res["seconds"],
+                                                              "" if res["ok"] else " -- " + res["error"]), file=sys.stderr, flush=True)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -354,6 +459,11 @@ def main():
     ap.add_argument("--eps-dtype", default=None, choices=["fp16", "fp32", "bf16"],
                     help="dtype of the network output (default: the state dtype); fp16 with --dtype fp32 = SD under autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preflight", action="store_true",
+                    help="run the per-rank preflight (smoke trajectory, clustered thresholding launch, all-gather -- each on the "
+                         "rank's own device ordinal), print its JSON record and exit; it also runs, untimed, at the start of every "
+                         "N > 1 / torch.distributed.run launch")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (the other BASELINE configurations)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (profiling runs)")
     args = ap.parse_args()
     dtype = _DT[args.dtype]
@@ -414,6 +524,24 @@ def main():
     from dpm_solver_amd import _lib as L
     assert STUB or not L.IS_LAB or os.environ.get("DPM_BENCH_ALLOW_LAB") == "1", \
         "bench.py times the PRODUCT library (unset DPM_SOLVER_AMD_LIB)"
+
+    # ---- preflight: every rank on its own ordinal, before anything is timed; all ranks report, then a failure stops the run --
+    pre = None
+    if True:
+        mine = preflight(D, L, dev, rank, world, dist, stub=STUB)
+        allp = [mine]
+        if dist is not None:
+            allp = [None] * world
+            dist.all_gather_object(allp, mine)
+        pre = dict(ok=all(p["ok"] for p in allp), ranks=allp, seconds=max(p["seconds"] for p in allp))
+        if args.preflight:
+            if rank == 0:
+                print(json.dumps(dict(preflight=pre, n_gpus=world, device_ordinals=[p["ordinal"] for p in allp])), flush=True)
+            if dist is not None:
+                dist.barrier()
+                dist.destroy_process_group()
+            sys.exit(0 if pre["ok"] else 1)
+        assert pre["ok"], "preflight failed: %s" % [p.get("error") for p in allp if not p["ok"]]
 
     ac = sd_alphas_cumprod()
     ns = D.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(ac))
@@ -657,6 +785,7 @@ def main():
 
     # ---- secondaries on the LAB build, in a subprocess: the stage kernel inside a real torch network loop (one request,
     # the drop-in sample() call), the no-arithmetic ceilings, the floor of the lone launch ------------------------------
+    lab_configs = None
     if not args.no_secondary and world == 1:
         torch.cuda.synchronize(dev)
         lab = lab_secondary(args.dtype, args.eps_dtype, args.loop_net, R)
@@ -666,6 +795,7 @@ def main():
             for k in ("in_network_loop", "no_arithmetic_ceiling", "lone_launch_floor"):
                 if k in lab:
                     roofline[k] = lab[k]
+            lab_configs = lab.get("configs_in_loop")
             nac = roofline.get("no_arithmetic_ceiling")
             if nac and "fused_size_us" in nac and "kernel_only" in roofline:
                 nac["stage_kernel_vs_ceiling"] = round(nac["fused_size_us"] / roofline["kernel_only"]["us"], 3)
@@ -680,6 +810,22 @@ def main():
             if rows:
                 inl["rocprofv3_rows_committed"] = dict(rows, measured_in_this_run=False,
                                                        source="profiles/in_loop.json (tools/in_loop.py under rocprofv3 --kernel-trace)")
+
+    # ---- the OTHER BASELINE configurations on this run's clock (product library, this process): tools/config_bench.py ----
+    configs = None
+    if world == 1 and not args.no_secondary and not args.no_configs and not STUB:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        try:
+            import config_bench
+            torch.cuda.synchronize(dev)
+            tcb = time.perf_counter()
+            configs = config_bench.run_all(dev)
+            for k, v in (lab_configs or {}).items():
+                if k in configs and isinstance(configs[k], dict):
+                    configs[k]["in_network_loop"] = v
+            configs["seconds"] = round(time.perf_counter() - tcb, 2)
+        except Exception as e:
+            configs = dict(error="%s: %s" % (type(e).__name__, e))
 
     if rank == 0:
         samples = world * steps * P * R * B
@@ -714,7 +860,14 @@ def main():
             "value_per_gpu": round(samples / wall / 1e6 / world, 4),
             "fastest_rank_value_per_gpu": round(samples / world / wall_min / 1e6, 4),
             "launcher": "torch.distributed.run" if "RANK" in os.environ else "python",
+            # what the collectives of this run really spanned: ranks of the process group (RCCL on GPUs) and the device
+            # ordinal every rank computed on (from the preflight's all-gather; a plain python launch has no group)
+            "rccl_ranks": (dist.get_world_size() if dist is not None else 0),
+            "collective_backend": (dist.get_backend() if dist is not None else None),
+            "device_ordinals": ([p["ordinal"] for p in pre["ranks"]] if pre is not None else [None if STUB else local_rank]),
+            "preflight": pre,
         }
+
         if STUB:
             line["stub"] = True
             line["value"] = line["roofline"] = line["value_per_gpu"] = line["fastest_rank_value_per_gpu"] = None   # nothing was measured
@@ -733,6 +886,49 @@ def main():
                                                           "rel_err_vs_reference_on_gpu")} for r in gr["rows"]])
         except Exception:
             pass
+        if isinstance(line.get("roofline"), dict):
+            # The driver's record of this line keeps the SCALAR fields of `roofline` / `cpu_baseline` and the last 2000
+            # characters of the line (BENCH_r05.json: nested objects are dropped from `parsed`): the figures a reader needs are
+            # therefore repeated flat here, and the compact `configs` block is the line's LAST key.
+            rf = line["roofline"]
+            for k, sub, field in (("single_request_cold_us", "single_request_cold", "kernel_us"),
+                                  ("single_request_cold_frac", "single_request_cold", "frac"),
+                                  ("kernel_only_us", "kernel_only", "us"), ("kernel_only_frac", "kernel_only", "frac"),
+                                  ("cache_resident_frac", "cache_resident", "frac"),
+                                  ("in_network_loop_stage_kernel_us", "in_network_loop", "stage_kernel_us"),
+                                  ("in_network_loop_frac", "in_network_loop", "frac"),
+                                  ("in_network_loop_frac_of_floor", "in_network_loop", "frac_of_floor"),
+                                  ("copy_ceiling_frac", "copy_ceiling", "frac")):
+                if isinstance(rf.get(sub), dict) and field in rf[sub]:
+                    rf[k] = rf[sub][field]
+        if configs is not None:
+            line["configs_detail"] = configs
+            compact = {}
+            for name, r in configs.items():
+                if not isinstance(r, dict) or "case" not in r:
+                    continue
+                if "error" in r:
+                    compact[name] = dict(error=r["error"][:80], measured_in_this_run=False)
+                    continue
+                c_ = dict(shape="x".join(str(v) for v in r["shape"]), stages=r["stages_per_trajectory"], us=r["us_per_stage"],
+                          captured_us=r.get("captured", {}).get("us_per_stage"), algorithmic_bytes=r["algorithmic_bytes_per_stage"],
+                          frac=r["frac"], captured_frac=r.get("captured", {}).get("frac"), x_floor=r.get("x_latency_bound_stage"),
+                          measured_in_this_run=True)
+                if "us_per_order3_step" in r:
+                    c_["us_per_order3_step"] = r["us_per_order3_step"]
+                il = r.get("in_network_loop")
+                if isinstance(il, dict) and "stage_kernel_us" in il:
+                    c_["in_loop_kernel_us"], c_["in_loop_frac"] = il["stage_kernel_us"], il["frac"]
+                compact[name] = c_
+                if isinstance(line.get("roofline"), dict):
+                    line["roofline"]["%s_us_per_stage" % name] = r["us_per_stage"]
+                    line["roofline"]["%s_frac" % name] = r["frac"]
+                    if c_.get("in_loop_kernel_us") is not None:
+                        line["roofline"]["%s_in_loop_kernel_us" % name] = c_["in_loop_kernel_us"]
+            compact["how"] = ("us = HIP-event time of K eager DPM_Solver.sample() trajectories / stages, frozen model_fn, product "
+                              "library, this run; captured = hipGraph replay; x_floor = us / cfg1's us; in_loop = kernel-only "
+                              "behind a conv network (lab subprocess); detail: configs_detail")
+            line["configs"] = compact                            # LAST key: inside the tail the driver keeps
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

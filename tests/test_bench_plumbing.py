@@ -52,6 +52,30 @@ def test_bench_multi_rank_plumbing_with_a_stubbed_timed_region(world):
     assert w["max"] >= line["steps"] * 3 * 2e-4 * world, (w, line["steps"])
     assert line["gather_ms"] is not None and line["gather_ms"] >= 0     # the single end-of-sampling collective, timed apart
     assert "cpu_baseline" not in line                                   # rank 0 at N = 1 only, and not with --no-cpu-baseline
+    # the preflight ran on every rank before the timed region and its all-gather spanned the whole group
+    pre = line["preflight"]
+    assert pre["ok"] is True and [p["rank"] for p in pre["ranks"]] == list(range(world))
+    assert all(p["collective"]["ok"] and p["collective"]["ranks"] == world and p["collective"]["bytes_per_rank"] == 512 * 1024
+               for p in pre["ranks"])
+    assert line["rccl_ranks"] == world and line["collective_backend"] == "gloo" and len(line["device_ordinals"]) == world
+    assert r.stderr.count("[preflight] rank") == world and "FAIL" not in r.stderr
+
+
+def test_preflight_only_mode_prints_its_record_and_exits():
+    """`bench.py --gpus N --preflight`: the per-rank checks and nothing else -- under two gloo ranks
+    the device checks are stubbed, the plumbing (per-rank lines on stderr, the gathered record, the exit code) is real"""
+    env = dict(os.environ, DPM_BENCH_STUB="1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--preflight"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["preflight"]["ok"] is True and len(rec["preflight"]["ranks"]) == 2
+    assert "metric" not in rec and "value" not in rec                   # nothing was timed
 
 
 def test_cpu_baseline_record_is_what_this_run_timed():
@@ -93,3 +117,22 @@ def test_secondaries_that_need_a_gpu_report_an_error_instead_of_raising():
     assert isinstance(out, dict) and "error" in out and "cold_start.py" in out["error"]
     lab = bench.lab_secondary("fp16", "fp16", "conv", 2, timeout=240)
     assert isinstance(lab, dict) and "error" in lab
+
+
+def test_preflight_checker_agrees_with_the_oracle():
+    """bench.py's preflight checks each rank's smoke trajectory against a torch-double restatement of DPM-Solver++(2M) it
+    carries itself (bench.py may not touch oracle/ outside its cpu_baseline leg); HERE that restatement is held against the
+    oracle, so the checker is itself checked"""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import dpm_oracle as O
+    ac = bench.sd_alphas_cumprod()
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 4, 8, 8)).astype(np.float32)
+    e = rng.standard_normal((2, 4, 8, 8)).astype(np.float32)
+    osch = O.Schedule.from_alphas_cumprod(ac)
+    want = O.Solver(O.wrap_model(lambda xx, t: e, osch), osch).sample(x, steps=20, order=2)
+    got = bench._torch_2m_double(ac, torch.from_numpy(x), torch.from_numpy(e), 20).numpy()
+    assert np.abs(got - want).max() / np.abs(want).max() < 2e-6

@@ -26,10 +26,21 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "cpu_baseline_reference.json"))
     ap.add_argument("--where", default="build container (no GPU)")
     ap.add_argument("--budget", type=float, default=30.0)
+    ap.add_argument("--no-port", action="store_true", help="do not time the numpy port beside the reference")
     args = ap.parse_args()
     ref = bench.reference_dir()
     assert ref, "no reference checkout (DPM_REFERENCE_DIR)"
     out = bench.cpu_baseline_reference(ref, bench.sd_alphas_cumprod(), budget_s=args.budget)
+    if not args.no_port:
+        # the numpy port (what bench.py times where the reference is absent) on the SAME cores in the SAME run: the ratio
+        # bench.py's line carries as cpu_baseline.port_over_reference
+        port = bench.cpu_baseline_port(bench.sd_alphas_cumprod(), budget_s=args.budget / 2)
+        out["port_same_box"] = port
+        out["port_over_reference"] = dict(
+            single_thread=round(port["single_thread"]["value"] / out["single_thread"]["value"], 4),
+            best=round(port["value"] / out["value"], 4),
+            what="numpy port (oracle/dpm_oracle.py) Msamples/s / unmodified reference Msamples/s on the same host cores in the same "
+                 "run: at one thread each, and best thread count of each (port %d threads, reference %d)" % (port["cores"], out["cores"]))
     cpu = ""
     try:
         cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]

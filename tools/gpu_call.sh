@@ -1,0 +1,75 @@
+#!/bin/bash
+# One parameterised GPU call (replaces the per-call scripts of rounds 1-5, now under tools/history/).
+#   usage (through gpurun):  bash tools/gpu_call.sh <tag> <step> [<step> ...]
+# Every step writes under gpurun_out/<tag>/ and prints one summary line; a failing step does not stop the later ones.
+#   tests        the GPU suite (pytest -m gpu), timed
+#   smoke        __graft_entry__.smoke()
+#   bench        the default bench line (what the driver runs), timed
+#   guard5       tests/test_gpu_perf_guard.py five times (its record: perf_guard.jsonl)
+#   torchrun1    the driver's N > 1 launch line with one rank (RCCL communicator, preflight, all-gather) + --preflight alone
+#   configs      tools/config_bench.py: figures + rocprofv3 kernel rows per BASELINE configuration (frozen model_fn, product library)
+#   configsloop  the same cases inside a conv-network loop, kernel-only (lab build)
+#   profile      tools/profile_round.sh (headline: kernel trace + counters)
+#   cpubase      the unmodified reference + the numpy port on this box's host cores (needs _refscratch/: tools/ref_scratch.sh make)
+#   dropin       the reference's own example call sites on the engine (needs _refscratch/)
+TAG=${1:?tag}; shift
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+O=gpurun_out/$TAG; mkdir -p $O
+[ -f _refscratch/dpm_solver_pytorch.py ] && export DPM_REFERENCE_DIR=_refscratch
+for STEP in "$@"; do
+case $STEP in
+tests)
+  ( time timeout 1500 python -m pytest tests -m gpu -q ) > $O/pytest.log 2>&1; echo "pytest rc=$?"
+  grep -E "passed|failed" $O/pytest.log | tail -1; grep -E "^FAILED|^ERROR" $O/pytest.log | head; grep real $O/pytest.log ;;
+smoke)
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log ;;
+bench)
+  ( time timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err ); echo "bench rc=$?"; tail -3 $O/bench_default.err
+  python - <<PY
+import json
+d = json.load(open("$O/bench_default.json")); r = d["roofline"]
+print("value", d["value"], "frac", r["frac"], "ms_per_step", d["ms_per_step"], "lone cold", r.get("single_request_cold_us"), r.get("single_request_cold_frac"))
+print("preflight", d.get("preflight", {}).get("ok"), d.get("preflight", {}).get("seconds"), "ordinals", d.get("device_ordinals"))
+for k, v in d.get("configs", {}).items():
+    print(" ", k, v if not isinstance(v, dict) else {a: b for a, b in v.items() if a != "measured_in_this_run"})
+print("configs seconds", d.get("configs_detail", {}).get("seconds"), "cpu_baseline", {k: v for k, v in d.get("cpu_baseline", {}).items() if not isinstance(v, (dict, list)) and k != "sample"})
+print("line bytes", len(json.dumps(d)), "configs bytes", len(json.dumps(d.get("configs", {}))))
+PY
+  ;;
+guard5)
+  rm -f gpurun_out/perf_guard.jsonl
+  for i in 1 2 3 4 5; do
+    ( time timeout 300 python -m pytest tests/test_gpu_perf_guard.py -m gpu -q -s -p no:cacheprovider ) > $O/guard_$i.log 2>&1; echo "guard $i rc=$? $(grep -E 'passed|failed' $O/guard_$i.log | tail -1) $(grep real $O/guard_$i.log)"
+  done
+  cp gpurun_out/perf_guard.jsonl $O/perf_guard.jsonl 2>/dev/null; cat $O/perf_guard.jsonl ;;
+torchrun1)
+  ( time timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > $O/bench_torchrun_1rank.json 2> $O/bench_torchrun_1rank.err ); echo "torchrun 1 rank rc=$?"
+  grep preflight $O/bench_torchrun_1rank.err
+  ( time timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --preflight > $O/preflight_1rank.json 2> $O/preflight_1rank.err ); echo "preflight-only rc=$?"; cat $O/preflight_1rank.json | cut -c1-600 ;;
+configs)
+  timeout 600 python tools/config_bench.py --out $O/configs.json > $O/configs.log 2>&1; echo "config_bench rc=$?"; cut -c1-420 $O/configs.log
+  for CASE in cfg1 cfg3 cfg5 cfg_sd64 one8192; do
+    timeout 420 rocprofv3 --kernel-trace --stats --output-format rocpd csv -d $O/kt_$CASE -o kt -- python tools/config_bench.py --cases $CASE --trace-only > $O/kt_$CASE.log 2>&1; echo "rocprof $CASE rc=$?"
+    find $O/kt_$CASE -name "*kernel_stats.csv" -exec cp {} $O/configs_${CASE}_kernel_stats.csv \;
+    rm -rf $O/kt_$CASE
+    head -4 $O/configs_${CASE}_kernel_stats.csv | cut -c1-260
+  done ;;
+configsloop)
+  timeout 600 python tools/config_bench.py --in-loop --cases cfg1,cfg3,cfg5,cfg_sd64 --out $O/configs_in_loop.json > $O/configs_in_loop.log 2>&1; echo "config_bench in-loop rc=$?"; cut -c1-420 $O/configs_in_loop.log ;;
+profile)
+  timeout 900 bash tools/profile_round.sh $TAG fp16 > $O/profile_fp16.log 2>&1; echo "profile rc=$?"; tail -32 $O/profile_fp16.log ;;
+cpubase)
+  if [ -f _refscratch/dpm_solver_pytorch.py ]; then
+    timeout 500 python tools/cpu_baseline.py --budget 40 --out $O/cpu_baseline_reference_gpubox.json --where "MI355X box host cores (gpurun)" > $O/cpu_baseline.log 2>&1; echo "cpu_baseline rc=$?"
+    python -c "import json; d=json.load(open('$O/cpu_baseline_reference_gpubox.json')); print(d['value'], d['cores'], d.get('port_over_reference'))"
+  else echo "cpubase: no _refscratch/"; fi ;;
+dropin)
+  if [ -d _refscratch/examples ]; then
+    timeout 300 python tools/dropin_examples.py --device cuda:0 --out $O/dropin.json > $O/dropin.log 2>&1; echo "dropin rc=$?"; tail -4 $O/dropin.log
+  else echo "dropin: no _refscratch/"; fi ;;
+*) echo "unknown step $STEP" ;;
+esac
+done
+find $O -name "*.db" -size +20M -delete
+du -sh $O

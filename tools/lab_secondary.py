@@ -9,6 +9,8 @@ product library only.  Prints ONE JSON line:
                          and -- `floor` -- the best no-arithmetic kernel of the floor sweep (tools/floor.py,
                          profiles/r05_lone_floor.md) in the same slot of the same loop: frac_of_floor = floor / stage kernel
   no_arithmetic_ceiling  three read + two write streams with no arithmetic: one request warm / cold, the fused launch's size
+  configs_in_loop        the stage kernels of the other BASELINE configurations (tools/config_bench.py: cfg1, cfg3, cfg5, cfg_sd64)
+                         inside a conv-network loop, kernel-only by traced launches
 """
 import argparse
 import ctypes as C
@@ -231,6 +233,8 @@ def main():
     ap.add_argument("--eps-dtype", default=None, choices=["fp16", "fp32", "bf16"])
     ap.add_argument("--loop-net", default="conv", choices=["gemm", "conv", "none"])
     ap.add_argument("--requests", type=int, default=32)
+    ap.add_argument("--configs", default="cfg1,cfg3,cfg5,cfg_sd64",
+                    help="cases of tools/config_bench.py whose stage kernels are timed inside a conv-network loop (traced launches)")
     args = ap.parse_args()
     import dpm_solver_amd as D
     from dpm_solver_amd import _lib as L
@@ -257,6 +261,14 @@ def main():
             out["no_arithmetic_ceiling"] = ceilings(L, dev, dtype, args.requests)
         except Exception as e:
             out["no_arithmetic_ceiling"] = dict(error="%s: %s" % (type(e).__name__, e))
+    if args.configs:
+        import config_bench
+        out["configs_in_loop"] = {}
+        for name in args.configs.split(","):
+            try:
+                out["configs_in_loop"][name] = config_bench.measure_in_loop(name, dev)
+            except Exception as e:
+                out["configs_in_loop"][name] = dict(error="%s: %s" % (type(e).__name__, e))
     print(json.dumps(out), flush=True)
 
 
