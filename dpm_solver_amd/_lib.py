@@ -168,6 +168,8 @@ _SIGNATURES = [
     ("dpm_threshold_workspace_bytes", C.c_size_t, [C.c_int64, C.c_int64]),
     ("dpm_add_noise_launch", C.c_int, [C.c_void_p, _P(C.c_float), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_int64, C.c_int, C.c_void_p]),
+    ("dpm_add_noise_launch_f64", C.c_int, [C.c_void_p, _P(C.c_double), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                           C.c_void_p]),
     ("dpm_blend_launch", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p,
                                    C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     ("dpm_adaptive_error_launch", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p,
@@ -258,8 +260,8 @@ for _i, _t in enumerate((Stage, Buffers, PlanDesc, RunBuffers, AdaptiveDesc, Lau
                           % (_t.__name__, C.sizeof(_t), lib.dpm_sizeof(_i)))
 
 
-if lib.dpm_version() < 200:
-    raise ImportError("dpm_solver_amd: libdpm_hip.so reports version %d, this binding needs >= 200 -- stale library, rebuild"
+if lib.dpm_version() < 201:
+    raise ImportError("dpm_solver_amd: libdpm_hip.so reports version %d, this binding needs >= 201 -- stale library, rebuild"
                       % lib.dpm_version())
 
 

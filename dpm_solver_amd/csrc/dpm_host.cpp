@@ -582,22 +582,32 @@ int plan_build(const S* s, const dpm_plan_desc* d, std::vector<ST>& stages, std:
 
   if (d->method == DPM_METHOD_MULTISTEP) {
     const int S_ = d->steps, P = d->order;
-    if (P < 1 || P > 3) rc = dpm_set_error(DPM_ERR_ARG, "Solver order must be 1 or 2 or 3, got %d", P);
+    // The reference validates the order where an update of that order is REACHED (multistep_dpm_solver_update, ref :948-954),
+    // not up front: sample(order=4, steps=5, lower_order_final=True) runs -- its step orders are 1, 2, 3, 2, 1 (ref
+    // :1185-1201) -- while order=4 with steps >= 7 raises at the first fourth-order update (and steps = 6 at the third-order
+    // update of the main loop, see below).  Same here: the step orders
+    // first, then the check on what they contain.  The history ring needs min(P, 3) slots.
+    const int PS = std::min(P, 3);
+    if (P < 1) rc = dpm_set_error(DPM_ERR_ARG, "Solver order must be 1 or 2 or 3, got %d", P);
     if (!rc && S_ < P) rc = dpm_set_error(DPM_ERR_ARG, "multistep needs steps >= order (steps=%d, order=%d)", S_, P);
     if (!rc) {
       grid.resize(S_ + 1);
       rc = time_steps(s, d->skip_type, t_T, t_0, S_, grid.data());  // ref :1173
     }
+    std::vector<int> ord(rc ? 0 : S_);
+    for (int i = 0; i < (int)ord.size(); ++i) {
+      const int step = i + 1;  // the reference's loop variable: this stage produces x at ts[step]
+      if (step < P)
+        ord[i] = step;  // warm-up, ref :1185-1187
+      else
+        ord[i] = (d->lower_order_final && S_ < 10) ? std::min(P, S_ + 1 - step) : P;  // ref :1198-1201
+      if (ord[i] > 3 && !rc) rc = dpm_set_error(DPM_ERR_ARG, "Solver order must be 1 or 2 or 3, got %d", ord[i]);
+      // ... and its third-order update unpacks the history list into exactly three names (ref :869): with order > 3 the
+      // list of the main loop is longer, and reaching a third-order update there is the ValueError Python raises for that
+      if (P > 3 && step >= P && ord[i] == 3 && !rc) rc = dpm_set_error(DPM_ERR_ARG, "too many values to unpack (expected 3)");
+    }
     if (!rc) {
       const F* ts = grid.data();
-      std::vector<int> ord(S_);
-      for (int i = 0; i < S_; ++i) {
-        int step = i + 1;  // the reference's loop variable: this stage produces x at ts[step]
-        if (step < P)
-          ord[i] = step;  // warm-up, ref :1185-1187
-        else
-          ord[i] = (d->lower_order_final && S_ < 10) ? std::min(P, S_ + 1 - step) : P;  // ref :1198-1201
-      }
       for (int i = 0; i < S_; ++i) {
         ST st;
         stage_init(&st);
@@ -609,19 +619,19 @@ int plan_build(const S* s, const dpm_plan_desc* d, std::vector<ST>& stages, std:
           coef_ms3(s, pp, ts[i - 2], ts[i - 1], ts[i], ts[i + 1], &st);
         st.outer_step = i + 1;
         if (P >= 2) {
-          if (ord[i] >= 2) st.h1_slot = (i - 1) % P;
-          if (ord[i] >= 3) st.h2_slot = (i - 2) % P;
+          if (ord[i] >= 2) st.h1_slot = (i - 1) % PS;
+          if (ord[i] >= 3) st.h2_slot = (i - 2) % PS;
           bool needed = false;  // does a later stage read this stage's model value?
           for (int j = i + 1; j < S_ && j <= i + 2; ++j)
             if (ord[j] > j - i) needed = true;
           if (needed) {
             st.flags |= DPM_F_STORE_M;
-            st.m_slot = i % P;
+            st.m_slot = i % PS;
           }
         }
         finish_stage(st, ts[i], grid_f64 ? 3 : 0);
       }
-      slots_out = P >= 2 ? P : 0;
+      slots_out = P >= 2 ? PS : 0;
       last_step = S_;
     }
   } else {

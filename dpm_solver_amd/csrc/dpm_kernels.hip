@@ -194,6 +194,21 @@ extern "C" size_t dpm_threshold_workspace_bytes(int64_t batch, int64_t per_sampl
   return (size_t)thr_ws_bytes(batch, per_sample, di.n_cu > 0 ? di.n_cu : 256);
 }
 
+extern "C" int dpm_add_noise_launch_f64(const dpm_schedule* s, const double* t_host, int nt, const void* x, const void* noise,
+                                        void* out, int64_t n, void* stream) {
+  if (!s || !t_host || !x || !noise || !out || nt < 1 || n < 0) return dpm_set_error(DPM_ERR_ARG, "add_noise: bad arguments");
+  if (n == 0) return DPM_OK;
+  for (int j = 0; j < nt; ++j) {  // the schedule in double at the double time (fp32 tables are promoted exactly, ref :127-134)
+    double a64 = 0., s64 = 0.;
+    dpm_schedule_eval_f64(s, DPM_EVAL_ALPHA, &t_host[j], 1, &a64);
+    dpm_schedule_eval_f64(s, DPM_EVAL_STD, &t_host[j], 1, &s64);
+    const int rc = dpm_add_noise_f64(a64, s64, x, static_cast<const double*>(noise) + (int64_t)j * n,
+                                     static_cast<double*>(out) + (int64_t)j * n, n, stream);
+    if (rc) return rc;
+  }
+  return DPM_OK;
+}
+
 extern "C" int dpm_add_noise_launch(const dpm_schedule* s, const float* t_host, int nt, const void* x, const void* noise,
                                     void* out, int64_t n, int dtype, void* stream) {
   if (!s || !t_host || !x || !noise || !out || nt < 1 || n < 0) return dpm_set_error(DPM_ERR_ARG, "add_noise: bad arguments");

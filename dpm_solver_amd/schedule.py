@@ -149,6 +149,12 @@ class NoiseScheduleVP:
             la = yp[i0] + (x - xp[i0]) * (yp[i1] - yp[i0]) / (xp[i1] - xp[i0])
         elif self.schedule == 'linear':
             la = -0.25 * tt ** 2 * (self.beta_1 - self.beta_0) - 0.5 * tt * self.beta_0
+        elif self.schedule == 'cosine':
+            # older vendored revision (examples/score_sde_pytorch/dpm_solver.py:135-138): log alpha_t = log cos((t + s) / (1 + s)
+            # * pi / 2) - log cos(s / (1 + s) * pi / 2), the reference's own tensor expression
+            import math
+            s = self.cosine_s
+            la = torch.log(torch.cos((tt + s) / (1. + s) * math.pi / 2.)) - math.log(math.cos(s / (1. + s) * math.pi / 2.))
         else:
             raise NotImplementedError("device_alpha_sigma: schedule %r" % self.schedule)
         return torch.exp(la), torch.sqrt(1. - torch.exp(2. * la))

@@ -210,13 +210,19 @@ def _cluster_workspace(dev, idx, stream, nbytes):
 
 
 def _add_noise(sched_handle, x, noise, t_host):
-    """out[j] = alpha(t_j) * x + sigma(t_j) * noise[j] for the host times t_host (fp32 numpy): one kernel per time"""
+    """out[j] = alpha(t_j) * x + sigma(t_j) * noise[j] for the host times t_host (numpy): one kernel per time.  fp32 times:
+    the schedule in fp32 (converted exactly when x is double); float64 times (x must be double): the schedule in double."""
     nt = int(t_host.shape[0])
     out = torch.empty((nt, *x.shape), dtype=x.dtype, device=x.device)
+    stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     with torch.cuda.device(x.device):
-        L.check(L.lib.dpm_add_noise_launch(sched_handle, t_host.ctypes.data_as(C.POINTER(C.c_float)), nt, _ptr(x),
-                                           _ptr(noise), _ptr(out), x.numel(), _DT[x.dtype],
-                                           C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)))
+        if t_host.dtype == np.float64:
+            assert x.dtype is torch.float64
+            L.check(L.lib.dpm_add_noise_launch_f64(sched_handle, t_host.ctypes.data_as(C.POINTER(C.c_double)), nt, _ptr(x),
+                                                   _ptr(noise), _ptr(out), x.numel(), stream))
+        else:
+            L.check(L.lib.dpm_add_noise_launch(sched_handle, t_host.ctypes.data_as(C.POINTER(C.c_float)), nt, _ptr(x),
+                                               _ptr(noise), _ptr(out), x.numel(), _DT[x.dtype], stream))
     return out
 
 
@@ -274,6 +280,8 @@ class _Plan:
         self._dev = {}
         self._views = {}
         self.times_written = False
+        # a singlestep update of order >= 2 is part of the plan (a stage evaluates the network on an intermediate state)
+        self.has_inner_nodes = any(st.xe_src == L.SRC_TMP for st in self.stages)
         # static buffer roles per stage, as plan_run_impl (dpm_host.cpp) rotates them: indices into
         # [x_T, scratch 1, scratch 2, scratch 3] for the update's x, the state the network saw, and the output
         self.roles = []
@@ -737,17 +745,38 @@ class DPM_Solver:
             return self._wrapped.raw_outputs(x_eval, te, ti, t2, x_in2=x_in2)
         return self._model_fn(x_eval, te), None, None
 
-    def _promoted(self, sd, e0):
+    def _promoted(self, sd, e0, plan=None):
         """State dtype after the first network evaluation.  Without an explicit `state_dtype` the reference's type
         promotion applies: a half-precision state combined with a network output of another floating dtype (fp32
         eps next to an fp16 x on a 'linear' schedule, or fp16 next to bf16) continues in fp32 from the first update on
         (ref :573-576 are plain tensor expressions).  An explicit `state_dtype` keeps the state there and the output
-        is converted to it."""
+        is converted to it.
+
+        A half state on a continuous schedule also leaves half precision when a singlestep update of order >= 2 runs: its
+        intermediate time comes out of inverse_lambda, which for 'linear' builds a (1,)-shaped tensor (ref :161: `torch.zeros((1,))`)
+        -- a dimensioned fp32 coefficient, and the state is fp32 from that update on (measured against the reference:
+        tests/test_differential_reference.py).  The first such update is the trajectory's first or second, so the run continues
+        in fp32 from its first update; the one deviation is that the reference rounds the FIRST model value to half once."""
         if self._state_dtype is None and e0.dtype is torch.float64:
             return torch.float64                    # a double network output promotes every state
         if self._state_dtype is None and sd not in (torch.float32, torch.float64) and e0.dtype is not sd and e0.dtype in _DT:
             return torch.float32
+        if (self._state_dtype is None and sd not in (torch.float32, torch.float64) and plan is not None and plan.has_inner_nodes
+                and self.noise_schedule.schedule != 'discrete'):
+            return torch.float32
         return sd
+
+    def _cfg_pre(self, outs, sd):
+        """Double state, classifier-free guidance, a noise-prediction network that answers in a narrower dtype: the reference
+        blends `uncond + scale * (cond - uncond)` in the NETWORK's dtype (ref :326-330, a Python-float scale) before any double
+        scalar touches the result.  The double kernel would blend in double, so the blend is taken here, in the reference's
+        own expression, and handed on as both halves (e1 + s * (e0 - e1) with e0 == e1 is exact)."""
+        e0, e1, g = outs
+        if (sd is torch.float64 and e1 is not None and e0.dtype is not torch.float64 and self._wrapped is not None
+                and self._wrapped.model_type == "noise"):
+            e = e1 + self._wrapped.guidance_scale * (e0 - e1)
+            return e, e, g
+        return outs
 
     def _stage64(self, st, s64=None):
         """the dpm_stage_f64 of a launch on a double state: the double-precision plan's record, or -- fp32 scalars (an fp32
@@ -779,7 +808,7 @@ class DPM_Solver:
     def _run_stage(self, st, x, xe, outs, h1, h2, sd, t_eval_t, want_m=None, ext=None, coef64=None):
         """outs = (e0, e1, g) fresh network outputs.  Handles a *callable* correcting_x0_fn by splitting the
         stage: prologue kernel -> user function (opaque torch) -> combination kernel."""
-        e0, e1, g = outs
+        e0, e1, g = outs if sd is not torch.float64 else self._cfg_pre(outs, sd)
         if self._user_x0 is not None and (st.flags & L.F_TO_X0):
             s1 = st.copy()
             s1.form = L.FORM_DENOISE
@@ -841,7 +870,17 @@ class DPM_Solver:
         st.flags = L.F_TO_X0 if to_x0 else 0
         self._prep_stage(st)
         outs = self._network(x, te_t, ti_t)
-        sd = torch.float64 if dbl else self._sdtype(x)
+        # Which operands the reference's expression really involves decides the result's dtype (ref :288-330, :433-442): the
+        # schedule's scalars (doubles when `dbl`) and x enter through the x_start / v / score conversions, the classifier term
+        # and eps -> x0 only.  A noise-prediction network asked for its noise comes back untouched -- in the NETWORK's dtype --
+        # and its classifier-free blend `uncond + scale * (cond - uncond)` (a Python-float scale) stays there too.
+        pure_noise = (not to_x0) and mt == L.MODEL["noise"] and gd != L.GUIDE["classifier"]
+        if pure_noise and gd == L.GUIDE["uncond"]:
+            return outs[0]
+        if pure_noise:
+            sd = outs[0].dtype if outs[0].dtype in _DT else torch.float32
+        else:
+            sd = torch.float64 if dbl else self._sdtype(x)
         out, _ = self._run_stage(st, None, x, outs, None, None, sd, t if torch.is_tensor(t) else self._tt(tf, dev), want_m=False,
                                  coef64=self._stage64(st, c64) if sd is torch.float64 else None)
         return out
@@ -1143,6 +1182,23 @@ class DPM_Solver:
                 ctx.__exit__(None, None, None)
         return xs
 
+    def _adaptive_runs_on_device(self, x):
+        """True when method='adaptive' on `x` takes the device-side controller, False when it takes the reference's host loop
+        (one .item() per iteration) -- the ONE predicate dpm_solver_adaptive, capture() and auto_capture share: a host loop
+        synchronises every iteration and can never be recorded into a graph.
+
+        The device path's state dtype is _sdtype(x): fp32 for a 'discrete' schedule whatever x is (the reference's (1,)-shaped
+        fp32 coefficients promote the first update), the explicit state_dtype when given.  The one case it cannot know before
+        the first network output is a half-precision x on a 'linear' schedule (see _promoted): host loop.  So are dynamic
+        thresholding, a callable correcting_x0_fn and double states.
+        The choice must be the same on every rank of a batch-sharded run (error_reduce set): the two loops issue different
+        numbers of all-reduces.  Every condition is rank-uniform; an EMPTY shard (batch < world) takes the device path too
+        when sharded -- it runs the controller and the collectives, no stage launches."""
+        half_unknown = self._state_dtype is None and x.dtype is not torch.float32 and self.noise_schedule.schedule != 'discrete'
+        nonempty = x.numel() > 0 or (self.error_reduce is not None and x.dim() > 0)
+        return bool(self.adaptive_on_device and x.is_cuda and x.dim() > 0 and nonempty and not self._thresholding
+                    and self._user_x0 is None and not half_unknown and self._sdtype(x) is not torch.float64)
+
     def dpm_solver_adaptive(self, x, order, t_T, t_0, h_init=0.05, atol=0.0078, rtol=0.05, theta=0.9, t_err=1e-5,
                             solver_type='dpmsolver'):
         _require_gpu(x)
@@ -1150,16 +1206,7 @@ class DPM_Solver:
             raise ValueError("For adaptive step size solver, order must be 2 or 3, got {}".format(order))
         if solver_type not in ['dpmsolver', 'taylor']:
             raise ValueError("'solver_type' must be either 'dpmsolver' or 'taylor', got {}".format(solver_type))
-        # State dtype of the device path = _sdtype(x): fp32 for a 'discrete' schedule whatever x is (the reference's (1,)-
-        # shaped fp32 coefficients promote the first update), the explicit state_dtype when given.  The one case it cannot
-        # know before the first network output is a half-precision x on a 'linear' schedule (see _promoted): host loop.
-        half_unknown = self._state_dtype is None and x.dtype is not torch.float32 and self.noise_schedule.schedule != 'discrete'
-        # The choice must be the same on every rank of a batch-sharded run (error_reduce set): the two loops issue
-        # different numbers of all-reduces.  Every condition below is rank-uniform; an EMPTY shard (batch < world) takes
-        # the device path too when sharded -- it runs the controller and the collectives, no stage launches.
-        nonempty = x.numel() > 0 or (self.error_reduce is not None and x.dim() > 0)
-        if (self.adaptive_on_device and x.is_cuda and x.dim() > 0 and nonempty and not self._thresholding
-                and self._user_x0 is None and not half_unknown and self._sdtype(x) is not torch.float64):
+        if self._adaptive_runs_on_device(x):
             return self._adaptive_device(x, order, t_T, t_0, h_init, atol, rtol, theta, t_err, solver_type)
         ns = self.noise_schedule
         # the reference's loop variables are tensors of x's dtype (`t_T * torch.ones((1,)).to(x)`, ref :958): with a double
@@ -1215,13 +1262,19 @@ class DPM_Solver:
     def add_noise(self, x, t, noise=None):
         """xt = alpha_t * x + sigma_t * noise for every t; returns (t_size, batch, *shape) (ref :1012-1030)."""
         _require_gpu(x)
-        th = t.detach().to(device="cpu", dtype=torch.float32).reshape(-1).numpy().copy()
-        nt = int(th.shape[0])
+        nt = int(t.reshape(-1).shape[0])
         if noise is None:
             noise = torch.randn((nt, *x.shape), device=x.device)
         if x.dtype not in _DT:
             raise NotImplementedError("add_noise: dtype %s" % x.dtype)
-        out = _add_noise(self._h, x.contiguous(), noise.to(x.dtype).contiguous(), th)
+        dbl, _ = self._double_call(x, t)
+        # alpha_t / sigma_t of the reference are (nt,)-shaped tensors (ref :1023): when they are doubles -- a double t, or tables
+        # declared dtype=float64 -- or x / noise is, torch's type promotion makes the result float64.  Double scalars are
+        # evaluated in double at the double times; fp32 scalars meeting a double tensor are converted exactly.
+        wide = dbl or x.dtype is torch.float64 or noise.dtype is torch.float64
+        xdt = torch.float64 if wide else x.dtype
+        th = t.detach().to(device="cpu", dtype=torch.float64 if dbl else torch.float32).reshape(-1).numpy().copy()
+        out = _add_noise(self._h, x.to(xdt).contiguous(), noise.to(xdt).contiguous(), th)
         return out.squeeze(0) if nt == 1 else out
 
     def inverse(self, x, steps=20, t_start=None, t_end=None, order=2, skip_type='time_uniform',
@@ -1294,9 +1347,10 @@ class DPM_Solver:
                 if solver_type not in L.SOLVER:
                     raise ValueError("'solver_type' must be either 'dpmsolver' or 'taylor', got {}".format(solver_type))
                 if method == 'multistep':
+                    # the order is validated where the reference validates it -- when an update of that order is reached
+                    # (ref :948-954): order=4 with steps <= 6 and lower_order_final never reaches one and runs (the planner
+                    # raises the reference's ValueError otherwise)
                     assert steps >= order
-                    if order not in (1, 2, 3):
-                        raise ValueError("Solver order must be 1 or 2 or 3, got {}".format(order))
                 elif order not in (1, 2, 3):
                     raise ValueError("'order' must be '1' or '2' or '3'.")
                 plan = self._get_plan(precision=self._precision(self._sdtype(x)), method=method, order=order, steps=steps,
@@ -1360,7 +1414,7 @@ class DPM_Solver:
             V = self._time_views(plan, device, shape[0], cfg)
             tb, ti, t2 = _Cloning(V["t_eval_b"]), _Cloning(V["t_input_b"]), (_Cloning(V["t_input_2b"]) if cfg else None)
         first = [first0] + [net(x, 0) for x in xs[1:]]
-        sd = self._promoted(sd, first[0][0])
+        sd = self._promoted(sd, first[0][0], plan)
         mf = _mf_of(first[0][0]) if first[0][0].shape == shape else None
         key = (id(plan), tuple(shape), sd, idx, stream, cfg, R, mf, bool(self.cluster_in_graph), int(self.thr_spin_limit))
         grp = None if capturing else self._fast_groups.get(key)
@@ -1399,6 +1453,8 @@ class DPM_Solver:
                 if i == last:
                     b.x_out = outs[r].data_ptr()
                 e = first[r] if i == 0 else net(xe_t, i, x2)
+                if sd is torch.float64:
+                    e = self._cfg_pre(e, sd)
                 keep.append(_bind_outputs(b, e[0], e[1], e[2], sd, shape, mf))
             st_ref = runs[0].refs[i][0]
             if other:
@@ -1413,17 +1469,27 @@ class DPM_Solver:
     def _auto_captured(self, x, kw, return_intermediate):
         """auto_capture: the replayed result of this call, or None when the call is not (yet) served by a graph"""
         if (return_intermediate or self.correcting_xt_fn is not None or self._user_x0 is not None or not x.is_cuda or x.dim() == 0
-                or x.numel() == 0 or (kw["method"] == "adaptive" and not self.adaptive_on_device)):
-            return None
+                or x.numel() == 0 or (kw["method"] == "adaptive" and not self._adaptive_runs_on_device(x))):
+            return None                           # Python callbacks / a host-side adaptive loop: never captured
         dev = x.device
+        # everything a replay bakes in: the call's arguments, the tensor's geometry, the stream -- and every solver / wrapper
+        # setting the plan and the kernels depend on (the components of _get_plan's key + the state dtype): changing one of
+        # them between calls must miss the cache, not replay the old settings (ADVICE round 5)
+        w = self._wrapped
         key = (tuple(sorted((k, (float(v) if isinstance(v, (int, float)) and not isinstance(v, bool) else v)) for k, v in kw.items())),
                tuple(x.shape), x.dtype, x.stride(), dev.index, torch.cuda.current_stream(dev).cuda_stream,
-               bool(self.cluster_in_graph), int(self.thr_spin_limit))
+               bool(self.cluster_in_graph), int(self.thr_spin_limit), self._model_codes(), self._thresholding,
+               float(self.dynamic_thresholding_ratio), float(self.thresholding_max_val), self.algorithm_type, self._state_dtype,
+               self._sdtype(x), bool(self.adaptive_on_device), int(self.adaptive_lookahead), self.adaptive_max_iterations,
+               None if w is None else (id(w.condition), id(w.unconditional_condition), id(w.model), id(w.classifier_fn),
+                                       float(w.classifier_scale) if hasattr(w, "classifier_scale") else None))
         ent = self._auto.get(key)
         if ent is None:
             if len(self._auto) >= 4:
                 self._auto.pop(next(iter(self._auto)))
             ent = self._auto[key] = [0, None]
+        if ent[1] is False:
+            return None                           # a capture of this call failed once: it stays eager
         if ent[1] is None:
             ent[0] += 1
             if ent[0] <= int(self.auto_capture):
@@ -1431,6 +1497,13 @@ class DPM_Solver:
             saved, self.auto_capture = self.auto_capture, 0      # the capture's own warm-up runs go through sample()
             try:
                 ent[1] = self.capture(x, **kw)
+            except Exception:
+                # a network that is not capturable (host synchronisation, data-dependent control flow): auto_capture is an
+                # optimisation the caller opted into, not a contract -- the call is served eagerly, now and from now on
+                ent[1] = False
+                import warnings
+                warnings.warn("dpm_solver_amd: auto_capture could not record this sample() call into a graph; it stays eager")
+                return None
             finally:
                 self.auto_capture = saved
         return ent[1](x).clone()                  # a graph's output buffer is overwritten by the next replay: hand out a copy
@@ -1448,9 +1521,10 @@ class DPM_Solver:
         synchronisation, no data-dependent control flow), shapes are frozen, and the returned tensors are static
         buffers that the next replay overwrites.  method='adaptive' is captured with its device-side controller: exactly
         `adaptive_max_iterations` (default 64) iterations are recorded, those after t_end is reached do nothing."""
-        if sample_kwargs.get("method", "multistep") == "adaptive" and not self.adaptive_on_device:
+        if sample_kwargs.get("method", "multistep") == "adaptive" and not self._adaptive_runs_on_device(x):
             raise NotImplementedError("the host-side adaptive control loop synchronises every iteration; it cannot be "
-                                      "captured into a graph (adaptive_on_device = True can)")
+                                      "captured into a graph (the device-side controller can: adaptive_on_device = True, no "
+                                      "dynamic thresholding / callable correcting_x0_fn, an fp32 or explicit half state)")
         return GraphedSample(self, x, warmup, sample_kwargs)
 
     def _run_plan_fast(self, plan, x, sd, cfg):
@@ -1471,7 +1545,7 @@ class DPM_Solver:
             first = wrapped.raw_outputs(x, tb[0], ti[0], t2[0] if cfg else None, x_in2=None)
         else:
             first = (model_fn(x, tb[0]), None, None)
-        sd = self._promoted(sd, first[0])
+        sd = self._promoted(sd, first[0], plan)
         # the network's layout is the run's (see _mf_of): an NHWC network gets NHWC states and its outputs are bound as
         # they are; x_T is brought there once and the result goes back to x_T's layout, like ATen would return it
         mf = _mf_of(first[0]) if first[0].shape == x.shape else None
@@ -1506,6 +1580,8 @@ class DPM_Solver:
                 e0, e1, g = wrapped.raw_outputs(xe_t, tb[i], ti[i], t2[i] if cfg else None, x_in2=x2)
             else:
                 e0, e1, g = model_fn(xe_t, tb[i]), None, None
+            if sd is torch.float64:
+                e0, e1, g = self._cfg_pre((e0, e1, g), sd)
             keep = _bind_outputs(b, e0, e1, g, sd, x.shape, mf)
             if other:
                 with torch.cuda.device(idx):
@@ -1520,10 +1596,21 @@ class DPM_Solver:
         device = x.device
         sd = self._sdtype(x)
         cfg = self._wrapped is not None and self._wrapped.effective_guidance == "classifier-free"
-        if cxt is None and not keep and self._user_x0 is None and x.dim() > 0 and x.numel() > 0:
+        # denoise_to_zero evaluates the data prediction at a (1,)-shaped time (ref :1236: `torch.ones((1,)) * t_0`): on a
+        # continuous schedule its alpha_t / sigma_t are then dimensioned fp32 tensors and the RESULT of a half-precision run
+        # is fp32 (on a discrete schedule every run is fp32 anyway).  That last stage runs in fp32 in the general loop below.
+        wide_last = (self._state_dtype is None and sd not in (torch.float32, torch.float64) and len(plan.stages) > 0
+                     and plan.stages[-1].form == L.FORM_DENOISE and self.noise_schedule.schedule != 'discrete')
+        if cxt is None and not keep and self._user_x0 is None and x.dim() > 0 and x.numel() > 0 and not wide_last:
             if self._group is not None:
                 return self._run_plan_group(plan, self._group, sd, cfg)
             return self._run_plan_fast(plan, x, sd, cfg)
+        if self._group is not None:          # (requests that need the general loop run one after the other)
+            grp, self._group = self._group, None
+            try:
+                return [self._run_plan(plan, xg, method, cxt, keep, intermediates) for xg in grp]
+            finally:
+                self._group = grp
         V = self._time_views(plan, device, x.shape[0] if x.dim() > 0 else 1, cfg)
         if self.fresh_time_tensors:
             V = dict(V, t_eval_b=_Cloning(V["t_eval_b"]), t_input_b=_Cloning(V["t_input_b"]),
@@ -1545,7 +1632,7 @@ class DPM_Solver:
             outs = self._network(xe, None, None, x_in2=tmp2 if from_tmp else state2,
                                  pre=(V["t_eval_b"][i], V["t_input_b"][i], V["t_input_2b"][i] if cfg else None))
             if i == 0:
-                sd = self._promoted(sd, outs[0])
+                sd = self._promoted(sd, outs[0], plan)
             if i == 0 and method == 'multistep':
                 # ref :1179-1183: the model sees the caller's x_T; the corrector and the list see it afterwards
                 if cxt is not None:
@@ -1564,6 +1651,8 @@ class DPM_Solver:
             c64 = None
             if sd is torch.float64:
                 c64 = self._stage64(st, plan.stages64[i] if plan.stages64 is not None else None)
+            if wide_last and i == n_st - 1:
+                sd = torch.float32
             x_out, m_out = self._run_stage(st, state, xe, outs, h1, h2, sd, V["t_eval"][i], ext=ext or None, coef64=c64)
             if st.m_slot >= 0:
                 hist[st.m_slot] = m_out

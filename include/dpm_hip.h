@@ -49,11 +49,13 @@ extern "C" {
    what a caller may legitimately choose per call travels in dpm_launch_opts (dpm_buffers.opts / dpm_run_buffers.opts);
    DPM_DTYPE_F64 (double-precision state, NoiseScheduleVP(dtype=torch.float64) callers).  The product library has no
    process-global mutable state: per-device contexts only (the chain of clustered launches, the diagnostics word).
+   201 (round 6) dpm_add_noise_launch_f64 (double times on double tensors); -fvisibility=hidden + DPM_API: the dynamic symbol
+   table is this header's functions and nothing else.
    The structs grow at their END only.  A host MUST zero-initialise every struct it passes (memset / = {0}: new trailing
    fields then read as "absent") and SHOULD check at load time that dpm_version() >= the version it was built against and
    that dpm_sizeof(DPM_SIZEOF_*) == its own sizeof() -- a host compiled against an older header passes shorter structs,
    and the library would read past their end (examples/native_host.c and dpm_solver_amd/_lib.py do both checks). */
-#define DPM_HIP_VERSION 200
+#define DPM_HIP_VERSION 201
 
 /* ---- status --------------------------------------------------------------------------- */
 enum {
@@ -333,6 +335,11 @@ DPM_API int dpm_cluster_timeout_poll(void);
 /* x_t = alpha_t*x + sigma_t*noise for nt times (add_noise, ref :1012-1030); out is [nt, n] */
 DPM_API int dpm_add_noise_launch(const dpm_schedule* s, const float* t_host, int nt, const void* x, const void* noise,
                          void* out, int64_t n, int dtype, void* stream);
+/* the same with DOUBLE times on double tensors (version 201): alpha_t / sigma_t evaluated in double at the double times -- what
+   the reference's type promotion makes of add_noise(x, t) when t is a double tensor or the schedule's tables are
+   (NoiseScheduleVP(dtype=torch.float64)): the result is float64 whatever x was (the host converts x / noise first) */
+DPM_API int dpm_add_noise_launch_f64(const dpm_schedule* s, const double* t_host, int nt, const void* x, const void* noise,
+                             void* out, int64_t n, void* stream);
 /* stand-alone mask blend  out = x*mask + (1-mask)*(alpha*a + sigma*b)  (b NULL: (1-mask)*a): the DPM_F_BLEND
    epilogue as its own launch, for callable use of the corrector and for x_T before the first update (ref :1180) */
 DPM_API int dpm_blend_launch(const void* x, const void* mask, const void* a, const void* b, float alpha, float sigma, void* out,

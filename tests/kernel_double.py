@@ -182,6 +182,18 @@ def adaptive_error_double(x_lower, x_higher, x_prev, atol, rtol):
 def add_noise_double(sched_handle, x, noise, t_host):
     """numpy double of dpm_add_noise_launch (ref :1012-1030): alpha*x + sigma*noise, fp32, no fused multiply-add"""
     import ctypes as C
+    if x.dtype is torch.float64:          # double tensors: the schedule in double at double times, else fp32 values promoted
+        if t_host.dtype == np.float64:
+            def ev(what):
+                o = np.empty(len(t_host), dtype=F64)
+                L.check(L.lib.dpm_schedule_eval_f64(sched_handle, what, t_host.ctypes.data_as(C.POINTER(C.c_double)), len(t_host),
+                                                    o.ctypes.data_as(C.POINTER(C.c_double))))
+                return o
+        else:
+            ev = lambda what: np.array([_eval1(sched_handle, what, t) for t in t_host], dtype=F32).astype(F64)
+        a, s = ev(L.EVAL_ALPHA), ev(L.EVAL_STD)
+        xn, nz = x.numpy(), noise.numpy()
+        return torch.from_numpy(np.stack([a[j] * xn + s[j] * nz[j] for j in range(len(t_host))]))
     ev = lambda what: np.array([_eval1(sched_handle, what, t) for t in t_host], dtype=F32)
     a, s = ev(L.EVAL_ALPHA), ev(L.EVAL_STD)
     xn, nz = _np(x), _np(noise)

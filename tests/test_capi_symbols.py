@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PRODUCT_ABI = """
 dpm_adaptive_begin dpm_adaptive_create dpm_adaptive_destroy dpm_adaptive_done_at dpm_adaptive_error
 dpm_adaptive_error_launch dpm_adaptive_poll dpm_adaptive_reset dpm_adaptive_stage_launch dpm_adaptive_stage_template
-dpm_add_noise_launch dpm_blend_launch dpm_cluster_timeout_poll dpm_coef_first dpm_coef_multistep dpm_coef_multistep_f64
+dpm_add_noise_launch dpm_add_noise_launch_f64 dpm_blend_launch dpm_cluster_timeout_poll dpm_coef_first dpm_coef_multistep dpm_coef_multistep_f64
 dpm_coef_prologue dpm_coef_prologue_f64 dpm_coef_singlestep dpm_coef_singlestep_f64 dpm_device_info dpm_graph_create dpm_graph_destroy dpm_graph_launch dpm_graph_num_nodes
 dpm_graph_result dpm_last_error dpm_numerical_clip_len_f32 dpm_numerical_clip_len_f64 dpm_plan_create dpm_plan_destroy
 dpm_plan_num_slots dpm_plan_num_stages dpm_plan_run dpm_plan_run_multi dpm_plan_stage dpm_plan_stage_f64 dpm_plan_timesteps
@@ -62,7 +62,7 @@ def test_product_library_exports_the_pinned_abi_and_nothing_else():
     """no tuning knob, no fault-injection switch, no calibration kernel, no experiment in the shipped library"""
     got = exported(PRODUCT_LIB)
     assert got == sorted(PRODUCT_ABI), (set(got) ^ set(PRODUCT_ABI))
-    assert len(got) == 61 and not [n for n in got if n.startswith("_Z")]
+    assert len(got) == 62 and not [n for n in got if n.startswith("_Z")]
     lab_only = declared_functions("dpm_lab.h")
     assert lab_only and not (set(got) & set(lab_only))
     # ... and no process-global tuning state either: the lab build's knobs live in a variable the product does not have
@@ -95,7 +95,7 @@ def test_struct_layouts_match_header():
 def test_version_and_error_text():
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'dpm_hip.h')).read()
     import re
-    assert L.lib.dpm_version() == int(re.search(r'#define DPM_HIP_VERSION (\d+)', hdr).group(1)) >= 200
+    assert L.lib.dpm_version() == int(re.search(r'#define DPM_HIP_VERSION (\d+)', hdr).group(1)) >= 201
     rc = L.lib.dpm_time_steps(None, 0, 1.0, 0.001, 5, None)
     assert rc == L.ERR_ARG and b"time_steps" in L.lib.dpm_last_error()
 

@@ -346,6 +346,135 @@ def test_capture_rejects_the_host_side_adaptive_loop():
         dpm.capture(torch.zeros(2, 4, 8, 8, device=DEV), method="adaptive")
 
 
+def test_auto_capture_stays_eager_where_the_adaptive_solver_takes_its_host_loop():
+    """auto_capture (and capture()) use the SAME predicate dpm_solver_adaptive uses to choose the device
+    controller.  With dynamic thresholding, a double state or a half x on a continuous schedule the adaptive solver runs its
+    host loop (one .item() per iteration): such calls are never recorded -- they run eagerly call after call, no exception."""
+    ns = make_schedule("sd")
+    x = torch.randn((2, 3, 16, 16), device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    dpm = D.DPM_Solver(D.model_wrapper(lambda xx, t: xx * 0.3, ns), ns, correcting_x0_fn="dynamic_thresholding")
+    kw = dict(method="adaptive", order=2, atol=0.05, rtol=0.1)
+    want = dpm.sample(x, **kw)
+    dpm.auto_capture = 1
+    outs = [dpm.sample(x, **kw) for _ in range(4)]
+    assert all(torch.equal(o, want) for o in outs) and not dpm._auto          # never entered the capture bookkeeping
+    with pytest.raises(NotImplementedError, match="adaptive"):
+        dpm.capture(x, **kw)
+    d64 = D.DPM_Solver(D.model_wrapper(lambda xx, t: xx * 0.3, ns), ns)
+    d64.auto_capture = 1
+    xd = x.double()
+    w64 = d64.sample(xd, **kw)
+    assert all(torch.equal(d64.sample(xd, **kw), w64) for _ in range(3)) and not d64._auto
+    # ... while the device-side controller IS captured
+    dev = D.DPM_Solver(D.model_wrapper(lambda xx, t: xx * 0.3, ns), ns)
+    dev.auto_capture = 1
+    wdev = dev.sample(x, **kw)
+    for _ in range(3):
+        assert rel_err(dev.sample(x, **kw).cpu().numpy(), wdev.cpu().numpy()) < TOL
+    assert [e[1] is not None and e[1] is not False for e in dev._auto.values()] == [True]
+
+
+def test_auto_capture_key_follows_solver_and_wrapper_settings():
+    """a captured call bakes in the solver's settings; changing one between calls (thresholding ratio,
+    guidance scale, algorithm type, state dtype) must miss the cache and be computed with the NEW setting -- as the eager
+    path's plan cache does -- not replay the old graph"""
+    ns = make_schedule("ddpm")
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn((4, 3, 32, 32), device=DEV, generator=g) * 1.5
+    eps = torch.randn((8, 3, 32, 32), device=DEV, generator=g)
+    cond = torch.ones(4, device=DEV)
+    fn = D.model_wrapper(lambda xx, t, c: eps, ns, guidance_type="classifier-free", condition=cond, unconditional_condition=cond * 0,
+                         guidance_scale=2.0)
+    dpm = D.DPM_Solver(fn, ns, correcting_x0_fn="dynamic_thresholding")
+    kw = dict(steps=8, order=2)
+
+    def eager():
+        saved, dpm.auto_capture = dpm.auto_capture, 0
+        try:
+            return dpm.sample(x, **kw)
+        finally:
+            dpm.auto_capture = saved
+    dpm.auto_capture = 1
+    w0 = eager()
+    for _ in range(3):
+        assert torch.equal(dpm.sample(x, **kw), w0)
+    n0 = len(dpm._auto)
+    dpm.dynamic_thresholding_ratio = 0.9
+    w1 = eager()
+    assert not torch.equal(w1, w0)
+    assert torch.equal(dpm.sample(x, **kw), w1) and len(dpm._auto) > n0          # a new entry, the new ratio
+    fn.guidance_scale = 5.0
+    w2 = eager()
+    assert not torch.equal(w2, w1)
+    for _ in range(3):
+        assert torch.equal(dpm.sample(x, **kw), w2)
+    dpm.dynamic_thresholding_ratio, fn.guidance_scale = 0.995, 2.0
+    assert torch.equal(dpm.sample(x, **kw), w0)                                  # back to the first settings
+
+
+def test_auto_capture_falls_back_when_the_network_cannot_be_captured():
+    """a network that synchronises with the host cannot be recorded: the failed capture is remembered, the call is served
+    eagerly from then on (one warning), results unchanged"""
+    ns = make_schedule("sd")
+    x = torch.randn((2, 4, 16, 16), device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
+
+    def net(xx, t):
+        float(t[0].item())                    # a device -> host synchronisation: illegal under stream capture
+        return xx * 0.25
+    dpm = D.DPM_Solver(D.model_wrapper(net, ns), ns)
+    want = dpm.sample(x, steps=6, order=2)
+    dpm.auto_capture = 1
+    with pytest.warns(UserWarning, match="auto_capture"):
+        outs = [dpm.sample(x, steps=6, order=2) for _ in range(3)]
+    assert all(torch.equal(o, want) for o in outs)
+    assert [e[1] for e in dpm._auto.values()] == [False]
+    torch.cuda.synchronize()
+    assert torch.equal(dpm.sample(x, steps=6, order=2), want)
+
+
+@pytest.mark.parametrize("x_dtype,t_dtype,ns_dtype", [(torch.float32, torch.float64, torch.float32),
+                                                      (torch.float32, torch.float32, torch.float64),
+                                                      (torch.float64, torch.float64, torch.float64)])
+def test_add_noise_with_double_scalars_on_the_gpu(x_dtype, t_dtype, ns_dtype):
+    """dpm_add_noise_launch_f64 (version 201): a double t or double tables make the result float64 with the schedule
+    evaluated in double (ref :1012-1030 under torch's type promotion) -- against the same expression in torch double"""
+    betas = torch.linspace(1e-4, 0.02, 1000, dtype=torch.float64)
+    ns = D.NoiseScheduleVP("discrete", betas=betas, dtype=ns_dtype)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn((3, 4, 8, 8), device=DEV, generator=g, dtype=torch.float32).to(x_dtype)
+    t = torch.tensor([0.9, 0.31, 0.02], dtype=t_dtype, device=DEV)
+    noise = torch.randn((3, 3, 4, 8, 8), device=DEV, generator=g, dtype=torch.float32).to(x_dtype)
+    dpm = D.DPM_Solver(D.model_wrapper(lambda xx, tt_: xx, ns), ns)
+    got = dpm.add_noise(x, t, noise=noise)
+    assert got.dtype == torch.float64 and got.shape == (3, 3, 4, 8, 8)
+    a = ns.marginal_alpha(t.cpu()).double().to(DEV).reshape(3, 1, 1, 1, 1)
+    s_ = ns.marginal_std(t.cpu()).double().to(DEV).reshape(3, 1, 1, 1, 1)
+    assert ns.marginal_alpha(t.cpu()).dtype == torch.float64
+    want = a * x.double().unsqueeze(0) + s_ * noise.double()
+    assert float((got - want).abs().max()) <= 1e-15 * float(want.abs().max()) + 1e-300
+    assert torch.equal(dpm.add_noise(x, t[:1], noise=noise[:1]), got[0])
+
+
+def test_multistep_order_four_runs_where_the_reference_runs_it():
+    """sample(order=4, steps=5, lower_order_final=True): step orders 1, 2, 3, 2, 1 (ref :1185-1201) -- the same trajectory as
+    order=3 at these sizes -- on the fast path and in the general loop, against the oracle; steps=7 raises the reference's error"""
+    from oracle import dpm_oracle as O
+    ac = np.cumprod(1.0 - np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=np.float64) ** 2).astype(F32)
+    ns = D.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(ac))
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((2, 4, 16, 16)).astype(F32)
+    dpm = D.DPM_Solver(D.model_wrapper(lambda xx, t: xx * 0.5, ns), ns)
+    got = dpm.sample(torch.from_numpy(x).to(DEV), steps=5, order=4)
+    osch = O.Schedule.from_alphas_cumprod(ac)
+    want = O.Solver(O.wrap_model(lambda xx, t: xx * F32(0.5), osch), osch).sample(x, steps=5, order=4)
+    assert rel_err(got.cpu().numpy(), want) < TOL
+    assert torch.equal(dpm.sample(torch.from_numpy(x).to(DEV), steps=5, order=3), got)
+    gi, inter = dpm.sample(torch.from_numpy(x).to(DEV), steps=5, order=4, return_intermediate=True)
+    assert torch.equal(gi, got) and len(inter) == 6
+    with pytest.raises(ValueError, match="Solver order must be 1 or 2 or 3, got 4"):
+        dpm.sample(torch.from_numpy(x).to(DEV), steps=7, order=4)
+
+
 @pytest.mark.parametrize("sdt", [torch.float32, torch.float16])
 def test_native_graph_equals_native_loop(sdt):
     """C ABI: dpm_graph_create / dpm_graph_launch replay the 20 launches of dpm_plan_run"""
