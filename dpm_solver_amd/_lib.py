@@ -39,7 +39,7 @@ TUNE_MULTI_FUSE, TUNE_MULTI_BLOCKS_PER_CU, TUNE_CLUSTER_IN_GRAPH, TUNE_CLUSTER_O
 TUNE_MULTI_XCD_REMAP = 8
 TUNE_THR_PREDICT = 9
 TUNE_THR_SPIN_LIMIT, TUNE_THR_DEBUG_FAULT, TUNE_BLOCK_THREADS = 10, 11, 12
-TUNE_FORCE_GENERIC, TUNE_THR_ELECT, TUNE_LDS_DMA, TUNE_THR_STAGGER = 13, 14, 15, 16
+TUNE_FORCE_GENERIC, TUNE_THR_ELECT, TUNE_LDS_DMA, TUNE_THR_STAGGER, TUNE_BIG_TILES = 13, 14, 15, 16, 17
 MULTI_MAX = 32
 THR_HINT_WORDS = 4
 

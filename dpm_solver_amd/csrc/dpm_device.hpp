@@ -44,6 +44,15 @@ int dpm_set_error(int code, const char* fmt, ...);  // dpm_host.cpp
 #define DPM_LAB 0   // 1: the lab build (include/dpm_lab.h): process-global tuning knobs, fault injection, experiments
 #endif
 
+// Round 6 (tools/big_single.py, profiles/r06_big_single.md): plain sample() on ONE [8192,4,64,64] fp16 tensor ran its 1.3 GB
+// stages at 0.68-0.72 of the HBM peak through the capped, looping single-request shape and at 0.77-0.79 through the fused
+// kernel's uncapped one.  Kernel-only with inputs from HBM, single shape -> fused shape: 65536 tiles 206.7 -> 185.6 us (fp16),
+// 449.9 -> 411.1 (fp32), 408.7 -> 370.7 (fp32 state, fp16 network); 32768 tiles 100.0 -> 94.3 / 209.2 -> 191.1 / 180.4 -> 171.0;
+// 16384 tiles 51.8 -> 50.0 / 97.2 -> 94.7 / 88.2 -> 86.7; at 8192 tiles and below the two are within the +-3 % of the
+// measurement (and the single shape is ahead at 2048: fp32 + fp16 14.2 against 15.1 us).
+#ifndef DPM_BIG_TILES_DEFAULT
+#define DPM_BIG_TILES_DEFAULT 16384
+#endif
 namespace dpmk {
 // Launch-shape parameters.  In the PRODUCT build this is a constant: every launch starts from the defaults below (the
 // measured best) and takes what the caller may choose per call from dpm_launch_opts -- no process-global mutable state.
@@ -62,6 +71,9 @@ struct Tuning {
   int thr_predict = 1;      // clustered thresholding: predict the select bound from the previous stages (thr_hint)
   int thr_spin_limit = 1 << 12;  // clustered thresholding: polls before a wait on a peer gives up (THR_SPIN_LIMIT)
   int block_threads = 0;    // streaming kernel: threads per workgroup (256 / 512); 0 = by size (launch_stream)
+  int big_tiles = DPM_BIG_TILES_DEFAULT;  // a single launch of at least this many 2048-element tiles takes the fused kernel's
+                            // launch shape (one workgroup per super-tile, no grid-stride loop, XCD-contiguous tiles for 2-byte
+                            // states): dpm_stage_launch hands it to the multi-request launcher as a group of one; 0 = never
   int lds_dma = -1;         // lone-launch north-star kernels: read streams by LDS-DMA (1) / through registers (0); -1 = default
   int force_generic = 0;    // LAB: take the run-time-prologue kernels (SPEC_GENERIC / HOT 3) where a compile-time one exists (A/B)
   int thr_elect = -1;       // clustered thresholding: one elected reducer per sample (1) / every workgroup reads every slot (0)

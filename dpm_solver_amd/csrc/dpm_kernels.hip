@@ -83,6 +83,26 @@ int dpm_stage_launch_dyn(const dpm_stage* st, const dpm_buffers* b, void* stream
     if (dyn) return dpm_set_error(DPM_ERR_UNSUPPORTED, "stage_launch: device-resident coefficients with a double state");
     return dpm_launch_f64(st, &bb, stream, ev_start, ev_stop);
   }
+  // A LARGE launch takes the fused multi-request kernel's shape -- one workgroup per super-tile instead of a grid capped at 8
+  // workgroups per CU walking the tiles in a loop, an XCD-contiguous tile mapping for 2-byte states, two tiles per workgroup
+  // for 4-byte states -- as a "group" of one request (Tuning::big_tiles; the same arithmetic, the same bits).  Stages the fused
+  // family does not build (thresholding, mask blend, classifier guidance, SS3T / DENOISE, unaligned or strided operands)
+  // come back MULTI_NOT_BUILT and take the single-request path below.
+  if (!dyn && !(st->flags & (DPM_F_THRESH | DPM_F_BLEND))) {
+    const int big = tuning_for(bb.opts).big_tiles;
+    if (big > 0 && (bb.n / EPT + 255) / 256 >= big) {
+      int (*fn)(const dpm_stage*, const dpm_buffers*, int, void*, void*, void*) = nullptr;
+      if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_F32) fn = dpm_launch_multi_f32_f32;
+      else if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_F16) fn = dpm_launch_multi_f32_f16;
+      else if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_BF16) fn = dpm_launch_multi_f32_bf16;
+      else if (sd == DPM_DTYPE_F16 && ed == DPM_DTYPE_F16) fn = dpm_launch_multi_f16_f16;
+      else if (sd == DPM_DTYPE_BF16 && ed == DPM_DTYPE_BF16) fn = dpm_launch_multi_bf16_bf16;
+      if (fn) {
+        const int rc = fn(st, &bb, 1, stream, ev_start, ev_stop);
+        if (rc != MULTI_NOT_BUILT) return rc;
+      }
+    }
+  }
   if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_F32) return dpm_launch_f32_f32(st, &bb, stream, ev_start, ev_stop, dyn, skip);
   if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_F16) return dpm_launch_f32_f16(st, &bb, stream, ev_start, ev_stop, dyn, skip);
   if (sd == DPM_DTYPE_F32 && ed == DPM_DTYPE_BF16) return dpm_launch_f32_bf16(st, &bb, stream, ev_start, ev_stop, dyn, skip);

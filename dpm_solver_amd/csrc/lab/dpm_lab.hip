@@ -250,6 +250,7 @@ extern "C" int dpm_tuning_set(int knob, int value) {
       if (value < 0 || value > 4096) return dpm_set_error(DPM_ERR_ARG, "multi_blocks_per_cu must be in 0..4096");
       g_lab_tuning.multi_blocks_per_cu = value;
       return DPM_OK;
+    case DPM_TUNE_BIG_TILES: g_lab_tuning.big_tiles = value < 0 ? DPM_BIG_TILES_DEFAULT : value; return DPM_OK;
   }
   return dpm_set_error(DPM_ERR_ARG, "unknown tuning knob %d", knob);
 }
@@ -265,6 +266,7 @@ extern "C" int dpm_tuning_get(int knob) {
     case DPM_TUNE_MULTI_XCD_REMAP: return g_lab_tuning.multi_xcd_remap;
     case DPM_TUNE_CLUSTER_ONE_HOP: return g_lab_tuning.cluster_one_hop;
     case DPM_TUNE_MULTI_BLOCKS_PER_CU: return g_lab_tuning.multi_blocks_per_cu;
+    case DPM_TUNE_BIG_TILES: return g_lab_tuning.big_tiles;
     case DPM_TUNE_THR_PREDICT: return g_lab_tuning.thr_predict;
     case DPM_TUNE_THR_SPIN_LIMIT: return g_lab_tuning.thr_spin_limit;
     case DPM_TUNE_THR_DEBUG_FAULT: return g_lab_tuning.thr_debug_fault;

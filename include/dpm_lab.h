@@ -47,6 +47,8 @@ enum {
                                        -1 (default): through registers, like the product (measured equal: r05_lone_floor.md) */
   DPM_TUNE_THR_STAGGER = 16,        /* clustered thresholding: cluster g starts (g % groups) * ticks x 0.1 us late; value = groups << 16
                                        | ticks (groups 0 = 2); 0 (default): off (profiles/r05_thresholding.md)         */
+  DPM_TUNE_BIG_TILES = 17,          /* a single stage launch of at least this many 2048-element tiles is launched with the fused
+                                       kernel's shape (as a group of one request); 0: never; default: the library's            */
   DPM_TUNE_THR_ELECT = 14           /* clustered thresholding: 1 = one elected reducer per sample selects on the union and
                                        publishes the result (k slot reads per sample), 0 = every workgroup reads every slot
                                        (k^2); -1 (default): the library's choice                                        */

@@ -456,3 +456,34 @@ def test_sample_requests_cfg_duplicate_store_at_sd_size(sd, ed, monkeypatch):
                 want = O.Solver(ofn, osch, algorithm_type="dpmsolver++").sample(xs_cpu[r][lo:lo + 8].numpy(), steps=20, order=2)
                 err = float(np.abs(out[lo:lo + 8].numpy().astype(np.float64) - want).max() / np.abs(want).max())
                 assert err <= 1e-5, (r, lo, err)
+
+
+@pytest.mark.parametrize("sd,ed", [(torch.float16, torch.float16), (torch.float32, torch.float16)])
+def test_a_large_single_launch_takes_the_fused_shape_and_keeps_its_bits(sd, ed):
+    """Round 6 (Tuning::big_tiles, profiles/r06_big_single.md): a stage launch of >= 16384 tiles -- plain sample() on one large
+    tensor -- is handed to the fused multi-request kernel as a group of one (uncapped grid, XCD-contiguous tiles).  Same
+    arithmetic, same bits: the trajectory of a [2304,4,64,64] tensor (18432 tiles) equals the trajectories of its nine
+    [256,4,64,64] slices, each far below the threshold, bit for bit -- second and third order, unguided and under CFG."""
+    ns = sd_schedule()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    B = 2304
+    x = torch.randn((B, 4, 64, 64), device=DEV, generator=g).to(sd)
+    eps = torch.randn((2 * B, 4, 64, 64), device=DEV, generator=g).to(ed)
+    assert x.numel() // 2048 >= 16384
+    kw_state = {} if sd is torch.float32 else dict(state_dtype=sd)
+    for cfg in (False, True):
+        for order in (2, 3):
+            def solver(lo, hi):
+                if cfg:
+                    e = torch.cat([eps[lo:hi], eps[B + lo:B + hi]])
+                    cond = torch.ones(hi - lo, device=DEV)
+                    fn = D.model_wrapper(lambda xx, t, c: e, ns, guidance_type="classifier-free", condition=cond,
+                                         unconditional_condition=cond * 0, guidance_scale=3.0)
+                else:
+                    e = eps[lo:hi]
+                    fn = D.model_wrapper(lambda xx, t: e, ns)
+                return D.DPM_Solver(fn, ns, algorithm_type="dpmsolver++", **kw_state)
+            big = solver(0, B).sample(x, steps=6, order=order)
+            for lo in range(0, B, 256):
+                small = solver(lo, lo + 256).sample(x[lo:lo + 256], steps=6, order=order)
+                assert torch.equal(big[lo:lo + 256], small), (cfg, order, lo)

@@ -8,9 +8,11 @@ showed the gap on the drop-in path: 226.8 us per stage through sample() against 
 sample_requests.  This tool measures, per batch size and dtype pair (frozen network, HIP events around whole trajectories,
 lab build for the knobs):
 
-  default          DPM_Solver.sample(x)                                    (the library's own choice of shape)
-  capN             the same with the grid cap at N workgroups per CU       (DPM_TUNE_BLOCKS_PER_CU)
-  requests         sample_requests over 32 (or fewer) equal batch slices of the same tensor: the fused kernel
+  default          DPM_Solver.sample(x) with the single-request shape: grid capped at 8 workgroups per CU, grid-stride loop
+  capN             the same with the cap at N workgroups per CU              (DPM_TUNE_BLOCKS_PER_CU)
+  multi            the launch handed to the fused kernel as a group of one   (DPM_TUNE_BIG_TILES = 1: Tuning::big_tiles)
+each `frozen` (stages back to back: inputs of the smaller sizes sit in the Infinity Cache) and `evicted` (768 MiB streamed through
+the chip before every launch, kernel-only by dpm_stage_launch_timed: inputs from HBM, what a network between the stages does).
 
     python tools/big_single.py [--sizes 256,512,1024,2048,8192] [--out FILE]
 """
@@ -42,16 +44,53 @@ def events(fn, reps):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
+_SCRATCH = None
+
+
+def evict(dev):
+    """stream 768 MiB through the chip (read-only): nothing the previous stage wrote is left in L2 / the Infinity Cache"""
+    global _SCRATCH
+    if _SCRATCH is None:
+        _SCRATCH = torch.zeros(768 * 1024 * 1024 // 4, dtype=torch.float32, device=dev)
+    _SCRATCH.sum()
+
+
+def evicted_us(dpm, x, dev):
+    """kernel-only median of the steady-state stages with the caches evicted before every launch (dpm_stage_launch_timed)"""
+    import ctypes as C
+    import numpy as np
+    import dpm_solver_amd.solver as S
+    real = S._stage_launch_raw
+    rows = []
+
+    def shim(st, b, stream):
+        evict(dev)
+        ms = C.c_float()
+        rc = L.lib.dpm_stage_launch_timed(st, b, stream, C.byref(ms))
+        rows.append(ms.value * 1e3)
+        return rc
+    S._stage_launch_raw = shim
+    try:
+        for _ in range(3):
+            dpm.sample(x, steps=20, order=2)
+    finally:
+        S._stage_launch_raw = real
+    us = np.array(rows).reshape(3, 20)[1:, 1:19]
+    return float(np.median(us))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--sizes", default="256,512,1024,2048,8192")
+    ap.add_argument("--sizes", default="256,384,512,768,1024,2048,4096,8192")
     ap.add_argument("--pairs", default="fp16:fp16,fp32:fp32,fp32:fp16")
-    ap.add_argument("--caps", default="16,32,4096")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     L.require_lab("tools/big_single.py")
     dev = torch.device("cuda", 0)
     ns = D.NoiseScheduleVP("discrete", alphas_cumprod=torch.from_numpy(bench.sd_alphas_cumprod()))
+    variants = [("default", {}), ("cap16", {L.TUNE_BLOCKS_PER_CU: 16}), ("cap64", {L.TUNE_BLOCKS_PER_CU: 64}),
+                ("multi", {L.TUNE_BIG_TILES: 1})]
+    base = {L.TUNE_BLOCKS_PER_CU: 8, L.TUNE_BIG_TILES: 0}
     rows = []
     for pair in args.pairs.split(","):
         sname, ename = pair.split(":")
@@ -67,43 +106,27 @@ def main():
             n = x.numel()
             ssz, esz = x.element_size(), eps.element_size()
             traj_bytes = n * (18 * (4 * ssz + esz) + 2 * (3 * ssz + esz))
+            stage_bytes = n * (4 * ssz + esz)
             reps = max(3, min(40, int(2e9 / traj_bytes)))
             run = lambda: dpm.sample(x, steps=20, order=2)
-            res = dict(batch=B, state=sname, eps=ename, MB_per_stage=round(traj_bytes / 20 / 1e6, 1))
+            res = dict(batch=B, state=sname, eps=ename, tiles=n // 2048, MB_per_stage=round(stage_bytes / 1e6, 1))
             with torch.no_grad():
+                for k, v in base.items():
+                    L.check(L.lib.dpm_tuning_set(k, v))
                 want = run()
-                run()
-                res["default_us"] = round(min(events(run, reps) for _ in range(3)) / 20, 2)
-                for cap in (int(v) for v in args.caps.split(",")):
-                    L.check(L.lib.dpm_tuning_set(L.TUNE_BLOCKS_PER_CU, cap))
+                for name, knobs in variants:
+                    for k, v in {**base, **knobs}.items():
+                        L.check(L.lib.dpm_tuning_set(k, v))
                     got = run()
-                    assert torch.equal(got, want)
-                    res["cap%d_us" % cap] = round(min(events(run, reps) for _ in range(3)) / 20, 2)
-                L.check(L.lib.dpm_tuning_set(L.TUNE_BLOCKS_PER_CU, 8))
-                R = 32
-                while R > 1 and (B % R or (n // R) % 4096):
-                    R //= 2
-                if R > 1:
-                    xs = list(x.chunk(R))
-                    es = list(eps.chunk(R))
-                    calls = [0]
-
-                    def frozen(xx, t):
-                        calls[0] += 1
-                        return es[(calls[0] - 1) % R]
-                    dpr = D.DPM_Solver(D.model_wrapper(frozen, ns), ns, **kwargs)
-
-                    def runr():
-                        calls[0] = 0
-                        return dpr.sample_requests(xs, steps=20, order=2)
-                    outs = runr()
-                    assert torch.equal(torch.cat(outs), want)
-                    runr()
-                    res["requests_us"] = round(min(events(runr, reps) for _ in range(3)) / 20, 2)
-                    res["requests_R"] = R
-            best = min(v for k, v in res.items() if k.endswith("_us"))
-            res["default_frac"] = round(traj_bytes / 20 / res["default_us"] / 1e3 / PEAK, 4)
-            res["best_frac"] = round(traj_bytes / 20 / best / 1e3 / PEAK, 4)
+                    assert torch.equal(got, want), name
+                    res[name + "_frozen_us"] = round(min(events(run, reps) for _ in range(3)) / 20, 2)
+                    res[name + "_evicted_us"] = round(evicted_us(dpm, x, dev), 2)
+                for k, v in base.items():
+                    L.check(L.lib.dpm_tuning_set(k, v))
+            for mode in ("frozen", "evicted"):
+                res["best_" + mode] = min((res[nm + "_" + mode + "_us"], nm) for nm, _ in variants)[1]
+            res["default_evicted_frac"] = round(stage_bytes / res["default_evicted_us"] / 1e3 / PEAK, 4)
+            res["multi_evicted_frac"] = round(stage_bytes / res["multi_evicted_us"] / 1e3 / PEAK, 4)
             rows.append(res)
             print(json.dumps(res), flush=True)
             del x, eps, dpm

@@ -12,6 +12,8 @@
 #   profile      tools/profile_round.sh (headline: kernel trace + counters)
 #   cpubase      the unmodified reference + the numpy port on this box's host cores (needs _refscratch/: tools/ref_scratch.sh make)
 #   dropin       the reference's own example call sites on the engine (needs _refscratch/)
+#   bigsingle    tools/big_single.py: launch shape of ONE large stage launch (lab build)
+#   newtests     the GPU tests added this round (quick iteration before the full suite)
 TAG=${1:?tag}; shift
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
@@ -68,6 +70,10 @@ dropin)
   if [ -d _refscratch/examples ]; then
     timeout 300 python tools/dropin_examples.py --device cuda:0 --out $O/dropin.json > $O/dropin.log 2>&1; echo "dropin rc=$?"; tail -4 $O/dropin.log
   else echo "dropin: no _refscratch/"; fi ;;
+bigsingle)
+  timeout 900 python tools/big_single.py --out $O/big_single.json > $O/big_single.log 2>&1; echo "big_single rc=$?"; grep '^{' $O/big_single.log | cut -c1-330; grep -v '^{' $O/big_single.log | tail -5 ;;
+newtests)
+  ( time timeout 900 python -m pytest tests/test_gpu_extensions.py -m gpu -q -x -k "auto_capture or add_noise_with_double or order_four or capture_rejects" ) > $O/newtests.log 2>&1; echo "newtests rc=$?"; tail -15 $O/newtests.log ;;
 *) echo "unknown step $STEP" ;;
 esac
 done
