@@ -103,6 +103,12 @@ def test_cpu_baseline_record_is_what_this_run_timed():
     assert ref["kind"] == "reference" and ref["measured_in_this_run"] is False
     assert ref["source"].startswith("profiles/cpu_baseline_reference_gpubox.json")
     assert ref["cores"] == ref["threads"] == ref["best"]["threads"] and ref["value"] == ref["best"]["value"]
+    # the committed same-box ratio port / reference rides along as scalars, with its source, and the
+    # live port figure scaled by it is labelled an estimate
+    assert 0.3 < out["port_over_reference"] < 3.0 and 0.3 < out["port_over_reference_single_thread"] < 3.0
+    assert out["port_over_reference_source"].startswith("profiles/r06_cpu_baseline_port_vs_reference.json")
+    assert abs(out["reference_estimate"] - out["value"] / out["port_over_reference"]) < 1e-6 and "not a measurement" in out["reference_estimate_unit"]
+    assert out["reference_best_seen"] == ref["value"]
 
 
 def test_secondaries_that_need_a_gpu_report_an_error_instead_of_raising():

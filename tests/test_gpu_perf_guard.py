@@ -1,7 +1,7 @@
 """Performance regression guard: the other GPU tests pin bits, this one pins time.
 
 Four figures of the PRODUCT library, each measured in well under a second, against thresholds that are the figure measured
-on MI355X boxes (profiles/r06_perf_guard.md: five runs on one box, plus the spread over the boxes of this round) + 8 %:
+on MI355X boxes (profiles/r06_perf_guard.md: ten runs on two boxes, plus the spread over the boxes of rounds 3-5) + 8 %:
 
   fused           the headline launch -- 32 requests of [256,4,64,64] fp16 advanced by ONE stage_kernel_multi launch per stage,
                   inputs from HBM -- by HIP events around whole trajectories on the launch stream: >= FUSED_MIN_FRAC of 8 TB/s
@@ -28,11 +28,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-# thresholds = measured + 8 % (profiles/r06_perf_guard.md)
-FUSED_MIN_FRAC = 0.72           # 0.767-0.795 measured over the boxes of rounds 3-6
-LONE_COLD_MAX_US = 9.3          # 8.2-8.6 us measured
-CFG5_STAGE_MAX_US = 12.5        # 10.4-11.6 us measured
-SMALL_STAGE_MAX_US = 6.5        # 2.6 us captured / 4.9 us eager measured
+# thresholds = worst figure measured + 8 % (profiles/r06_perf_guard.md: ten runs on two boxes, plus the spread over the boxes of
+# rounds 3-5 for the two headline figures)
+FUSED_MIN_FRAC = 0.72           # 0.782-0.789 here; 0.767-0.795 over ten boxes of rounds 3-6
+LONE_COLD_MAX_US = 9.3          # 8.39-8.50 (one run 8.995); 8.16-8.60 over the boxes of round 5
+CFG5_STAGE_MAX_US = 13.1        # 12.09-12.16 captured (10.17 by rocprofv3 rows + the graph's node-to-node latency)
+CFG5_CLUSTERED_MAX_US = 13.1    # the clustered route (what the eager loop launches) kept under capture
+SMALL_STAGE_MAX_US = 3.0        # 2.51-2.61 captured
 
 RESULTS = {}
 
@@ -126,6 +128,10 @@ def test_small_and_thresholded_stages(dev):
     t0 = time.perf_counter()
     small = config_bench.measure_frozen("cfg1", dev, captured=True, scale_k=0.25)
     thr = config_bench.measure_frozen("cfg5", dev, captured=True, scale_k=0.25)
+    # under capture a sample that fits one workgroup takes the cluster-free shape by default; the eager loop -- what
+    # sample() runs -- uses k = 6 workgroup clusters per sample here: the guard watches that kernel too (cluster_in_graph)
+    thr_k = config_bench.measure_frozen("cfg5", dev, captured=True, scale_k=0.25, attrs=dict(cluster_in_graph=True))
+    RESULTS["cfg5_stage_clustered_us"] = thr_k["captured"]["us_per_stage"]
     RESULTS["small_stage_us"] = small["captured"]["us_per_stage"]
     RESULTS["small_stage_eager_us"] = small["us_per_stage"]
     RESULTS["cfg5_stage_us"] = thr["captured"]["us_per_stage"]
@@ -135,6 +141,8 @@ def test_small_and_thresholded_stages(dev):
                               thr["us_per_stage"], time.perf_counter() - t0))
     assert small["captured"]["us_per_stage"] <= SMALL_STAGE_MAX_US, small["captured"]
     assert thr["captured"]["us_per_stage"] <= CFG5_STAGE_MAX_US, thr["captured"]
+    print("[perf guard] cfg5 stage with its workgroup clusters kept under capture: %.2f us" % thr_k["captured"]["us_per_stage"])
+    assert thr_k["captured"]["us_per_stage"] <= CFG5_CLUSTERED_MAX_US, thr_k["captured"]
 
 
 def test_write_guard_record(dev):

@@ -10,7 +10,8 @@ the same process, and returns one dict per case for the `configs` block of bench
   cfg5       DPM-Solver++ 2M + dynamic thresholding, 25 steps, [32,3,64,64] fp32                             ref :416-425
   cfg_sd64   DPM-Solver++ 2M, 20 steps, [64,4,64,64] fp32 state / fp16 network, CFG 7.5 (SD under autocast)  ref :322-330
   one8192    DPM-Solver++ 2M, 20 steps, ONE [8192,4,64,64] fp16 tensor: the headline's bytes per stage       ref :1047
-             through DPM_Solver.sample() / dpm_stage_launch (stage_kernel), not sample_requests / stage_kernel_multi
+             through plain DPM_Solver.sample() / dpm_stage_launch (which hands a launch this large to the fused kernel as a
+             group of one, Tuning::big_tiles, profiles/r06_big_single.md), not sample_requests
 
 How a case is timed (`frozen`, the mode BASELINE's "dummy model_fn" describes): the network is a function that returns a
 pre-staged tensor, so a trajectory is the solver's launches and nothing else; K trajectories of `sample()` are bracketed by
@@ -66,7 +67,7 @@ CASES = {
     "one8192": dict(shape=(8192, 4, 64, 64), state="fp16", net="fp16", cfg=None, thr=False, algo="dpmsolver++",
                     kw=dict(steps=20, order=2), sched="sd", K=(20, 20), width=0,
                     workload="DPM-Solver++ 2M, 20 steps, ONE [8192,4,64,64] fp16 tensor through plain DPM_Solver.sample(): the "
-                             "headline's bytes per stage through dpm_stage_launch (stage_kernel), not sample_requests",
+                             "headline's bytes per stage through the drop-in call, not sample_requests",
                     ref="dpm_solver_pytorch.py:1047"),
 }
 ORDER = ("cfg1", "cfg3", "cfg5", "cfg_sd64", "one8192")
@@ -154,10 +155,13 @@ def _events(dev, fn, reps):
     return e0.elapsed_time(e1) * 1e3 / reps                      # us per call
 
 
-def measure_frozen(name, dev, captured=True, scale_k=1.0):
-    """the `frozen` figures of a case on whatever library the process loaded (bench.py: the product library)"""
+def measure_frozen(name, dev, captured=True, scale_k=1.0, attrs=None):
+    """the `frozen` figures of a case on whatever library the process loaded (bench.py: the product library); attrs: engine
+    options set on the solver (e.g. cluster_in_graph=True: thresholding keeps its workgroup clusters under capture)"""
     import torch
     dpm, x, kw, c = build(name, dev, "frozen")
+    for k, v in (attrs or {}).items():
+        setattr(dpm, k, v)
     with torch.no_grad():
         for _ in range(3):
             out = dpm.sample(x, **kw)
