@@ -81,7 +81,7 @@ class WrappedModel:
         tensor expressions in torch on x's device -- per-sample times (`t_continuous` of shape (B,) with distinct entries)
         included, no host synchronisation (the schedule is evaluated on the device, NoiseScheduleVP.device_alpha_sigma)."""
         from .utils import expand_dims
-        from .solver import _require_gpu
+        from ._device import _require_gpu
         _require_gpu(x)
         e0, e1, g = self.raw_outputs(x, t_continuous)
         mt = self.model_type
