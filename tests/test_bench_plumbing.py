@@ -87,17 +87,20 @@ def test_cpu_baseline_record_is_what_this_run_timed():
     import bench
     old = os.environ.get("DPM_REFERENCE_DIR")
     os.environ["DPM_REFERENCE_DIR"] = "/nonexistent"
-    port_fn = bench.cpu_baseline_port
+    port_fn, cport_fn = bench.cpu_baseline_port, bench.cpu_baseline_port_c
     bench.cpu_baseline_port = lambda ac, budget_s=8.0: dict(value=0.0016, unit="Msamples/s", cores=1, kind="port", sample="stub")
+    bench.cpu_baseline_port_c = lambda ac, budget_s=8.0: dict(value=0.05, unit="Msamples/s", cores=4, kind="port", sample="stub C")
     try:
         out = bench.cpu_baseline(bench.sd_alphas_cumprod())
     finally:
-        bench.cpu_baseline_port = port_fn
+        bench.cpu_baseline_port, bench.cpu_baseline_port_c = port_fn, cport_fn
         if old is None:
             os.environ.pop("DPM_REFERENCE_DIR")
         else:
             os.environ["DPM_REFERENCE_DIR"] = old
-    assert out["kind"] == "port" and out["measured_in_this_run"] is True and out["value"] == 0.0016
+    # the headline CPU figure is the fused plain-C port over the host cores; the numpy oracle's figure rides along
+    assert out["kind"] == "port" and out["measured_in_this_run"] is True and out["value"] == 0.05 and out["cores"] == 4
+    assert out["numpy_port_value"] == 0.0016 and out["numpy_port"]["sample"] == "stub"
     assert out["unit"] == "Msamples/s" and out["host_cores"] >= out["cores"] >= 1
     ref = out["reference_committed"]
     assert ref["kind"] == "reference" and ref["measured_in_this_run"] is False
@@ -107,7 +110,7 @@ def test_cpu_baseline_record_is_what_this_run_timed():
     # live port figure scaled by it is labelled an estimate
     assert 0.3 < out["port_over_reference"] < 3.0 and 0.3 < out["port_over_reference_single_thread"] < 3.0
     assert out["port_over_reference_source"].startswith("profiles/r06_cpu_baseline_port_vs_reference.json")
-    assert abs(out["reference_estimate"] - out["value"] / out["port_over_reference"]) < 1e-6 and "not a measurement" in out["reference_estimate_unit"]
+    assert abs(out["reference_estimate"] - out["numpy_port_value"] / out["port_over_reference"]) < 1e-6 and "not a measurement" in out["reference_estimate_unit"]
     assert out["reference_best_seen"] == ref["value"]
 
 
@@ -142,3 +145,14 @@ def test_preflight_checker_agrees_with_the_oracle():
     want = O.Solver(O.wrap_model(lambda xx, t: e, osch), osch).sample(x, steps=20, order=2)
     got = bench._torch_2m_double(ac, torch.from_numpy(x), torch.from_numpy(e), 20).numpy()
     assert np.abs(got - want).max() / np.abs(want).max() < 2e-6
+
+
+def test_c_port_cpu_baseline_runs_here():
+    """the plain-C fused port that bench.py times as `cpu_baseline` (oracle/dpm_oracle_kernels.c): a short run on this machine's cores"""
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import dpm_oracle_c as OC
+    OC.build()
+    out = bench.cpu_baseline_port_c(bench.sd_alphas_cumprod(), budget_s=2.0)
+    assert out["kind"] == "port" and out["value"] > 0 and 1 <= out["cores"] <= out["host_cores"]
+    assert out["single_thread"]["threads"] == 1 and "dpm_oracle_kernels.c" in out["sample"]

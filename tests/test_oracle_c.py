@@ -79,7 +79,7 @@ def test_update_formulas_bitwise(algo, sname):
 def test_trajectories_equal_the_numpy_oracle_bitwise(algo, steps, order):
     sch = _sched("sd")
     x = _rand((3, 4, 8, 8), steps * 10 + order)
-    net = O.wrap_model(lambda xx, ti: C.model_tdep_np(xx, ti) if hasattr(C, "model_tdep_np") else (xx * F32(0.5)).astype(F32), sch)
+    net = O.wrap_model(lambda xx, ti: np.asarray(C.model_tdep(xx, ti), dtype=F32), sch)
     want = O.Solver(net, sch, algorithm_type=algo).sample(x, steps=steps, order=order)
     got = OC.Stepper(sch, algo).sample(net, x, steps=steps, order=order)
     assert np.array_equal(got, want)
@@ -98,20 +98,21 @@ def test_fused_2m_stage_equals_the_unfused_trajectory_and_is_thread_invariant():
 
 
 def test_c_oracle_against_the_reference_goldens(golden):
-    """the multistep noise-network cases of tests/golden/e2e.npz (outputs of the unmodified reference): the C restatement
-    is pinned to the reference itself, not only to the numpy oracle"""
+    """the multistep, time_uniform, unguided noise-network cases of tests/golden/e2e.npz (outputs of the unmodified
+    reference): the C restatement is pinned to the reference itself, not only to the numpy oracle"""
     n = 0
     for case in C.E2E_CASES:
-        if case.get("method", "multistep") != "multistep" or case.get("model_type", "noise") != "noise":
+        if (case["method"] != "multistep" or case["model_type"] != "noise" or case["guidance_type"] != "uncond"
+                or case["skip_type"] != "time_uniform" or case["denoise_to_zero"] or case["t_start"] is not None
+                or case["t_end"] is not None or case["call"] != "sample"):
             continue
-        if case.get("guidance", "uncond") != "uncond" or case.get("skip_type", "time_uniform") != "time_uniform":
-            continue
-        if case.get("cxt") or case.get("cx0") or case.get("denoise_to_zero") or case.get("t_start") or case.get("t_end"):
-            continue
-        if case.get("dtype", "float32") != "float32":
-            continue
-        xo, _ = TO.run_oracle_case(case)
-        sch = TO.oracle_schedule(case["schedule"]) if hasattr(TO, "oracle_schedule") else _sched(case["schedule"])
-        net = O.wrap_model(C.MODELS_NP[case["model"]] if hasattr(C, "MODELS_NP") else None, sch) if False else None
+        sch = TO.make_schedule(case["schedule"])
+        base = C.MODELS[case["model"]]
+        net = O.wrap_model(lambda xx, ti: np.asarray(base(xx, ti), dtype=F32), sch)
+        got = OC.Stepper(sch, case["algorithm_type"], thresholding=case["thresholding"]).sample(
+            net, C.x_T_for(case).astype(F32), steps=case["steps"], order=case["order"],
+            lower_order_final=case["lower_order_final"], solver_type=case["solver_type"])
+        ref = golden.get("e2e", "e2e/%s/final" % case["name"])
+        assert rel_err(got, ref) < TO.E2E_TOL, (case["name"], rel_err(got, ref))
         n += 1
-    assert n >= 0
+    assert n >= 5, n

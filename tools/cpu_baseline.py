@@ -35,6 +35,14 @@ def main():
         # the numpy port (what bench.py times where the reference is absent) on the SAME cores in the SAME run: the ratio
         # bench.py's line carries as cpu_baseline.port_over_reference
         port = bench.cpu_baseline_port(bench.sd_alphas_cumprod(), budget_s=args.budget / 2)
+        try:
+            cport = bench.cpu_baseline_port_c(bench.sd_alphas_cumprod(), budget_s=args.budget / 2)
+            out["c_port_same_box"] = cport
+            out["c_port_over_reference"] = dict(single_thread=round(cport["single_thread"]["value"] / out["single_thread"]["value"], 3),
+                                                best=round(cport["value"] / out["value"], 3),
+                                                what="plain-C fused port (oracle/dpm_oracle_kernels.c) / unmodified reference, same cores, same run")
+        except Exception as e:
+            out["c_port_same_box"] = dict(error="%s: %s" % (type(e).__name__, e))
         out["port_same_box"] = port
         out["port_over_reference"] = dict(
             single_thread=round(port["single_thread"]["value"] / out["single_thread"]["value"], 4),
