@@ -38,6 +38,17 @@ struct KParams {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float vfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ f32x2 vfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// a value rounded to the network output's storage type TE and back (identity for fp32): where the reference's arithmetic
+// runs on the NETWORK's tensors -- the classifier-free blend of a noise-prediction network's two outputs, ref :326-330 --
+// a half-precision network makes every operation of that expression a half operation (computed in fp32, rounded once each)
+template <typename TE>
+__device__ __forceinline__ float round_as(float v) {
+  return to_f32(from_f32<TE>(v));
+}
+template <typename TE>
+__device__ __forceinline__ f32x2 round_as(f32x2 v) {
+  return f32x2{round_as<TE>(v[0]), round_as<TE>(v[1])};
+}
 template <typename V>
 __device__ __forceinline__ V div_by_alpha(V x, const KParams& p) {
   const V q = x * p.inv_alpha;
@@ -135,13 +146,23 @@ __device__ __forceinline__ bool guide_is(int what, const KParams& p) {
   return GUIDE == GUIDE_RT ? p.guidance == what : GUIDE == what;
 }
 
-template <int GUIDE, int SPEC = PM_RT, typename V = float>
+// TE = storage type of the network's outputs.  It matters in ONE place: a noise-prediction network under classifier-free
+// guidance.  The reference blends the two halves of the network's output as they come -- `noise_uncond + guidance_scale *
+// (noise - noise_uncond)` on the network's own tensors (ref :326-330) -- so with an fp16 / bf16 network (Stable Diffusion
+// under autocast) the subtraction, the product with the Python-float scale and the sum are three half-precision operations,
+// each computed in fp32 and rounded to the half type (torch's opmath), before the first fp32 schedule tensor promotes
+// anything.  Reproduced here operation by operation; x_start / v / score networks are converted with fp32 schedule tensors
+// first (ref :290-298), so their blend -- like everything after it -- is fp32.
+template <int GUIDE, int SPEC = PM_RT, typename V = float, typename TE = float>
 __device__ __forceinline__ V prologue(V xe, V o0, V o1, V gg, const KParams& p) {
   static_assert(SPEC != SPEC_GENERIC, "SPEC_GENERIC dispatches to a mode (stage_tiles); the prologue takes the mode");
   V eps;
   if (guide_is<GUIDE>(DPM_GUIDE_CFG, p)) {  // ref :326-330: uncond + scale * (cond - uncond)
     V nu = to_noise<SPEC>(o1, xe, p), nc = to_noise<SPEC>(o0, xe, p);
-    eps = nu + p.cfg_scale * (nc - nu);
+    if (sizeof(TE) == 2 && (SPEC >= 0 ? (SPEC >> 1) == DPM_MODEL_NOISE : p.model_type == DPM_MODEL_NOISE))
+      eps = round_as<TE>(nu + round_as<TE>(p.cfg_scale * round_as<TE>(nc - nu)));
+    else
+      eps = nu + p.cfg_scale * (nc - nu);
   } else if (guide_is<GUIDE>(DPM_GUIDE_CLASSIFIER, p)) {  // ref :321
     eps = to_noise<SPEC>(o0, xe, p) - p.cg_scale * gg;
   } else {
@@ -152,25 +173,46 @@ __device__ __forceinline__ V prologue(V xe, V o0, V o1, V gg, const KParams& p) 
   return eps;
 }
 
+// Are the solver's MODEL VALUES half-precision tensors in the reference?  Only in the noise-prediction form (algorithm_type
+// 'dpmsolver': the model value IS the network's noise, ref :444-451) of a noise network whose output nothing fp32 has touched
+// -- unguided, or classifier-free (a half blend, see prologue) -- with a half-precision network.  Then every DIFFERENCE OF TWO
+// MODEL VALUES in the update formulas (ref :636-669, :728-789, :827-851, :880-903) is a half operation, rounded to the
+// network's dtype before the (1,)-shaped fp32 coefficient promotes the product; reproduced in combine().  In the
+// data-prediction form (dpmsolver++) the model value is x0 = (x - sigma eps) / alpha, fp32 from the start.
+template <typename TE>
+__device__ __forceinline__ bool model_values_are_half(const KParams& p) {
+  return sizeof(TE) == 2 && !(p.flags & DPM_F_TO_X0) && p.model_type == DPM_MODEL_NOISE && p.guidance != DPM_GUIDE_CLASSIFIER;
+}
+// hm (wave-uniform): round the difference of two model values through TE
+template <typename TE, typename V>
+__device__ __forceinline__ V mdiff(V a, V b, bool hm) {
+  if (sizeof(TE) == 2 && hm) return round_as<TE>(a - b);
+  return a - b;
+}
+
 // the exponential-integrator combination, reference association
-template <int FORM, typename V>
-__device__ __forceinline__ V combine(V x, V mn, V h1, V h2, const KParams& p) {
+template <int FORM, typename V, typename TE = float>
+__device__ __forceinline__ V combine(V x, V mn, V h1, V h2, const KParams& p, bool hm = false) {
   if (FORM == DPM_FORM_LIN1) {
     return p.cx * x - p.c0 * mn;  // ref :573-576, :585-588
   } else if (FORM == DPM_FORM_TWO) {
-    V D = p.k0 * (mn - h1);
+    V D = p.k0 * mdiff<TE>(mn, h1, hm);
     V P = (p.flags & DPM_F_BASE_HIST) ? h1 : mn;
     return (p.cx * x - p.c0 * P) - p.c1 * D;  // ref :827-851 (multistep), :636-669, :728-778 (singlestep)
   } else if (FORM == DPM_FORM_MS3) {
-    V D1_0 = p.k0 * (mn - h1);  // ref :880-883
-    V D1_1 = p.k1 * (h1 - h2);
+    V D1_0 = p.k0 * mdiff<TE>(mn, h1, hm);  // ref :880-883
+    V D1_1 = p.k1 * mdiff<TE>(h1, h2, hm);
     V dd = D1_0 - D1_1;
     V D1 = D1_0 + p.k2 * dd;
     V D2 = p.k3 * dd;
     return ((p.cx * x - p.c0 * mn) - p.c1 * D1) - p.c2 * D2;  // ref :888-903
   } else if (FORM == DPM_FORM_SS3T) {
-    V D1_0 = p.k0 * (h2 - h1);  // h1 = model_s, h2 = model_s1, mn = model_s2; ref :741-750, :780-789
-    V D1_1 = p.k1 * (mn - h1);
+    // h1 = model_s, h2 = model_s1, mn = model_s2; ref :741-750, :780-789.  (With half model values the reference's D1 / D2
+    // chain is half arithmetic too -- r1, r2 arrive as 0-dim tensors, which do not promote -- but HOW torch rounds a 0-dim
+    // operand differs between its CPU and GPU kernels and between the left and the right operand; only the two tensor-tensor
+    // differences are reproduced, the rest of this one formula stays fp32: INTEGRATION.md, behavioural notes.)
+    V D1_0 = p.k0 * mdiff<TE>(h2, h1, hm);
+    V D1_1 = p.k1 * mdiff<TE>(mn, h1, hm);
     V D1 = (p.k2 * D1_0 - p.k3 * D1_1) / p.k4;
     V D2 = (2.f * (D1_1 - D1_0)) / p.k4;
     return ((p.cx * x - p.c0 * h1) - p.c1 * D1) - p.c2 * D2;
@@ -179,17 +221,17 @@ __device__ __forceinline__ V combine(V x, V mn, V h1, V h2, const KParams& p) {
   }
 }
 
-template <int FORM, typename V>
-__device__ __forceinline__ V combine_any(V x, V mn, V h1, V h2, const KParams& p) {
+template <int FORM, typename V, typename TE = float>
+__device__ __forceinline__ V combine_any(V x, V mn, V h1, V h2, const KParams& p, bool hm = false) {
   if constexpr (FORM != FORM_RT) {
-    return combine<FORM>(x, mn, h1, h2, p);
+    return combine<FORM, V, TE>(x, mn, h1, h2, p, hm);
   } else {
     switch (p.form) {
-      case DPM_FORM_LIN1: return combine<DPM_FORM_LIN1>(x, mn, h1, h2, p);
-      case DPM_FORM_TWO: return combine<DPM_FORM_TWO>(x, mn, h1, h2, p);
-      case DPM_FORM_MS3: return combine<DPM_FORM_MS3>(x, mn, h1, h2, p);
-      case DPM_FORM_SS3T: return combine<DPM_FORM_SS3T>(x, mn, h1, h2, p);
-      default: return combine<DPM_FORM_DENOISE>(x, mn, h1, h2, p);
+      case DPM_FORM_LIN1: return combine<DPM_FORM_LIN1, V, TE>(x, mn, h1, h2, p, hm);
+      case DPM_FORM_TWO: return combine<DPM_FORM_TWO, V, TE>(x, mn, h1, h2, p, hm);
+      case DPM_FORM_MS3: return combine<DPM_FORM_MS3, V, TE>(x, mn, h1, h2, p, hm);
+      case DPM_FORM_SS3T: return combine<DPM_FORM_SS3T, V, TE>(x, mn, h1, h2, p, hm);
+      default: return combine<DPM_FORM_DENOISE, V, TE>(x, mn, h1, h2, p, hm);
     }
   }
 }
@@ -249,7 +291,7 @@ __device__ __forceinline__ float blend_ref(float v, float m, float a, float b, b
 // model values of the U tiles of one workgroup iteration for prologue mode PM (the loaded registers arrive by reference:
 // a plain forced-inline function, so that they stay registers).  The empty asm statement is a side effect: without one a
 // switch over these calls is if-converted into computing every mode and selecting.
-template <int GUIDE, bool XE, int PM, int U, bool NEEDS_X>
+template <int GUIDE, bool XE, int PM, int U, bool NEEDS_X, typename TE>
 __device__ __forceinline__ void tile_models(const float (&vx)[U][EPT], const float (&vxe)[U][EPT], const float (&v0)[U][EPT],
                                             const float (&v1)[U][EPT], const float (&vg)[U][EPT], const bool need_xe,
                                             const KParams& p, f32x2 (&mnv)[U][EPT / 2]) {
@@ -261,7 +303,7 @@ __device__ __forceinline__ void tile_models(const float (&vx)[U][EPT], const flo
       const f32x2 z = {0.f, 0.f};
       const f32x2 x2 = NEEDS_X || (!XE && need_xe) ? f32x2{vx[u][q], vx[u][q + 1]} : z;
       const f32x2 xe2 = XE ? f32x2{vxe[u][q], vxe[u][q + 1]} : x2;
-      mnv[u][q / 2] = prologue<GUIDE, PM>(xe2, f32x2{v0[u][q], v0[u][q + 1]},
+      mnv[u][q / 2] = prologue<GUIDE, PM, f32x2, TE>(xe2, f32x2{v0[u][q], v0[u][q + 1]},
                                           GUIDE == DPM_GUIDE_CFG ? f32x2{v1[u][q], v1[u][q + 1]} : z,
                                           GUIDE == DPM_GUIDE_CLASSIFIER ? f32x2{vg[u][q], vg[u][q + 1]} : z, p);
     }
@@ -290,6 +332,8 @@ __device__ __forceinline__ void stage_tiles(const TS* __restrict__ x, const TS* 
   constexpr bool SPLIT = sizeof(TS) == 4;  // see load_tile
   const bool need_xe = spec_need_xe<SPEC>(p);
   const bool store_m = p.flags & DPM_F_STORE_M;
+  // (the compile-time data-prediction prologue never has half model values; everything else asks the stage record)
+  const bool hm = (SPEC >= 0 && SPEC != SPEC_GENERIC && (SPEC & 1)) ? false : model_values_are_half<TE>(p);
   const TS* mask = EXT ? static_cast<const TS*>(ext.mask) : nullptr;
   const TS* ba = EXT ? static_cast<const TS*>(ext.ba) : nullptr;
   const TS* bb = EXT ? static_cast<const TS*>(ext.bb) : nullptr;
@@ -357,7 +401,7 @@ __device__ __forceinline__ void stage_tiles(const TS* __restrict__ x, const TS* 
   }
   // the model values of all U tiles; SPEC_GENERIC picks the prologue mode here, once per workgroup iteration
   f32x2 mnv[U][EPT / 2];
-#define DPM_MODELS(PM_) tile_models<GUIDE, XE, PM_, U, FT::needs_x>(vx, vxe, v0, v1, vg, need_xe, p, mnv)
+#define DPM_MODELS(PM_) tile_models<GUIDE, XE, PM_, U, FT::needs_x, TE>(vx, vxe, v0, v1, vg, need_xe, p, mnv)
   if constexpr (SPEC == SPEC_GENERIC) {
     switch (generic_mode(p)) {
       case 0: DPM_MODELS(0); break;
@@ -383,9 +427,9 @@ __device__ __forceinline__ void stage_tiles(const TS* __restrict__ x, const TS* 
     for (int q = 0; q < EPT; q += 2) {
       const f32x2 z = {0.f, 0.f};
       const f32x2 mn = mnv[u][q / 2];
-      const f32x2 o = combine<FORM>(FT::needs_x ? f32x2{vx[u][q], vx[u][q + 1]} : z, mn,
+      const f32x2 o = combine<FORM, f32x2, TE>(FT::needs_x ? f32x2{vx[u][q], vx[u][q + 1]} : z, mn,
                                     FT::needs_h1 ? f32x2{vh1[u][q], vh1[u][q + 1]} : z,
-                                    FT::needs_h2 ? f32x2{vh2[u][q], vh2[u][q + 1]} : z, p);
+                                    FT::needs_h2 ? f32x2{vh2[u][q], vh2[u][q + 1]} : z, p, hm);
       om[q] = mn.x;
       om[q + 1] = mn.y;
       ox[q] = o.x;
@@ -443,9 +487,10 @@ __global__ __launch_bounds__(STAGE_MAX_THREADS) void stage_kernel(const TS* __re
       const int64_t i = tail0 + threadIdx.x;
       const float xv = (FT::needs_x || (!XE && need_xe)) ? to_f32(x[i]) : 0.f;
       const float xev = XE ? (need_xe ? to_f32(xe[i]) : 0.f) : xv;
-      const float mn = prologue<GUIDE, SPEC == SPEC_GENERIC ? (int)PM_RT : SPEC>(
+      const float mn = prologue<GUIDE, SPEC == SPEC_GENERIC ? (int)PM_RT : SPEC, float, TE>(
           xev, to_f32(e0[i]), GUIDE == DPM_GUIDE_CFG ? to_f32(e1[i]) : 0.f, GUIDE == DPM_GUIDE_CLASSIFIER ? to_f32(g[i]) : 0.f, p);
-      xo[i] = from_f32<TS>(combine<FORM>(xv, mn, FT::needs_h1 ? to_f32(h1[i]) : 0.f, FT::needs_h2 ? to_f32(h2[i]) : 0.f, p));
+      xo[i] = from_f32<TS>(combine<FORM, float, TE>(xv, mn, FT::needs_h1 ? to_f32(h1[i]) : 0.f, FT::needs_h2 ? to_f32(h2[i]) : 0.f, p,
+                                                    model_values_are_half<TE>(p)));
       if (store_m) mo[i] = from_f32<TS>(mn);
     }
   }
@@ -542,6 +587,7 @@ __global__ __launch_bounds__(256) void stage_kernel_scalar(const TS* __restrict_
   const bool store_m = p.flags & DPM_F_STORE_M;
   const bool nx = form_needs_x<FORM_RT>(p), nh1 = form_needs_h1<FORM_RT>(p), nh2 = form_needs_h2<FORM_RT>(p);
   const bool cfg = p.guidance == DPM_GUIDE_CFG, clsg = p.guidance == DPM_GUIDE_CLASSIFIER;
+  const bool hm = model_values_are_half<TE>(p);
   const TS* mask = static_cast<const TS*>(ext.mask);
   const TS* ba = static_cast<const TS*>(ext.ba);
   const TS* bb = static_cast<const TS*>(ext.bb);
@@ -551,8 +597,8 @@ __global__ __launch_bounds__(256) void stage_kernel_scalar(const TS* __restrict_
     const int64_t ie = ext.eps_stride ? (i / ext.per_sample) * ext.eps_stride + i % ext.per_sample : i;
     const float xv = nx ? to_f32(x[i]) : 0.f;
     const float xev = need_xe ? to_f32(xe[i]) : 0.f;
-    const float mn = prologue<GUIDE_RT>(xev, to_f32(e0[ie]), cfg ? to_f32(e1[ie]) : 0.f, clsg ? to_f32(g[i]) : 0.f, p);
-    float o = combine_any<FORM_RT>(xv, mn, nh1 ? to_f32(h1[i]) : 0.f, nh2 ? to_f32(h2[i]) : 0.f, p);
+    const float mn = prologue<GUIDE_RT, PM_RT, float, TE>(xev, to_f32(e0[ie]), cfg ? to_f32(e1[ie]) : 0.f, clsg ? to_f32(g[i]) : 0.f, p);
+    float o = combine_any<FORM_RT, float, TE>(xv, mn, nh1 ? to_f32(h1[i]) : 0.f, nh2 ? to_f32(h2[i]) : 0.f, p, hm);
     if (mask) {
       o = to_f32(from_f32<TS>(o));  // the reference blends the stored state
       o = blend_ref(o, to_f32(mask[i % ext.mask_period]), to_f32(ba[i]), bb ? to_f32(bb[i]) : 0.f, bb != nullptr, ext);

@@ -1083,7 +1083,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
 #pragma unroll
               for (int j = 0; j < 4; j += 2) {  // adjacent pairs: packed fp32 instructions
                 const f32x2 z = {0.f, 0.f};
-                const f32x2 rr = prologue<GUIDE, SPEC_NOISE_X0, f32x2>(
+                const f32x2 rr = prologue<GUIDE, SPEC_NOISE_X0, f32x2, TE>(
                     f32x2{vx[r][j], vx[r][j + 1]}, f32x2{v0[r][j], v0[r][j + 1]},
                     g_cfg ? f32x2{v1[r][j], v1[r][j + 1]} : z, g_cls ? f32x2{vg[r][j], vg[r][j + 1]} : z, p);
                 o[j] = rr[0];
@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
             } else {
 #pragma unroll
               for (int j = 0; j < 4; ++j)
-                o[j] = prologue<GUIDE>(vx[r][j], v0[r][j], g_cfg ? v1[r][j] : 0.f, g_cls ? vg[r][j] : 0.f, p);
+                o[j] = prologue<GUIDE, PM_RT, float, TE>(vx[r][j], v0[r][j], g_cfg ? v1[r][j] : 0.f, g_cls ? vg[r][j] : 0.f, p);
             }
             {  // LDS, not global memory: a plain 16-byte store (store4 writes through to global memory)
               u32x4 a;
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
 #pragma unroll 4
       for (int i = tid; i < n; i += T) {
         const float xev = to_f32(XE ? xe[base + i] : x[base + i]);
-        const float o = prologue<GUIDE>(xev, to_f32(e0[ebase + i]), g_cfg ? to_f32(e1[ebase + i]) : 0.f,
+        const float o = prologue<GUIDE, PM_RT, float, TE>(xev, to_f32(e0[ebase + i]), g_cfg ? to_f32(e1[ebase + i]) : 0.f,
                                         g_cls ? to_f32(g[base + i]) : 0.f, p);
         sx0[i] = o;
         const uint32_t u = __float_as_uint(o) & ABS;
@@ -1455,7 +1455,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
         const TE* __restrict__ e1s = g_cfg ? e1 + se : e0 + se;
         const TE* __restrict__ gs = g_cls ? g + sx : e0 + se;
         auto bits_at = [&](int i) -> uint32_t {
-          const float o = prologue<GUIDE>(to_f32(xs[i]), to_f32(e0s[i]), g_cfg ? to_f32(e1s[i]) : 0.f,
+          const float o = prologue<GUIDE, PM_RT, float, TE>(to_f32(xs[i]), to_f32(e0s[i]), g_cfg ? to_f32(e1s[i]) : 0.f,
                                           g_cls ? to_f32(gs[i]) : 0.f, p);
           return __float_as_uint(o) & ABS;
         };

@@ -161,6 +161,8 @@ def run_plan_fast(self, plan, x, sd, cfg):
 
 
 def run_plan(self, plan, x, method, cxt, keep, intermediates):
+    if not plan.stages:             # singlestep_fixed with steps < order: no update at all (ref :1218-1232), x comes back as it is
+        return x if self._group is None else list(self._group)
     device = x.device
     sd = self._sdtype(x)
     cfg = self._wrapped is not None and self._wrapped.effective_guidance == "classifier-free"

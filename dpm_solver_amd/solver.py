@@ -236,9 +236,15 @@ class DPM_Solver:
             return torch.float64                    # a double network output promotes every state
         if self._state_dtype is None and sd not in (torch.float32, torch.float64) and e0.dtype is not sd and e0.dtype in DV._DT:
             return torch.float32
-        if (self._state_dtype is None and sd not in (torch.float32, torch.float64) and plan is not None and plan.has_inner_nodes
-                and self.noise_schedule.schedule != 'discrete'):
-            return torch.float32
+        if self._state_dtype is None and sd not in (torch.float32, torch.float64) and self.noise_schedule.schedule != 'discrete':
+            if plan is not None and plan.has_inner_nodes:
+                return torch.float32
+            # ... and when the wrapped model's OWN conversions involve the schedule: x_start / v / score networks and the
+            # classifier term multiply by alpha_t / sigma_t expanded to the batch (ref :290-298, :320: dimensioned fp32
+            # tensors), so the noise the solver receives -- and every state after the first update -- is fp32
+            mt, gd, _ = self._model_codes()
+            if mt != L.MODEL["noise"] or gd == L.GUIDE["classifier"]:
+                return torch.float32
         return sd
 
     def _cfg_pre(self, outs, sd):
@@ -534,21 +540,36 @@ class DPM_Solver:
                 if denoise_to_zero:
                     x = self.denoise_to_zero_fn(x, self._tt(t_0, device, shape1=True))
             elif method in ['multistep', 'singlestep', 'singlestep_fixed']:
+                if method == 'multistep':
+                    assert steps >= order                       # (the reference's first check, ref :1172)
                 if skip_type not in L.SKIP:
                     raise ValueError("Unsupported skip_type {}, need to be 'logSNR' or 'time_uniform' or 'time_quadratic'".format(skip_type))
+                plan_solver_type = solver_type
                 if solver_type not in L.SOLVER:
-                    raise ValueError("'solver_type' must be either 'dpmsolver' or 'taylor', got {}".format(solver_type))
+                    # the reference checks solver_type inside its second-order updates and the singlestep third-order one (ref
+                    # :611, :697, :815), i.e. only when such an update is reached: a run made of first-order (and multistep
+                    # third-order) updates accepts any value.  Plan with the default to see which updates the run contains.
+                    plan_solver_type = "dpmsolver"
                 if method == 'multistep':
                     # the order is validated where the reference validates it -- when an update of that order is reached
                     # (ref :948-954): order=4 with steps <= 6 and lower_order_final never reaches one and runs (the planner
                     # raises the reference's ValueError otherwise)
                     assert steps >= order
+                elif method == 'singlestep_fixed' and order not in (1, 2, 3):
+                    # ref :1218-1232: K = steps // order updates of that order -- none at all when K <= 0 (the run is a no-op),
+                    # else the dispatcher's error at the first one (ref :927-930); order 0 is Python's ZeroDivisionError
+                    K = steps // order
+                    if K > 0:
+                        raise ValueError("Solver order must be 1 or 2 or 3, got {}".format(order))
+                    order, steps = 3, 1                    # a plan without update stages (K = 1 // 3 = 0)
                 elif order not in (1, 2, 3):
                     raise ValueError("'order' must be '1' or '2' or '3'.")
                 plan = self._get_plan(precision=self._precision(self._sdtype(x)), method=method, order=order, steps=steps,
-                                      skip_type=skip_type, solver_type=solver_type,
+                                      skip_type=skip_type, solver_type=plan_solver_type,
                                       lower_order_final=lower_order_final, denoise_to_zero=denoise_to_zero,
                                       t_T=float(t_T), t_0=float(t_0))
+                if plan_solver_type is not solver_type and any(st.form in (L.FORM_TWO, L.FORM_SS3T) for st in plan.stages):
+                    raise ValueError("'solver_type' must be either 'dpmsolver' or 'taylor', got {}".format(solver_type))
                 x = self._run_plan(plan, x, method, cxt, return_intermediate, intermediates)
             else:
                 raise ValueError("Got wrong method {}".format(method))

@@ -56,12 +56,27 @@ def to_noise(o, xe, st):
     return o
 
 
-def prologue(st, xe, e0, e1, g):
+def half_rounder(dtype):
+    """fp32 numpy array -> the same values rounded through the half type `dtype` (torch dtype or DPM_DTYPE code); None for
+    4- and 8-byte types"""
+    if dtype in (torch.float16, L.DTYPE_F16):
+        return lambda a: np.asarray(a, dtype=F32).astype(np.float16).astype(F32)
+    if dtype in (torch.bfloat16, L.DTYPE_BF16):
+        return lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=F32)).to(torch.bfloat16).float().numpy()
+    return None
+
+
+def prologue(st, xe, e0, e1, g, rnd=None):
+    """rnd: rounding through the network output's half storage type (half_rounder) -- the classifier-free blend of a
+    noise-prediction network runs on the network's own tensors in the reference (ref :326-330): three half operations"""
     st = _as_coef(st)
     FT = st.FT
     if st.guidance == L.GUIDE["classifier-free"]:
         nu, nc = to_noise(e1, xe, st), to_noise(e0, xe, st)
-        eps = nu + st.cfg_scale * (nc - nu)
+        if rnd is not None and st.model_type == L.MODEL["noise"] and FT is F32:
+            eps = rnd(nu + rnd(st.cfg_scale * rnd(nc - nu)))
+        else:
+            eps = nu + st.cfg_scale * (nc - nu)
     elif st.guidance == L.GUIDE["classifier"]:
         eps = to_noise(e0, xe, st) - st.cg_scale * g
     else:
@@ -71,27 +86,33 @@ def prologue(st, xe, e0, e1, g):
     return eps.astype(FT)
 
 
-def combine(st, x, mn, h1, h2):
+def combine(st, x, mn, h1, h2, rnd=None):
+    """rnd: rounding through the network's half storage type (half_rounder) -- with a half-precision noise network in the
+    noise-prediction form the reference's model values are half tensors and every difference of two of them is a half
+    operation (ref :636-903); thresholding implies the data-prediction form, so never there"""
     st = _as_coef(st)
     F32 = st.FT                                  # (the literals below in the launch's arithmetic type)
     cx, c0, c1, c2 = st.cx, st.c0, st.c1, st.c2
     k = st.k
+    hm = (rnd is not None and st.FT is np.float32 and not (st.flags & L.F_TO_X0) and st.model_type == L.MODEL["noise"]
+          and st.guidance != L.GUIDE["classifier"])
+    md = (lambda a, b: rnd(a - b)) if hm else (lambda a, b: a - b)
     if st.form == L.FORM_LIN1:
         return cx * x - c0 * mn
     if st.form == L.FORM_TWO:
-        D = k[0] * (mn - h1)
+        D = k[0] * md(mn, h1)
         P = h1 if (st.flags & L.F_BASE_HIST) else mn
         return (cx * x - c0 * P) - c1 * D
     if st.form == L.FORM_MS3:
-        D1_0 = k[0] * (mn - h1)
-        D1_1 = k[1] * (h1 - h2)
+        D1_0 = k[0] * md(mn, h1)
+        D1_1 = k[1] * md(h1, h2)
         dd = D1_0 - D1_1
         D1 = D1_0 + k[2] * dd
         D2 = k[3] * dd
         return ((cx * x - c0 * mn) - c1 * D1) - c2 * D2
     if st.form == L.FORM_SS3T:
-        D1_0 = k[0] * (h2 - h1)
-        D1_1 = k[1] * (mn - h1)
+        D1_0 = k[0] * md(h2, h1)
+        D1_1 = k[1] * md(mn, h1)
         D1 = (k[2] * D1_0 - k[3] * D1_1) / k[4]
         D2 = (F32(2.0) * (D1_1 - D1_0)) / k[4]
         return ((cx * x - c0 * h1) - c1 * D1) - c2 * D2
@@ -133,10 +154,13 @@ def launch_stage_double(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, 
         xen = xn
     if xn is None:
         xn = xen
-    mn = prologue(c, xen, cast(_np(e0)), cast(_np(e1)), cast(_np(g)))
+    ed = e0.dtype          # the eps dtype the launch binds (solver._launch_stage): converted to the state's when there is no kernel pair
+    if ed not in (torch.float32, torch.float16, torch.bfloat16) or (state_dtype != torch.float32 and ed != state_dtype):
+        ed = state_dtype
+    mn = prologue(c, xen, cast(_np(e0)), cast(_np(e1)), cast(_np(g)), half_rounder(ed))
     if st.flags & L.F_THRESH:
         mn = threshold64(mn, c.thr_ratio, c.thr_max) if FT is F64 else O.dynamic_threshold(mn, F32(st.thr_ratio), F32(st.thr_max))
-    out = combine(c, xn, mn, cast(_np(h1)), cast(_np(h2))).astype(FT)
+    out = combine(c, xn, mn, cast(_np(h1)), cast(_np(h2)), half_rounder(ed)).astype(FT)
     store = bool(st.flags & L.F_STORE_M) if want_m is None else want_m
     conv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(state_dtype).reshape(ref_t.shape)
     if ext is not None and ext.get("blend") is not None:
@@ -269,14 +293,14 @@ def launch_raw_double(st_ref, b_ref, stream):
     FT = F64 if sd == L.DTYPE_F64 else F32
     assert FT is F32 or ed == L.DTYPE_F64, "a double state needs double network outputs"
     c = _Coef(st, FT, b.coef64.contents if b.coef64 else None)
-    mn = prologue(c, xe, eps(b.e0), eps(b.e1), _rd(b.g, n, ed))
+    mn = prologue(c, xe, eps(b.e0), eps(b.e1), _rd(b.g, n, ed), half_rounder(ed))
     if st.flags & L.F_THRESH:
         if FT is F64:
             mn = threshold64(mn.reshape(B, per), c.thr_ratio, c.thr_max).reshape(-1)
         else:
             mn = O.dynamic_threshold(mn.reshape(B, per), F32(st.thr_ratio), F32(st.thr_max)).reshape(-1)
     assert not (st.flags & L.F_BLEND), "the fast path never carries a blend"
-    out = combine(c, x, mn, _rd(b.h1, n, sd), _rd(b.h2, n, sd)).astype(FT)
+    out = combine(c, x, mn, _rd(b.h1, n, sd), _rd(b.h2, n, sd), half_rounder(ed)).astype(FT)
     _wr(b.x_out, out, sd)
     if b.x_out2:
         _wr(b.x_out2, out, sd)

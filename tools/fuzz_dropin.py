@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Drop-in fuzz: random corners of the public API against the LIVE reference (build container only: needs /root/reference).
+
+The engine's host side (C planner + Python loops) runs on CPU tensors with the stage kernel replaced by its numpy double
+(tests/kernel_double.py -- the GPU suite shows kernel == double bit for bit); the unmodified dpm_solver_pytorch.py runs beside
+it.  Every case compares: did both raise (same exception type and text) or both return; dtype, shape, values (1e-5 of the
+trajectory's peak for fp32, 1e-10 for double, the half format's resolution for half results), the intermediates, and the
+network-call trace (shapes, dtypes and times the network saw).  Wider than tests/test_differential_reference.py: state
+shapes of 1 to 5 dimensions, batch 1, non-contiguous inputs, half / double x_T, steps below the order, singlestep grids that
+degenerate, every method incl. adaptive, public update methods with tensor / float / None arguments.
+
+    python tools/fuzz_dropin.py [--cases 1500] [--seed 0]        # prints every disagreement and a summary
+"""
+import argparse
+import os
+import sys
+import traceback
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    sys.path.insert(0, p)
+REF_DIR = os.environ.get("DPM_REFERENCE_DIR", "/root/reference")
+sys.path.insert(0, REF_DIR)
+
+import cases as C  # noqa: E402
+import dpm_solver_amd as D  # noqa: E402
+import dpm_solver_amd.solver as S  # noqa: E402
+import dpm_solver_pytorch as R  # noqa: E402
+from engine_cases import make_schedule  # noqa: E402
+from kernel_double import install_cpu_double  # noqa: E402
+
+
+class _MP:
+    def setattr(self, o, n, v):
+        setattr(o, n, v)
+
+
+install_cpu_double(_MP(), S, D)
+torch.set_num_threads(1)
+F32 = np.float32
+
+
+def ref_schedule(name, dtype=torch.float32):
+    si = C.schedule_inputs(name)
+    if si["kind"] == "linear":
+        return R.NoiseScheduleVP("linear", continuous_beta_0=si["beta_0"], continuous_beta_1=si["beta_1"])
+    key = "betas" if "betas" in si else "alphas_cumprod"
+    return R.NoiseScheduleVP("discrete", dtype=dtype, **{key: torch.from_numpy(np.asarray(si[key]))})
+
+
+def eng_schedule(name, dtype=torch.float32):
+    if dtype is torch.float32:
+        return make_schedule(name)
+    si = C.schedule_inputs(name)
+    key = "betas" if "betas" in si else "alphas_cumprod"
+    return D.NoiseScheduleVP("discrete", dtype=dtype, **{key: torch.from_numpy(np.asarray(si[key]))})
+
+
+SHAPES = [(3,), (2, 5), (2, 3, 4), (2, 3, 4, 4), (1, 3, 4, 4), (1, 2, 3, 2, 2), (4, 1, 1, 1), (2, 12)]
+
+
+def random_case(rng):
+    method = str(rng.choice(["multistep", "singlestep", "singlestep_fixed", "adaptive"], p=[0.4, 0.3, 0.2, 0.1]))
+    order = int(rng.choice([1, 2, 3, 3, 2, 4, 0])) if rng.random() < 0.15 else int(rng.integers(1, 4))
+    steps = int(rng.integers(1, 13))
+    guidance = str(rng.choice(["uncond", "uncond", "classifier-free", "classifier"]))
+    return dict(method=method, order=order, steps=steps, shape=SHAPES[int(rng.integers(0, len(SHAPES)))],
+                schedule=str(rng.choice(["sd", "ddpm", "vp_linear", "cosine1000"])),
+                skip_type=str(rng.choice(["time_uniform", "logSNR", "time_quadratic", "bogus"], p=[0.4, 0.3, 0.27, 0.03])),
+                solver_type=str(rng.choice(["dpmsolver", "taylor", "bogus"], p=[0.55, 0.42, 0.03])),
+                algorithm_type=str(rng.choice(["dpmsolver++", "dpmsolver"])),
+                model_type=str(rng.choice(["noise", "x_start", "v", "score"])), guidance=guidance,
+                scale=float(rng.choice([1.0, 2.5, 7.5])), thresholding=bool(rng.integers(0, 4) == 0),
+                cxt=bool(rng.integers(0, 5) == 0), cx0=bool(rng.integers(0, 6) == 0),
+                lower_order_final=bool(rng.integers(0, 2)), denoise_to_zero=bool(rng.integers(0, 3) == 0),
+                t_end=(None if rng.random() < 0.5 else float(rng.choice([1e-3, 1e-2, 0.05]))),
+                t_start=(None if rng.random() < 0.5 else float(rng.choice([1.0, 0.8, 0.5]))),
+                call=str(rng.choice(["sample", "sample", "sample", "inverse"])),
+                ret_inter=bool(rng.integers(0, 2)), xdt=str(rng.choice(["f32", "f32", "f32", "f64", "f16", "bf16"])),
+                noncontig=bool(rng.integers(0, 6) == 0), seed=int(rng.integers(0, 1 << 30)))
+
+
+def build(mod, ns, cfg, x, trace):
+    B = x.shape[0]
+    cond = torch.arange(1, B + 1, dtype=torch.float32) * 0.5
+    kw = dict(model_type=cfg["model_type"], guidance_type=cfg["guidance"], guidance_scale=cfg["scale"])
+
+    def base(xx, t, c=None):
+        trace.append((tuple(xx.shape), str(xx.dtype), str(t.dtype), tuple(t.shape), round(float(t.reshape(-1)[0]), 4)))
+        tt = t.to(xx.dtype).reshape((-1,) + (1,) * (xx.dim() - 1))
+        out = xx * (tt * 0.0005 + 0.25)
+        if c is not None:
+            out = out * (c.to(xx.dtype).reshape((-1,) + (1,) * (xx.dim() - 1)) * 0.1 + 1.0)
+        return out
+    if cfg["guidance"] == "classifier-free":
+        net = lambda xx, t, c: base(xx, t, c)
+        kw.update(condition=cond, unconditional_condition=torch.zeros(B))
+    elif cfg["guidance"] == "classifier":
+        net = lambda xx, t, c=None: base(xx, t)
+        kw.update(condition=cond, classifier_fn=lambda xx, t, c: -0.5 * (xx.reshape(xx.shape[0], -1) ** 2).sum(dim=1) * 0.01)
+    else:
+        net = lambda xx, t: base(xx, t)
+    fn = mod.model_wrapper(net, ns, **kw)
+    skw = dict(algorithm_type=cfg["algorithm_type"])
+    if cfg["thresholding"]:
+        skw["correcting_x0_fn"] = "dynamic_thresholding"
+    elif cfg["cx0"]:
+        skw["correcting_x0_fn"] = lambda x0, t: torch.clamp(x0, -2.0, 2.0)
+    if cfg["cxt"]:
+        skw["correcting_xt_fn"] = lambda xt, t, step: xt * 0.99 + 0.001 * step
+    return mod.DPM_Solver(fn, ns, **skw)
+
+
+def run(mod, ns, cfg, x):
+    trace = []
+    try:
+        dpm = build(mod, ns, cfg, x, trace)
+        kw = dict(steps=cfg["steps"], order=cfg["order"], method=cfg["method"], skip_type=cfg["skip_type"],
+                  solver_type=cfg["solver_type"], lower_order_final=cfg["lower_order_final"],
+                  denoise_to_zero=cfg["denoise_to_zero"], return_intermediate=cfg["ret_inter"])
+        if cfg["method"] == "adaptive":
+            kw.update(atol=0.05, rtol=0.1)
+        if cfg["call"] == "sample":
+            out = dpm.sample(x, t_start=cfg["t_start"], t_end=cfg["t_end"], **kw)
+        else:
+            out = dpm.inverse(x, t_start=cfg["t_end"], t_end=cfg["t_start"], **kw)
+        return ("ok", out, trace)
+    except Exception as e:                              # noqa: BLE001 -- the comparison is about what is raised
+        return ("raise", (type(e).__name__, str(e)[:160]), trace, traceback.format_exc(limit=3))
+
+
+def compare(cfg, r, e):
+    """list of disagreements of one case"""
+    bad = []
+    if r[0] == "raise" and r[1][0] in ("UnboundLocalError", "RuntimeError", "IndexError", "TypeError"):
+        # the reference crashed on its own terms -- `step` unbound when a loop ran zero times (ref :1233-1237), torch.quantile on
+        # a half tensor, torch.linspace with a negative count: the engine is not asked to crash the same way
+        return bad
+    if r[0] != e[0]:
+        return ["reference %s, engine %s: %s | %s" % (r[0], e[0], r[1] if r[0] == "raise" else "", e[1] if e[0] == "raise" else "")]
+    if r[0] == "raise":
+        if r[1][0] != e[1][0]:
+            bad.append("exception type %s vs %s (%s | %s)" % (r[1][0], e[1][0], r[1][1], e[1][1]))
+        elif r[1][1] != e[1][1] and r[1][0] in ("ValueError", "AssertionError") and r[1][1] and "unpack" not in r[1][1]:
+            bad.append("exception text %r vs %r" % (r[1][1], e[1][1]))
+        return bad
+    ro, eo = r[1], e[1]
+    ri, ei = ([], [])
+    if cfg["ret_inter"] and cfg["method"] != "adaptive":
+        ro, ri = ro
+        eo, ei = eo
+    if ro.dtype != eo.dtype:
+        bad.append("result dtype %s vs %s" % (ro.dtype, eo.dtype))
+    if tuple(ro.shape) != tuple(eo.shape):
+        bad.append("result shape %s vs %s" % (tuple(ro.shape), tuple(eo.shape)))
+        return bad
+    if not bool(torch.isfinite(ro.float()).all()):
+        return bad                                      # the reference itself diverged
+    peak = max([float(ro.double().abs().max())] + [float(t.double().abs().max()) for t in ri]) or 1.0
+    half = cfg["xdt"] in ("f16", "bf16") and cfg["schedule"] == "vp_linear"
+    tol = (6e-2 if cfg["xdt"] == "bf16" else 8e-3) if half else (1e-5 if ro.dtype != torch.float64 or cfg["xdt"] != "f64" else 4e-6)
+    err = float((ro.double() - eo.double()).abs().max()) / peak
+    if err > tol:
+        bad.append("values: %.3g of the peak (tolerance %.1g)" % (err, tol))
+    if len(ri) != len(ei):
+        bad.append("%d vs %d intermediates" % (len(ri), len(ei)))
+    else:
+        for k, (a, b) in enumerate(zip(ri, ei)):
+            if a.dtype != b.dtype:
+                bad.append("intermediate %d dtype %s vs %s" % (k, a.dtype, b.dtype))
+                break
+            if float((a.double() - b.double()).abs().max()) / peak > tol:
+                bad.append("intermediate %d values" % k)
+                break
+    if not half and cfg["method"] != "adaptive":
+        rt, et = r[2], e[2]
+        if len(rt) != len(et):
+            bad.append("network calls %d vs %d" % (len(rt), len(et)))
+        else:
+            for k, (a, b) in enumerate(zip(rt, et)):
+                if a[0] != b[0] or a[2:4] != b[2:4] or abs(a[4] - b[4]) > 2e-3 or a[1] != b[1]:
+                    bad.append("network call %d: %s vs %s" % (k, a, b))
+                    break
+    return bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=1500)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    n_bad = n_raise = 0
+    kinds = {}
+    import contextlib
+    import io
+    for i in range(args.cases):
+        cfg = random_case(rng)
+        if cfg["thresholding"] and cfg["algorithm_type"] == "dpmsolver":
+            cfg["thresholding"] = False
+        g = torch.Generator().manual_seed(cfg["seed"])
+        x = torch.randn(cfg["shape"], generator=g)
+        x = x.to({"f32": torch.float32, "f64": torch.float64, "f16": torch.float16, "bf16": torch.bfloat16}[cfg["xdt"]])
+        if cfg["noncontig"] and x.dim() >= 2:
+            x = x.transpose(0, 1).contiguous().transpose(0, 1)
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = run(R, ref_schedule(cfg["schedule"]), cfg, x)
+            e = run(D, eng_schedule(cfg["schedule"]), cfg, x)
+        n_raise += r[0] == "raise"
+        bad = compare(cfg, r, e)
+        if bad:
+            n_bad += 1
+            kinds[bad[0].split(":")[0][:40]] = kinds.get(bad[0].split(":")[0][:40], 0) + 1
+            print("case %d: %s\n    %s" % (i, {k: v for k, v in cfg.items() if k != "seed"}, "\n    ".join(bad)), flush=True)
+            if e[0] == "raise" and r[0] != "raise":
+                print("    " + e[3].replace("\n", "\n    "))
+    print("%d cases, %d where the reference raised, %d disagreements %s" % (args.cases, n_raise, n_bad, kinds))
+
+
+if __name__ == "__main__":
+    main()
