@@ -289,6 +289,14 @@ def wrap_model(model, sch, model_type="noise", guidance_type="uncond", condition
             c_in = np.concatenate([unconditional_condition, condition])
             both = noise_pred(x_in, t_in, cond=c_in)
             nu, nc = both[: x.shape[0]], both[x.shape[0]:]
+            if both.dtype == np.float16 and model_type == "noise":
+                # a half-precision noise network: the reference blends on the network's own tensors (ref :330) -- three
+                # half operations, each computed in fp32 and rounded once (torch's opmath; the Python-float scale is an fp32
+                # scalar there, NOT rounded to half).  The result stays a half tensor, like the reference's.
+                F16 = np.float16
+                d = (nc.astype(F32) - nu.astype(F32)).astype(F16)
+                p = (F32(guidance_scale) * d.astype(F32)).astype(F16)
+                return (nu.astype(F32) + p.astype(F32)).astype(F16)
             return (nu + F32(guidance_scale) * (nc - nu)).astype(F32)
         raise AssertionError(guidance_type)
 
