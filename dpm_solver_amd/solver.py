@@ -542,6 +542,10 @@ class DPM_Solver:
             elif method in ['multistep', 'singlestep', 'singlestep_fixed']:
                 if method == 'multistep':
                     assert steps >= order                       # (the reference's first check, ref :1172)
+                elif method == 'singlestep' and order not in (1, 2, 3):
+                    raise ValueError("'order' must be '1' or '2' or '3'.")    # ref :533, before the grid is built
+                elif method == 'singlestep_fixed':
+                    steps // order                              # ref :1218: K = steps // order (ZeroDivisionError for order 0)
                 if skip_type not in L.SKIP:
                     raise ValueError("Unsupported skip_type {}, need to be 'logSNR' or 'time_uniform' or 'time_quadratic'".format(skip_type))
                 plan_solver_type = solver_type

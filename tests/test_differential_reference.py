@@ -625,3 +625,19 @@ def test_half_precision_noise_network_follows_the_reference_s_half_arithmetic(R,
                 assert float(d.max()) <= 4 * flip * peak, (mt, skw, akw, float(d.max()) / peak)
             n_exact += int(torch.equal(got, want))
     assert n_exact >= 4, n_exact          # the 2M trajectories (and most others) are bit-identical to the reference
+
+
+def test_drop_in_fuzz_slice(R, monkeypatch, capsys):
+    """250 cases of tools/fuzz_dropin.py (one seed; the tool runs thousands): random corners of sample() / inverse() -- state
+    shapes of 1 to 5 dimensions, batch 1, non-contiguous and half / double x_T, steps below the order, orders 0 and 4, unknown
+    skip / solver types, every method incl. adaptive -- against the live reference: same exception type and text or same
+    dtype, shape, values, intermediates and network-call trace.  Cases where the fp32 reference is as far from its own
+    double-precision run as the two codes are from each other count as ill-conditioned, not as disagreements."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_dropin as FZ
+    monkeypatch.setattr(sys, "argv", ["fuzz_dropin.py", "--cases", "250", "--seed", "11"])
+    monkeypatch.setattr(FZ, "install", lambda mp=None: None)         # this module's autouse fixture has installed the double
+    n_bad = FZ.main()
+    out = capsys.readouterr().out
+    assert n_bad == 0, out[-3000:]
+    assert "250 cases" in out
