@@ -234,7 +234,7 @@ def main():
         import signal
         import time
 
-        class _Slow(Exception):
+        class _Slow(BaseException):
             pass
 
         def _alarm(sig, frm):
