@@ -166,6 +166,8 @@ def compare(cfg, r, e, yardstick=None, half_yardstick=None):
     peak = max([float(ro.double().abs().max())] + [float(t.double().abs().max()) for t in ri]) or 1.0
     half = cfg["xdt"] in ("f16", "bf16") and cfg["schedule"] == "vp_linear"
     tol = (0.15 if cfg["xdt"] == "bf16" else 2e-2) if half else (1e-5 if ro.dtype != torch.float64 or cfg["xdt"] != "f64" else 6e-6)
+    if cfg["method"] == "adaptive" and cfg["xdt"] in ("f16", "bf16"):
+        tol = max(tol, 5e-2)        # the reference's loop scalars (t, h, atol) are half until the first accepted step: INTEGRATION.md
     err = float((ro.double() - eo.double()).abs().max()) / peak
     if err > tol and yardstick is not None and ro.dtype == torch.float32:
         # the judge's yardstick: how far is the fp32 reference from ITS OWN double-precision run?  A case
