@@ -1,6 +1,6 @@
 // dpm_device.hpp -- gfx950 (MI355X, CDNA4) device code of the DPM-Solver engine: element types, the fused stage
 // kernels (streaming + dynamic thresholding) and their launch plumbing, in five parts included at the end of this
-// file (dpm_access.hpp, dpm_stage_kernel.hpp, dpm_thresh_kernel.hpp, dpm_aux_kernels.hpp, dpm_launch.hpp).  Included by
+// file (dpm_access.hpp, dpm_stage_kernel.hpp, dpm_thresh_{common,select,kernel}.hpp, dpm_aux_kernels.hpp, dpm_launch.hpp).  Included by
 // two translation units per (state dtype, eps dtype) pair (dpm_stage_*.hip) so the instantiation matrix compiles in
 // parallel, and by dpm_kernels.hip (C ABI entry points, add_noise, adaptive error norm, calibration).
 //
@@ -131,6 +131,8 @@ const void* dpm_catchall_scalar();
 
 #include "dpm_access.hpp"
 #include "dpm_stage_kernel.hpp"
+#include "dpm_thresh_common.hpp"
+#include "dpm_thresh_select.hpp"
 #include "dpm_thresh_kernel.hpp"
 #include "dpm_aux_kernels.hpp"
 #include "dpm_launch.hpp"
