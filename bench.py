@@ -23,7 +23,7 @@ half over its first half (a throttling check).
 
 Back-to-back fused launches are also the CONSERVATIVE regime: each launch finds the write-back Infinity Cache full of its
 predecessor's dirty stores and pays for them; behind a real network (reads) the cache is clean, absorbs up to 256 MB of the
-launch's stores and the same launch is 12-14 % shorter (tools/duty_cycle.py, profiles/r03_in_loop.md).  Every byte of the
+launch's stores and the same launch is 12-14 % shorter (tools/history/duty_cycle.py, profiles/r03_in_loop.md).  Every byte of the
 timed region is paid for inside it.
 
 One JSON line on rank 0:
