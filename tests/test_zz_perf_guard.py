@@ -10,8 +10,10 @@ on MI355X boxes (profiles/r06_perf_guard.md: ten runs on two boxes, plus the spr
   small_stage     [8,4,64,64] fp32 2M stages back to back, hipGraph-replayed (latency-bound): <= SMALL_STAGE_MAX_US
 
 The captured (hipGraph) form is used for the two small cases so that the figure is the GPU's, not the Python host's.  A
-shared or throttled box can be slower than any kernel regression: every figure is the best of three short regions, and the
-test prints what it measured (`pytest -s`) so that a failure shows by how much.
+shared or throttled box can be slower than any kernel regression: every figure is the best of three short regions, a figure
+that misses its threshold is measured again (up to three attempts, a second apart) before the test fails, and the test prints
+what it measured (`pytest -s`) so that a failure shows by how much.  The file sorts LAST in the suite (test_zz_*): the
+driver runs `pytest -x`, and a noisy box must not keep the bit-parity tests from running.
 """
 import ctypes as C
 import os
@@ -72,6 +74,17 @@ def _requests(R, dev):
     return rbs, keep
 
 
+def _attempts(measure, ok, n=3):
+    """measure() until ok(result) or n attempts; returns the last result"""
+    res = None
+    for k in range(n):
+        res = measure()
+        if ok(res):
+            break
+        time.sleep(1.0)
+    return res
+
+
 def test_fused_and_lone_launch_of_the_headline_workload(dev):
     import bench
     import dpm_solver_amd as D
@@ -90,33 +103,40 @@ def test_fused_and_lone_launch_of_the_headline_workload(dev):
     with torch.cuda.stream(stream):
         for _ in range(2):
             L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, R, sptr, None, res))
-        best = None
-        for _ in range(3):
-            torch.cuda.synchronize(dev)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            for _ in range(4):                                    # 80 fused launches, ~17 ms
-                L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, R, sptr, None, res))
-            e1.record(stream)
-            torch.cuda.synchronize(dev)
-            us = e0.elapsed_time(e1) * 1e3 / 4
-            best = us if best is None else min(best, us)
+
+        def fused():
+            best = None
+            for _ in range(3):
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(4):                                # 80 fused launches, ~17 ms
+                    L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, R, sptr, None, res))
+                e1.record(stream)
+                torch.cuda.synchronize(dev)
+                us = e0.elapsed_time(e1) * 1e3 / 4
+                best = us if best is None else min(best, us)
+            return best
+        best = _attempts(fused, lambda us: traj_bytes / us / 1e3 / 8000.0 >= FUSED_MIN_FRAC)
         frac = traj_bytes / best / 1e3 / 8000.0
         RESULTS["fused_frac"] = round(frac, 4)
         RESULTS["fused_launch_us"] = round(best / n_st, 2)
         # the same requests, one launch each, kernel-only (start -> stop events of every launch)
         opts = L.LaunchOpts()
         opts.no_fuse = 1
-        rbs[0].opts = C.pointer(opts)
         ms = (C.c_float * (R * n_st))()
-        cold = []
-        for _ in range(2):
-            L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, R, sptr, ms, res))
-            cold.append(np.frombuffer(ms, dtype=np.float32).reshape(R, n_st)[:, 1:n_st - 1].astype(np.float64) * 1e3)
-        rbs[0].opts = None
-        cold = np.concatenate(cold)
-        med = float(np.median(cold))
-        lone = float(cold[cold < 50.0 * med].mean())
+
+        def lone_cold():
+            rbs[0].opts = C.pointer(opts)
+            cold = []
+            for _ in range(2):
+                L.check(L.lib.dpm_plan_run_multi(plan.handle, rbs, R, sptr, ms, res))
+                cold.append(np.frombuffer(ms, dtype=np.float32).reshape(R, n_st)[:, 1:n_st - 1].astype(np.float64) * 1e3)
+            rbs[0].opts = None
+            cold = np.concatenate(cold)
+            med = float(np.median(cold))
+            return float(cold[cold < 50.0 * med].mean())
+        lone = _attempts(lone_cold, lambda us: us <= LONE_COLD_MAX_US)
         RESULTS["lone_cold_us"] = round(lone, 3)
     print("\n[perf guard] fused: %.4f of 8 TB/s (%.1f us per launch); lone cold launch: %.2f us" % (frac, best / n_st, lone))
     assert frac >= FUSED_MIN_FRAC, "fused 32-request 2M launch: %.4f of peak < %.2f" % (frac, FUSED_MIN_FRAC)
@@ -126,11 +146,13 @@ def test_fused_and_lone_launch_of_the_headline_workload(dev):
 def test_small_and_thresholded_stages(dev):
     import config_bench
     t0 = time.perf_counter()
-    small = config_bench.measure_frozen("cfg1", dev, captured=True, scale_k=0.25)
-    thr = config_bench.measure_frozen("cfg5", dev, captured=True, scale_k=0.25)
+    cap = lambda r: r["captured"]["us_per_stage"]
+    small = _attempts(lambda: config_bench.measure_frozen("cfg1", dev, captured=True, scale_k=0.25), lambda r: cap(r) <= SMALL_STAGE_MAX_US)
+    thr = _attempts(lambda: config_bench.measure_frozen("cfg5", dev, captured=True, scale_k=0.25), lambda r: cap(r) <= CFG5_STAGE_MAX_US)
     # under capture a sample that fits one workgroup takes the cluster-free shape by default; the eager loop -- what
     # sample() runs -- uses k = 6 workgroup clusters per sample here: the guard watches that kernel too (cluster_in_graph)
-    thr_k = config_bench.measure_frozen("cfg5", dev, captured=True, scale_k=0.25, attrs=dict(cluster_in_graph=True))
+    thr_k = _attempts(lambda: config_bench.measure_frozen("cfg5", dev, captured=True, scale_k=0.25, attrs=dict(cluster_in_graph=True)),
+                      lambda r: cap(r) <= CFG5_CLUSTERED_MAX_US)
     RESULTS["cfg5_stage_clustered_us"] = thr_k["captured"]["us_per_stage"]
     RESULTS["small_stage_us"] = small["captured"]["us_per_stage"]
     RESULTS["small_stage_eager_us"] = small["us_per_stage"]

@@ -5,7 +5,7 @@
 #   tests        the GPU suite (pytest -m gpu), timed
 #   smoke        __graft_entry__.smoke()
 #   bench        the default bench line (what the driver runs), timed
-#   guard5       tests/test_gpu_perf_guard.py five times (its record: perf_guard.jsonl)
+#   guard5       tests/test_zz_perf_guard.py five times (its record: perf_guard.jsonl)
 #   torchrun1    the driver's N > 1 launch line with one rank (RCCL communicator, preflight, all-gather) + --preflight alone
 #   configs      tools/config_bench.py: figures + rocprofv3 kernel rows per BASELINE configuration (frozen model_fn, product library)
 #   configsloop  the same cases inside a conv-network loop, kernel-only (lab build)
@@ -42,7 +42,7 @@ PY
 guard5)
   rm -f gpurun_out/perf_guard.jsonl
   for i in 1 2 3 4 5; do
-    ( time timeout 300 python -m pytest tests/test_gpu_perf_guard.py -m gpu -q -s -p no:cacheprovider ) > $O/guard_$i.log 2>&1; echo "guard $i rc=$? $(grep -E 'passed|failed' $O/guard_$i.log | tail -1) $(grep real $O/guard_$i.log)"
+    ( time timeout 300 python -m pytest tests/test_zz_perf_guard.py -m gpu -q -s -p no:cacheprovider ) > $O/guard_$i.log 2>&1; echo "guard $i rc=$? $(grep -E 'passed|failed' $O/guard_$i.log | tail -1) $(grep real $O/guard_$i.log)"
   done
   cp gpurun_out/perf_guard.jsonl $O/perf_guard.jsonl 2>/dev/null; cat $O/perf_guard.jsonl ;;
 torchrun1)
