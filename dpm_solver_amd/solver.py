@@ -193,6 +193,48 @@ class DPM_Solver:
         ns = self.noise_schedule
         return bool(tf64 or (ns.schedule == 'discrete' and getattr(ns, "dtype", torch.float32) == torch.float64)), tf64
 
+    def _out_double(self, x, times=(), models=(), evaluates=False):
+        """Is the RESULT of a public per-update call a double tensor?  (Whether its SCALARS are doubles is _double_call's
+        question: a double time makes them so.)  torch's type promotion: x or a model value handed in is double; a coefficient
+        is a DIMENSIONED double tensor -- every scalar of a 'discrete' schedule is (1,)-shaped (ref :130), on a continuous one
+        a scalar has its time argument's shape, so a 0-dim double time does not promote an fp32 tensor; or a model evaluation
+        inside the call converts with alpha_t / sigma_t of the time expanded to the batch (x_start / v / score, classifier)."""
+        if self._sdtype(x) is torch.float64 or any(m is not None and m.dtype is torch.float64 for m in models):
+            return True
+        ns = self.noise_schedule
+        disc = ns.schedule == 'discrete'
+        if disc and getattr(ns, "dtype", torch.float32) == torch.float64:
+            return True
+        t64 = [t for t in times if torch.is_tensor(t) and t.dtype is torch.float64]
+        if any(disc or t.dim() >= 1 for t in t64):
+            return True
+        if t64 and evaluates:
+            mt, gd, _ = self._model_codes()
+            return mt != L.MODEL["noise"] or gd == L.GUIDE["classifier"]
+        return False
+
+    def _call_sdtype(self, x, times=(), models=(), evaluates=False):
+        """State dtype of ONE public per-update call (the fp32 / half side; doubles are _double_call's).  _sdtype(x), widened
+        by what torch's type promotion does to the reference's expression: model values handed in by the caller take part
+        as they are; and a half state on a CONTINUOUS schedule -- kept by 0-dim coefficients -- becomes fp32 as soon as a
+        coefficient is a dimensioned tensor: a time argument of shape (1,) (ref :553-590: every scalar inherits its shape), or
+        a model evaluation inside the call whose conversions multiply by alpha_t / sigma_t expanded to the batch (x_start / v /
+        score networks, the classifier term: ref :290-298, :320)."""
+        sd = self._sdtype(x)
+        if self._state_dtype is not None:
+            return sd
+        for m in models:
+            if m is not None and m.dtype in DV._DT and m.dtype is not torch.float64:
+                sd = torch.promote_types(sd, m.dtype)
+        if sd in (torch.float16, torch.bfloat16):
+            wide = any(torch.is_tensor(t) and t.dim() >= 1 for t in times)
+            if evaluates and not wide:
+                mt, gd, _ = self._model_codes()
+                wide = mt != L.MODEL["noise"] or gd == L.GUIDE["classifier"]
+            if wide:
+                sd = torch.float32
+        return sd
+
     def _time_views(self, plan, device, batch, cfg):
         """plan.time_views; a network that was caught writing into the shared time vectors gets clones from now on"""
         V = plan.time_views(device, batch, cfg)
@@ -382,8 +424,8 @@ class DPM_Solver:
 
     def dpm_solver_first_update(self, x, s, t, model_s=None, return_intermediate=False):
         """DPM-Solver-1 (equivalent to DDIM) from time `s` to time `t` (ref :547-592)."""
-        stages, c64s, tf64 = self._singlestep_stages(x, 1, 0, s, t, 0., 0., 0)
-        x_t, ms = self._exec_single(stages, x, {0: model_s} if model_s is not None else {}, return_intermediate, c64s, tf64)
+        stages, c64s, tf64 = self._singlestep_stages(x, 1, 0, s, t, 0., 0., 0, models=(model_s,))
+        x_t, ms = self._exec_single(stages, x, {0: model_s} if model_s is not None else {}, return_intermediate, c64s, tf64, times=(s, t))
         return (x_t, {'model_s': ms[0]}) if return_intermediate else x_t
 
     def singlestep_dpm_solver_second_update(self, x, s, t, r1=0.5, model_s=None, return_intermediate=False,
@@ -394,8 +436,11 @@ class DPM_Solver:
         if r1 is None:
             r1 = 0.5
         mode = 1 if torch.is_tensor(r1) else 0
-        stages, c64s, tf64 = self._singlestep_stages(x, 2, L.SOLVER[solver_type], s, t, r1 if mode else float(r1), 0., mode)
-        x_t, ms = self._exec_single(stages, x, {0: model_s} if model_s is not None else {}, return_intermediate, c64s, tf64)
+        stages, c64s, tf64 = self._singlestep_stages(x, 2, L.SOLVER[solver_type], s, t, r1 if mode else float(r1), 0., mode,
+                                                     models=(model_s,))
+        # (the intermediate time s1 comes out of inverse_lambda, (1,)-shaped on a 'linear' schedule, ref :161: dimensioned)
+        x_t, ms = self._exec_single(stages, x, {0: model_s} if model_s is not None else {}, return_intermediate, c64s, tf64,
+                                    times=(s, t, torch.zeros(1)))
         return (x_t, {'model_s': ms[0], 'model_s1': ms[1]}) if return_intermediate else x_t
 
     def singlestep_dpm_solver_third_update(self, x, s, t, r1=1. / 3., r2=2. / 3., model_s=None, model_s1=None,
@@ -409,7 +454,7 @@ class DPM_Solver:
             r2 = 2. / 3.
         mode = 1 if (torch.is_tensor(r1) or torch.is_tensor(r2)) else 0
         stages, c64s, tf64 = self._singlestep_stages(x, 3, L.SOLVER[solver_type], s, t, r1 if mode else float(r1),
-                                                     r2 if mode else float(r2), mode)
+                                                     r2 if mode else float(r2), mode, models=(model_s, model_s1))
         given = {}
         if model_s is not None:
             given[0] = model_s
@@ -419,7 +464,8 @@ class DPM_Solver:
             # reference: model_s is evaluated at (x, s) even when model_s1 is supplied (ref :720-721)
             given[0] = self.model_fn(x, s)
         # the taylor combination reads model_s1 (h2): keep it even when not asked for
-        x_t, ms = self._exec_single(stages, x, given, return_intermediate or solver_type == 'taylor', c64s, tf64)
+        x_t, ms = self._exec_single(stages, x, given, return_intermediate or solver_type == 'taylor', c64s, tf64,
+                                    times=(s, t, torch.zeros(1)))
         return (x_t, {'model_s': ms[0], 'model_s1': ms[1], 'model_s2': ms[2]}) if return_intermediate else x_t
 
 
@@ -488,7 +534,8 @@ class DPM_Solver:
         # declared dtype=float64 -- or x / noise is, torch's type promotion makes the result float64.  Double scalars are
         # evaluated in double at the double times; fp32 scalars meeting a double tensor are converted exactly.
         wide = dbl or x.dtype is torch.float64 or noise.dtype is torch.float64
-        xdt = torch.float64 if wide else x.dtype
+        # (alpha_t / sigma_t are fp32 tensors of shape (nt,): half x / noise are promoted to fp32 as well)
+        xdt = torch.float64 if wide else torch.promote_types(torch.promote_types(x.dtype, noise.dtype), torch.float32)
         th = t.detach().to(device="cpu", dtype=torch.float64 if dbl else torch.float32).reshape(-1).numpy().copy()
         out = DV._add_noise(self._h, x.to(xdt).contiguous(), noise.to(xdt).contiguous(), th)
         return out.squeeze(0) if nt == 1 else out

@@ -641,3 +641,18 @@ def test_drop_in_fuzz_slice(R, monkeypatch, capsys):
     out = capsys.readouterr().out
     assert n_bad == 0, out[-3000:]
     assert "250 cases" in out
+
+
+def test_drop_in_fuzz_slice_of_the_public_methods(R, monkeypatch, capsys):
+    """400 random calls of the public per-update methods, the model evaluations, add_noise, the time grids, thresholding,
+    the schedule's functions and interpolate_fn (tools/fuzz_dropin.py --mode methods: time tensors 0-dim / (1,)-shaped, fp32 /
+    double, half / fp32 / double states, model values handed in or not, r1 / r2 as floats, tensors or None, orders 0 to 4)
+    against the live reference: same exception or same dtype, shape and values -- torch's type promotion operand by operand."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_dropin as FZ
+    monkeypatch.setattr(sys, "argv", ["fuzz_dropin.py", "--mode", "methods", "--cases", "400", "--seed", "0"])
+    monkeypatch.setattr(FZ, "install", lambda mp=None: None)
+    n_bad = FZ.main()
+    out = capsys.readouterr().out
+    assert n_bad == 0, out[-3000:]
+    assert "400 method calls" in out

@@ -208,13 +208,193 @@ def compare(cfg, r, e, yardstick=None, half_yardstick=None):
     return bad
 
 
+# ------------------------------------------------------------------------------------------------
+# mode "methods": the public per-update methods, the schedule's functions and the helpers, one random call each
+# ------------------------------------------------------------------------------------------------
+def _tens(rng, shape, dt):
+    return torch.from_numpy(rng.standard_normal(shape)).to(dt)
+
+
+def random_method_call(rng):
+    """(name, builder): builder(mod, ns, dpm) -> the call's result; the same random arguments for either module"""
+    sched = str(rng.choice(["sd", "ddpm", "vp_linear", "cosine1000"]))
+    shape = SHAPES[int(rng.integers(0, len(SHAPES)))]
+    xdt = {"f32": torch.float32, "f64": torch.float64, "f16": torch.float16}[str(rng.choice(["f32", "f32", "f32", "f64", "f16"]))]
+    tdt = torch.float64 if rng.random() < 0.15 else torch.float32
+    algo = str(rng.choice(["dpmsolver++", "dpmsolver"]))
+    mt = str(rng.choice(["noise", "noise", "x_start", "v", "score"]))
+    guid = str(rng.choice(["uncond", "uncond", "classifier-free", "classifier"]))
+    thr = bool(rng.integers(0, 5) == 0) and algo == "dpmsolver++"
+    seed = int(rng.integers(0, 1 << 30))
+    tshape = [(1,), (), (1,)][int(rng.integers(0, 3))]
+    ts = sorted(rng.uniform(0.02, 0.98, size=4).tolist(), reverse=True)
+    solver_type = str(rng.choice(["dpmsolver", "taylor", "bogus"], p=[0.5, 0.45, 0.05]))
+    what = str(rng.choice(["first", "ss2", "ss3", "ms2", "ms3", "ss_disp", "ms_disp", "noise_fn", "data_fn", "model_fn", "denoise", "add_noise",
+                           "time_steps", "orders", "thresh", "marginals", "inv_lambda", "interp"]))
+    r_kind = str(rng.choice(["default", "float", "tensor", "none"]))
+    given = int(rng.integers(0, 4))
+    ret_i = bool(rng.integers(0, 2))
+    order = int(rng.choice([1, 2, 3, 0, 4], p=[0.3, 0.3, 0.3, 0.05, 0.05]))
+    nt = int(rng.integers(1, 4))
+    cfg = dict(what=what, schedule=sched, shape=shape, xdt=str(xdt)[6:], tdt=str(tdt)[6:], algorithm_type=algo, model_type=mt, guidance=guid, thr=thr,
+               tshape=tshape, solver_type=solver_type, r=r_kind, given=given, ret_inter=ret_i, order=order, nt=nt)
+
+    def call(mod, ns, util):
+        g = np.random.default_rng(seed)
+        x = _tens(g, shape, xdt)
+        tt = lambda v: torch.full(tshape, v, dtype=tdt)
+        c = dict(method="multistep", order=2, steps=5, shape=shape, schedule=sched, skip_type="time_uniform", solver_type="dpmsolver",
+                 algorithm_type=algo, model_type=mt, guidance=guid, scale=2.5, thresholding=thr, cxt=False, cx0=False)
+        trace = []
+        dpm = build(mod, ns, c, x, trace)
+        s_, t_ = tt(ts[1]), tt(ts[2])
+        r1 = {"default": 0.5, "float": 0.37, "tensor": torch.tensor(0.41), "none": None}[r_kind]
+        r2 = {"default": 2. / 3., "float": 0.71, "tensor": torch.tensor(0.77), "none": None}[r_kind]
+        if what == "first":
+            ms = dpm.model_fn(x, s_) if given & 1 else None
+            return dpm.dpm_solver_first_update(x, s_, t_, model_s=ms, return_intermediate=ret_i)
+        if what == "ss2":
+            ms = dpm.model_fn(x, s_) if given & 1 else None
+            kw = {} if r_kind == "default" else dict(r1=r1)
+            return dpm.singlestep_dpm_solver_second_update(x, s_, t_, model_s=ms, return_intermediate=ret_i, solver_type=solver_type, **kw)
+        if what == "ss3":
+            ms = dpm.model_fn(x, s_) if given & 1 else None
+            ms1 = dpm.model_fn(x * 0.9, tt(ts[1] * 0.9 + ts[2] * 0.1)) if given & 2 else None
+            kw = {} if r_kind == "default" else dict(r1=(r1 if r1 is None else r1 * 0.6), r2=r2)
+            return dpm.singlestep_dpm_solver_third_update(x, s_, t_, model_s=ms, model_s1=ms1, return_intermediate=ret_i,
+                                                          solver_type=solver_type, **kw)
+        if what in ("ms2", "ms3", "ms_disp"):
+            tl = [tt(ts[0]), tt(ts[0] * 0.5 + ts[1] * 0.5), tt(ts[1])]
+            ml = [dpm.model_fn(x, v) for v in tl]
+            if what == "ms2":
+                return dpm.multistep_dpm_solver_second_update(x, ml[1:], tl[1:], t_, solver_type=solver_type)
+            if what == "ms3":
+                return dpm.multistep_dpm_solver_third_update(x, ml, tl, t_, solver_type=solver_type)
+            return dpm.multistep_dpm_solver_update(x, ml, tl, t_, order, solver_type=solver_type)
+        if what == "ss_disp":
+            return dpm.singlestep_dpm_solver_update(x, s_, t_, order, return_intermediate=ret_i, solver_type=solver_type)
+        if what == "noise_fn":
+            return dpm.noise_prediction_fn(x, s_)
+        if what == "data_fn":
+            return dpm.data_prediction_fn(x, s_)
+        if what == "model_fn":
+            return dpm.model_fn(x, s_)
+        if what == "denoise":
+            return dpm.denoise_to_zero_fn(x, s_)
+        if what == "add_noise":
+            tv = torch.tensor(ts[:nt], dtype=tdt)
+            return dpm.add_noise(x, tv, noise=_tens(g, (nt,) + tuple(shape), xdt))
+        if what == "time_steps":
+            sk = str(np.random.default_rng(seed).choice(["time_uniform", "logSNR", "time_quadratic", "bogus"], p=[0.35, 0.3, 0.3, 0.05]))
+            return dpm.get_time_steps(sk, ts[0], ts[3] * 0.1 + 1e-3, int(seed % 12) + 1, "cpu")
+        if what == "orders":
+            sk = str(np.random.default_rng(seed).choice(["time_uniform", "logSNR", "time_quadratic"]))
+            t_, o_ = dpm.get_orders_and_timesteps_for_singlestep_solver(int(seed % 14) + 1, order, sk, ts[0], ts[3] * 0.1 + 1e-3, "cpu")
+            return (t_, torch.tensor(o_))
+        if what == "thresh":
+            return mod.DPM_Solver(dpm.model if False else (lambda a, b: a), ns, correcting_x0_fn="dynamic_thresholding",
+                                  dynamic_thresholding_ratio=float(0.9 + 0.099 * g.random()), thresholding_max_val=float(g.choice([1.0, 0.5, 2.0]))
+                                  ).dynamic_thresholding_fn(x.float() * 2, None)
+        tv = torch.tensor(g.uniform(0.001, 0.999, size=tuple(int(v) for v in g.integers(1, 4, size=int(g.integers(1, 3))))), dtype=tdt)
+        if what == "marginals":
+            return (ns.marginal_log_mean_coeff(tv), ns.marginal_alpha(tv), ns.marginal_std(tv), ns.marginal_lambda(tv))
+        if what == "inv_lambda":
+            return ns.inverse_lambda(ns.marginal_lambda(tv))
+        if what == "interp":
+            xp = torch.sort(torch.from_numpy(g.uniform(0, 1, size=(1, 9))).float(), dim=1)[0]
+            yp = torch.from_numpy(g.standard_normal((1, 9))).float()
+            xq = torch.from_numpy(g.uniform(-0.2, 1.2, size=(5, 1))).float()
+            return util.interpolate_fn(xq, xp, yp)
+        raise AssertionError(what)
+    return cfg, call
+
+
+def _flatten(o):
+    if torch.is_tensor(o):
+        return [o]
+    if isinstance(o, dict):
+        return [v for k in sorted(o) for v in _flatten(o[k])]
+    if isinstance(o, (tuple, list)):
+        return [v for it in o for v in _flatten(it)]
+    return [] if o is None else [torch.as_tensor(o)]
+
+
+def fuzz_methods(args):
+    import contextlib
+    import io
+    import dpm_solver_amd.utils as U
+    rng = np.random.default_rng(args.seed)
+    n_bad = n_raise = 0
+    kinds = {}
+    for i in range(args.cases):
+        cfg, call = random_method_call(rng)
+        res = []
+        for mod, mk, util in ((R, ref_schedule, R), (D, eng_schedule, U)):
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    res.append(("ok", call(mod, mk(cfg["schedule"]), util)))
+            except Exception as ex:                     # noqa: BLE001
+                res.append(("raise", (type(ex).__name__, str(ex)[:160]), traceback.format_exc(limit=4)))
+        r, e = res
+        n_raise += r[0] == "raise"
+        bad = []
+        if r[0] == "raise" and r[1][0] in ("RuntimeError", "IndexError", "TypeError", "UnboundLocalError", "AttributeError"):
+            continue                                    # the reference crashed on its own terms
+        if r[0] != e[0]:
+            bad.append("reference %s, engine %s: %s | %s" % (r[0], e[0], r[1] if r[0] == "raise" else "", e[1] if e[0] == "raise" else ""))
+        elif r[0] == "raise":
+            if r[1][0] != e[1][0] or (r[1][1] != e[1][1] and r[1][0] == "ValueError" and "unpack" not in r[1][1]):
+                bad.append("exception %s vs %s" % (r[1], e[1]))
+        else:
+            ra, ea = _flatten(r[1]), _flatten(e[1])
+            if len(ra) != len(ea):
+                bad.append("%d vs %d tensors returned" % (len(ra), len(ea)))
+            for k, (a, b) in enumerate(zip(ra, ea)):
+                if k > 0 and isinstance(r[1], tuple) and isinstance(r[1][-1], dict) and a.dtype != b.dtype and tuple(a.shape) == tuple(b.shape):
+                    # a model value handed back by return_intermediate: the reference returns the raw network output in the
+                    # network's dtype, the engine the stored copy in the state's dtype -- same values
+                    if float((a.double() - b.double()).abs().max()) <= 1e-6 * (float(a.double().abs().max()) or 1.0):
+                        continue
+                if a.dtype != b.dtype or tuple(a.shape) != tuple(b.shape):
+                    bad.append("tensor %d: %s %s vs %s %s" % (k, a.dtype, tuple(a.shape), b.dtype, tuple(b.shape)))
+                    break
+                if not bool(torch.isfinite(a.double()).all()):
+                    continue
+                pk = float(a.double().abs().max()) or 1.0
+                tol = 1e-10 if a.dtype == torch.float64 and cfg["tdt"] == "float64" else (5e-6 if a.dtype == torch.float64 else (1e-5 if a.dtype == torch.float32 else 8e-3))
+                if cfg["xdt"] == "float16":
+                    tol = max(tol, 8e-3)        # a half x: the reference's partial sums are half operations (INTEGRATION.md)
+                elif a.dtype == torch.float64 and cfg["xdt"] == "float32":
+                    tol = max(tol, 2e-7)        # a double result from an fp32 x: the reference's `coefficient * x` is still an fp32
+                                                # product where the coefficient is 0-dim; the engine's whole expression is double
+                elif a.dtype == torch.float64:
+                    tol = max(tol, 1e-9)
+                err = float((a.double() - b.double()).abs().max()) / pk
+                if err > tol:
+                    bad.append("tensor %d values: %.3g (tolerance %.1g)" % (k, err, tol))
+                    break
+        if bad:
+            n_bad += 1
+            kinds[cfg["what"]] = kinds.get(cfg["what"], 0) + 1
+            print("call %d: %s\n    %s" % (i, cfg, "\n    ".join(bad)), flush=True)
+            if e[0] == "raise" and r[0] != "raise":
+                print("    " + e[2].replace("\n", "\n    "))
+    print("%d method calls, %d where the reference raised, %d disagreements %s" % (args.cases, n_raise, n_bad, kinds))
+    return n_bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=1500)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--case-timeout", type=int, default=60)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--mode", default="sample", choices=["sample", "methods"])
     args = ap.parse_args()
+    if args.mode == "methods":
+        install()
+        torch.set_num_threads(1)
+        return fuzz_methods(args)
     rng = np.random.default_rng(args.seed)
     n_bad = n_raise = n_slow = n_cond = 0
     install()
