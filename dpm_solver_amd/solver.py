@@ -424,7 +424,7 @@ class DPM_Solver:
 
     def dpm_solver_first_update(self, x, s, t, model_s=None, return_intermediate=False):
         """DPM-Solver-1 (equivalent to DDIM) from time `s` to time `t` (ref :547-592)."""
-        stages, c64s, tf64 = self._singlestep_stages(x, 1, 0, s, t, 0., 0., 0, models=(model_s,))
+        stages, c64s, tf64 = self._singlestep_stages(x, 1, 0, s, t, 0., 0., 0)
         x_t, ms = self._exec_single(stages, x, {0: model_s} if model_s is not None else {}, return_intermediate, c64s, tf64, times=(s, t))
         return (x_t, {'model_s': ms[0]}) if return_intermediate else x_t
 
@@ -436,8 +436,7 @@ class DPM_Solver:
         if r1 is None:
             r1 = 0.5
         mode = 1 if torch.is_tensor(r1) else 0
-        stages, c64s, tf64 = self._singlestep_stages(x, 2, L.SOLVER[solver_type], s, t, r1 if mode else float(r1), 0., mode,
-                                                     models=(model_s,))
+        stages, c64s, tf64 = self._singlestep_stages(x, 2, L.SOLVER[solver_type], s, t, r1 if mode else float(r1), 0., mode)
         # (the intermediate time s1 comes out of inverse_lambda, (1,)-shaped on a 'linear' schedule, ref :161: dimensioned)
         x_t, ms = self._exec_single(stages, x, {0: model_s} if model_s is not None else {}, return_intermediate, c64s, tf64,
                                     times=(s, t, torch.zeros(1)))
@@ -454,7 +453,7 @@ class DPM_Solver:
             r2 = 2. / 3.
         mode = 1 if (torch.is_tensor(r1) or torch.is_tensor(r2)) else 0
         stages, c64s, tf64 = self._singlestep_stages(x, 3, L.SOLVER[solver_type], s, t, r1 if mode else float(r1),
-                                                     r2 if mode else float(r2), mode, models=(model_s, model_s1))
+                                                     r2 if mode else float(r2), mode)
         given = {}
         if model_s is not None:
             given[0] = model_s

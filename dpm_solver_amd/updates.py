@@ -41,7 +41,8 @@ def eval_model(self, x, t, to_x0):
     if pure_noise:
         sd = outs[0].dtype if outs[0].dtype in DV._DT else torch.float32
     else:
-        sd = torch.float64 if (dbl and self._out_double(x, (t,), (), evaluates=True)) else self._call_sdtype(x, (t,), (), evaluates=True)
+        # (the scalars are doubles when `dbl`; whether the RESULT is double is torch's type promotion of the operands)
+        sd = torch.float64 if self._out_double(x, (t,), (), evaluates=True) else self._call_sdtype(x, (t,), (), evaluates=True)
         if not dbl and to_x0 and sd in (torch.float16, torch.bfloat16) and outs[0].dtype is torch.float32:
             sd = torch.float32
     out, _ = self._run_stage(st, None, x, outs, None, None, sd, t if torch.is_tensor(t) else self._tt(tf, dev), want_m=False,
@@ -57,7 +58,7 @@ def exec_single(self, stages, x, given, want, c64s=None, tf64=False, times=()):
     dev = x.device
     n_given = sum(1 for v in given.values() if v is not None)
     ev = n_given < len(stages)
-    sd = (torch.float64 if (c64s is not None and self._out_double(x, times, tuple(given.values()), evaluates=ev))
+    sd = (torch.float64 if self._out_double(x, times, tuple(given.values()), evaluates=ev)
           else self._call_sdtype(x, times, tuple(given.values()), evaluates=ev))
     mt, gd, sc = self._model_codes()
     k64 = lambda i, st_: (self._stage64(st_, c64s[i] if c64s is not None else None) if sd is torch.float64 else None)
@@ -95,10 +96,9 @@ def exec_single(self, stages, x, given, want, c64s=None, tf64=False, times=()):
     return x_t, ms
 
 
-def singlestep_stages(self, x, order, solver_code, s, t, r1, r2, mode, models=()):
+def singlestep_stages(self, x, order, solver_code, s, t, r1, r2, mode):
     """(stages, their doubles or None, the time tensors are doubles) of a singlestep update s -> t"""
     dbl, tf64 = self._double_call(x, s, t, r1, r2)
-    dbl = dbl or any(m is not None and m.dtype is torch.float64 for m in models)   # double model values handed in
     st = (L.Stage * order)()
     if not dbl:
         L.check(L.lib.dpm_coef_singlestep(self._h, self._algo, solver_code, order, self._tf(s), self._tf(t), r1 if not mode else
@@ -114,8 +114,6 @@ def multistep(self, x, model_prev_list, t_prev_list, t, order, solver_type):
     DV._require_gpu(x)
     st = L.Stage()
     dbl, tf64 = self._double_call(x, t, *t_prev_list[-order:])
-    # (model values handed in as doubles make the whole expression double, whatever the dtype of x and the times)
-    dbl = dbl or any(m is not None and m.dtype is torch.float64 for m in model_prev_list[-order:])
     c64 = None
     if dbl:
         tp = (C.c_double * order)(*[self._td(v) for v in t_prev_list[-order:]])
@@ -128,7 +126,7 @@ def multistep(self, x, model_prev_list, t_prev_list, t, order, solver_type):
     h1 = model_prev_list[-2] if order >= 2 else None
     h2 = model_prev_list[-3] if order >= 3 else None
     tms, mds = (t,) + tuple(t_prev_list[-order:]), tuple(model_prev_list[-order:])
-    sd = torch.float64 if (dbl and self._out_double(x, tms, mds)) else self._call_sdtype(x, tms, mds)
+    sd = torch.float64 if self._out_double(x, tms, mds) else self._call_sdtype(x, tms, mds)
     x_t, _ = self._run_given(st, x, model_prev_list[-1], h1, h2, sd, want_m=False,
                              coef64=self._stage64(st, c64) if sd is torch.float64 else None)
     return x_t
