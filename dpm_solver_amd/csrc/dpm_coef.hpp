@@ -49,8 +49,11 @@ DPM_HD inline F f_logaddexp(F a, F b) {
 
 // interpolate_fn (ref :1253-1292): piecewise-linear through (xp, yp), xp ascending, outermost segments
 // extended.  The reference locates the segment by sorting [x, xp]; a binary search finds the same one.
+// y_f32: a DOUBLE query on fp32 tables (a double time tensor on a schedule left at dtype=float32): `end_y - start_y`
+// (ref :1290) is then the one operation of the expression between two fp32 tensors -- an fp32 subtraction -- while the
+// x side went through the concatenation with the query (ref :1268) and is double.
 template <typename F>
-DPM_HD inline F interp(F x, const F* xp, const F* yp, int K) {
+DPM_HD inline F interp(F x, const F* xp, const F* yp, int K, bool y_f32 = false) {
   int lo = 0, hi = K;  // idx = #{xp < x} (std::lower_bound)
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
@@ -59,7 +62,8 @@ DPM_HD inline F interp(F x, const F* xp, const F* yp, int K) {
   const int idx = lo;
   int i0 = idx == 0 ? 0 : (idx == K ? K - 2 : idx - 1);
   int i1 = i0 + 1;
-  return yp[i0] + (x - xp[i0]) * (yp[i1] - yp[i0]) / (xp[i1] - xp[i0]);
+  const F dy = y_f32 ? (F)((float)yp[i1] - (float)yp[i0]) : yp[i1] - yp[i0];
+  return yp[i0] + (x - xp[i0]) * dy / (xp[i1] - xp[i0]);
 }
 DPM_HD inline float interp32(float x, const float* xp, const float* yp, int K) { return interp<float>(x, xp, yp, K); }
 
@@ -71,9 +75,10 @@ struct SchedViewT {
   int discrete, cosine, total_N;
   const F *la, *t, *la_rev, *t_rev;  // log_alpha_array / t_array (ref :105,:107) and their flipped copies (ref :166)
   double beta0, beta1, cos_s, cos_la0;
+  int tables_f32;  // the double view of a schedule whose tables the reference holds in fp32 (see interp)
 
   DPM_HD F log_alpha(F tt) const {  // marginal_log_mean_coeff, ref :127-134
-    if (discrete) return interp<F>(tt, t, la, total_N);
+    if (discrete) return interp<F>(tt, t, la, total_N, sizeof(F) == 8 && tables_f32);
     if (cosine) {  // legacy :135-137, one rounding per tensor-scalar operation
       const F a = (((tt + (F)cos_s) / (F)(1. + cos_s)) * (F)M_PI) / (F)2;
       return f_log(f_cos(a)) - (F)cos_la0;
@@ -98,7 +103,7 @@ struct SchedViewT {
       return tmp / (f_sqrt(delta) + (F)beta0) / (F)(beta1 - beta0);
     }
     F l = (F)-0.5 * f_logaddexp<F>((F)0, (F)-2 * lam);
-    return interp<F>(l, la_rev, t_rev, total_N);
+    return interp<F>(l, la_rev, t_rev, total_N, sizeof(F) == 8 && tables_f32);
   }
   // inverse_lambda of an fp32 TENSOR of lambdas (the logSNR grid: torch.linspace builds it in fp32, ref :470-472): the
   // reference's logaddexp then runs in fp32 (both of its operands are fp32 tensors, ref :165) and only the interpolation on
@@ -106,7 +111,7 @@ struct SchedViewT {
   DPM_HD F inv_lambda_of_f32(float lam) const {
     if (sizeof(F) == 4 || !discrete) return inv_lambda((F)lam);
     const float l = -0.5f * f_logaddexp<float>(0.f, -2.f * lam);
-    return interp<F>((F)l, la_rev, t_rev, total_N);
+    return interp<F>((F)l, la_rev, t_rev, total_N, sizeof(F) == 8 && tables_f32);
   }
 };
 typedef SchedViewT<float> SchedView;     // the fp32 view: the host planner's default and the device-side adaptive controller's
@@ -252,12 +257,14 @@ struct RT {
   bool tensor;
   DPM_HD F f() const { return (F)d; }
 };
+// (fp32 TENSORS r1 / r2: `0.5 / r1`, `r2 / r1`, `r2 - r1` are fp32 tensor operations in the reference whatever the dtype of
+// the rest of the expression -- also in a double-precision call, where only their fp32 result is widened)
 template <typename F>
-DPM_HD inline F r_div(double num, RT<F> r) { return r.tensor ? (F)num / r.f() : (F)(num / r.d); }
+DPM_HD inline F r_div(double num, RT<F> r) { return r.tensor ? (F)((float)num / (float)r.d) : (F)(num / r.d); }
 template <typename F>
-DPM_HD inline F r_ratio(RT<F> a, RT<F> b) { return (a.tensor) ? a.f() / b.f() : (F)(a.d / b.d); }
+DPM_HD inline F r_ratio(RT<F> a, RT<F> b) { return (a.tensor) ? (F)((float)a.d / (float)b.d) : (F)(a.d / b.d); }
 template <typename F>
-DPM_HD inline F r_diff(RT<F> a, RT<F> b) { return (a.tensor) ? a.f() - b.f() : (F)(a.d - b.d); }
+DPM_HD inline F r_diff(RT<F> a, RT<F> b) { return (a.tensor) ? (F)((float)a.d - (float)b.d) : (F)(a.d - b.d); }
 
 // singlestep_dpm_solver_second_update (ref :594-673): two stages
 template <class S, class ST>

@@ -93,7 +93,7 @@ struct dpm_schedule {
   // the evaluation code lives in dpm_coef.hpp (shared with the device): a view over this object's tables
   dpmc::SchedView view() const {
     return dpmc::SchedView{discrete ? 1 : 0, cosine ? 1 : 0, total_N, la.data(), t.data(), la_rev.data(), t_rev.data(),
-                           beta0, beta1, cos_s, cos_la0};
+                           beta0, beta1, cos_s, cos_la0, 0};
   }
   float log_alpha(float tt) const { return view().log_alpha(tt); }   // marginal_log_mean_coeff, ref :127-134
   float alpha(float tt) const { return view().alpha(tt); }           // ref :140
@@ -103,7 +103,7 @@ struct dpm_schedule {
   float inv_lambda_of_f32(float lam) const { return view().inv_lambda(lam); }
   dpmc::SchedView64 view64() const {
     return dpmc::SchedView64{discrete ? 1 : 0, cosine ? 1 : 0, total_N, d_la.data(), d_t.data(), d_la_rev.data(),
-                             d_t_rev.data(), beta0, beta1, cos_s, cos_la0};
+                             d_t_rev.data(), beta0, beta1, cos_s, cos_la0, table_f64 ? 0 : 1};
   }
   void build_double_tables() {
     if (!discrete) return;

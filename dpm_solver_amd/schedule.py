@@ -141,11 +141,13 @@ class NoiseScheduleVP:
             xp, yp = tab
             dt = torch.promote_types(tt.dtype, xp.dtype)
             x = tt.to(dt)
-            xp, yp = xp.to(dt), yp.to(dt)
+            xp = xp.to(dt)
             K = xp.shape[0]
             idx = torch.searchsorted(xp, x.contiguous(), right=False)          # #{xp < x}
             i0 = torch.where(idx == 0, torch.zeros_like(idx), torch.where(idx == K, torch.full_like(idx, K - 2), idx - 1))
             i1 = i0 + 1
+            # (`end_y - start_y`, ref :1290, is an operation between two table entries: in the tables' own dtype also when
+            # the times are doubles and the tables fp32)
             la = yp[i0] + (x - xp[i0]) * (yp[i1] - yp[i0]) / (xp[i1] - xp[i0])
         elif self.schedule == 'linear':
             la = -0.25 * tt ** 2 * (self.beta_1 - self.beta_0) - 0.5 * tt * self.beta_0

@@ -435,11 +435,12 @@ class DPM_Solver:
             raise ValueError("'solver_type' must be either 'dpmsolver' or 'taylor', got {}".format(solver_type))
         if r1 is None:
             r1 = 0.5
-        mode = 1 if torch.is_tensor(r1) else 0
+        mode = 1 if (torch.is_tensor(r1) and r1.dtype is not torch.float64) else 0    # (a double tensor acts like a Python float)
         stages, c64s, tf64 = self._singlestep_stages(x, 2, L.SOLVER[solver_type], s, t, r1 if mode else float(r1), 0., mode)
-        # (the intermediate time s1 comes out of inverse_lambda, (1,)-shaped on a 'linear' schedule, ref :161: dimensioned)
+        # (the intermediate time s1 comes out of inverse_lambda, (1,)-shaped on a 'linear' schedule, ref :161: dimensioned --
+        # and a double when the call's times are: the coefficients at s1 then promote the whole update to double)
         x_t, ms = self._exec_single(stages, x, {0: model_s} if model_s is not None else {}, return_intermediate, c64s, tf64,
-                                    times=(s, t, torch.zeros(1)))
+                                    times=(s, t, torch.zeros(1, dtype=torch.float64 if tf64 else torch.float32)))
         return (x_t, {'model_s': ms[0], 'model_s1': ms[1]}) if return_intermediate else x_t
 
     def singlestep_dpm_solver_third_update(self, x, s, t, r1=1. / 3., r2=2. / 3., model_s=None, model_s1=None,
@@ -451,7 +452,7 @@ class DPM_Solver:
             r1 = 1. / 3.
         if r2 is None:
             r2 = 2. / 3.
-        mode = 1 if (torch.is_tensor(r1) or torch.is_tensor(r2)) else 0
+        mode = 1 if any(torch.is_tensor(r) and r.dtype is not torch.float64 for r in (r1, r2)) else 0
         stages, c64s, tf64 = self._singlestep_stages(x, 3, L.SOLVER[solver_type], s, t, r1 if mode else float(r1),
                                                      r2 if mode else float(r2), mode)
         given = {}
@@ -464,7 +465,7 @@ class DPM_Solver:
             given[0] = self.model_fn(x, s)
         # the taylor combination reads model_s1 (h2): keep it even when not asked for
         x_t, ms = self._exec_single(stages, x, given, return_intermediate or solver_type == 'taylor', c64s, tf64,
-                                    times=(s, t, torch.zeros(1)))
+                                    times=(s, t, torch.zeros(1, dtype=torch.float64 if tf64 else torch.float32)))
         return (x_t, {'model_s': ms[0], 'model_s1': ms[1], 'model_s2': ms[2]}) if return_intermediate else x_t
 
 
@@ -605,6 +606,9 @@ class DPM_Solver:
                     # (ref :948-954): order=4 with steps <= 6 and lower_order_final never reaches one and runs (the planner
                     # raises the reference's ValueError otherwise)
                     assert steps >= order
+                    if order > 3 and plan_solver_type is not solver_type:
+                        # ... and the warm-up of such a run passes through a second-order update first (ref :1185-1193)
+                        raise ValueError("'solver_type' must be either 'dpmsolver' or 'taylor', got {}".format(solver_type))
                 elif method == 'singlestep_fixed' and order not in (1, 2, 3):
                     # ref :1218-1232: K = steps // order updates of that order -- none at all when K <= 0 (the run is a no-op),
                     # else the dispatcher's error at the first one (ref :927-930); order 0 is Python's ZeroDivisionError

@@ -656,3 +656,67 @@ def test_drop_in_fuzz_slice_of_the_public_methods(R, monkeypatch, capsys):
     out = capsys.readouterr().out
     assert n_bad == 0, out[-3000:]
     assert "400 method calls" in out
+
+
+# ------------------------------------------------------------------------------------------------
+# found by tools/fuzz_dropin.py after the slices above were cut (seeds 101 / 202): three corners of torch's type promotion
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("xdt", [torch.float32, torch.float16])
+@pytest.mark.parametrize("order", [2, 3])
+def test_singlestep_update_with_double_scalar_times_on_a_continuous_schedule_is_double(R, xdt, order):
+    """A 0-dim double time does not promote an fp32 / half state by itself, but the inner node of a singlestep update of
+    order >= 2 comes out of inverse_lambda as a (1,)-shaped tensor (ref :161) -- a DOUBLE one when the times are doubles -- and
+    its coefficients promote the whole update: the reference returns float64, and so must the engine."""
+    nsr, ns = ref_schedule(R, "vp_linear"), make_schedule("vp_linear")
+    x = torch.from_numpy(np.random.default_rng(5).standard_normal((2, 3, 4, 4))).to(xdt)
+    net = lambda xx, t: xx * (t.to(xx.dtype).reshape(-1, 1, 1, 1) * 0.0005 + 0.25)
+    s, t = torch.tensor(0.7, dtype=torch.float64), torch.tensor(0.45, dtype=torch.float64)
+    for algo in ("dpmsolver++", "dpmsolver"):
+        r = R.DPM_Solver(R.model_wrapper(net, nsr), nsr, algorithm_type=algo)
+        e = D.DPM_Solver(D.model_wrapper(net, ns), ns, algorithm_type=algo)
+        want = r.singlestep_dpm_solver_update(x, s, t, order)
+        got = e.singlestep_dpm_solver_update(x, s, t, order)
+        assert want.dtype is torch.float64 and got.dtype is torch.float64
+        tol = 8e-3 if xdt is torch.float16 else 2e-7        # (the reference's first products are still half / fp32 operations)
+        assert float((got - want).abs().max()) <= tol * float(want.abs().max()), (algo, order)
+        # the first-order update has no inner node: the state keeps its dtype
+        assert e.dpm_solver_first_update(x, s, t).dtype is r.dpm_solver_first_update(x, s, t).dtype is xdt
+
+
+@pytest.mark.parametrize("solver_type", ["dpmsolver", "taylor"])
+def test_fp32_tensor_r1_r2_in_a_double_precision_call(R, solver_type):
+    """r1 / r2 handed in as fp32 TENSORS: `0.5 / r1`, `r2 / r1`, `1. / r2`, `r2 - r1` (ref :638, :731, :738, :748) are operations
+    between fp32 tensors and Python floats -- fp32 results -- also when everything else of the call is double; only a double
+    tensor (or a Python float) makes them double divisions."""
+    nsr, ns = _f64_schedules(R, "sd", torch.float64)
+    x = torch.from_numpy(np.random.default_rng(6).standard_normal((2, 3, 4, 4)))
+    net = lambda xx, t: xx * (t.to(xx.dtype).reshape(-1, 1, 1, 1) * 0.0005 + 0.25)
+    s, t = torch.tensor([0.7], dtype=torch.float64), torch.tensor([0.45], dtype=torch.float64)
+    for algo in ("dpmsolver++", "dpmsolver"):
+        r = R.DPM_Solver(R.model_wrapper(net, nsr), nsr, algorithm_type=algo)
+        e = D.DPM_Solver(D.model_wrapper(net, ns), ns, algorithm_type=algo)
+        for rdt in (torch.float32, torch.float64):
+            r1, r2 = torch.tensor(0.41, dtype=rdt) * 0.6, torch.tensor(0.77, dtype=rdt)
+            want = r.singlestep_dpm_solver_third_update(x, s, t, r1=r1, r2=r2, solver_type=solver_type)
+            got = e.singlestep_dpm_solver_third_update(x, s, t, r1=r1, r2=r2, solver_type=solver_type)
+            assert float((got - want).abs().max()) <= 1e-12 * float(want.abs().max()), (algo, rdt)
+            want = r.singlestep_dpm_solver_second_update(x, s, t, r1=r2, solver_type=solver_type)
+            got = e.singlestep_dpm_solver_second_update(x, s, t, r1=r2, solver_type=solver_type)
+            assert float((got - want).abs().max()) <= 1e-12 * float(want.abs().max()), (algo, rdt)
+
+
+def test_multistep_order_above_three_with_an_unknown_solver_type_raises_about_the_solver_type(R):
+    """order = 4 AND an unknown solver_type: the reference's warm-up passes through a second-order update (ref :1185-1193),
+    whose solver_type check (ref :811) comes before any fourth-order update is reached."""
+    nsr, ns = ref_schedule(R, "ddpm"), make_schedule("ddpm")
+    x = torch.from_numpy(np.random.default_rng(3).standard_normal((2, 3, 6, 6)).astype(F32))
+    net = lambda xx, t: C.model_tdep(xx, t)
+    r = R.DPM_Solver(R.model_wrapper(net, nsr), nsr)
+    e = D.DPM_Solver(D.model_wrapper(net, ns), ns)
+    for lof in (True, False):
+        kw = dict(steps=7, order=4, solver_type="bogus", lower_order_final=lof, skip_type="time_quadratic")
+        with pytest.raises(ValueError) as er:
+            r.sample(x, **kw)
+        with pytest.raises(ValueError) as ee:
+            e.sample(x, **kw)
+        assert str(ee.value) == str(er.value) and "solver_type" in str(ee.value)

@@ -193,8 +193,19 @@ def compare(cfg, r, e, yardstick=None, half_yardstick=None):
             if a.dtype != b.dtype:
                 bad.append("intermediate %d dtype %s vs %s" % (k, a.dtype, b.dtype))
                 break
-            if float((a.double() - b.double()).abs().max()) / peak > tol:
-                bad.append("intermediate %d values" % k)
+            ierr = float((a.double() - b.double()).abs().max()) / peak
+            if ierr > tol:
+                own = yardstick(True) if (yardstick is not None and a.dtype == torch.float32) else None
+                if own is not None and own >= 0.2 * ierr:     # an early state of an ill-conditioned trajectory (see above)
+                    return bad + ["conditioning: intermediate %d %.3g of the peak, the fp32 reference is %.3g from its own double run" % (k, ierr, own)]
+                if half and half_yardstick is not None:       # half arithmetic: the same rule as for the result, state by state
+                    f32s = half_yardstick(True)
+                    if f32s is not None and len(f32s) == len(ri) + 1:
+                        e_eng = float((b.double() - f32s[k + 1].double()).abs().max()) / peak
+                        e_ref = float((a.double() - f32s[k + 1].double()).abs().max()) / peak
+                        if e_eng <= 1.5 * e_ref + 1e-3:
+                            return bad + ["conditioning: half arithmetic, intermediate %d engine %.3g / reference %.3g from the fp32 trajectory" % (k, e_eng, e_ref)]
+                bad.append("intermediate %d values: %.3g" % (k, ierr))
                 break
     if not half and cfg["method"] != "adaptive":
         rt, et = r[2], e[2]
@@ -328,6 +339,8 @@ def fuzz_methods(args):
     kinds = {}
     for i in range(args.cases):
         cfg, call = random_method_call(rng)
+        if args.only is not None and i != args.only:
+            continue
         res = []
         for mod, mk, util in ((R, ref_schedule, R), (D, eng_schedule, U)):
             try:
@@ -353,7 +366,10 @@ def fuzz_methods(args):
                 if k > 0 and isinstance(r[1], tuple) and isinstance(r[1][-1], dict) and a.dtype != b.dtype and tuple(a.shape) == tuple(b.shape):
                     # a model value handed back by return_intermediate: the reference returns the raw network output in the
                     # network's dtype, the engine the stored copy in the state's dtype -- same values
-                    if float((a.double() - b.double()).abs().max()) <= 1e-6 * (float(a.double().abs().max()) or 1.0):
+                    # (a half x on a continuous schedule: the reference's model value is a half tensor, the engine's fp32 copy
+                    # carries the value before that rounding)
+                    wtol = 8e-3 if cfg["xdt"] == "float16" else 1e-6
+                    if float((a.double() - b.double()).abs().max()) <= wtol * (float(a.double().abs().max()) or 1.0):
                         continue
                 if a.dtype != b.dtype or tuple(a.shape) != tuple(b.shape):
                     bad.append("tensor %d: %s %s vs %s %s" % (k, a.dtype, tuple(a.shape), b.dtype, tuple(b.shape)))
@@ -369,6 +385,11 @@ def fuzz_methods(args):
                                                 # product where the coefficient is 0-dim; the engine's whole expression is double
                 elif a.dtype == torch.float64:
                     tol = max(tol, 1e-9)
+                if a.dtype == torch.float64 and cfg["schedule"] in ("ddpm", "cosine1000"):
+                    # tables built from fp32 betas go through ATen's vectorised fp32 log (SLEEF, <= 1 ulp, and not the same
+                    # bits on an AVX2 and an AVX-512 host or on the GPU); the planner's is the correctly rounded one: a few
+                    # table entries differ by one fp32 ulp (12 of 1000 / 3 of 996 here), which a double evaluation resolves
+                    tol = max(tol, 2e-7)
                 err = float((a.double() - b.double()).abs().max()) / pk
                 if err > tol:
                     bad.append("tensor %d values: %.3g (tolerance %.1g)" % (k, err, tol))
@@ -390,6 +411,7 @@ def main():
     ap.add_argument("--case-timeout", type=int, default=60)
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--mode", default="sample", choices=["sample", "methods"])
+    ap.add_argument("--only", type=int, default=None, help="replay one case of the seeded sequence (the earlier ones are drawn and skipped)")
     args = ap.parse_args()
     if args.mode == "methods":
         install()
@@ -404,6 +426,8 @@ def main():
     import io
     for i in range(args.cases):
         cfg = random_case(rng)
+        if args.only is not None and i != args.only:
+            continue
         if cfg["thresholding"] and cfg["algorithm_type"] == "dpmsolver":
             cfg["thresholding"] = False
         if cfg["method"] == "adaptive":
@@ -441,7 +465,7 @@ def main():
             print("case %d %.2f s (reference %.2f) %s %s steps=%d" % (i, time.perf_counter() - t0, t1 - t0, cfg["method"], cfg["schedule"], cfg["steps"]), flush=True)
         n_raise += r[0] == "raise"
 
-        def yardstick():
+        def yardstick(with_intermediates=False):
             if cfg["xdt"] == "f64" or (cfg["xdt"] != "f32" and cfg["schedule"] == "vp_linear"):
                 return None
             with contextlib.redirect_stdout(io.StringIO()):
@@ -454,12 +478,17 @@ def main():
             o64 = r64[1][0] if (cfg["ret_inter"] and cfg["method"] != "adaptive") else r64[1]
             o32 = r32[1][0] if (cfg["ret_inter"] and cfg["method"] != "adaptive") else r32[1]
             pk = float(o32.double().abs().max()) or 1.0
+            if with_intermediates and cfg["ret_inter"] and cfg["method"] != "adaptive" and len(r32[1][1]) == len(r64[1][1]):
+                pk = max([pk] + [float(t.double().abs().max()) for t in r32[1][1]])
+                return max(float((a.double() - b).abs().max()) for a, b in zip([o32] + list(r32[1][1]), [o64] + list(r64[1][1]))) / pk
             return float((o32.double() - o64).abs().max()) / pk
-        def half_yardstick():
+        def half_yardstick(with_intermediates=False):
             with contextlib.redirect_stdout(io.StringIO()):
                 r32 = run(R, ref_schedule(cfg["schedule"]), cfg, x.float())
             if r32[0] != "ok":
                 return None
+            if with_intermediates:
+                return ([r32[1][0]] + list(r32[1][1])) if (cfg["ret_inter"] and cfg["method"] != "adaptive") else None
             return r32[1][0] if (cfg["ret_inter"] and cfg["method"] != "adaptive") else r32[1]
         bad = compare(cfg, r, e, yardstick, half_yardstick)
         if bad and bad[-1].startswith("conditioning"):

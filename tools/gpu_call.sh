@@ -14,6 +14,7 @@
 #   dropin       the reference's own example call sites on the engine (needs _refscratch/)
 #   bigsingle    tools/big_single.py: launch shape of ONE large stage launch (lab build)
 #   newtests     the GPU tests added this round (quick iteration before the full suite)
+#   fuzzgpu      tools/fuzz_gpu.py: the drop-in fuzz's random cases, engine on the GPU vs the engine's host code on the numpy double
 TAG=${1:?tag}; shift
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
@@ -74,6 +75,11 @@ bigsingle)
   timeout 900 python tools/big_single.py --out $O/big_single.json > $O/big_single.log 2>&1; echo "big_single rc=$?"; grep '^{' $O/big_single.log | cut -c1-330; grep -v '^{' $O/big_single.log | tail -5 ;;
 newtests)
   ( time timeout 900 python -m pytest tests/test_gpu_extensions.py -m gpu -q -x -k "auto_capture or add_noise_with_double or order_four or capture_rejects" ) > $O/newtests.log 2>&1; echo "newtests rc=$?"; tail -15 $O/newtests.log ;;
+fuzzgpu)
+  for SEED in ${FUZZ_SEEDS:-0 1}; do
+    timeout 1500 python tools/fuzz_gpu.py --cases ${FUZZ_CASES:-1500} --seed $SEED --out $O/fuzz_gpu_seed$SEED.json > $O/fuzz_gpu_seed$SEED.log 2>&1; echo "fuzz_gpu seed $SEED rc=$?"
+    tail -1 $O/fuzz_gpu_seed$SEED.log | cut -c1-700; grep -c "^case" $O/fuzz_gpu_seed$SEED.log
+  done ;;
 *) echo "unknown step $STEP" ;;
 esac
 done
