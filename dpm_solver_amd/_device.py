@@ -114,6 +114,8 @@ def _launch_stage(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=No
     ed = e0.dtype
     if ed not in _DT or (sd != torch.float32 and ed != sd) or ed is torch.float64:
         ed = sd  # only (fp32 state, any eps), equal low-precision pairs and (double, double) have kernels
+    if g is not None and g.dtype is not ed and sd is torch.float32:
+        ed = torch.float32  # an fp32 classifier gradient next to a half network output: widen the output (see _bind_outputs)
     eps_stride = 0
     if mf is None and e0.dtype == ed and not e0.is_contiguous() and _sample_strided(e0) and e0.shape == ref_t.shape and (
             e1 is None or (e1.dtype == ed and _sample_strided(e1) and e1.stride(0) == e0.stride(0))):
@@ -234,6 +236,10 @@ def _adaptive_error(x_lower, x_higher, x_prev, atol, rtol):
         return torch.sqrt(torch.square(v).mean(dim=-1)).max()
     per_sample = x_lower.numel() // max(B, 1)
     e_dev = torch.empty((B + 1,), dtype=torch.float32, device=x_lower.device)
+    if x_higher.dtype != x_lower.dtype:
+        # a half-precision state on a continuous schedule: the lower-order estimate is still half, the higher-order one already
+        # fp32 (its inner node promotes it, ref :161) -- the kernel reads all three tensors in ONE dtype: widen (exact)
+        x_lower, x_higher = x_lower.float(), x_higher.float()
     xp = x_prev if x_prev.dtype == x_lower.dtype else x_prev.to(x_lower.dtype)
     with torch.cuda.device(x_lower.device):
         L.check(L.lib.dpm_adaptive_error_launch(

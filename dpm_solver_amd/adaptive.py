@@ -257,6 +257,10 @@ def solve(self, x, order, t_T, t_0, h_init=0.05, atol=0.0078, rtol=0.05, theta=0
         if self.error_reduce is not None:
             E_dev = self.error_reduce(E_dev)     # batch-sharded runs: MAX all-reduce over the ranks
         E = FT(E_dev.item())                     # the one host sync per iteration, as in the reference (ref :1002)
+        if E != E:
+            # a NaN estimate is never accepted and turns h into NaN: the reference's loop then spins forever (ref :1002-1008)
+            raise FloatingPointError("adaptive solver: the error estimate is NaN at t = %r (the state or the network output "
+                                     "is not finite); the reference's loop would not terminate here" % float(s))
         if E <= 1.:
             x = x_higher
             s = t

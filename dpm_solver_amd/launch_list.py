@@ -17,6 +17,10 @@ def _bind_outputs(b, e0, e1, g, sd, shape, mf=None):
     ed = e0.dtype
     if ed is not sd and (sd is not torch.float32 or ed not in DV._DT):
         ed = sd
+    if g is not None and g.dtype is not ed and sd is torch.float32:
+        # the classifier's gradient is an fp32 tensor next to a half-precision network output (ref :320-321: `noise - scale *
+        # sigma_t * cond_grad` promotes to fp32): the kernel reads both in ONE dtype -- widen the output, never round the gradient
+        ed = torch.float32
     stride = 0
     if mf is not None:
         dense = lambda t: t.is_contiguous(memory_format=mf)

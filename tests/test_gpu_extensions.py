@@ -949,3 +949,100 @@ def test_quickstart_example_runs():
     assert r.returncode == 0, r.stdout[-3000:]
     for needle in ("sample:", "captured", "sample_requests: 8 requests", "channels_last: result in channels_last = True", "inpaint:"):
         assert needle in r.stdout, r.stdout[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------
+# round 6, found by tools/fuzz_gpu.py (the drop-in fuzz's cases, engine on the GPU vs the engine's host code on the numpy double)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("edt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("method,order", [("multistep", 2), ("singlestep", 3), ("multistep", 1)])
+def test_classifier_gradient_stays_fp32_next_to_a_half_precision_network(edt, method, order, monkeypatch):
+    """Classifier guidance with a network that answers in half precision (fp32 state: guided diffusion under autocast).  The
+    reference's `noise - scale * sigma_t * cond_grad` (ref :320-321) promotes to fp32 -- the gradient is an fp32 tensor and is
+    never rounded to the network's dtype.  The stage kernel reads the output and the gradient in ONE dtype: the launch must
+    widen the output (exact), not narrow the gradient (1e-4 of the state, the bug this test pins).  Bit-equal to the double,
+    which the CPU differential holds to the live reference for exactly this combination (tools/fuzz_dropin.py: net_dt)."""
+    from kernel_double import install_cpu_double
+    ns = make_schedule("ddpm")
+    x = torch.from_numpy(np.random.default_rng(17).standard_normal((3, 3, 16, 16)).astype(np.float32))
+
+    def mk(dev):
+        cond = torch.arange(1, 4, dtype=torch.float32, device=dev) * 0.5
+        net = lambda xx, t, c=None: (xx * (t.reshape(-1, 1, 1, 1) * 0.0005 + 0.25)).to(edt)
+        clf = lambda xx, t, c: -0.5 * (xx.reshape(xx.shape[0], -1) ** 2).sum(dim=1) * 0.013
+        fn = D.model_wrapper(net, ns, guidance_type="classifier", condition=cond, guidance_scale=7.5, classifier_fn=clf)
+        return D.DPM_Solver(fn, ns, algorithm_type="dpmsolver++")
+    kw = dict(steps=6, order=order, method=method, return_intermediate=True)
+    got, gi = mk(DEV).sample(x.to(DEV), **kw)
+    with monkeypatch.context() as m:
+        install_cpu_double(m, S, D)
+        want, wi = mk("cpu").sample(x, **kw)
+    assert got.dtype is torch.float32 and torch.equal(got.cpu(), want)
+    assert len(gi) == len(wi) and all(torch.equal(a.cpu(), b) for a, b in zip(gi, wi))
+    # ... and the fast path (no intermediates: prebuilt launch records, launch_list._bind_outputs) binds the same way
+    assert torch.equal(mk(DEV).sample(x.to(DEV), steps=6, order=order, method=method).cpu(), want)
+
+
+def test_drop_in_fuzz_slice_on_the_gpu(monkeypatch, capsys):
+    """300 random cases of tools/fuzz_gpu.py (the generator of the CPU drop-in fuzz plus larger shapes and networks that
+    answer in another dtype): the engine on the GPU against the engine's host code on the numpy double -- raised or returned,
+    exception, dtype, shape, network-call trace, values (fp32 and double results bit-identical up to the adaptive solver's
+    accept / reject decisions).  The CPU suite holds the double to the live reference over the same kind of cases."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_gpu as FG
+    monkeypatch.setattr(sys, "argv", ["fuzz_gpu.py", "--cases", "300", "--seed", "7"])
+    undo = []
+
+    class MP:
+        def setattr(self, o, n, v):
+            undo.append((o, n, getattr(o, n)))
+            setattr(o, n, v)
+    monkeypatch.setattr(FG, "_MP", MP)
+    try:
+        n_bad = FG.main()
+    finally:
+        for o, n, v in reversed(undo):
+            setattr(o, n, v)
+    out = capsys.readouterr().out
+    assert n_bad == 0, out[-3000:]
+    assert '"cases": 300' in out
+
+
+@pytest.mark.parametrize("hdt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("order", [2, 3])
+def test_adaptive_host_loop_with_a_half_state_on_a_continuous_schedule(hdt, order, monkeypatch, capsys):
+    """A half x_T on a 'linear' schedule takes the reference's host loop (the state dtype is only known after the first
+    network output): its lower-order estimate is still a half tensor, the higher-order one already fp32 (the inner node
+    promotes it, ref :161).  The error-norm kernel reads its three operands in one dtype -- the launch must widen them, not
+    reinterpret the fp32 tensor's bytes as half (an infinite / NaN estimate and a loop that never ends: found by
+    tools/fuzz_gpu.py).  Same accept / reject sequence and result as the host code on the numpy double."""
+    from kernel_double import install_cpu_double
+    ns = make_schedule("vp_linear")
+    x = torch.from_numpy(np.random.default_rng(23).standard_normal((4, 3, 8, 8)).astype(np.float32)).to(hdt)
+    net = lambda xx, t: (xx.float() * (t.float().reshape(-1, 1, 1, 1) * 0.0005 + 0.25)).to(xx.dtype)
+
+    def mk():
+        dpm = D.DPM_Solver(D.model_wrapper(net, ns), ns, algorithm_type="dpmsolver")
+        dpm.adaptive_on_device = False
+        return dpm
+    kw = dict(method="adaptive", order=order, atol=0.05, rtol=0.1, solver_type="taylor")
+    got = mk().sample(x.to(DEV), **kw)
+    nfe_gpu = capsys.readouterr().out
+    with monkeypatch.context() as m:
+        install_cpu_double(m, S, D)
+        want = mk().sample(x, **kw)
+    nfe_cpu = capsys.readouterr().out
+    assert nfe_gpu == nfe_cpu and "adaptive solver nfe" in nfe_gpu
+    assert got.dtype is want.dtype and bool(torch.isfinite(got).all())
+    assert rel_err(got.float().cpu().numpy(), want.float().numpy()) < 1e-4
+
+
+def test_adaptive_host_loop_raises_on_a_nan_estimate_instead_of_spinning():
+    ns = make_schedule("vp_linear")
+    x = torch.randn(2, 3, 4, 4, device=DEV)
+    dpm = D.DPM_Solver(D.model_wrapper(lambda xx, t: xx * float("nan"), ns), ns)
+    dpm.adaptive_on_device = False
+    with pytest.raises(FloatingPointError, match="error estimate is NaN"):
+        dpm.sample(x, method="adaptive", order=2)

@@ -878,3 +878,14 @@ def test_channels_last_x_T_with_a_default_layout_network(monkeypatch):
     got = D.DPM_Solver(_nhwc_model(ns, False, fmt=None), ns).sample(x.contiguous(memory_format=torch.channels_last), steps=5, order=2)
     assert torch.equal(got, want) and got.is_contiguous(memory_format=torch.channels_last)
     assert spy.copies == 2
+
+
+def test_adaptive_host_loop_raises_on_a_nan_estimate_instead_of_spinning():
+    """A NaN error estimate is never accepted and turns the step size into NaN: the reference's loop (ref :1002-1008) then never
+    ends.  The engine raises where the reference would hang (the device-side controller is bounded by adaptive_max_iterations)."""
+    ns = make_schedule("vp_linear")
+    x = torch.from_numpy(np.random.default_rng(1).standard_normal((2, 3, 4, 4)).astype(F32))
+    dpm = D.DPM_Solver(D.model_wrapper(lambda xx, t: xx * float("nan"), ns), ns)
+    dpm.adaptive_on_device = False
+    with pytest.raises(FloatingPointError, match="error estimate is NaN"):
+        dpm.sample(x, method="adaptive", order=2)

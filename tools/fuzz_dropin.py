@@ -7,7 +7,8 @@ it.  Every case compares: did both raise (same exception type and text) or both 
 trajectory's peak for fp32, 1e-10 for double, the half format's resolution for half results), the intermediates, and the
 network-call trace (shapes, dtypes and times the network saw).  Wider than tests/test_differential_reference.py: state
 shapes of 1 to 5 dimensions, batch 1, non-contiguous inputs, half / double x_T, steps below the order, singlestep grids that
-degenerate, every method incl. adaptive, public update methods with tensor / float / None arguments.
+degenerate, every method incl. adaptive, networks that answer in half precision or fp32 whatever the state's dtype (Stable
+Diffusion under autocast), public update methods with tensor / float / None arguments.
 
     python tools/fuzz_dropin.py [--cases 1500] [--seed 0]        # prints every disagreement and a summary
 """
@@ -84,7 +85,8 @@ def random_case(rng):
                 t_start=(None if rng.random() < 0.5 else float(rng.choice([1.0, 0.8, 0.5]))),
                 call=str(rng.choice(["sample", "sample", "sample", "inverse"])),
                 ret_inter=bool(rng.integers(0, 2)), xdt=str(rng.choice(["f32", "f32", "f32", "f64", "f16", "bf16"])),
-                noncontig=bool(rng.integers(0, 6) == 0), seed=int(rng.integers(0, 1 << 30)))
+                noncontig=bool(rng.integers(0, 6) == 0), seed=int(rng.integers(0, 1 << 30)),
+                net_dt=str(rng.choice(["same", "same", "same", "f16", "f32"])))
 
 
 def build(mod, ns, cfg, x, trace):
@@ -98,7 +100,9 @@ def build(mod, ns, cfg, x, trace):
         out = xx * (tt * 0.0005 + 0.25)
         if c is not None:
             out = out * (c.to(xx.dtype).reshape((-1,) + (1,) * (xx.dim() - 1)) * 0.1 + 1.0)
-        return out
+        # (a network that answers in its own dtype: Stable Diffusion under autocast hands fp16 to an fp32 state)
+        return out if (ndt is None or xx.dtype is torch.float64) else out.to(ndt)
+    ndt = {"same": None, "f16": torch.float16, "f32": torch.float32}[cfg.get("net_dt", "same")]
     if cfg["guidance"] == "classifier-free":
         net = lambda xx, t, c: base(xx, t, c)
         kw.update(condition=cond, unconditional_condition=torch.zeros(B))
@@ -250,10 +254,11 @@ def random_method_call(rng):
     cfg = dict(what=what, schedule=sched, shape=shape, xdt=str(xdt)[6:], tdt=str(tdt)[6:], algorithm_type=algo, model_type=mt, guidance=guid, thr=thr,
                tshape=tshape, solver_type=solver_type, r=r_kind, given=given, ret_inter=ret_i, order=order, nt=nt)
 
-    def call(mod, ns, util):
+    def call(mod, ns, util, eps=0.0):
+        """eps: relative perturbation of every time argument (the conditioning yardstick of fuzz_methods)"""
         g = np.random.default_rng(seed)
         x = _tens(g, shape, xdt)
-        tt = lambda v: torch.full(tshape, v, dtype=tdt)
+        tt = lambda v: torch.full(tshape, v * (1.0 + eps), dtype=tdt)
         c = dict(method="multistep", order=2, steps=5, shape=shape, schedule=sched, skip_type="time_uniform", solver_type="dpmsolver",
                  algorithm_type=algo, model_type=mt, guidance=guid, scale=2.5, thresholding=thr, cxt=False, cx0=False)
         trace = []
@@ -335,7 +340,7 @@ def fuzz_methods(args):
     import io
     import dpm_solver_amd.utils as U
     rng = np.random.default_rng(args.seed)
-    n_bad = n_raise = 0
+    n_bad = n_raise = n_cond = 0
     kinds = {}
     for i in range(args.cases):
         cfg, call = random_method_call(rng)
@@ -392,6 +397,20 @@ def fuzz_methods(args):
                     tol = max(tol, 2e-7)
                 err = float((a.double() - b.double()).abs().max()) / pk
                 if err > tol:
+                    # conditioning yardstick: the reference against ITSELF with every time argument moved by one part in 1e7
+                    # (an fp32 ulp -- the size of the table differences noted below): update formulas between nearly equal
+                    # times divide by tiny logSNR steps and amplify that as much as they amplify anything else
+                    try:
+                        with contextlib.redirect_stdout(io.StringIO()):
+                            own = _flatten(call(R, ref_schedule(cfg["schedule"]), R, eps=1e-7))[k]
+                        moved = float((a.double() - own.double()).abs().max()) / pk
+                    except Exception:                   # noqa: BLE001
+                        moved = 0.0
+                    if moved >= 0.2 * err:
+                        n_cond += 1
+                        if args.verbose:
+                            print("call %d: conditioning: %.3g, the reference moves %.3g when its times move by 1e-7" % (i, err, moved))
+                        break
                     bad.append("tensor %d values: %.3g (tolerance %.1g)" % (k, err, tol))
                     break
         if bad:
@@ -400,7 +419,8 @@ def fuzz_methods(args):
             print("call %d: %s\n    %s" % (i, cfg, "\n    ".join(bad)), flush=True)
             if e[0] == "raise" and r[0] != "raise":
                 print("    " + e[2].replace("\n", "\n    "))
-    print("%d method calls, %d where the reference raised, %d disagreements %s" % (args.cases, n_raise, n_bad, kinds))
+    print("%d method calls, %d where the reference raised, %d ill-conditioned (the reference moves as far when its times move by "
+          "1e-7), %d disagreements %s" % (args.cases, n_raise, n_cond, n_bad, kinds))
     return n_bad
 
 

@@ -59,6 +59,14 @@ def random_case(rng):
                 seed=int(rng.integers(0, 1 << 30)))
 
 
+RECORD = None          # --debug-case: list receiving (what, tensor on the host) at the network / callback boundary
+
+
+def _rec(what, t):
+    if RECORD is not None:
+        RECORD.append((what, t.detach().cpu().clone()))
+
+
 def build(ns, cfg, x, trace):
     B = x.shape[0]
     dev = x.device
@@ -68,12 +76,20 @@ def build(ns, cfg, x, trace):
 
     def base(xx, t, c=None):
         trace.append((tuple(xx.shape), str(xx.dtype), str(t.dtype), tuple(t.shape), round(float(t.reshape(-1)[0]), 4)))
-        tt = t.to(xx.dtype).reshape((-1,) + (1,) * (xx.dim() - 1))
-        out = xx * (tt * 0.0005 + 0.25)
+        _rec("network input", xx)
+        _rec("network time", t)
+        # (half inputs: arithmetic in fp32, ONE rounding -- torch's half operations with Python scalars do not round alike on
+        # the CPU and on the GPU, and this tool compares a CPU run with a GPU run)
+        wd = xx.dtype if xx.dtype in (torch.float32, torch.float64) else torch.float32
+        tt = t.to(wd).reshape((-1,) + (1,) * (xx.dim() - 1))
+        out = xx.to(wd) * (tt * 0.0005 + 0.25)
         if c is not None:
-            out = out * (c.to(xx.dtype).reshape((-1,) + (1,) * (xx.dim() - 1)) * 0.1 + 1.0)
+            out = out * (c.to(wd).reshape((-1,) + (1,) * (xx.dim() - 1)) * 0.1 + 1.0)
+        out = out.to(xx.dtype)
         # (a network that answers in its own dtype: Stable Diffusion under autocast hands fp16 to an fp32 state)
-        return out if (ndt is None or xx.dtype is torch.float64) else out.to(ndt)
+        out = out if (ndt is None or xx.dtype is torch.float64) else out.to(ndt)
+        _rec("network output", out)
+        return out
     if cfg["guidance"] == "classifier-free":
         net = lambda xx, t, c: base(xx, t, c)
         kw.update(condition=cond, unconditional_condition=torch.zeros(B, device=dev))
@@ -87,9 +103,17 @@ def build(ns, cfg, x, trace):
     if cfg["thresholding"]:
         skw["correcting_x0_fn"] = "dynamic_thresholding"
     elif cfg["cx0"]:
-        skw["correcting_x0_fn"] = lambda x0, t: torch.clamp(x0, -2.0, 2.0)
+        def cx0(x0, t):
+            _rec("correcting_x0_fn input", x0)
+            return torch.clamp(x0, -2.0, 2.0)
+        skw["correcting_x0_fn"] = cx0
     if cfg["cxt"]:
-        skw["correcting_xt_fn"] = lambda xt, t, step: xt * 0.99 + 0.001 * step
+        def cxt(xt, t, step):
+            _rec("correcting_xt_fn input", xt)
+            out = (xt.to(torch.float32 if xt.dtype is not torch.float64 else xt.dtype) * 0.99 + 0.001 * step).to(xt.dtype)
+            _rec("correcting_xt_fn output", out)
+            return out
+        skw["correcting_xt_fn"] = cxt
     dpm = D.DPM_Solver(fn, ns, **skw)
     dpm.adaptive_on_device = False          # the reference's host loop on both sides: the same sequence of launches
     return dpm
@@ -177,13 +201,44 @@ class _MP:
         setattr(o, n, v)
 
 
+def debug_case(args):
+    """the tensors at the network / callback boundary of both runs, in order: the first that differs says whether a stage kernel
+    (an input differs after equal outputs) or a torch operation of the stand-in network (an output differs for equal inputs)"""
+    global RECORD
+    rng = np.random.default_rng(args.seed)
+    for _ in range(args.debug_case + 1):
+        cfg = random_case(rng)
+    if cfg["thresholding"] and cfg["algorithm_type"] == "dpmsolver":
+        cfg["thresholding"] = False
+    print({k: v for k, v in cfg.items() if k != "seed"})
+    RECORD = []
+    g = run(cfg, args.device)
+    rg, RECORD = RECORD, []
+    install_cpu_double(_MP(), S, D)
+    c = run(cfg, "cpu")
+    rc = RECORD
+    print("GPU:", g[0], "double:", c[0], "boundary tensors:", len(rg), len(rc))
+    for k, ((wa, a), (wb, b)) in enumerate(zip(rg, rc)):
+        same = wa == wb and a.dtype == b.dtype and a.shape == b.shape and bool(torch.equal(a, b))
+        d = float((a.double() - b.double()).abs().max()) if a.shape == b.shape and a.numel() else float("nan")
+        print("%3d %-26s %-15s %-15s %s max|d| %.3g of %.3g" % (k, wa, str(a.dtype)[6:], str(b.dtype)[6:], "same" if same else "DIFFERENT", d,
+                                                               float(b.double().abs().max()) if b.numel() else 0.0))
+    bad, worst, same = compare(cfg, g, c)
+    print(bad, worst, same)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=1500)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=None)
     ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--case-timeout", type=int, default=60)
+    ap.add_argument("--debug-case", type=int, default=None, help="replay ONE case and print where the two runs part")
     args = ap.parse_args()
+    if args.debug_case is not None:
+        return debug_case(args)
     rng = np.random.default_rng(args.seed)
     cfgs = []
     for _ in range(args.cases):
@@ -197,9 +252,18 @@ def main():
     gpu = []
     if args.device == "cpu":                  # plumbing check of this tool where there is no GPU: the double on both sides
         install_cpu_double(_MP(), S, D)
+    import faulthandler
+    cur = (os.path.splitext(args.out)[0] if args.out else "/tmp/fuzz_gpu") + "_current_case.txt"
     with contextlib.redirect_stdout(io.StringIO()):
-        for cfg in cfgs:
+        for i, cfg in enumerate(cfgs):
+            # a case that does not come back (a host loop that never ends, a kernel that never finishes) must say which one it
+            # is: the stack of every thread after --case-timeout seconds, then exit
+            with open(cur, "w") as f:
+                f.write("%d %s\n" % (i, cfg))
+            faulthandler.dump_traceback_later(args.case_timeout, exit=True, file=sys.__stderr__)
             gpu.append(run(cfg, args.device))
+            faulthandler.cancel_dump_traceback_later()
+    os.remove(cur)
     if args.device != "cpu":
         torch.cuda.synchronize()
     t_gpu = time.perf_counter() - t0
