@@ -241,9 +241,14 @@ def _adaptive_error(x_lower, x_higher, x_prev, atol, rtol):
         # fp32 (its inner node promotes it, ref :161) -- the kernel reads all three tensors in ONE dtype: widen (exact)
         x_lower, x_higher = x_lower.float(), x_higher.float()
     xp = x_prev if x_prev.dtype == x_lower.dtype else x_prev.to(x_lower.dtype)
+    # dense copies in the default order where an operand is not (a channels_last network: the states are in its layout) -- held
+    # by NAME until the launch is enqueued: a temporary dropped right after its data_ptr() was taken hands its block back to
+    # the caching allocator, and the next copy may land in it (two operands aliasing: a zero estimate, every step accepted)
+    xl_c, xh_c, xp_c = x_lower.contiguous(), x_higher.contiguous(), xp.contiguous()
     with torch.cuda.device(x_lower.device):
         L.check(L.lib.dpm_adaptive_error_launch(
-            _ptr(x_lower.contiguous()), _ptr(x_higher.contiguous()), _ptr(xp.contiguous()), float(atol), float(rtol),
+            _ptr(xl_c), _ptr(xh_c), _ptr(xp_c), float(atol), float(rtol),
             _ptr(e_dev), B, per_sample, _DT[x_lower.dtype],
             C.c_void_p(torch.cuda.current_stream(x_lower.device).cuda_stream)))
+    del xl_c, xh_c, xp_c
     return e_dev[B]

@@ -157,6 +157,19 @@ def launch_stage_double(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, 
     ed = e0.dtype          # the eps dtype the launch binds (solver._launch_stage): converted to the state's when there is no kernel pair
     if ed not in (torch.float32, torch.float16, torch.bfloat16) or (state_dtype != torch.float32 and ed != state_dtype):
         ed = state_dtype
+    if g is not None and g.dtype != ed and state_dtype == torch.float32:
+        ed = torch.float32  # an fp32 classifier gradient next to a half network output: the output is widened (_device._launch_stage)
+    # operands are brought to the launch's dtypes like _device._launch_stage does (`_conv`): the states and cached model
+    # values to the state dtype, the network outputs to `ed` -- a rounding where that narrows (an explicit half state_dtype
+    # meeting an fp32 x_T or an fp32 network), exact everywhere else
+    to = lambda t, dt: None if t is None else (t if t.dtype == dt else t.to(dt))
+    x, xe, h1, h2 = to(x, state_dtype), to(xe, state_dtype), to(h1, state_dtype), to(h2, state_dtype)
+    e0, e1, g = to(e0, ed), to(e1, ed), to(g, ed)
+    xn, xen = cast(_np(x)), cast(_np(xe))
+    if xen is None:
+        xen = xn
+    if xn is None:
+        xn = xen
     mn = prologue(c, xen, cast(_np(e0)), cast(_np(e1)), cast(_np(g)), half_rounder(ed))
     if st.flags & L.F_THRESH:
         mn = threshold64(mn, c.thr_ratio, c.thr_max) if FT is F64 else O.dynamic_threshold(mn, F32(st.thr_ratio), F32(st.thr_max))

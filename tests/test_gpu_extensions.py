@@ -1046,3 +1046,60 @@ def test_adaptive_host_loop_raises_on_a_nan_estimate_instead_of_spinning():
     dpm.adaptive_on_device = False
     with pytest.raises(FloatingPointError, match="error estimate is NaN"):
         dpm.sample(x, method="adaptive", order=2)
+
+
+@pytest.mark.parametrize("order", [2, 3])
+def test_adaptive_host_loop_behind_a_channels_last_network(order, monkeypatch, capsys):
+    """The host-side adaptive loop with a network that answers in channels_last: its states are in the network's layout, and
+    the error-norm launch makes dense default-order copies of them.  Those copies must outlive the launch call -- taken as
+    `_ptr(t.contiguous())` the temporary was freed at once and the next copy landed in the same block: two operands aliasing,
+    a zero estimate, every step accepted (found by tools/fuzz_gpu_api.py: 18 network calls where the double makes 81)."""
+    from kernel_double import install_cpu_double
+    ns = make_schedule("cosine1000")
+    x = torch.from_numpy(np.random.default_rng(29).standard_normal((3, 3, 32, 32)).astype(np.float32))
+
+    def mk(nhwc):
+        def net(xx, t):
+            out = xx * (t.reshape(-1, 1, 1, 1) * 0.0005 + 0.25)
+            return out.contiguous(memory_format=torch.channels_last) if nhwc else out
+        dpm = D.DPM_Solver(D.model_wrapper(net, ns, model_type="score"), ns, algorithm_type="dpmsolver")
+        dpm.adaptive_on_device = False
+        return dpm
+    kw = dict(method="adaptive", order=order, atol=0.05, rtol=0.1, solver_type="taylor", t_end=0.01)
+    got = mk(True).sample(x.to(DEV), **kw)
+    nfe_nhwc = capsys.readouterr().out
+    plain = mk(False).sample(x.to(DEV), **kw)
+    nfe_plain = capsys.readouterr().out
+    with monkeypatch.context() as m:
+        install_cpu_double(m, S, D)
+        want = mk(False).sample(x, **kw)
+    nfe_cpu = capsys.readouterr().out
+    assert nfe_nhwc == nfe_plain == nfe_cpu and "adaptive solver nfe" in nfe_cpu
+    assert torch.equal(got, plain) and rel_err(got.cpu().numpy(), want.numpy()) < 1e-5
+
+
+def test_drop_in_fuzz_slice_of_the_extensions_on_the_gpu(monkeypatch, capsys):
+    """240 random cases of tools/fuzz_gpu_api.py: sample_requests, capture, auto_capture, a channels_last network, a non-default
+    stream, explicit half states, MaskBlend and the device-side adaptive controller on the GPU against plain sample() of the
+    engine's host code on the numpy double -- bit-identical results (6000 cases recorded: profiles/r06_fuzz_gpu_api.json)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_gpu as FG
+    import fuzz_gpu_api as FA
+    monkeypatch.setattr(sys, "argv", ["fuzz_gpu_api.py", "--cases", "240", "--seed", "9"])
+    undo = []
+
+    class MP:
+        def setattr(self, o, n, v):
+            undo.append((o, n, getattr(o, n)))
+            setattr(o, n, v)
+    monkeypatch.setattr(FG, "_MP", MP)
+    try:
+        n_bad = FA.main()
+    finally:
+        for o, n, v in reversed(undo):
+            setattr(o, n, v)
+    out = capsys.readouterr().out
+    assert n_bad == 0, out[-3000:]
+    assert '"cases": 240' in out

@@ -67,7 +67,8 @@ def _rec(what, t):
         RECORD.append((what, t.detach().cpu().clone()))
 
 
-def build(ns, cfg, x, trace):
+def build(ns, cfg, x, trace, solver_kwargs=None):
+    """trace: list receiving one record per network call, or None (a network without host reads: capturable)"""
     B = x.shape[0]
     dev = x.device
     cond = torch.arange(1, B + 1, dtype=torch.float32, device=dev) * 0.5
@@ -75,7 +76,8 @@ def build(ns, cfg, x, trace):
     ndt = None if cfg["net_dt"] == "same" else DT[cfg["net_dt"]]
 
     def base(xx, t, c=None):
-        trace.append((tuple(xx.shape), str(xx.dtype), str(t.dtype), tuple(t.shape), round(float(t.reshape(-1)[0]), 4)))
+        if trace is not None:
+            trace.append((tuple(xx.shape), str(xx.dtype), str(t.dtype), tuple(t.shape), round(float(t.reshape(-1)[0]), 4)))
         _rec("network input", xx)
         _rec("network time", t)
         # (half inputs: arithmetic in fp32, ONE rounding -- torch's half operations with Python scalars do not round alike on
@@ -88,6 +90,8 @@ def build(ns, cfg, x, trace):
         out = out.to(xx.dtype)
         # (a network that answers in its own dtype: Stable Diffusion under autocast hands fp16 to an fp32 state)
         out = out if (ndt is None or xx.dtype is torch.float64) else out.to(ndt)
+        if cfg.get("_nhwc") and out.dim() == 4:          # (tools/fuzz_gpu_api.py: a network that works in channels_last)
+            out = out.contiguous(memory_format=torch.channels_last)
         _rec("network output", out)
         return out
     if cfg["guidance"] == "classifier-free":
@@ -114,6 +118,7 @@ def build(ns, cfg, x, trace):
             _rec("correcting_xt_fn output", out)
             return out
         skw["correcting_xt_fn"] = cxt
+    skw.update(solver_kwargs or {})
     dpm = D.DPM_Solver(fn, ns, **skw)
     dpm.adaptive_on_device = False          # the reference's host loop on both sides: the same sequence of launches
     return dpm

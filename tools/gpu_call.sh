@@ -14,6 +14,7 @@
 #   dropin       the reference's own example call sites on the engine (needs _refscratch/)
 #   bigsingle    tools/big_single.py: launch shape of ONE large stage launch (lab build)
 #   newtests     the GPU tests added this round (quick iteration before the full suite)
+#   fuzzapi      tools/fuzz_gpu_api.py: the same for the GPU-side extensions (requests, capture, auto_capture, NHWC, streams, half states, MaskBlend, device adaptive)
 #   fuzzgpu      tools/fuzz_gpu.py: the drop-in fuzz's random cases, engine on the GPU vs the engine's host code on the numpy double
 TAG=${1:?tag}; shift
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -79,6 +80,11 @@ fuzzgpu)
   for SEED in ${FUZZ_SEEDS:-0 1}; do
     timeout 1500 python tools/fuzz_gpu.py --cases ${FUZZ_CASES:-1500} --seed $SEED --out $O/fuzz_gpu_seed$SEED.json > $O/fuzz_gpu_seed$SEED.log 2>&1; echo "fuzz_gpu seed $SEED rc=$?"
     tail -1 $O/fuzz_gpu_seed$SEED.log | cut -c1-700; grep -c "^case" $O/fuzz_gpu_seed$SEED.log
+  done ;;
+fuzzapi)
+  for SEED in ${FUZZ_SEEDS:-0 1}; do
+    timeout 1200 python tools/fuzz_gpu_api.py --cases ${FUZZ_CASES:-1200} --seed $SEED --case-timeout 30 --out $O/fuzz_gpu_api_seed$SEED.json > $O/fuzz_gpu_api_seed$SEED.log 2>&1; echo "fuzz_gpu_api seed $SEED rc=$?"
+    tail -1 $O/fuzz_gpu_api_seed$SEED.log | cut -c1-1500; grep -c "^case" $O/fuzz_gpu_api_seed$SEED.log; cat $O/*current_case.txt 2>/dev/null | cut -c1-700
   done ;;
 *) echo "unknown step $STEP" ;;
 esac
