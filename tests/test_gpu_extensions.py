@@ -1103,3 +1103,19 @@ def test_drop_in_fuzz_slice_of_the_extensions_on_the_gpu(monkeypatch, capsys):
     out = capsys.readouterr().out
     assert n_bad == 0, out[-3000:]
     assert '"cases": 240' in out
+
+
+def test_fuzz_slice_of_the_native_sample_loop(monkeypatch, capsys):
+    """300 random plans of tools/fuzz_gpu_capi.py: the C ABI's native loop -- dpm_plan_run with an enqueue-only model callback,
+    dpm_plan_run_multi over frozen outputs, dpm_graph_create / dpm_graph_launch -- against DPM_Solver.sample() on the same GPU,
+    bit for bit: every method, order, skip / solver type, parameterisation, classifier-free guidance with and without
+    dup_state, thresholding, fp32 / fp16 / bf16 states (10 000 cases recorded: profiles/r06_fuzz_gpu_capi.json)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_gpu_capi as FC
+    monkeypatch.setattr(sys, "argv", ["fuzz_gpu_capi.py", "--cases", "300", "--seed", "5"])
+    n_bad = FC.main()
+    out = capsys.readouterr().out
+    assert n_bad == 0, out[-3000:]
+    assert '"cases": 300' in out
