@@ -1119,3 +1119,31 @@ def test_fuzz_slice_of_the_native_sample_loop(monkeypatch, capsys):
     out = capsys.readouterr().out
     assert n_bad == 0, out[-3000:]
     assert '"cases": 300' in out
+
+
+def test_fuzz_slice_of_the_public_methods_on_the_gpu(monkeypatch, capsys):
+    """600 random calls of tools/fuzz_gpu_methods.py (the generator of fuzz_dropin.py --mode methods): the per-update methods,
+    model evaluations, add_noise, time grids, thresholding, the schedule's functions and interpolate_fn on the GPU against the
+    engine's host code on the numpy double -- same exception or bit-identical tensors (12 000 recorded:
+    profiles/r06_fuzz_gpu_methods.json)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_gpu_methods as FM
+    monkeypatch.setattr(sys, "argv", ["fuzz_gpu_methods.py", "--cases", "600", "--seed", "13"])
+    undo = []
+
+    class MP:
+        def setattr(self, o, n, v):
+            undo.append((o, n, getattr(o, n)))
+            setattr(o, n, v)
+    monkeypatch.setattr(FM, "_MP", MP)
+    monkeypatch.setattr(FM.FD, "WIDE_NET", True)
+    try:
+        n_bad = FM.main()
+    finally:
+        for o, n, v in reversed(undo):
+            setattr(o, n, v)
+    out = capsys.readouterr().out
+    assert n_bad == 0, out[-3000:]
+    assert '"calls": 600' in out

@@ -16,6 +16,7 @@
 #   newtests     the GPU tests added this round (quick iteration before the full suite)
 #   fuzzapi      tools/fuzz_gpu_api.py: the same for the GPU-side extensions (requests, capture, auto_capture, NHWC, streams, half states, MaskBlend, device adaptive)
 #   fuzzcapi     tools/fuzz_gpu_capi.py: the C ABI's native sample loop (dpm_plan_run / _multi / dpm_graph_*) with a model callback vs sample()
+#   fuzzmethods  tools/fuzz_gpu_methods.py: the public per-update / evaluation / schedule methods on the GPU vs the double
 #   fuzzgpu      tools/fuzz_gpu.py: the drop-in fuzz's random cases, engine on the GPU vs the engine's host code on the numpy double
 TAG=${1:?tag}; shift
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -91,6 +92,11 @@ fuzzcapi)
   for SEED in ${FUZZ_SEEDS:-0 1}; do
     timeout 1200 python tools/fuzz_gpu_capi.py --cases ${FUZZ_CASES:-1500} --seed $SEED --case-timeout 30 --out $O/fuzz_gpu_capi_seed$SEED.json > $O/fuzz_gpu_capi_seed$SEED.log 2>&1; echo "fuzz_gpu_capi seed $SEED rc=$?"
     tail -1 $O/fuzz_gpu_capi_seed$SEED.log | cut -c1-900; grep -c "^case" $O/fuzz_gpu_capi_seed$SEED.log; grep -A2 "^case" $O/fuzz_gpu_capi_seed$SEED.log | cut -c1-700 | head -24; cat $O/*current_case.txt 2>/dev/null | cut -c1-700
+  done ;;
+fuzzmethods)
+  for SEED in ${FUZZ_SEEDS:-0 1}; do
+    timeout 1200 python tools/fuzz_gpu_methods.py --cases ${FUZZ_CASES:-4000} --seed $SEED --case-timeout 30 --out $O/fuzz_gpu_methods_seed$SEED.json > $O/fuzz_gpu_methods_seed$SEED.log 2>&1; echo "fuzz_gpu_methods seed $SEED rc=$?"
+    tail -1 $O/fuzz_gpu_methods_seed$SEED.log | cut -c1-500; grep -c "^call" $O/fuzz_gpu_methods_seed$SEED.log; grep -A2 "^call" $O/fuzz_gpu_methods_seed$SEED.log | cut -c1-600 | head -30; cat $O/*current_case.txt 2>/dev/null | cut -c1-700
   done ;;
 *) echo "unknown step $STEP" ;;
 esac
