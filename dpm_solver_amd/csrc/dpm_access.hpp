@@ -18,7 +18,15 @@ __device__ __forceinline__ T from_f32(float v);
 template <>
 __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <>
-__device__ __forceinline__ __half from_f32<__half>(float v) { return __float2half_rn(v); }
+__device__ __forceinline__ __half from_f32<__half>(float v) {
+  // What is converted is the ROUNDED fp32 value (torch's opmath: the operation in fp32, then one conversion).  Without the
+  // empty asm the compiler folds a preceding fp32 multiply into v_fma_mixlo_f16, which rounds the exact product ONCE to
+  // fp16: one fp16 ulp off wherever the fp32 rounding lands on an fp16 tie -- guidance_scale 7.3 times an 11-bit
+  // difference does in ~1 % of elements (the classifier-free blend of an fp16 network in the one-element-per-lane and
+  // thresholding kernels; found by tools/fuzz_gpu_kernel.py in round 6, build() checks the listing for the instruction).
+  asm("" : "+v"(v));
+  return __float2half_rn(v);
+}
 template <>
 __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) {
   uint32_t u = __float_as_uint(v);

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(T64) void stage_thresh_kernel_f64(const Ptrs64 q, c
   }
   const double a = __longlong_as_double((long long)a_bits), bb = __longlong_as_double((long long)b_bits);
   const double diff = bb - a;
-  const double qv = w < 0.5 ? a + w * diff : bb - diff * (1. - w);  // ATen lerp
+  const double qv = w < 0.5 ? __builtin_fma(w, diff, a) : __builtin_fma(w - 1., diff, bb);  // ATen lerp: one fused multiply-add
   const double s = fmax(qv, p.thr_max);                               // ref :423
   for (int64_t j = tid; j < per_sample; j += (int64_t)UF64 * T64) {
     In64 v[UF64];

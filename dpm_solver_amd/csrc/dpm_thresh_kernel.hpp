@@ -315,7 +315,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
         const bool c1 = mine > 0 && (m1 >> 20) >= bin_lo, c2 = mine > 1 && (m2 >> 20) >= bin_lo;
         const bool c3 = mine > 2 && (m3 >> 20) >= bin_lo, c4 = mine > 3 && (m4 >> 20) >= bin_lo;
         if (__ballot(c4 && mine > 4)) {
-          (void)compact_candidates<T, true>(sx0, n, bin_lo, misc, cand, tid);
+          if (vec)
+            (void)compact_candidates<T, true>(sx0, n, bin_lo, misc, cand, tid);
+          else  // one element per lane: the wavefront's own elements are not its 16-byte rows
+            compact_own_elements<T>(sx0, n, bin_lo, misc, cand, tid);
         } else {
           const uint32_t cnt = (c1 ? 1u : 0u) + (c2 ? 1u : 0u) + (c3 ? 1u : 0u) + (c4 ? 1u : 0u);
           const uint32_t incl = wave_incl_scan(cnt);
@@ -580,9 +583,13 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
     uint32_t done_old = 0u;
     if (k > 1 && tid == 0)
       done_old = __hip_atomic_fetch_add(ws + THR_WS_DONE, 1u + (misc[30] ? 0x10000u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // torch.quantile 'linear' = ATen lerp(a, b, w)
+    // torch.quantile 'linear' = ATen lerp(a, b, w), which is ONE fused multiply-add on every path torch takes (the CPU
+    // kernel is vec::fmadd(w or w - 1, b - a, a or b) for whole vectors and tails alike, the device kernel's
+    // "a + w * diff" / "b - diff * (1 - w)" is contracted by its compiler): with this library's -ffp-contract=off the fma
+    // is written out.  (Rounds 1-5 had the two-rounding form: one ulp off torch.quantile in ~2 % of random samples, found by
+    // tools/fuzz_gpu_thresh.py.)
     const float diff = b - a;
-    const float q = tp.w < 0.5f ? a + tp.w * diff : b - diff * (1.f - tp.w);
+    const float q = tp.w < 0.5f ? __builtin_fmaf(tp.w, diff, a) : __builtin_fmaf(tp.w - 1.f, diff, b);
     const float s = fmaxf(q, tp.max_val);  // ref :423
     // x0 / s for every element of the sample: the same division by an invariant (the guard of div_by_alpha, evaluated
     // here because s is born on the device); ref :424 divides

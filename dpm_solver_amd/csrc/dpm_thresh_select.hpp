@@ -105,6 +105,36 @@ __device__ __forceinline__ uint32_t compact_candidates(const float* sx0, int n, 
   return hi;
 }
 
+// A WAVEFRONT-conditional sweep ("one of my threads holds more than four candidates": the callers' __ballot) must read the
+// elements its own threads produced.  In the 16-byte layout those are the rows compact_candidates reads (thread t: elements
+// 4t .. 4t+3 of every row of 4T); in the one-element-per-lane layout (unaligned or ragged samples) element i belongs to
+// thread i % T, and the 16-byte rows of a wavefront hold other wavefronts' elements -- sweeping them there listed some
+// elements twice and dropped others (a wrong order statistic in samples of 2049 .. 12288 elements whose length is not a
+// multiple of 4, K close to T/4; found by tools/fuzz_gpu_thresh.py in round 6).  Same list protocol as compact_candidates.
+template <int T>
+__device__ __forceinline__ void compact_own_elements(const float* sx0, int n, uint32_t bin, uint32_t* misc, uint32_t* cand,
+                                                     int tid, int shift = 20, uint32_t dbase = 0u) {
+  constexpr uint32_t ABS = 0x7fffffffu;
+  uint32_t cnt = 0u;
+  for (int i = tid; i < n; i += T) {
+    const uint32_t u = __float_as_uint(sx0[i]) & ABS;
+    const uint32_t dr = u >> shift, d = dr > dbase ? dr - dbase : 0u;
+    cnt += d >= bin ? 1u : 0u;
+  }
+  const uint32_t incl = wave_incl_scan(cnt);
+  uint32_t slot = 0u;
+  if ((tid & 63) == 63 && incl) slot = atomicAdd(&misc[4], incl);
+  uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)slot, 63) + incl - cnt;
+  for (int i = tid; i < n; i += T) {
+    const uint32_t u = __float_as_uint(sx0[i]) & ABS;
+    const uint32_t dr = u >> shift, d = dr > dbase ? dr - dbase : 0u;
+    if (d >= bin) {
+      if (off < (uint32_t)THR_CAP) cand[off] = u;
+      ++off;
+    }
+  }
+}
+
 // maximum over the 64 lanes of a wavefront, valid in lane 63 (the DPP ladder of wave_incl_scan with max; 0 is the identity)
 __device__ __forceinline__ uint32_t wave_max_to_lane63(uint32_t v) {
 #define DPM_DPP_MAX(ctrl, rmask, bc)                                                              \
@@ -387,7 +417,12 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
     const bool c1 = mine > 0 && qual(m1), c2 = mine > 1 && qual(m2);
     const bool c3 = mine > 2 && qual(m3), c4 = mine > 3 && qual(m4);
     if (__ballot(c4 && mine > 4)) {
-      if (pbound)  // digit = the whole pattern: d >= bin is u >= pbound
+      if (!vec) {  // one element per lane: the sweep reads this wavefront's own elements (compact_own_elements)
+        if (pbound)
+          compact_own_elements<T>(sx0, n, pbound, misc, cand, tid, 0, 0u);
+        else
+          compact_own_elements<T>(sx0, n, bin_lo, misc, cand, tid, THR_FSHIFT, dbase);
+      } else if (pbound)  // digit = the whole pattern: d >= bin is u >= pbound
         (void)compact_candidates<T, true>(sx0, n, pbound, misc, cand, tid, 0, 0u);
       else
         (void)compact_candidates<T, true>(sx0, n, bin_lo, misc, cand, tid, THR_FSHIFT, dbase);

@@ -21,12 +21,29 @@ relative rather than bit-exact.  Tensor arithmetic (+,-,*,/) is IEEE and bit-ide
 
 Citations `ref:NNN` are line numbers in /root/reference/dpm_solver_pytorch.py.
 """
+import ctypes
+import ctypes.util
 import math
 
 import numpy as np
 
 F32 = np.float32
 F64 = np.float64
+
+_libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+_libm.fmaf.restype, _libm.fmaf.argtypes = ctypes.c_float, [ctypes.c_float] * 3
+_libm.fma.restype, _libm.fma.argtypes = ctypes.c_double, [ctypes.c_double] * 3
+
+
+def fma_rows(a, b, c, dtype=F32):
+    """a * b + c with ONE rounding (the C library's fmaf / fma), elementwise over broadcast operands"""
+    f = _libm.fmaf if dtype is F32 else _libm.fma
+    a, b, c = np.broadcast_arrays(np.asarray(a, dtype), np.asarray(b, dtype), np.asarray(c, dtype))
+    out = np.empty(a.shape, dtype)
+    of, af, bf, cf = out.reshape(-1), a.reshape(-1), b.reshape(-1), c.reshape(-1)
+    for i in range(of.size):
+        of[i] = f(af[i], bf[i], cf[i])
+    return out
 
 
 # --------------------------------------------------------------------------------------------
@@ -309,7 +326,10 @@ def wrap_model(model, sch, model_type="noise", guidance_type="uncond", condition
 def quantile_rows32(a, q):
     """torch.quantile(a, q, dim=1) for fp32 `a` [B, n], linear interpolation.  The fractional rank is
     computed in fp32 (q is materialised as an fp32 tensor), which matters: for n = 12288, q = 0.995
-    the fp32 rank is 12225.5654296875, not 12225.565."""
+    the fp32 rank is 12225.5654296875, not 12225.565.  The interpolation is ATen's lerp, which is one fused multiply-add
+    on the CPU (vec::fmadd(w or w - 1, hi - lo, lo or hi), whole vectors and tails alike) and on the device (the compiler
+    contracts Lerp.h's two-operation form): checked against torch.quantile over 10^5 random rows in
+    tests/test_oracle_golden.py."""
     n = a.shape[1]
     s = np.sort(a, axis=1)
     rank = F32(q) * F32(n - 1)
@@ -319,8 +339,8 @@ def quantile_rows32(a, q):
     lo_v, hi_v = s[:, lo], s[:, hi]
     d = hi_v - lo_v
     if w < F32(0.5):                                                          # ATen lerp
-        return (lo_v + w * d).astype(F32)
-    return (hi_v - d * (F32(1.0) - w)).astype(F32)
+        return fma_rows(w, d, lo_v)
+    return fma_rows(F32(w - F32(1.0)), d, hi_v)
 
 
 def dynamic_threshold(x0, ratio=0.995, max_val=1.0):

@@ -96,7 +96,7 @@ DPMO_API int dpmo_dynamic_threshold(float* x0, int64_t batch, int64_t per, float
     const int64_t lo = (int64_t)floorf(rank), hi = (int64_t)ceilf(rank);
     const float w = rank - (float)lo;
     const float d = a[hi] - a[lo];
-    float s = (w < 0.5f) ? a[lo] + w * d : a[hi] - d * (1.0f - w);
+    float s = (w < 0.5f) ? fmaf(w, d, a[lo]) : fmaf(w - 1.0f, d, a[hi]);   /* ATen lerp: one fused multiply-add */
     if (!(s > max_val)) s = max_val;   /* torch.maximum */
     if (s_out) s_out[b] = s;
     for (int64_t i = 0; i < per; ++i) {

@@ -139,7 +139,7 @@ def threshold64(x0, ratio, max_val):
     lo, hi = int(np.floor(rank)), int(np.ceil(rank))
     w = rank - F64(lo)
     a, b = srt[:, lo], srt[:, hi]
-    q = a + w * (b - a) if w < 0.5 else b - (b - a) * (F64(1.0) - w)
+    q = O.fma_rows(w, b - a, a, F64) if w < 0.5 else O.fma_rows(w - F64(1.0), b - a, b, F64)   # one fused multiply-add
     s = np.maximum(q, F64(max_val)).reshape((-1,) + (1,) * (x0.ndim - 1))
     return np.clip(x0, -s, s) / s
 

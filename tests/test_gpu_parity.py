@@ -170,6 +170,44 @@ def test_dynamic_thresholding_topk_front_end():
         np.testing.assert_array_equal(y.cpu().numpy(), O.dynamic_threshold(x0, p, 1.0), err_msg=str((shape, p, top)))
 
 
+def test_thresholding_one_element_per_lane_layout_sweeps_its_own_elements():
+    """Round 6, found by tools/fuzz_gpu_thresh.py: samples whose length is not a multiple of 4 (or whose storage is not
+    16-byte aligned) are walked one element per lane; when a wavefront's threads held more than four candidates each
+    (K = n - floor(p (n - 1)) just under T / 4 = 128) the sweep that lists them read the wavefront's 16-byte rows -- other
+    wavefronts' elements in this layout -- and returned the order statistic a few ranks off (39 of 390 samples at
+    [130, 4095], p = 0.97).  One workgroup per sample and clusters, against torch.quantile itself (ref :420)."""
+    ns = make_schedule("ddpm")
+    for (B, per, offset) in [(130, 4095, 0), (130, 4092, 1), (130, 3071, 0), (130, 11210, 0), (130, 2049, 0), (3, 49153, 0),
+                             (5, 98305, 1)]:
+        for K in (60, 100, 110, 120, 127, 128, 129):
+            p = (per - K + 0.3) / (per - 1.0)
+            x0 = torch.from_numpy((np.random.default_rng(per + K).standard_normal((B, per))).astype(F32))
+            flat = torch.empty(B * per + 8, dtype=torch.float32, device=DEV)
+            xg = flat[offset:offset + B * per].reshape(B, per)
+            xg.copy_(x0)
+            dpm = D.DPM_Solver(lambda x, t: x, ns, correcting_x0_fn="dynamic_thresholding", dynamic_thresholding_ratio=p,
+                               thresholding_max_val=0.5)
+            got = dpm.dynamic_thresholding_fn(xg, None).cpu()
+            s = torch.maximum(torch.quantile(x0.abs(), p, dim=1), torch.tensor(0.5))[:, None]
+            assert torch.equal(got, torch.clamp(x0, -s, s) / s), (B, per, offset, K)
+            np.testing.assert_array_equal(got.numpy(), O.dynamic_threshold(x0.numpy(), p, 0.5), err_msg=str((B, per, offset, K)))
+
+
+def test_fuzz_slice_of_thresholding_against_torch_quantile(monkeypatch, capsys):
+    """500 random cases of tools/fuzz_gpu_thresh.py: dynamic_thresholding_fn on the GPU against the reference's own three
+    lines (torch.quantile on the CPU, maximum, clamp / divide) -- sample sizes around the kernels' boundaries, any ratio,
+    tie-heavy values, outliers, fp32 and fp64 -- bit for bit (recorded: profiles/r06_fuzz_gpu_thresh.json)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_gpu_thresh as FT
+    monkeypatch.setattr(sys, "argv", ["fuzz_gpu_thresh.py", "--cases", "500", "--seed", "3"])
+    n_bad = FT.main()
+    out = capsys.readouterr().out
+    assert n_bad == 0, out[-3000:]
+    assert '"cases": 500' in out
+
+
 @pytest.mark.lab
 def test_cluster_single_exchange_route_and_its_fallback():
     """Clusters (k workgroups per sample) first try to settle a sample with one exchange of per-chunk candidates

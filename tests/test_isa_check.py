@@ -55,6 +55,15 @@ def test_rejects_scratch_in_the_catch_all_thresholding_kernel_too():
         G.scan_disassembly(bad)
 
 
+def test_rejects_a_mixed_precision_fused_instruction():
+    """round 6: v_fma_mixlo_f16 rounds an fp32 product and its fp16 conversion once -- the reference's half arithmetic is an
+    fp32 operation, then a conversion (two roundings); the compiler folded the pair in the classifier-free blend of fp16
+    networks until from_f32<__half> hid the fp32 value from it"""
+    bad = GOOD[:2] + ["\tv_fma_mixlo_f16 v3, v5, s8, 0 op_sel_hi:[1,0,0]"] + GOOD[2:]
+    with pytest.raises(AssertionError, match="rounds an fp32 operation"):
+        G.scan_disassembly(bad)
+
+
 NOTES = """
     .group_segment_fixed_size: 0
     .kernarg_segment_size: 240

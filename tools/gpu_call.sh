@@ -17,6 +17,9 @@
 #   fuzzapi      tools/fuzz_gpu_api.py: the same for the GPU-side extensions (requests, capture, auto_capture, NHWC, streams, half states, MaskBlend, device adaptive)
 #   fuzzcapi     tools/fuzz_gpu_capi.py: the C ABI's native sample loop (dpm_plan_run / _multi / dpm_graph_*) with a model callback vs sample()
 #   fuzzmethods  tools/fuzz_gpu_methods.py: the public per-update / evaluation / schedule methods on the GPU vs the double
+#   fuzzkernel   tools/fuzz_gpu_kernel.py: one dpm_stage_launch per case (random stage record, tiling-boundary geometry, dtype pairs, layouts) vs the double
+#   fuzzthresh   tools/fuzz_gpu_thresh.py: dynamic_thresholding_fn on the GPU vs torch.quantile on the CPU (boundary sample sizes, ties, any ratio)
+#   torchprobe   tools/torch_on_device_probe.py: torch's own half * scalar and quantile interpolation on this GPU vs its CPU kernels
 #   fuzzgpu      tools/fuzz_gpu.py: the drop-in fuzz's random cases, engine on the GPU vs the engine's host code on the numpy double
 TAG=${1:?tag}; shift
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -77,7 +80,7 @@ dropin)
 bigsingle)
   timeout 900 python tools/big_single.py --out $O/big_single.json > $O/big_single.log 2>&1; echo "big_single rc=$?"; grep '^{' $O/big_single.log | cut -c1-330; grep -v '^{' $O/big_single.log | tail -5 ;;
 newtests)
-  ( time timeout 900 python -m pytest tests/test_gpu_extensions.py -m gpu -q -x -k "auto_capture or add_noise_with_double or order_four or capture_rejects" ) > $O/newtests.log 2>&1; echo "newtests rc=$?"; tail -15 $O/newtests.log ;;
+  ( time timeout 900 python -m pytest tests -m gpu -q -x -k "${NEWTESTS_K:-thresh}" ) > $O/newtests.log 2>&1; echo "newtests rc=$?"; tail -15 $O/newtests.log ;;
 fuzzgpu)
   for SEED in ${FUZZ_SEEDS:-0 1}; do
     timeout 1500 python tools/fuzz_gpu.py --cases ${FUZZ_CASES:-1500} --seed $SEED --out $O/fuzz_gpu_seed$SEED.json > $O/fuzz_gpu_seed$SEED.log 2>&1; echo "fuzz_gpu seed $SEED rc=$?"
@@ -98,6 +101,18 @@ fuzzmethods)
     timeout 1200 python tools/fuzz_gpu_methods.py --cases ${FUZZ_CASES:-4000} --seed $SEED --case-timeout 30 --out $O/fuzz_gpu_methods_seed$SEED.json > $O/fuzz_gpu_methods_seed$SEED.log 2>&1; echo "fuzz_gpu_methods seed $SEED rc=$?"
     tail -1 $O/fuzz_gpu_methods_seed$SEED.log | cut -c1-500; grep -c "^call" $O/fuzz_gpu_methods_seed$SEED.log; grep -A2 "^call" $O/fuzz_gpu_methods_seed$SEED.log | cut -c1-600 | head -30; cat $O/*current_case.txt 2>/dev/null | cut -c1-700
   done ;;
+fuzzkernel)
+  for SEED in ${FUZZ_SEEDS:-0 1}; do
+    timeout 1400 python tools/fuzz_gpu_kernel.py --cases ${FUZZ_CASES:-3000} --seed $SEED --case-timeout 60 --out $O/fuzz_gpu_kernel_seed$SEED.json > $O/fuzz_gpu_kernel_seed$SEED.log 2>&1; echo "fuzz_gpu_kernel seed $SEED rc=$?"
+    tail -1 $O/fuzz_gpu_kernel_seed$SEED.log | cut -c1-1500; grep -c "^case" $O/fuzz_gpu_kernel_seed$SEED.log; grep -A2 "^case" $O/fuzz_gpu_kernel_seed$SEED.log | cut -c1-600 | head -40; cat $O/*current_case.txt 2>/dev/null | cut -c1-700
+  done ;;
+fuzzthresh)
+  for SEED in ${FUZZ_SEEDS:-0 1}; do
+    timeout 1400 python tools/fuzz_gpu_thresh.py --cases ${FUZZ_CASES:-3000} --seed $SEED --case-timeout 60 --out $O/fuzz_gpu_thresh_seed$SEED.json > $O/fuzz_gpu_thresh_seed$SEED.log 2>&1; echo "fuzz_gpu_thresh seed $SEED rc=$?"
+    tail -1 $O/fuzz_gpu_thresh_seed$SEED.log | cut -c1-1500; grep -c "^case" $O/fuzz_gpu_thresh_seed$SEED.log; grep -A2 "^case" $O/fuzz_gpu_thresh_seed$SEED.log | cut -c1-600 | head -40; cat $O/*current_case.txt 2>/dev/null | cut -c1-700
+  done ;;
+torchprobe)
+  timeout 600 python tools/torch_on_device_probe.py > $O/torch_on_device.json 2> $O/torch_on_device.err; echo "torchprobe rc=$?"; cat $O/torch_on_device.json ;;
 *) echo "unknown step $STEP" ;;
 esac
 done
