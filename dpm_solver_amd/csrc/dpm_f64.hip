@@ -279,7 +279,7 @@ __global__ __launch_bounds__(T64) void stage_thresh_kernel_f64(const Ptrs64 q, c
   const double a = __longlong_as_double((long long)a_bits), bb = __longlong_as_double((long long)b_bits);
   const double diff = bb - a;
   const double qv = w < 0.5 ? __builtin_fma(w, diff, a) : __builtin_fma(w - 1., diff, bb);  // ATen lerp: one fused multiply-add
-  const double s = fmax(qv, p.thr_max);                               // ref :423
+  const double s = qv != qv ? qv : fmax(qv, p.thr_max);               // ref :423, torch.maximum keeps a NaN
   for (int64_t j = tid; j < per_sample; j += (int64_t)UF64 * T64) {
     In64 v[UF64];
 #pragma unroll
@@ -291,7 +291,10 @@ __global__ __launch_bounds__(T64) void stage_thresh_kernel_f64(const Ptrs64 q, c
 #pragma unroll
     for (int r = 0; r < UF64; ++r) {
       const int64_t jj = j + (int64_t)r * T64;
-      if (jj < per_sample) finish64(q, p, base + jj, v[r], fmin(fmax(model_value64(v[r], p), -s), s) / s);  // ref :424
+      if (jj < per_sample) {
+        const double mv = model_value64(v[r], p);
+        finish64(q, p, base + jj, v[r], (mv != mv ? mv : fmin(fmax(mv, -s), s)) / s);  // ref :424, torch.clamp keeps a NaN
+      }
     }
   }
 }

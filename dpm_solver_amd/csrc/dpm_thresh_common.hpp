@@ -132,6 +132,13 @@ struct ThrTab {
   uint32_t* ws[MULTI_MAX];
 };
 
+// torch.clamp(v, -s, s) (ref :424): a NaN element stays NaN (fminf / fmaxf return their other operand), a NaN bound makes
+// the division that follows NaN anyway.  Non-finite values: INTEGRATION.md, behavioural notes.
+__device__ __forceinline__ float clamp_ref(float v, float s) {
+  const float c = fminf(fmaxf(v, -s), s);
+  return v != v ? v : c;
+}
+
 // inclusive prefix sum over the 64 lanes of a wavefront: DPP row shifts inside the rows of 16 lanes, then the two row
 // broadcasts (no LDS traffic, six VALU instructions).  Needs all 64 lanes active.
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {

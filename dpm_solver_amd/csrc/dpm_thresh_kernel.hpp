@@ -590,7 +590,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
     // tools/fuzz_gpu_thresh.py.)
     const float diff = b - a;
     const float q = tp.w < 0.5f ? __builtin_fmaf(tp.w, diff, a) : __builtin_fmaf(tp.w - 1.f, diff, b);
-    const float s = fmaxf(q, tp.max_val);  // ref :423
+    // ref :423, torch.maximum: a NaN quantile (a NaN among the two order statistics, inf - inf) stays NaN -- fmaxf drops it
+    const float s = q != q ? q : fmaxf(q, tp.max_val);
     // x0 / s for every element of the sample: the same division by an invariant (the guard of div_by_alpha, evaluated
     // here because s is born on the device); ref :424 divides
     const uint32_t s_bits = __float_as_uint(s), s_ex = (s_bits >> 23) & 0xffu;
@@ -614,7 +615,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
               if (bb) load4(bb, gi, vb);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) om[j] = fminf(fmaxf(sx0[i + j], -s), s);  // ref :424
+            for (int j = 0; j < 4; ++j) om[j] = clamp_ref(sx0[i + j], s);  // ref :424
             if (s_fast) {
 #pragma unroll
               for (int j = 0; j < 4; j += 2) {
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
     } else {
       for (int i = tid; i < n; i += T) {
         const int64_t gi = base + i;
-        const float mn = fminf(fmaxf(sx0[i], -s), s) / s;  // ref :424
+        const float mn = clamp_ref(sx0[i], s) / s;  // ref :424
         const float xv = nx ? to_f32(x[gi]) : 0.f;
         float o = combine_any<FORM>(xv, mn, nh1 ? to_f32(h1[gi]) : 0.f, nh2 ? to_f32(h2[gi]) : 0.f, p);
         if (mask)

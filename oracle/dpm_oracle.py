@@ -337,18 +337,23 @@ def quantile_rows32(a, q):
     hi = int(np.ceil(rank))
     w = F32(rank - F32(lo))
     lo_v, hi_v = s[:, lo], s[:, hi]
-    d = hi_v - lo_v
+    with np.errstate(invalid="ignore"):
+        d = hi_v - lo_v                                                       # (inf - inf = NaN, like the reference)
     if w < F32(0.5):                                                          # ATen lerp
-        return fma_rows(w, d, lo_v)
-    return fma_rows(F32(w - F32(1.0)), d, hi_v)
+        out = fma_rows(w, d, lo_v)
+    else:
+        out = fma_rows(F32(w - F32(1.0)), d, hi_v)
+    out[np.isnan(a).any(axis=1)] = np.nan                                     # torch.quantile: a row holding a NaN gives NaN
+    return out
 
 
 def dynamic_threshold(x0, ratio=0.995, max_val=1.0):
     B = x0.shape[0]
     s = quantile_rows32(np.abs(x0).reshape(B, -1), ratio)
-    s = np.maximum(s, F32(max_val))
+    s = np.maximum(s, F32(max_val))                                           # (NaN-propagating, like torch.maximum)
     sb = _b(s, x0)
-    return (np.clip(x0, -sb, sb) / sb).astype(F32)
+    with np.errstate(invalid="ignore"):
+        return (np.minimum(np.maximum(x0, -sb), sb) / sb).astype(F32)         # torch.clamp = min(max(x, lo), hi), NaNs kept
 
 
 # --------------------------------------------------------------------------------------------

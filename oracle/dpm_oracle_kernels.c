@@ -90,14 +90,19 @@ DPMO_API int dpmo_dynamic_threshold(float* x0, int64_t batch, int64_t per, float
       fail = 1;
       continue;
     }
-    for (int64_t i = 0; i < per; ++i) a[i] = fabsf(row[i]);
-    qsort(a, (size_t)per, sizeof(float), cmp_f32);
+    int has_nan = 0;
+    for (int64_t i = 0; i < per; ++i) {
+      a[i] = fabsf(row[i]);
+      has_nan |= a[i] != a[i];
+    }
+    if (!has_nan) qsort(a, (size_t)per, sizeof(float), cmp_f32);
     const float rank = ratio * (float)(per - 1);
     const int64_t lo = (int64_t)floorf(rank), hi = (int64_t)ceilf(rank);
     const float w = rank - (float)lo;
     const float d = a[hi] - a[lo];
     float s = (w < 0.5f) ? fmaf(w, d, a[lo]) : fmaf(w - 1.0f, d, a[hi]);   /* ATen lerp: one fused multiply-add */
-    if (!(s > max_val)) s = max_val;   /* torch.maximum */
+    if (has_nan) s = NAN;              /* torch.quantile: a row holding a NaN gives NaN */
+    if (s == s && !(s > max_val)) s = max_val;   /* torch.maximum (a NaN stays) */
     if (s_out) s_out[b] = s;
     for (int64_t i = 0; i < per; ++i) {
       float v = row[i];

@@ -140,8 +140,10 @@ def threshold64(x0, ratio, max_val):
     w = rank - F64(lo)
     a, b = srt[:, lo], srt[:, hi]
     q = O.fma_rows(w, b - a, a, F64) if w < 0.5 else O.fma_rows(w - F64(1.0), b - a, b, F64)   # one fused multiply-add
+    q = np.where(np.isnan(rows).any(axis=1), np.nan, q)        # torch.quantile: a row holding a NaN gives NaN
     s = np.maximum(q, F64(max_val)).reshape((-1,) + (1,) * (x0.ndim - 1))
-    return np.clip(x0, -s, s) / s
+    with np.errstate(invalid="ignore"):
+        return np.minimum(np.maximum(x0, -s), s) / s
 
 
 def launch_stage_double(st, x, xe, e0, e1, g, h1, h2, state_dtype, want_m=None, ext=None, opts=None, coef64=None):
