@@ -30,8 +30,10 @@ struct KParams {
 // x / alpha_e for a wave-uniform divisor whose correctly rounded reciprocal r = RN(1/alpha) is known: q = RN(x*r),
 // then one exact-residual correction q' = RN(q + RN(x - q*alpha) * r) (both fused: the residual is exact).  This is
 // the correctly rounded quotient -- bit-identical to IEEE division, which the reference uses -- for every finite
-// x whose quotient is a normal number, provided alpha's significand is not all ones (Markstein's theorem; the launch
-// falls back to the generic prologue with a true division when that guard fails).  3 VALU ops instead of ~12.
+// x whose quotient is a normal number and whose residual does not underflow (|x| above ~2^-100 = 8e-31), provided
+// alpha's significand is not all ones (Markstein's theorem; the launch falls back to the generic prologue with a
+// true division when that guard fails).  3 VALU ops instead of ~12.  Below that magnitude the result may be one ulp
+// off, and an infinite x gives NaN where the division gives inf (tools/fuzz_gpu_kernel.py --extreme measures both).
 // The arithmetic below is written once for V = float and V = f32x2 (two adjacent elements): the streaming kernel works
 // on adjacent pairs so that the packed fp32 instructions (v_pk_mul/add/fma_f32) take their operands from the register
 // pairs the loads and conversions produce, and v_cvt_pk_f16_f32 packs the two halves of one output dword directly.

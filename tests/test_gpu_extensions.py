@@ -1121,6 +1121,23 @@ def test_fuzz_slice_of_the_native_sample_loop(monkeypatch, capsys):
     assert '"cases": 300' in out
 
 
+def test_fuzz_slice_of_single_stage_launches(monkeypatch, capsys):
+    """500 random cases of tools/fuzz_gpu_kernel.py --extreme: ONE dpm_stage_launch per case -- random stage record (form,
+    eps -> x0, parameterisation, guidance, thresholding, random coefficients), geometry around every tiling boundary, all six
+    dtype pairs, unaligned views, channel-sliced outputs, NHWC, the duplicated store; one case in six with magnitudes 1e-45 ..
+    1e38, inf and NaN -- against the numpy double from the same inputs, bit for bit (12 000 recorded:
+    profiles/r06_fuzz_gpu_kernel.json; found the v_fma_mixlo_f16 fold of the fp16 classifier-free blend)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_gpu_kernel as FK
+    monkeypatch.setattr(sys, "argv", ["fuzz_gpu_kernel.py", "--cases", "500", "--seed", "17", "--extreme"])
+    n_bad = FK.main()
+    out = capsys.readouterr().out
+    assert n_bad == 0, out[-3000:]
+    assert '"cases": 500' in out
+
+
 def test_fuzz_slice_of_the_public_methods_on_the_gpu(monkeypatch, capsys):
     """600 random calls of tools/fuzz_gpu_methods.py (the generator of fuzz_dropin.py --mode methods): the per-update methods,
     model evaluations, add_noise, time grids, thresholding, the schedule's functions and interpolate_fn on the GPU against the

@@ -103,7 +103,7 @@ fuzzmethods)
   done ;;
 fuzzkernel)
   for SEED in ${FUZZ_SEEDS:-0 1}; do
-    timeout 1400 python tools/fuzz_gpu_kernel.py --cases ${FUZZ_CASES:-3000} --seed $SEED --case-timeout 60 --out $O/fuzz_gpu_kernel_seed$SEED.json > $O/fuzz_gpu_kernel_seed$SEED.log 2>&1; echo "fuzz_gpu_kernel seed $SEED rc=$?"
+    timeout 1400 python tools/fuzz_gpu_kernel.py ${FUZZ_KERNEL_FLAGS:-} --cases ${FUZZ_CASES:-3000} --seed $SEED --case-timeout 60 --out $O/fuzz_gpu_kernel_seed$SEED.json > $O/fuzz_gpu_kernel_seed$SEED.log 2>&1; echo "fuzz_gpu_kernel seed $SEED rc=$?"
     tail -1 $O/fuzz_gpu_kernel_seed$SEED.log | cut -c1-1500; grep -c "^case" $O/fuzz_gpu_kernel_seed$SEED.log; grep -A2 "^case" $O/fuzz_gpu_kernel_seed$SEED.log | cut -c1-600 | head -40; cat $O/*current_case.txt 2>/dev/null | cut -c1-700
   done ;;
 fuzzthresh)
