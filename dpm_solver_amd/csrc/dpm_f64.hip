@@ -163,6 +163,7 @@ __global__ __launch_bounds__(T64) void stage_thresh_kernel_f64(const Ptrs64 q, c
   const int tid = threadIdx.x;
   const int64_t b = blockIdx.x, base = b * per_sample, ebase = b * (q.eps_stride ? q.eps_stride : per_sample);
   // the patterns of elements j, j + T64, .. (UT64 of them, loads issued together); beyond the sample: TOP + 1 (matches no prefix)
+  bool nan_seen = false;  // torch.quantile: a sample holding a NaN anywhere gives NaN (every pass sees every element)
   auto bitsU = [&](int64_t j, uint64_t (&u)[UT64]) {
     In64 v[UT64];
 #pragma unroll
@@ -173,6 +174,8 @@ __global__ __launch_bounds__(T64) void stage_thresh_kernel_f64(const Ptrs64 q, c
 #pragma unroll
     for (int r = 0; r < UT64; ++r)
       u[r] = j + (int64_t)r * T64 < per_sample ? ((uint64_t)__double_as_longlong(model_value64(v[r], p)) & TOP) : ~0ull;
+#pragma unroll
+    for (int r = 0; r < UT64; ++r) nan_seen |= u[r] != ~0ull && u[r] > 0x7ff0000000000000ull;
   };
   uint64_t prefix = 0ull, known = 0ull;
   int64_t rank = lo, cnt = per_sample;
@@ -276,6 +279,7 @@ __global__ __launch_bounds__(T64) void stage_thresh_kernel_f64(const Ptrs64 q, c
       if (sh_min != TOP) b_bits = sh_min;
     }
   }
+  if (__syncthreads_or(nan_seen)) a_bits = b_bits = TOP;  // (a NaN pattern)
   const double a = __longlong_as_double((long long)a_bits), bb = __longlong_as_double((long long)b_bits);
   const double diff = bb - a;
   const double qv = w < 0.5 ? __builtin_fma(w, diff, a) : __builtin_fma(w - 1., diff, bb);  // ATen lerp: one fused multiply-add

@@ -132,6 +132,16 @@ struct ThrTab {
   uint32_t* ws[MULTI_MAX];
 };
 
+// torch.quantile gives NaN for a sample that holds a NaN ANYWHERE (ref :420), whatever the rank asked for.  Phase 1 stores
+// every NaN as the one pattern 0x7fffffff (canon_nan): the largest |x0| key there is and the only one with the top digit
+// 0x7ff, so "the sample holds a NaN" is "bin 2047 of a level-0 histogram (of the elements, or of the per-thread maxima) is
+// not empty" (locate_bin, top = true) or "the largest chunk maximum is that pattern" (cluster_select_once) -- words every
+// route already merges across the cluster.  The verdict is misc[THR_NANW] == the sample's tag (sample index + 1: never
+// reset, a stale tag of an earlier sample does not match).
+constexpr uint32_t THR_NAN_KEY = 0x7fffffffu;
+constexpr int THR_NANW = 15;
+__device__ __forceinline__ float canon_nan(float v) { return v != v ? __uint_as_float(THR_NAN_KEY) : v; }
+
 // torch.clamp(v, -s, s) (ref :424): a NaN element stays NaN (fminf / fmaxf return their other operand), a NaN bound makes
 // the division that follows NaN anyway.  Non-finite values: INTEGRATION.md, behavioural notes.
 __device__ __forceinline__ float clamp_ref(float v, float s) {

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
   constexpr int dbg_fault = 0;
 #endif
   if (threadIdx.x == 0) misc[30] = (k > 1 && dbg_fault >= 2 && c == 1) ? 1u : 0u;
+  if (threadIdx.x == 0) misc[THR_NANW] = 0u;  // no sample's tag (the first barrier of the first sample is ahead)
 #if DPM_LAB
   if (tp.stagger) {  // experiment: phase offset between clusters (all workgroups of a cluster wait alike)
     const uint32_t ng = (uint32_t)tp.stagger >> 16 ? (uint32_t)tp.stagger >> 16 : 2u;
@@ -181,13 +182,13 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
                 const f32x2 rr = prologue<GUIDE, SPEC_NOISE_X0, f32x2, TE>(
                     f32x2{vx[r][j], vx[r][j + 1]}, f32x2{v0[r][j], v0[r][j + 1]},
                     g_cfg ? f32x2{v1[r][j], v1[r][j + 1]} : z, g_cls ? f32x2{vg[r][j], vg[r][j + 1]} : z, p);
-                o[j] = rr[0];
-                o[j + 1] = rr[1];
+                o[j] = canon_nan(rr[0]);
+                o[j + 1] = canon_nan(rr[1]);
               }
             } else {
 #pragma unroll
               for (int j = 0; j < 4; ++j)
-                o[j] = prologue<GUIDE, PM_RT, float, TE>(vx[r][j], v0[r][j], g_cfg ? v1[r][j] : 0.f, g_cls ? vg[r][j] : 0.f, p);
+                o[j] = canon_nan(prologue<GUIDE, PM_RT, float, TE>(vx[r][j], v0[r][j], g_cfg ? v1[r][j] : 0.f, g_cls ? vg[r][j] : 0.f, p));
             }
             {  // LDS, not global memory: a plain 16-byte store (store4 writes through to global memory)
               u32x4 a;
@@ -220,8 +221,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
 #pragma unroll 4
       for (int i = tid; i < n; i += T) {
         const float xev = to_f32(XE ? xe[base + i] : x[base + i]);
-        const float o = prologue<GUIDE, PM_RT, float, TE>(xev, to_f32(e0[ebase + i]), g_cfg ? to_f32(e1[ebase + i]) : 0.f,
-                                        g_cls ? to_f32(g[base + i]) : 0.f, p);
+        const float o = canon_nan(prologue<GUIDE, PM_RT, float, TE>(xev, to_f32(e0[ebase + i]), g_cfg ? to_f32(e1[ebase + i]) : 0.f,
+                                                  g_cls ? to_f32(g[base + i]) : 0.f, p));
         sx0[i] = o;
         const uint32_t u = __float_as_uint(o) & ABS;
         if (track)
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
     // phase 2: the lo-th smallest |x0| of the whole sample.
     uint32_t prefix = 0u, known = 0u, rank = (uint32_t)tp.lo, cnt_sel = 0u;
     uint32_t hi = ABS, nc = 0u;
+    const uint32_t nan_tag = (uint32_t)s_idx + 1u;  // misc[THR_NANW] == nan_tag: this sample holds a NaN (dpm_thresh_common.hpp)
     bool use_cand = false, local_only = k == 1;  // local_only: no further cluster-wide step is needed
     bool hist_ready = !track;                    // the level-0 histogram of the whole chunk exists
     bool fast = false;                           // the candidates are few: finish by rank counting
@@ -269,14 +271,14 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
     if (pbound && !lost) {  // the predicted attempt has a slot area of its own (a rejected one leaves its slots dirty)
       solved = cluster_select_once<T>(sx0, n, vec, m1, m2, m3, m4, has, hist, misc, cand,
                                       ws + THR_WS_WORDS + (size_t)k * THR_SLOTW, tp, k, c, tid, a1, b1, s_idx == grp,
-                                      ws + THR_WS_POISON, pbound);
+                                      ws + THR_WS_POISON, nan_tag, pbound);
       route = solved ? 1u : 2u;
       lost = !solved && misc[30] != 0u;
     }
     const bool searched = route1 && !solved && !lost;  // the searched-bound attempt runs (and dirties the first slot area)
     if (searched) {
       solved = cluster_select_once<T>(sx0, n, vec, m1, m2, m3, m4, has, hist, misc, cand, ws + THR_WS_WORDS, tp, k, c, tid,
-                                      a1, b1, s_idx == grp && !pbound, ws + THR_WS_POISON);
+                                      a1, b1, s_idx == grp && !pbound, ws + THR_WS_POISON, nan_tag);
       if (solved && route != 2u) route = 3u;
       lost = !solved && misc[30] != 0u;
     }
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
           hist[j * T + tid] = __hip_atomic_load(&gh[j * T + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
       }
-      locate_bin<T>(hist, misc, (uint32_t)tp.mrank, tid);
+      locate_bin<T>(hist, misc, (uint32_t)tp.mrank, tid, nan_tag);  // (the per-thread maxima: a NaN is some thread's maximum)
       const uint32_t bin_lo = misc[0];
       DPM_TSTAMP(5)
       {
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
           hist[j * T + tid] = __hip_atomic_load(&gh[j * T + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
       }
-      locate_bin<T>(hist, misc, rank, tid);
+      locate_bin<T>(hist, misc, rank, tid, pass == 0 ? nan_tag : 0u);
       prefix |= misc[0] << shift;
       known |= dmask << shift;
       rank = misc[1];
@@ -555,10 +557,10 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
         auto bits_at = [&](int i) -> uint32_t {
           const float o = prologue<GUIDE, PM_RT, float, TE>(to_f32(xs[i]), to_f32(e0s[i]), g_cfg ? to_f32(e1s[i]) : 0.f,
                                           g_cls ? to_f32(gs[i]) : 0.f, p);
-          return __float_as_uint(o) & ABS;
+          return __float_as_uint(canon_nan(o)) & ABS;
         };
         uint32_t sa, sb;
-        solo_select<T>(bits_at, (int)tp.per_sample, (uint32_t)tp.lo, tp.hi != tp.lo, hist, misc, tid, sa, sb);
+        solo_select<T>(bits_at, (int)tp.per_sample, (uint32_t)tp.lo, tp.hi != tp.lo, hist, misc, tid, sa, sb, nan_tag);
         a = __uint_as_float(sa);
         b = __uint_as_float(sb);
         // the operand rows fetched before the select are re-fetched here: not live across this (rare) detour, which
@@ -588,6 +590,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(HOT != 0 ? 4 
     // "a + w * diff" / "b - diff * (1 - w)" is contracted by its compiler): with this library's -ffp-contract=off the fma
     // is written out.  (Rounds 1-5 had the two-rounding form: one ulp off torch.quantile in ~2 % of random samples, found by
     // tools/fuzz_gpu_thresh.py.)
+    if (misc[THR_NANW] == nan_tag) a = b = __uint_as_float(THR_NAN_KEY);  // ref :420: a NaN anywhere in the sample
     const float diff = b - a;
     const float q = tp.w < 0.5f ? __builtin_fmaf(tp.w, diff, a) : __builtin_fmaf(tp.w - 1.f, diff, b);
     // ref :423, torch.maximum: a NaN quantile (a NaN among the two order statistics, inf - inf) stays NaN -- fmaxf drops it

@@ -22,12 +22,15 @@ __device__ __forceinline__ void top4_insert(uint32_t u, uint32_t& m1, uint32_t& 
 // Every thread owns 4 consecutive bins of the workgroup's LDS histogram (THR_NB = 4 T): one conflict-free 16-byte
 // read, a wavefront scan, the wavefront totals through LDS.  The thread whose bins hold the ascending `rank`
 // publishes misc[0] = bin, misc[1] = rank inside that bin, misc[2] = the bin's count.  The histogram is left ZEROED.
+// nan_tag != 0: the histogram is a level-0 one (digit = top 11 bits of the pattern) -- a non-empty last bin means the sample
+// holds a NaN (canon_nan): misc[THR_NANW] = nan_tag.
 template <int T>
-__device__ __forceinline__ void locate_bin(uint32_t* hist, uint32_t* misc, uint32_t rank, int tid) {
+__device__ __forceinline__ void locate_bin(uint32_t* hist, uint32_t* misc, uint32_t rank, int tid, uint32_t nan_tag = 0u) {
   static_assert(THR_NB == 4 * T, "one 16-byte histogram slice per thread");
   u32x4* h4 = reinterpret_cast<u32x4*>(hist);
   const u32x4 v = h4[tid];
   h4[tid] = u32x4{0u, 0u, 0u, 0u};
+  if (nan_tag && tid == T - 1 && v[3]) misc[THR_NANW] = nan_tag;
   const uint32_t tot = (v[0] + v[1]) + (v[2] + v[3]);
   const uint32_t incl = wave_incl_scan(tot);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wavefront-uniform: scalar compares below
@@ -373,7 +376,7 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
                                                     uint32_t m3, uint32_t m4, bool has, uint32_t* hist, uint32_t* misc,
                                                     uint32_t* cand, uint32_t* slots, const ThrParams& tp, uint32_t k, int c,
                                                     int tid, uint32_t& a_out, uint32_t& b_out, bool stamp,
-                                                    uint32_t* poison, const uint32_t pbound = 0u) {
+                                                    uint32_t* poison, uint32_t nan_tag, const uint32_t pbound = 0u) {
   // pbound != 0 (bit pattern of a positive float): the bound is PREDICTED from the previous stages' thresholds (same value
   // in every workgroup of the cluster) instead of searched in the histogram of the per-thread maxima: no histogram, no
   // locate_bin, and a union of ~1.3 K entries instead of k * quota.  Every element >= pbound of every chunk is published,
@@ -583,6 +586,7 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
   }
   __syncthreads();
   const uint32_t total = misc[24], bound_max = misc[9], umax = misc[12];
+  if (tid == 0 && umax == THR_NAN_KEY) misc[THR_NANW] = nan_tag;  // a chunk's maximum is a NaN (read behind the next barrier)
   const bool ok = !misc[10] && total >= K && total <= (uint32_t)THR_CAP;
   // 6. the union -> cand[]: entry i of slot s goes to off[s] + i
   if (ok) {
@@ -656,7 +660,7 @@ __device__ __forceinline__ bool cluster_select_once(const float* sx0, int n, boo
 // left zeroed.  Slow (four passes over the sample through L2) and rare.
 template <int T, typename F>
 __device__ __forceinline__ void solo_select(F&& bits_at, int n, uint32_t rank, bool need_next, uint32_t* hist,
-                                            uint32_t* misc, int tid, uint32_t& a, uint32_t& b) {
+                                            uint32_t* misc, int tid, uint32_t& a, uint32_t& b, uint32_t nan_tag) {
 #pragma unroll
   for (int j = 0; j < THR_NB / T; ++j) hist[j * T + tid] = 0u;
   __syncthreads();
@@ -671,7 +675,7 @@ __device__ __forceinline__ void solo_select(F&& bits_at, int n, uint32_t rank, b
       if ((u & known) == prefix) atomicAdd(&hist[(u >> shift) & dmask], 1u);
     }
     __syncthreads();
-    locate_bin<T>(hist, misc, rank, tid);
+    locate_bin<T>(hist, misc, rank, tid, pass == 0 ? nan_tag : 0u);
     prefix |= misc[0] << shift;
     known |= dmask << shift;
     rank = misc[1];

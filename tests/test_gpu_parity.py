@@ -899,6 +899,75 @@ def _thr_solver(ns, model=lambda xx, t: xx * 0.5, **kw):
     return D.DPM_Solver(D.model_wrapper(model, ns, **kw), ns, correcting_x0_fn="dynamic_thresholding")
 
 
+def _non_finite_rows(shape, p, seed):
+    """every row of a batch with one kind of non-finite content: nothing / one NaN / one inf / infs around the wanted rank /
+    -infs / a NaN and infs; returns the fp32 tensor"""
+    g = np.random.default_rng(seed)
+    B, n = shape[0], int(np.prod(shape[1:]))
+    x = g.standard_normal((B, n)).astype(F32)
+    K = max(1, int(n - np.floor(F32(p) * F32(n - 1))))
+    for b in range(B):
+        kind, idx = b % 6, g.permutation(n)
+        if kind in (1, 5):
+            x[b, idx[0]] = np.nan
+        if kind == 2:
+            x[b, idx[0]] = np.inf
+        if kind == 3:
+            x[b, idx[:K + 1]] = np.inf
+        if kind == 4:
+            x[b, idx[:K]] = -np.inf
+        if kind == 5:
+            x[b, idx[1:K + 1]] = np.inf
+    return torch.from_numpy(x.reshape(shape))
+
+
+def _thr_reference(x0, p, max_val):
+    """ref :416-425 on the CPU"""
+    pq = torch.quantile(x0.abs().reshape(x0.shape[0], -1), p, dim=1)
+    s = torch.maximum(pq, max_val * torch.ones_like(pq))[(...,) + (None,) * (x0.dim() - 1)]
+    return torch.clamp(x0, -s, s) / s
+
+
+@pytest.mark.parametrize("shape", [(12, 7), (12, 513), (13, 4095), (40, 3, 64, 64), (6, 3, 64, 64), (12, 12289), (6, 3, 256, 256),
+                                   (1030, 3, 64, 64)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_thresholding_of_non_finite_samples_is_the_reference_lines(shape, dt):
+    """Round 6 (rounds 1-5 clamped a NaN element to +-1 and never looked for one): torch.quantile gives NaN for a sample that
+    holds a NaN anywhere, so the reference's whole sample is NaN; infinite values go through its three lines (an infinite
+    quantile divides finite elements to 0, inf / inf and inf - inf between the order statistics are NaN).  One workgroup per
+    sample, clusters on the single-exchange and the general route, ragged rows, full histograms (p = 0.5): bit for bit."""
+    if dt is torch.float64 and int(np.prod(shape)) > 3_000_000:
+        pytest.skip("size covered in fp32")
+    ns = make_schedule("ddpm")
+    for p in (0.5, 0.97, 0.995, 1.0):
+        x0 = _non_finite_rows(shape, p, seed=len(shape) + shape[0]).to(dt)
+        dpm = D.DPM_Solver(lambda x, t: x, ns, correcting_x0_fn="dynamic_thresholding", dynamic_thresholding_ratio=p)
+        got = dpm.dynamic_thresholding_fn(x0.to(DEV), None).cpu()
+        want = _thr_reference(x0, p, 1.0)
+        assert bool(((got == want) | (got.isnan() & want.isnan())).all()), (shape, p)
+        assert bool(want.reshape(shape[0], -1)[1].isnan().all())          # (row 1 holds one NaN: the whole row)
+        if dt is torch.float32:
+            np.testing.assert_array_equal(got.numpy(), O.dynamic_threshold(x0.numpy(), p, 1.0))
+
+
+@pytest.mark.lab
+@pytest.mark.parametrize("mode,one_hop", [(1, 1), (2, 1), (3, 0)])
+def test_non_finite_samples_when_a_cluster_wait_times_out(mode, one_hop):
+    """the recovery path (solo_select) and the peers that go on without the lost workgroup look for the NaN like the healthy
+    routes do"""
+    ns = make_schedule("ddpm")
+    for shape in ((6, 3, 64, 64), (3, 3, 160, 160)):
+        for p in (0.5, 0.995):
+            x0 = _non_finite_rows(shape, p, seed=7)
+            dpm = D.DPM_Solver(lambda x, t: x, ns, correcting_x0_fn="dynamic_thresholding", dynamic_thresholding_ratio=p)
+            with _Tuned(thr_debug_fault=mode, thr_spin_limit=48, cluster_one_hop=one_hop):
+                got = dpm.dynamic_thresholding_fn(x0.to(DEV), None).cpu()
+                torch.cuda.synchronize()
+            want = _thr_reference(x0, p, 1.0)
+            assert bool(((got == want) | (got.isnan() & want.isnan())).all()), (shape, p, mode)
+    L.cluster_timeout_poll()
+
+
 @pytest.mark.lab
 @pytest.mark.parametrize("shape", [(32, 3, 64, 64), (5, 3, 64, 64), (2, 3, 160, 160), (300, 1, 128, 128)])
 @pytest.mark.parametrize("mode,one_hop", [(1, 1), (2, 1), (3, 1), (1, 0), (2, 0), (3, 0)])
