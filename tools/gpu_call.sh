@@ -19,6 +19,7 @@
 #   fuzzmethods  tools/fuzz_gpu_methods.py: the public per-update / evaluation / schedule methods on the GPU vs the double
 #   fuzzkernel   tools/fuzz_gpu_kernel.py: one dpm_stage_launch per case (random stage record, tiling-boundary geometry, dtype pairs, layouts) vs the double
 #   fuzzthresh   tools/fuzz_gpu_thresh.py: dynamic_thresholding_fn on the GPU vs torch.quantile on the CPU (boundary sample sizes, ties, any ratio)
+#   sweeps       test_thresholded_sampling_random_sweep extended: 10 000 configurations on the product, 3 x 3000 under forced faults + 3000 on the general route (lab build)
 #   torchprobe   tools/torch_on_device_probe.py: torch's own half * scalar and quantile interpolation on this GPU vs its CPU kernels
 #   fuzzgpu      tools/fuzz_gpu.py: the drop-in fuzz's random cases, engine on the GPU vs the engine's host code on the numpy double
 TAG=${1:?tag}; shift
@@ -111,6 +112,13 @@ fuzzthresh)
     timeout 1400 python tools/fuzz_gpu_thresh.py --cases ${FUZZ_CASES:-3000} --seed $SEED --case-timeout 60 --out $O/fuzz_gpu_thresh_seed$SEED.json > $O/fuzz_gpu_thresh_seed$SEED.log 2>&1; echo "fuzz_gpu_thresh seed $SEED rc=$?"
     tail -1 $O/fuzz_gpu_thresh_seed$SEED.log | cut -c1-1500; grep -c "^case" $O/fuzz_gpu_thresh_seed$SEED.log; grep -A2 "^case" $O/fuzz_gpu_thresh_seed$SEED.log | cut -c1-600 | head -40; cat $O/*current_case.txt 2>/dev/null | cut -c1-700
   done ;;
+sweeps)
+  # the long thresholded-sampling sweeps: the product (DPM_THR_SWEEP configurations), then the lab build under forced faults
+  ( time DPM_THR_SWEEP=${SWEEP_N:-10000} timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -k test_thresholded_sampling_random_sweep ) > $O/sweep_product.log 2>&1; echo "sweep product rc=$? $(grep -E 'passed|failed' $O/sweep_product.log | tail -1) $(grep real $O/sweep_product.log)"
+  for F in 1 2 3; do
+    ( time DPM_SOLVER_AMD_LIB=tools/_variants/lab/libdpm_lab.so DPM_THR_SWEEP=${SWEEP_FAULT_N:-3000} DPM_THR_SWEEP_FAULT=$F timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -k test_thresholded_sampling_random_sweep ) > $O/sweep_fault$F.log 2>&1; echo "sweep fault $F rc=$? $(grep -E 'passed|failed' $O/sweep_fault$F.log | tail -1) $(grep real $O/sweep_fault$F.log)"
+  done
+  ( time DPM_SOLVER_AMD_LIB=tools/_variants/lab/libdpm_lab.so DPM_THR_SWEEP=${SWEEP_FAULT_N:-3000} DPM_THR_SWEEP_ONE_HOP=0 timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -k test_thresholded_sampling_random_sweep ) > $O/sweep_general.log 2>&1; echo "sweep general route rc=$? $(grep -E 'passed|failed' $O/sweep_general.log | tail -1) $(grep real $O/sweep_general.log)" ;;
 torchprobe)
   timeout 600 python tools/torch_on_device_probe.py > $O/torch_on_device.json 2> $O/torch_on_device.err; echo "torchprobe rc=$?"; cat $O/torch_on_device.json ;;
 *) echo "unknown step $STEP" ;;
