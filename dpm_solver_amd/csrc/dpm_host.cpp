@@ -665,7 +665,11 @@ int plan_build(const S* s, const dpm_plan_desc* d, std::vector<ST>& stages, std:
         if (o >= 2 && (d->solver_type < 0 || d->solver_type > 1))
           rc = dpm_set_error(DPM_ERR_ARG, "'solver_type' must be either 'dpmsolver' or 'taylor', got %d", d->solver_type);
         if (rc) break;
-        singlestep_fill(s, d->algorithm_type, d->solver_type, o, ts_, tt_, r1, r2, 1, st);
+        // r1 / r2 are tensors of the run's scalar type: fp32 tensors in an fp32 plan (their quotients `0.5 / r1`, `r2 / r1` are
+        // fp32 operations), DOUBLE tensors in a double-precision plan -- which behave like Python floats there (r_mode 0).
+        // (Round 6 passed 1 for both: 3e-8 off the reference on double tables, unseen while the differential tests compared the
+        // engine with itself -- tests/test_differential_reference.py: load_reference.)
+        singlestep_fill(s, d->algorithm_type, d->solver_type, o, ts_, tt_, r1, r2, sizeof(F) == 8 ? 0 : 1, st);
         for (int i = 0; i < o; ++i) {
           st[i].outer_step = (int)j;
           F te = (F)st[i].t_eval;

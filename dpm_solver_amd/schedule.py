@@ -186,7 +186,8 @@ class NoiseScheduleVP:
         else:
             out = torch.from_numpy(self._eval_np(L.EVAL_INV_LAMBDA, lamb.detach().to(device="cpu", dtype=torch.float32).numpy()))
         if self.schedule != 'discrete':
-            out = out.reshape(lamb.shape)
+            # (ref :158: logaddexp against a (1,)-shaped zero -- a 0-dim lambda comes back (1,)-shaped)
+            out = out.reshape(lamb.shape if lamb.dim() else (1,))
         return out.to(device=lamb.device)
 
 

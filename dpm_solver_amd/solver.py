@@ -396,6 +396,12 @@ class DPM_Solver:
     def get_time_steps(self, skip_type, t_T, t_0, N, device):
         if skip_type not in L.SKIP:
             raise ValueError("Unsupported skip_type {}, need to be 'logSNR' or 'time_uniform' or 'time_quadratic'".format(skip_type))
+        ns = self.noise_schedule
+        if skip_type == 'logSNR' and ns.schedule == 'discrete' and ns.dtype == torch.float64:
+            # ref :467-471 on double tables: the fp32 logSNR grid goes through inverse_lambda, whose interpolation concatenates
+            # it with the tables -- the time steps are doubles (the values the double-precision plan of sample() uses)
+            lambda_T, lambda_0 = ns.marginal_lambda(torch.tensor(t_T)), ns.marginal_lambda(torch.tensor(t_0))
+            return ns.inverse_lambda(torch.linspace(lambda_T.item(), lambda_0.item(), N + 1)).to(device)
         out = np.empty(N + 1, dtype=np.float32)
         L.check(L.lib.dpm_time_steps(self._h, L.SKIP[skip_type], float(t_T), float(t_0), int(N),
                                      out.ctypes.data_as(C.POINTER(C.c_float))))
@@ -411,7 +417,12 @@ class DPM_Solver:
         n = C.c_int()
         L.check(L.lib.dpm_singlestep_grid(self._h, int(steps), int(order), L.SKIP[skip_type], float(t_T), float(t_0),
                                           outer.ctypes.data_as(C.POINTER(C.c_float)), orders, C.byref(n)))
-        return torch.from_numpy(outer[: n.value + 1].copy()).to(device), [int(orders[i]) for i in range(n.value)]
+        orders = [int(orders[i]) for i in range(n.value)]
+        ns = self.noise_schedule
+        if skip_type == 'logSNR' and ns.schedule == 'discrete' and ns.dtype == torch.float64:
+            # (double time steps, see get_time_steps; ref :534-536: with 'logSNR' the outer grid is a grid of K = len(orders) steps)
+            return self.get_time_steps(skip_type, t_T, t_0, len(orders), device), orders
+        return torch.from_numpy(outer[: n.value + 1].copy()).to(device), orders
 
     # ------------------------------------------------------------------------------------------
     # public per-update methods (ref :547-954)

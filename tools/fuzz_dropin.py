@@ -29,7 +29,17 @@ sys.path.insert(0, REF_DIR)
 import cases as C  # noqa: E402
 import dpm_solver_amd as D  # noqa: E402
 import dpm_solver_amd.solver as S  # noqa: E402
-import dpm_solver_pytorch as R  # noqa: E402
+import importlib.util  # noqa: E402
+# the reference BY FILE under a name of its own: the repository root holds a drop-in shim called dpm_solver_pytorch too (the
+# engine), and whichever of the two was imported first owns that name in sys.modules
+_ref_path = os.path.join(REF_DIR, "dpm_solver_pytorch.py")
+if os.path.exists(_ref_path):
+    _spec = importlib.util.spec_from_file_location("_the_reference_dpm_solver_pytorch", _ref_path)
+    R = importlib.util.module_from_spec(_spec)
+    _spec.loader.exec_module(R)
+    assert R.DPM_Solver is not D.DPM_Solver, "the reference module resolved to the engine's shim"
+else:
+    R = None          # (the GPU box: tools/fuzz_gpu*.py import this module for its case generator only)
 from engine_cases import make_schedule  # noqa: E402
 from kernel_double import install_cpu_double  # noqa: E402
 
@@ -432,6 +442,7 @@ def fuzz_methods(args):
 
 
 def main():
+    assert R is not None, "no reference at %s (DPM_REFERENCE_DIR)" % _ref_path
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=1500)
     ap.add_argument("--seed", type=int, default=0)
