@@ -655,6 +655,22 @@ def test_drop_in_fuzz_slice(R, monkeypatch, capsys):
     assert "250 cases" in out
 
 
+def test_drop_in_fuzz_slice_on_double_tables(R, monkeypatch, capsys):
+    """200 cases of tools/fuzz_dropin.py --double-tables: the same random corners with every discrete schedule declared
+    dtype=torch.float64 (double input arrays): the run is a double run from its first update whatever x_T's dtype -- fp32, half,
+    non-contiguous, networks pinned to another dtype -- and agrees with the live reference to 1e-11 (2e-7 on a logSNR grid, whose
+    logaddexp runs on an fp32 linspace in the reference).  (Round 6: singlestep plans of order >= 2 were 3e-8 off -- r1 / r2
+    treated as fp32 tensors -- while this module compared the engine with itself.)"""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_dropin as FZ
+    monkeypatch.setattr(sys, "argv", ["fuzz_dropin.py", "--cases", "200", "--seed", "17", "--double-tables"])
+    monkeypatch.setattr(FZ, "install", lambda mp=None: None)
+    n_bad = FZ.main()
+    out = capsys.readouterr().out
+    assert n_bad == 0, out[-3000:]
+    assert "200 cases" in out
+
+
 def test_drop_in_fuzz_slice_of_the_public_methods(R, monkeypatch, capsys):
     """400 random calls of the public per-update methods, the model evaluations, add_noise, the time grids, thresholding,
     the schedule's functions and interpolate_fn (tools/fuzz_dropin.py --mode methods: time tensors 0-dim / (1,)-shaped, fp32 /
