@@ -663,7 +663,7 @@ def test_drop_in_fuzz_slice_on_double_tables(R, monkeypatch, capsys):
     treated as fp32 tensors -- while this module compared the engine with itself.)"""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_dropin as FZ
-    monkeypatch.setattr(sys, "argv", ["fuzz_dropin.py", "--cases", "200", "--seed", "17", "--double-tables"])
+    monkeypatch.setattr(sys, "argv", ["fuzz_dropin.py", "--cases", "200", "--seed", "17", "--double-tables", "--case-timeout", "5"])
     monkeypatch.setattr(FZ, "install", lambda mp=None: None)
     n_bad = FZ.main()
     out = capsys.readouterr().out
