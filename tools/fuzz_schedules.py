@@ -67,7 +67,7 @@ def schedule_kwargs(cfg):
     return dict(schedule="discrete", betas=betas, dtype=dt)
 
 
-TOL = 2e-6   # of max(1, |value|): a few fp32 ulps (set per case: 1e-13 when every table and time is a double)
+TOL = 2e-6   # of max(1, |value|): a few fp32 ulps; BASE (per case) is 1e-12 where every table and time is a double
 
 
 def same(a, b):
@@ -111,6 +111,7 @@ def main():
         kw = schedule_kwargs(cfg)
         global TOL
         TOL = 2e-6
+        all_double = cfg["dt"] == "f64" and kw["schedule"] == "discrete"      # double tables from double arrays
         r = outcome(lambda: R.NoiseScheduleVP(**kw))
         e = outcome(lambda: D.NoiseScheduleVP(**kw))
         if r[0] != e[0] or (r[0] == "raise" and r[1] != e[1]):
@@ -136,7 +137,9 @@ def main():
                         n_checks += 1
                         # std = sqrt(1 - exp(2 log_alpha)) cancels near t = 0: one ulp of exp() is 6e-8 / (1 - alpha^2) of the
                         # result (1e-3 at alpha^2 = 1 - 6e-5) -- in both implementations; the bar follows the conditioning
-                        TOL = 2e-6
+                        BASE = 1e-12 if (all_double and tdt is torch.float64) else 2e-6
+                        EPS = 2e-16 if (all_double and tdt is torch.float64) else 4e-7
+                        TOL = BASE
                         outside = bool((t.double() < t_lo).any() or (t.double() > rs.T).any())
                         if outside:
                             # beyond the table both sides extrapolate with the outermost segment's slope, a quotient of
@@ -145,15 +148,15 @@ def main():
                             TOL = 1e-3
                         if fn in ("marginal_std", "marginal_lambda") and a[0] == "ok" and torch.is_tensor(a[1]):
                             al2 = torch.exp(2.0 * rs.marginal_log_mean_coeff(t).double())
-                            TOL = max(TOL, float(torch.clamp(4e-7 / torch.clamp(1.0 - al2, min=1e-9), min=2e-6, max=0.5).max()))
+                            TOL = max(TOL, float(torch.clamp(EPS / torch.clamp(1.0 - al2, min=1e-9), min=BASE, max=0.5).max()))
                         if a[0] != b[0] or not same(a[1], b[1]):
                             bad.append("%s(t %s %s): %s" % (fn, str(tdt)[6:], tuple(t.shape), _diff(a, b)))
-                    TOL = 2e-6
+                    TOL = BASE
                     lam = outcome(lambda: rs.marginal_lambda(t))
                     if lam[0] == "ok":
                         for shift in (0.0, 0.37, -0.21, 30.0, -30.0):
                             l2 = lam[1] + shift
-                            TOL = 1e-3 if (abs(shift) > 1 or outside) else 2e-6     # (extrapolation, see above)
+                            TOL = 1e-3 if (abs(shift) > 1 or outside) else BASE     # (extrapolation, see above)
                             a, b = outcome(lambda: rs.inverse_lambda(l2)), outcome(lambda: es.inverse_lambda(l2))
                             n_checks += 1
                             if a[0] == "ok" and bool(((a[1].double() < t_lo) | (a[1].double() > rs.T)).any()):
