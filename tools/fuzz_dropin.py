@@ -23,8 +23,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
     sys.path.insert(0, p)
-REF_DIR = os.environ.get("DPM_REFERENCE_DIR", "/root/reference")
-sys.path.insert(0, REF_DIR)
+REF_DIR = os.environ.get("DPM_REFERENCE_DIR", "/root/reference")     # (never put on sys.path: the reference is loaded by file)
 
 import cases as C  # noqa: E402
 import dpm_solver_amd as D  # noqa: E402
