@@ -135,7 +135,7 @@ struct ThrTab {
 // torch.quantile gives NaN for a sample that holds a NaN ANYWHERE (ref :420), whatever the rank asked for.  Phase 1 stores
 // every NaN as the one pattern 0x7fffffff (canon_nan): the largest |x0| key there is and the only one with the top digit
 // 0x7ff, so "the sample holds a NaN" is "bin 2047 of a level-0 histogram (of the elements, or of the per-thread maxima) is
-// not empty" (locate_bin, top = true) or "the largest chunk maximum is that pattern" (cluster_select_once) -- words every
+// not empty" (locate_bin with a nan_tag) or "the largest chunk maximum is that pattern" (cluster_select_once) -- words every
 // route already merges across the cluster.  The verdict is misc[THR_NANW] == the sample's tag (sample index + 1: never
 // reset, a stale tag of an earlier sample does not match).
 constexpr uint32_t THR_NAN_KEY = 0x7fffffffu;
